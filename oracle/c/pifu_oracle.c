@@ -1,0 +1,36 @@
+/* CPU oracle for the MonoPort / PIFu query hot path -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (monoport_amd/) never does.  Parity status: PINNED for the query /
+ * index path against golden vectors generated from the reference's own Python modules
+ * (oracle/gen_golden.py -> tests/golden/).  Exports an fp32 build (orc_*_f32, the timed CPU
+ * baseline: same arithmetic type as the reference) and an fp64 build (orc_*_f64, the
+ * high-precision checker).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define REAL float
+#define SUFFIX _f32
+#include "pifu_oracle_body.inc"
+#undef REAL
+#undef SUFFIX
+
+#define REAL double
+#define SUFFIX _f64
+#include "pifu_oracle_body.inc"
+#undef REAL
+#undef SUFFIX
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

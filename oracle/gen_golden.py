@@ -1,0 +1,169 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python modules.
+
+Run in the build container only (needs /root/reference):
+
+    python oracle/gen_golden.py
+
+It imports monoport.lib.modeling.* and RTL/recon.py from /root/reference (never copied),
+feeds them the seeded inputs of monoport_amd/synthetic.py and stores ONLY the reference outputs
+(+ the seeds that regenerate the inputs).  The GPU box has no /root/reference: tests read the
+committed fixtures.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("MONOPORT_REFERENCE", "/root/reference")
+sys.path[:0] = [os.path.join(HERE, "refshim"), REF, os.path.join(REF, "RTL"), ROOT]
+
+import torch  # noqa: E402
+
+from monoport_amd import synthetic as syn  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def ref_net(kind):
+    from monoport.lib.modeling.MonoPortNet import PIFuNetC, PIFuNetG
+    torch.manual_seed(0)
+    return (PIFuNetG() if kind == "G" else PIFuNetC()).eval()
+
+
+def load_mlp(net, layers):
+    sd = {}
+    for i, (w, b) in enumerate(layers):
+        sd["filters.%d.weight" % i] = torch.from_numpy(w)[:, :, None]
+        sd["filters.%d.bias" % i] = torch.from_numpy(b)
+    net.surface_classifier.load_state_dict(sd)
+
+
+@torch.no_grad()
+def gen_query():
+    import recon as ref_recon
+    cases = {
+        # name: (kind, mlp, feat, points, camera step)
+        "query_G_rand": ("G", ("rand", 11, 2.0), ("rand", 256, 21), (4096, 31, 1.2), 33),
+        "query_C_rand": ("C", ("rand", 12, 2.0), ("rand", 512, 22), (2048, 32, 1.2), 75),
+        "query_G_body": ("G", ("body", 13, 0.05), ("body", 256, 23), (4096, 33, 1.0), 12),
+    }
+    for name, (kind, mlp, feat, pts, step) in cases.items():
+        net = ref_net(kind)
+        layers = (syn.rand_mlp(kind, mlp[1], mlp[2]) if mlp[0] == "rand"
+                  else syn.body_mlp(kind, noise=mlp[2], seed=mlp[1]))
+        load_mlp(net, layers)
+        f = (syn.rand_feat(feat[1], 128, 128, feat[2]) if feat[0] == "rand"
+             else syn.body_feat(feat[1], 128, 128, feat[2]))
+        p = syn.rand_points(pts[0], pts[1], pts[2])
+        ext, intr = syn.scene_camera(step)
+        calib = ref_recon.pifu_calib(ext, intr, device="cpu")
+        # RTL/main.py:169-183 hands netG.query a 4-stage list and uses the last one
+        feats = [[torch.zeros(1, f.shape[0], 2, 2)]] * 3 + [[torch.from_numpy(f)[None]]]
+        out = net.query(feats, torch.from_numpy(p)[None], calibs=calib)[0][0].numpy()
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"), out=out, calib=calib.numpy(),
+            meta=np.array([repr(dict(kind=kind, mlp=mlp, feat=feat, pts=pts, step=step))]))
+        print(name, out.shape, float(out.min()), float(out.max()),
+              "zeros:", int((out == 0).all(0).sum()))
+
+
+@torch.no_grad()
+def gen_index_orthogonal_calib():
+    import recon as ref_recon
+    from monoport.lib.modeling.geometry import index, orthogonal
+    f = syn.rand_feat(256, 128, 128, 41)
+    rs = np.random.RandomState(42)
+    uv = rs.uniform(-1.1, 1.1, size=(2, 256)).astype(np.float32)
+    uv[:, :4] = np.array([[-1, 1, -1, 1], [-1, -1, 1, 1]], np.float32)  # exact corners
+    out = index(torch.from_numpy(f)[None], torch.from_numpy(uv)[None])[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "index.npz"), out=out, uv=uv,
+                        meta=np.array(["feat=rand_feat(256,128,128,41)"]))
+    p = syn.rand_points(1000, 43, 1.0)
+    ext, intr = syn.scene_camera(57)
+    calib = ref_recon.pifu_calib(ext, intr, device="cpu")
+    o = orthogonal(torch.from_numpy(p)[None], calib)[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "orthogonal.npz"), out=o, calib=calib.numpy(),
+                        meta=np.array(["points=rand_points(1000,43,1.0); scene_camera(57)"]))
+    steps = [0, 3, 33, 90, 181]
+    calibs = []
+    for s in steps:
+        ext, intr = syn.scene_camera(s)
+        e0, i0 = ext.copy(), intr.copy()
+        calibs.append(ref_recon.pifu_calib(ext, intr, device="cpu").numpy())
+        assert (e0 == ext).all() and (i0 == intr).all()
+    np.savez_compressed(os.path.join(OUT, "pifu_calib.npz"), steps=np.array(steps),
+                        calib=np.concatenate(calibs, 0))
+    print("index", out.shape, "orthogonal", o.shape, "calib", len(steps))
+
+
+@torch.no_grad()
+def gen_forward_vertices():
+    import recon as ref_recon
+    store = {}
+    for res, seed in ((33, 51), (65, 52)):
+        vol = syn.blob_volume(res, seed)
+        for d in ("front", "back", "left", "right"):
+            x, y, z, n = ref_recon.forward_vertices(torch.from_numpy(vol)[None, None], d)
+            key = "r%d_%s_" % (res, d)
+            store[key + "X"] = x.numpy()
+            store[key + "Y"] = y.numpy()
+            store[key + "Z"] = z.numpy()
+            store[key + "norm"] = n.numpy()
+            print("forward_vertices", res, d, x.shape[0], "nan:", int(torch.isnan(z).sum()))
+    store["meta"] = np.array(["vol=blob_volume(res,seed) for (33,51),(65,52)"])
+    np.savez_compressed(os.path.join(OUT, "forward_vertices.npz"), **store)
+
+
+@torch.no_grad()
+def gen_colorization():
+    """RTL/main.py:201-249 driven with the reference's orthogonal + netC.query + recon."""
+    import recon as ref_recon
+    from monoport.lib.modeling.geometry import orthogonal
+    res = 33
+    net = ref_net("C")
+    load_mlp(net, syn.rand_mlp("C", 61, 2.0))
+    f = syn.rand_feat(512, 128, 128, 62)
+    feats = [[torch.from_numpy(f)[None]]]
+    vol = syn.blob_volume(res, 63)
+    X, Y, Z, norm = ref_recon.forward_vertices(torch.from_numpy(vol)[None, None], "front")
+    ext, intr = syn.scene_camera(21)
+    calib = ref_recon.pifu_calib(ext, intr, device="cpu")
+    canvas = torch.ones((res, res, 3), dtype=torch.float32)
+    b_min = torch.tensor([-1.0, -1.0, -1.0])
+    b_max = torch.tensor([1.0, 1.0, 1.0])
+    mat = torch.eye(4, dtype=torch.float32)
+    length = b_max - b_min
+    for i in range(3):
+        mat[i, i] = length[i] / res
+    mat[0:3, 3] = b_min
+    # normal mode (main.py:219-225)
+    img_n = canvas.clone()
+    img_n[X, Y, :] = ((norm + 1) / 2).clamp(0, 1)
+    # texture mode (main.py:228-248)
+    verts = torch.stack([X.float(), Y.float(), res - Z.float()], dim=1)
+    samples = verts.unsqueeze(0).permute(0, 2, 1)
+    samples = orthogonal(samples, mat.unsqueeze(0))
+    preds = net.query(feats, points=samples, calibs=calib)[0]
+    color = (preds[0] * 0.5 + 0.5).t()
+    img_t = canvas.clone()
+    img_t[X, Y, :] = color
+    np.savez_compressed(os.path.join(OUT, "colorization.npz"), norm_image=img_n.numpy(),
+                        tex_image=img_t.numpy(), calib=calib.numpy(),
+                        meta=np.array(["res=33 netC=rand_mlp(C,61,2.0) feat=rand_feat(512,128,128,62) "
+                                       "vol=blob_volume(33,63) scene_camera(21)"]))
+    print("colorization", int(X.shape[0]), "verts")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["query", "misc", "vertices", "color"]
+    if "query" in which:
+        gen_query()
+    if "misc" in which:
+        gen_index_orthogonal_calib()
+    if "vertices" in which:
+        gen_forward_vertices()
+    if "color" in which:
+        gen_colorization()

@@ -1,0 +1,75 @@
+"""Octree driver oracle (OUR restatement of implicit_seg.Seg3dLossless; parity unpinned -- the
+dependency is not vendored).  Anchored on the property the upstream advertises: the
+thresholded coarse-to-fine volume equals the thresholded dense evaluation, and every voxel the
+octree queried carries the exact dense value.  CPU only."""
+import numpy as np
+import pytest
+
+from monoport_amd import synthetic as syn
+
+BMIN, BMAX = [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]
+
+
+@pytest.fixture(scope="module")
+def body_query(oracle):
+    layers = syn.body_mlp("G", noise=0.05, seed=1)
+    f = syn.body_feat(256, 128, 128, 2)
+    ext, intr = syn.scene_camera(30)
+    calib = oracle.pifu_calib(ext, intr)[0]
+    return lambda pts: oracle.query(f, pts, calib, layers, 1, syn.Z_SCALE, precision="f32")[0]
+
+
+def test_upsample2x_is_align_corners_trilinear(oracle):
+    rs = np.random.RandomState(0)
+    a = rs.rand(5, 5, 5).astype(np.float32)
+    up = oracle.upsample2x(a)
+    assert up.shape == (9, 9, 9)
+    assert np.array_equal(up[::2, ::2, ::2], a)
+    assert np.allclose(up[1, 0, 0], 0.5 * (a[0, 0, 0] + a[1, 0, 0]))
+    assert np.allclose(up[1, 1, 1], a[:2, :2, :2].mean(), atol=1e-6)
+    import torch
+    ref = torch.nn.functional.interpolate(torch.from_numpy(a)[None, None], size=(9, 9, 9),
+                                          mode="trilinear", align_corners=True)[0, 0].numpy()
+    assert np.array_equal(up, ref)  # bit-exact: weights are 0, 0.5, 1
+
+
+def test_dilate_box_matches_conv(oracle):
+    import torch
+    rs = np.random.RandomState(1)
+    m = rs.rand(12, 12, 12) > 0.97
+    for k in (3, 7, 9):
+        ref = torch.nn.functional.conv3d(torch.from_numpy(m.astype(np.float32))[None, None],
+                                         torch.ones(1, 1, k, k, k), padding=k // 2)[0, 0] > 0
+        assert np.array_equal(oracle.dilate_box(m, k), ref.numpy())
+
+
+def test_lattice_points_convention(oracle):
+    idx = np.array([[0, 0, 0], [16, 8, 4]])
+    p = oracle.lattice_points(idx, 16, 257, BMIN, BMAX)
+    assert p.shape == (3, 2) and p.dtype == np.float32
+    assert np.allclose(p[:, 0], (0.5 / 257) * 2 - 1, atol=1e-6)
+    # row is (z, y, x) -> world (x, y, z)
+    assert np.allclose(p[:, 1], [((4 * 16 + 0.5) / 257) * 2 - 1, ((8 * 16 + 0.5) / 257) * 2 - 1,
+                                 ((16 * 16 + 0.5) / 257) * 2 - 1], atol=1e-6)
+
+
+@pytest.mark.parametrize("res", [[9, 17, 33], [5, 9, 17, 33]])
+def test_lossless_vs_dense(oracle, body_query, res):
+    stats = []
+    vol = oracle.seg3d_lossless(body_query, BMIN, BMAX, res, stats=stats)
+    dense = oracle.dense_volume(body_query, BMIN, BMAX, res[-1])
+    assert vol.shape == dense.shape == (res[-1],) * 3
+    assert np.array_equal(vol > 0.5, dense > 0.5)
+    near = np.abs(dense - 0.5) < 0.3  # near-surface voxels were queried exactly
+    assert np.array_equal(vol[near], dense[near])
+    assert sum(stats) < 0.5 * res[-1] ** 3
+
+
+def test_empty_returns_none(oracle):
+    assert oracle.seg3d_lossless(lambda p: np.zeros(p.shape[1], np.float32), BMIN, BMAX,
+                                 [5, 9]) is None
+
+
+def test_rejects_non_doubling(oracle):
+    with pytest.raises(ValueError):
+        oracle.seg3d_lossless(lambda p: np.zeros(p.shape[1], np.float32), BMIN, BMAX, [5, 11])
