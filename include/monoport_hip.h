@@ -1,0 +1,138 @@
+/* monoport_hip.h -- C-ABI of the MI355X-native MonoPort reconstruction hot path.
+ *
+ * Drop-in boundary: plain pointers and sizes, no torch types, no C++
+ * exceptions.  Every entry point names the reference interface it replaces (file:line under
+ * the MonoPort tree).  The reference is pure Python; its "FFI" for this path is the set of
+ * torch ops listed in SURVEY.md section 2a, so a maintainer binds these symbols with ctypes (see
+ * INTEGRATION.md) exactly as monoport_amd/_lib.py does.
+ *
+ * Conventions
+ *   - all tensor arguments are DEVICE pointers on the context's GPU unless marked (host);
+ *   - fp32 everywhere ("f32" compute on v_mfma_f32_32x32x2_f32); int64 for vertex indices;
+ *   - work is enqueued on `stream` (a hipStream_t; NULL = the default stream) and the call
+ *     returns without synchronising, except where noted;
+ *   - the caller owns every input/output buffer; the context owns only its scratch arena and
+ *     the packed MLP weights;
+ *   - a context may be used from any host thread; calls on ONE context are serialised by an
+ *     internal mutex (RTL/dataloader.py:1026-1053 runs every pipeline stage on its own thread:
+ *     give each stage its own context);
+ *   - return value: MP_OK or a negative MP_ERR_*; mp_last_error(ctx) gives the message.
+ */
+#ifndef MONOPORT_HIP_H
+#define MONOPORT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mp_ctx mp_ctx;
+typedef void *mp_stream; /* hipStream_t */
+
+enum {
+  MP_OK = 0,
+  MP_ERR_ARG = -1,         /* bad pointer / size / enum */
+  MP_ERR_HIP = -2,         /* a HIP runtime call failed */
+  MP_ERR_UNSUPPORTED = -3, /* shape outside what the kernels are built for */
+  MP_ERR_STATE = -4,       /* e.g. querying an MLP whose layers are not all loaded */
+  MP_ERR_NOMEM = -5
+};
+
+/* SurfaceClassifier last_op (heads/SurfaceClassifier.py:68-69, :77, :85) */
+enum { MP_ACT_NONE = 0, MP_ACT_SIGMOID = 1, MP_ACT_TANH = 2 };
+
+/* forward_vertices direction (RTL/recon.py:39-49) */
+enum { MP_DIR_FRONT = 0, MP_DIR_BACK = 1, MP_DIR_LEFT = 2, MP_DIR_RIGHT = 3 };
+
+/* ---- context ---------------------------------------------------------------------------- */
+int mp_version(void);
+/* Creates a context bound to HIP device `device`.  Fails (MP_ERR_HIP) when no GPU is visible:
+ * there is no CPU fallback. */
+int mp_create(int device, mp_ctx **out);
+void mp_destroy(mp_ctx *ctx);
+const char *mp_last_error(mp_ctx *ctx); /* ctx may be NULL: last error of mp_create */
+
+/* ---- SurfaceClassifier weights ------------------------------------------------------------ */
+/* Replaces SurfaceClassifier.__init__ (heads/SurfaceClassifier.py:7-37) for the skip-concat
+ * MLPs the reference instantiates: channels = {C+1,1024,512,256,128,Cout} with C in {256,512},
+ * Cout in 1..4 (PIFuNetGMLP :74-79, PIFuNetCMLP :82-87).  Other shapes: MP_ERR_UNSUPPORTED. */
+int mp_mlp_create(mp_ctx *ctx, int n_layers, const int *channels /*host, n_layers+1*/,
+                  int last_op, int *mlp_out);
+/* Loads filters.{layer}.{weight,bias} (state-dict layout, weight [out,in(,1)] row-major with the
+ * K order [hidden | feature | z] of SurfaceClassifier.py:55) and re-packs it into MFMA fragment
+ * order.  W and b are DEVICE pointers.  Replaces load_state_dict / load_legacy_pifu
+ * (MonoPortNet.py:153-160). */
+int mp_mlp_load(mp_ctx *ctx, int mlp, int layer, const float *W, const float *b, int out_ch,
+                int in_ch, mp_stream stream);
+int mp_mlp_destroy(mp_ctx *ctx, int mlp);
+
+/* ---- feature-map layout ------------------------------------------------------------------ */
+/* Copies src [Csrc,H,W] (the NCHW map MonoPortNet.filter emits, MonoPortNet.py:31-46) into
+ * channels [c_offset, c_offset+Csrc) of the channels-last map dst [H,W,Cdst] the query kernels
+ * read.  netC's cat([feat_prior, feat]) (MonoPortNet.py:44) is two calls into one dst. */
+int mp_feat_pack_hwc(mp_ctx *ctx, const float *src_chw, int c_src, int h, int w, float *dst_hwc,
+                     int c_dst, int c_offset, mp_stream stream);
+
+/* ---- per-point ops ------------------------------------------------------------------------- */
+/* index(feat, uv) (geometry.py:4-16): bilinear grid_sample, align_corners=True, zero padding.
+ * feat_hwc [H,W,C]; uv [2,N] in [-1,1]; out [C,N]. */
+int mp_index(mp_ctx *ctx, const float *feat_hwc, int c, int h, int w, const float *uv, int64_t n,
+             float *out, mp_stream stream);
+/* orthogonal(points, calib) (geometry.py:19-34, transforms=None): out = R p + t.
+ * points/out [3,N]; calib = row-major [>=3,4] matrix (rows 0-2 used, row stride 4). */
+int mp_orthogonal(mp_ctx *ctx, const float *points, int64_t n, const float *calib, float *out,
+                  mp_stream stream);
+/* MonoPortNet.query in eval mode, one feature stage (MonoPortNet.py:48-91):
+ * project -> in-image mask -> z*z_scale -> bilinear sample -> skip-concat MLP -> mask.
+ * points: element (c, i) at points[i*stride_n + c*stride_c] (so both the [3,N] layout netG.query
+ * takes and the [N,3] one query_func receives, RTL/main.py:169-183, bind without a copy).
+ * out [Cout,N]; out-of-image points are exactly 0.0f. */
+int mp_query(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w,
+             const float *points, int64_t n, int64_t stride_n, int64_t stride_c,
+             const float *calib, float z_scale, float *out, mp_stream stream);
+
+/* Same, with the point count read from device memory at run time (netC.query over the vertices
+ * forward_vertices found, RTL/main.py:239-242, without a host round trip).  points [3,capacity],
+ * out [Cout,capacity]; only the first *count columns are read / written. */
+int mp_query_counted(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w,
+                     const float *points, int64_t capacity, const int32_t *count,
+                     const float *calib, float z_scale, float *out, mp_stream stream);
+
+/* ---- coarse-to-fine reconstruction --------------------------------------------------------- */
+/* Replaces implicit_seg.functional.Seg3dLossless.forward(faster=True) driving query_func
+ * (RTL/main.py:185-195, :392-394; un-vendored dependency, requirements.txt:15).
+ * resolutions (host) must satisfy r[i+1] = 2 r[i] - 1, r <= 1023.  volume [R,R,R] (z,y,x) f32
+ * with R = resolutions[n_levels-1].  status (device, int32[1+n_levels]): status[0] = 1 if the
+ * coarsest level has any value > balance (0 -> the reference returns None and `volume` is
+ * unspecified), status[1+l] = points queried at level l.  Fully asynchronous. */
+int mp_recon(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, const float *calib,
+             float z_scale, const float *b_min /*host[3]*/, const float *b_max /*host[3]*/,
+             const int *resolutions /*host*/, int n_levels, float balance, float *volume,
+             int32_t *status, mp_stream stream);
+
+/* ---- visible-surface extraction ------------------------------------------------------------ */
+/* forward_vertices (RTL/recon.py:27-89).  volume [R,R,R]; outputs sized for R*R rows:
+ * X, Y int64 [R*R]; Z f32 [R*R]; norm f32 [R*R,3]; count (device int32[1]) = rows written,
+ * in the reference's row order (x-major, RTL/recon.py:62). */
+int mp_forward_vertices(mp_ctx *ctx, const float *volume, int r, int direction, int64_t *x,
+                        int64_t *y, float *z, float *norm, int32_t *count, mp_stream stream);
+
+/* ---- colorization (RTL/main.py:212-249) ---------------------------------------------------- */
+/* verts = (X, Y, res - Z) mapped through the voxel->world matrix `mat` (host, row-major 4x4,
+ * RTL/main.py:204-210, :231-237) -> points [3,N] for netC.query.  `count` (device int32) gives N
+ * (<= capacity); rows beyond it are left untouched. */
+int mp_vertex_points(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *z,
+                     const int32_t *count, int64_t capacity, int res, const float *mat,
+                     float *points, mp_stream stream);
+/* image [res,res,3] = 1.0 then image[X[i],Y[i],:] = clamp(values[:,i]*scale + bias, lo, hi);
+ * values is [3,capacity] when channel_major != 0 (netC preds, main.py:244-248: scale=bias=0.5)
+ * or [capacity,3] otherwise (normals, main.py:220-225: scale=bias=0.5, clamp 0..1). */
+int mp_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *values,
+             int channel_major, const int32_t *count, int64_t capacity, int res, float scale,
+             float bias, float lo, float hi, float *image, mp_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONOPORT_HIP_H */

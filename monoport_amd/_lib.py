@@ -1,0 +1,72 @@
+"""ctypes binding of libmonoport_hip.so -- the C-ABI declared in include/monoport_hip.h.
+
+There is deliberately NO fallback: if the shared library is missing or fails to load, importing
+the product path raises, so a GPU test can never pass on a silent eager/PyTorch detour.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmonoport_hip.so")
+
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_f32 = ctypes.c_float
+c_vp = ctypes.c_void_p
+_pint = ctypes.POINTER(ctypes.c_int)
+_pf32 = ctypes.POINTER(ctypes.c_float)
+
+# name -> (restype, argtypes); kept in one table so tests can check the exported surface against
+# the header (tests/test_abi.py)
+SIGNATURES = {
+    "mp_version": (c_int, []),
+    "mp_create": (c_int, [c_int, ctypes.POINTER(c_vp)]),
+    "mp_destroy": (None, [c_vp]),
+    "mp_last_error": (ctypes.c_char_p, [c_vp]),
+    "mp_mlp_create": (c_int, [c_vp, c_int, _pint, c_int, _pint]),
+    "mp_mlp_load": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
+    "mp_mlp_destroy": (c_int, [c_vp, c_int]),
+    "mp_feat_pack_hwc": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
+    "mp_index": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
+    "mp_orthogonal": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "mp_query": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_i64, c_vp,
+                         c_f32, c_vp, c_vp]),
+    "mp_query_counted": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp,
+                                 c_f32, c_vp, c_vp]),
+    "mp_recon": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_f32, _pf32, _pf32, _pint,
+                         c_int, c_f32, c_vp, c_vp, c_vp]),
+    "mp_forward_vertices": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mp_vertex_points": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, _pf32, c_vp, c_vp]),
+    "mp_paint": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_f32, c_f32, c_f32,
+                         c_f32, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (no GPU needed for this step) and declare every signature."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "monoport_amd: %s is missing -- build it with `python -m monoport_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class MonoportError(RuntimeError):
+    """Raised for any non-zero status of the C-ABI (so pipeline stage threads surface it through
+    the ExceptionWrapper path of RTL/dataloader.py:1042-1047)."""
+
+
+def check(ctx_handle, rc, what):
+    if rc != 0:
+        msg = load().mp_last_error(ctx_handle)
+        raise MonoportError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,353 @@
+// C-ABI entry points of libmonoport_hip.so (see include/monoport_hip.h for the contract).
+#include <cstdarg>
+#include <cstring>
+
+#include "mp_internal.h"
+
+namespace mp {
+
+static thread_local std::string g_create_error;
+
+int fail(mp_ctx *ctx, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx)
+    ctx->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+int ensure_scratch(mp_ctx *ctx, hipStream_t st, size_t bytes, void **out) {
+  mp_ctx::Arena &a = ctx->arenas[(void *)st];
+  if (bytes > a.bytes) {
+    if (a.ptr) {
+      // the old arena may still be read by work queued on this stream
+      MP_HIP(ctx, hipStreamSynchronize(st));
+      MP_HIP(ctx, hipFree(a.ptr));
+    }
+    a.ptr = nullptr;
+    a.bytes = 0;
+    if (hipMalloc(&a.ptr, bytes) != hipSuccess)
+      return fail(ctx, MP_ERR_NOMEM, "scratch arena: hipMalloc(%zu) failed", bytes);
+    a.bytes = bytes;
+  }
+  *out = a.ptr;
+  return MP_OK;
+}
+
+MlpPack Mlp::pack() const {
+  MlpPack p;
+  p.base = buf;
+  for (int l = 0; l < 4; ++l) {
+    p.ah[l] = (int)off_ah[l];
+    p.ax[l] = (int)off_ax[l];
+    p.az[l] = (int)off_az[l];
+  }
+  for (int l = 0; l < 5; ++l) p.bias[l] = (int)off_bias[l];
+  p.w4 = (int)off_w4;
+  return p;
+}
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+static Mlp *get_mlp(mp_ctx *ctx, int id) {
+  if (id < 0 || id >= (int)ctx->mlps.size() || !ctx->mlps[id].used) return nullptr;
+  return &ctx->mlps[id];
+}
+
+static int check_ready(mp_ctx *ctx, const Mlp *m, int c) {
+  if (!m) return fail(ctx, MP_ERR_ARG, "unknown mlp id");
+  for (int l = 0; l < 5; ++l)
+    if (!m->loaded[l]) return fail(ctx, MP_ERR_STATE, "mlp layer %d has not been loaded", l);
+  if (m->c != c)
+    return fail(ctx, MP_ERR_ARG, "feature map has C=%d but the mlp was built for C=%d", c, m->c);
+  return MP_OK;
+}
+
+}  // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+int mp_version(void) { return 100; }
+
+int mp_create(int device, mp_ctx **out) {
+  if (!out) return fail(nullptr, MP_ERR_ARG, "mp_create: out is NULL");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(nullptr, MP_ERR_HIP, "mp_create: no HIP device visible (there is no CPU fallback)");
+  if (device < 0 || device >= count)
+    return fail(nullptr, MP_ERR_ARG, "mp_create: device %d out of range (%d visible)", device, count);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+    return fail(nullptr, MP_ERR_HIP, "mp_create: hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, MP_ERR_UNSUPPORTED, "mp_create: kernels are built for gfx950 only, device is %s",
+                prop.gcnArchName);
+  mp_ctx *ctx = new mp_ctx();
+  ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount;
+  *out = ctx;
+  return MP_OK;
+}
+
+void mp_destroy(mp_ctx *ctx) {
+  if (!ctx) return;
+  {
+    DeviceGuard g(ctx->device);
+    for (auto &m : ctx->mlps)
+      if (m.buf) (void)hipFree(m.buf);
+    for (auto &kv : ctx->arenas)
+      if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+  }
+  delete ctx;
+}
+
+const char *mp_last_error(mp_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mp_mlp_create(mp_ctx *ctx, int n_layers, const int *channels, int last_op, int *mlp_out) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!channels || !mlp_out) return fail(ctx, MP_ERR_ARG, "mp_mlp_create: NULL argument");
+  if (last_op < MP_ACT_NONE || last_op > MP_ACT_TANH)
+    return fail(ctx, MP_ERR_ARG, "mp_mlp_create: bad last_op %d", last_op);
+  if (n_layers != 5)
+    return fail(ctx, MP_ERR_UNSUPPORTED, "mp_mlp_create: only the 5-layer PIFu heads are built (got %d)",
+                n_layers);
+  const int c = channels[0] - 1, cout = channels[5];
+  bool ok = (c == 256 || c == 512) && (cout == 1 || cout == 3);
+  for (int l = 0; l < 4; ++l) ok = ok && channels[l + 1] == kHidden[l];
+  if (!ok)
+    return fail(ctx, MP_ERR_UNSUPPORTED,
+                "mp_mlp_create: channels must be {C+1,1024,512,256,128,Cout}, C in {256,512}, Cout in {1,3}");
+  DeviceGuard g(ctx->device);
+  Mlp m;
+  m.used = true;
+  m.c = c;
+  m.cout = cout;
+  m.act = last_op;
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    size_t o = off;
+    off += (n + 63) & ~size_t(63);
+    return o;
+  };
+  for (int l = 0; l < 4; ++l) {
+    const size_t n_out = kHidden[l], k_h = l == 0 ? 0 : kHidden[l - 1];
+    m.off_ah[l] = take(n_out * k_h);
+    m.off_ax[l] = take(n_out * c);
+    m.off_az[l] = take(n_out * 2);
+    m.off_bias[l] = take(n_out);
+  }
+  m.off_w4 = take((size_t)cout * ((kHidden[3] + c + 1 + 3) & ~3));
+  m.off_bias[4] = take(cout);
+  m.total = off;
+  if (hipMalloc(reinterpret_cast<void **>(&m.buf), off * sizeof(float)) != hipSuccess)
+    return fail(ctx, MP_ERR_NOMEM, "mp_mlp_create: hipMalloc of %zu floats failed", off);
+  int id = -1;
+  for (size_t i = 0; i < ctx->mlps.size(); ++i)
+    if (!ctx->mlps[i].used) id = (int)i;
+  if (id < 0) {
+    ctx->mlps.push_back(m);
+    id = (int)ctx->mlps.size() - 1;
+  } else {
+    ctx->mlps[id] = m;
+  }
+  *mlp_out = id;
+  return MP_OK;
+}
+
+int mp_mlp_load(mp_ctx *ctx, int mlp, int layer, const float *W, const float *b, int out_ch,
+                int in_ch, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  Mlp *m = get_mlp(ctx, mlp);
+  if (!m) return fail(ctx, MP_ERR_ARG, "mp_mlp_load: unknown mlp id %d", mlp);
+  if (!W || !b || layer < 0 || layer > 4) return fail(ctx, MP_ERR_ARG, "mp_mlp_load: bad argument");
+  const int want_out = layer < 4 ? kHidden[layer] : m->cout;
+  const int want_in = (layer == 0 ? 0 : kHidden[layer - 1]) + m->c + 1;
+  if (out_ch != want_out || in_ch != want_in)
+    return fail(ctx, MP_ERR_ARG, "mp_mlp_load: layer %d expects weight [%d,%d], got [%d,%d]", layer,
+                want_out, want_in, out_ch, in_ch);
+  DeviceGuard g(ctx->device);
+  int rc = launch_pack_layer(ctx, *m, layer, W, b, (hipStream_t)stream);
+  if (rc == MP_OK) m->loaded[layer] = true;
+  return rc;
+}
+
+int mp_mlp_destroy(mp_ctx *ctx, int mlp) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  Mlp *m = get_mlp(ctx, mlp);
+  if (!m) return fail(ctx, MP_ERR_ARG, "mp_mlp_destroy: unknown mlp id %d", mlp);
+  DeviceGuard g(ctx->device);
+  MP_HIP(ctx, hipDeviceSynchronize());
+  if (m->buf) MP_HIP(ctx, hipFree(m->buf));
+  *m = Mlp();
+  return MP_OK;
+}
+
+int mp_feat_pack_hwc(mp_ctx *ctx, const float *src_chw, int c_src, int h, int w, float *dst_hwc,
+                     int c_dst, int c_offset, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!src_chw || !dst_hwc || c_src <= 0 || h <= 0 || w <= 0 || c_offset < 0 ||
+      c_offset + c_src > c_dst)
+    return fail(ctx, MP_ERR_ARG, "mp_feat_pack_hwc: bad argument");
+  DeviceGuard g(ctx->device);
+  return launch_pack_hwc(ctx, src_chw, c_src, h, w, dst_hwc, c_dst, c_offset, (hipStream_t)stream);
+}
+
+int mp_index(mp_ctx *ctx, const float *feat_hwc, int c, int h, int w, const float *uv, int64_t n,
+             float *out, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!feat_hwc || (n > 0 && (!uv || !out)) || n < 0 || h <= 0 || w <= 0)
+    return fail(ctx, MP_ERR_ARG, "mp_index: bad argument");
+  if (!aligned16(feat_hwc)) return fail(ctx, MP_ERR_ARG, "mp_index: feat_hwc must be 16-byte aligned");
+  DeviceGuard g(ctx->device);
+  return launch_index(ctx, feat_hwc, c, h, w, uv, n, out, (hipStream_t)stream);
+}
+
+int mp_orthogonal(mp_ctx *ctx, const float *points, int64_t n, const float *calib, float *out,
+                  mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n < 0 || !calib || (n > 0 && (!points || !out)))
+    return fail(ctx, MP_ERR_ARG, "mp_orthogonal: bad argument");
+  DeviceGuard g(ctx->device);
+  return launch_orthogonal(ctx, points, n, calib, out, (hipStream_t)stream);
+}
+
+int mp_query(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, const float *points,
+             int64_t n, int64_t stride_n, int64_t stride_c, const float *calib, float z_scale,
+             float *out, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const Mlp *m = get_mlp(ctx, mlp);
+  int rc = check_ready(ctx, m, c);
+  if (rc != MP_OK) return rc;
+  if (!feat_hwc || !calib || n < 0 || h <= 0 || w <= 0 || (n > 0 && (!points || !out)))
+    return fail(ctx, MP_ERR_ARG, "mp_query: bad argument");
+  if (!aligned16(feat_hwc)) return fail(ctx, MP_ERR_ARG, "mp_query: feat_hwc must be 16-byte aligned");
+  if (n == 0) return MP_OK;
+  PointSrc src;
+  std::memset(&src, 0, sizeof(src));
+  src.pts = points;
+  src.sn = stride_n;
+  src.sc = stride_c;
+  src.n = n;
+  src.out_stride = n;
+  DeviceGuard g(ctx->device);
+  return launch_query(ctx, *m, feat_hwc, h, w, calib, z_scale, src, out, n, (hipStream_t)stream);
+}
+
+int mp_query_counted(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w,
+                     const float *points, int64_t capacity, const int32_t *count,
+                     const float *calib, float z_scale, float *out, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const Mlp *m = get_mlp(ctx, mlp);
+  int rc = check_ready(ctx, m, c);
+  if (rc != MP_OK) return rc;
+  if (!feat_hwc || !calib || !count || capacity < 0 || h <= 0 || w <= 0 ||
+      (capacity > 0 && (!points || !out)))
+    return fail(ctx, MP_ERR_ARG, "mp_query_counted: bad argument");
+  if (!aligned16(feat_hwc))
+    return fail(ctx, MP_ERR_ARG, "mp_query_counted: feat_hwc must be 16-byte aligned");
+  if (capacity == 0) return MP_OK;
+  PointSrc src;
+  std::memset(&src, 0, sizeof(src));
+  src.pts = points;
+  src.sn = 1;
+  src.sc = capacity;
+  src.n_dev = count;
+  src.out_stride = capacity;
+  DeviceGuard g(ctx->device);
+  return launch_query(ctx, *m, feat_hwc, h, w, calib, z_scale, src, out, capacity,
+                      (hipStream_t)stream);
+}
+
+int mp_recon(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, const float *calib,
+             float z_scale, const float *b_min, const float *b_max, const int *resolutions,
+             int n_levels, float balance, float *volume, int32_t *status, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const Mlp *m = get_mlp(ctx, mlp);
+  int rc = check_ready(ctx, m, c);
+  if (rc != MP_OK) return rc;
+  if (!feat_hwc || !calib || !b_min || !b_max || !resolutions || !volume || !status ||
+      n_levels < 1 || n_levels > 8 || h <= 0 || w <= 0)
+    return fail(ctx, MP_ERR_ARG, "mp_recon: bad argument");
+  if (m->cout != 1) return fail(ctx, MP_ERR_ARG, "mp_recon: needs a 1-channel (occupancy) mlp");
+  if (!aligned16(feat_hwc)) return fail(ctx, MP_ERR_ARG, "mp_recon: feat_hwc must be 16-byte aligned");
+  for (int l = 0; l < n_levels; ++l) {
+    if (resolutions[l] < 2 || resolutions[l] > 1023)
+      return fail(ctx, MP_ERR_UNSUPPORTED, "mp_recon: resolution %d outside [2,1023]", resolutions[l]);
+    if (l > 0 && resolutions[l] != 2 * resolutions[l - 1] - 1)
+      return fail(ctx, MP_ERR_UNSUPPORTED, "mp_recon: resolutions must follow r -> 2r-1 (got %d after %d)",
+                  resolutions[l], resolutions[l - 1]);
+  }
+  DeviceGuard g(ctx->device);
+  void *scratch = nullptr;
+  rc = ensure_scratch(ctx, (hipStream_t)stream, recon_scratch_bytes(resolutions, n_levels), &scratch);
+  if (rc != MP_OK) return rc;
+  return launch_recon(ctx, scratch, *m, feat_hwc, h, w, calib, z_scale, b_min, b_max, resolutions, n_levels,
+                      balance, volume, status, (hipStream_t)stream);
+}
+
+int mp_forward_vertices(mp_ctx *ctx, const float *volume, int r, int direction, int64_t *x,
+                        int64_t *y, float *z, float *norm, int32_t *count, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!volume || !x || !y || !z || !norm || !count || r < 1 || r > 4096 ||
+      direction < MP_DIR_FRONT || direction > MP_DIR_RIGHT)
+    return fail(ctx, MP_ERR_ARG, "mp_forward_vertices: bad argument");
+  DeviceGuard g(ctx->device);
+  void *scratch = nullptr;
+  int rc = ensure_scratch(ctx, (hipStream_t)stream, (size_t)r * r * sizeof(int32_t) + 4096, &scratch);
+  if (rc != MP_OK) return rc;
+  return launch_forward_vertices(ctx, scratch, volume, r, direction, x, y, z, norm, count,
+                                 (hipStream_t)stream);
+}
+
+int mp_vertex_points(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *z,
+                     const int32_t *count, int64_t capacity, int res, const float *mat,
+                     float *points, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!x || !y || !z || !count || !mat || !points || capacity < 0 || res < 1)
+    return fail(ctx, MP_ERR_ARG, "mp_vertex_points: bad argument");
+  DeviceGuard g(ctx->device);
+  return launch_vertex_points(ctx, x, y, z, count, capacity, res, mat, points, (hipStream_t)stream);
+}
+
+int mp_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *values,
+             int channel_major, const int32_t *count, int64_t capacity, int res, float scale,
+             float bias, float lo, float hi, float *image, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!x || !y || !values || !count || !image || capacity < 0 || res < 1)
+    return fail(ctx, MP_ERR_ARG, "mp_paint: bad argument");
+  DeviceGuard g(ctx->device);
+  return launch_paint(ctx, x, y, values, channel_major, count, capacity, res, scale, bias, lo, hi,
+                      image, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+// Internal declarations shared by the HIP translation units of libmonoport_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/monoport_hip.h"
+
+namespace mp {
+
+constexpr int kTilePts = 64;     // query points per workgroup tile
+constexpr int kQueryThreads = 256;
+constexpr int kHidden[4] = {1024, 512, 256, 128};  // SurfaceClassifier.py:76 / :84
+
+// Device-side view of one packed SurfaceClassifier (see pack.hip for the fragment order).
+// One base pointer + float offsets keeps the kernel's SGPR footprint small.
+struct MlpPack {
+  const float *base;
+  int ah[4];    // hidden-segment A fragments of MFMA layers 0..3 (ah[0] unused)
+  int ax[4];    // feature-segment A fragments
+  int az[4];    // z-column A fragments [n_out/32][64]
+  int bias[5];  // biases of layers 0..4
+  int w4;       // last layer, row-major [Cout][pad4(128 + C + 1)]
+};
+
+// Where a query launch takes its points from and where it puts the results.
+struct PointSrc {
+  // explicit mode (packed == nullptr): world coords, element (c, i) at pts[i*sn + c*sc]
+  const float *pts;
+  long long sn, sc;
+  // lattice mode: packed level-local node coords x | y<<10 | z<<20, scaled by `stride` into the
+  // final-resolution index space and mapped to world like Seg3dLossless.batch_eval
+  const uint32_t *packed;
+  int stride;       // final-res index step of this level
+  int level_res;    // nodes per axis at this level (scatter index = (z*res + y)*res + x)
+  float res_final;  // R as float
+  float half_step;  // (1/R)/2
+  float bmin[3], blen[3];
+  // count: *n_dev if n_dev != nullptr else n
+  const int32_t *n_dev;
+  long long n;
+  long long out_stride;  // explicit mode: out[o*out_stride + i]
+};
+
+struct Mlp {
+  bool used = false;
+  int c = 0, cout = 0, act = 0;
+  bool loaded[5] = {false, false, false, false, false};
+  float *buf = nullptr;  // one allocation holding every packed segment
+  size_t off_ah[4], off_ax[4], off_az[4], off_bias[5], off_w4;
+  size_t total = 0;
+  MlpPack pack() const;
+};
+
+}  // namespace mp
+
+struct mp_ctx {
+  int device = 0;
+  int n_cu = 0;
+  std::mutex mu;
+  std::string err;
+  std::vector<mp::Mlp> mlps;
+  // scratch arenas, one per stream the context has been used on (grown on demand): calls that
+  // are in flight on different streams never share scratch; calls on one stream are ordered.
+  struct Arena {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+  };
+  std::unordered_map<void *, Arena> arenas;
+};
+
+namespace mp {
+
+int fail(mp_ctx *ctx, int code, const char *fmt, ...);
+int ensure_scratch(mp_ctx *ctx, hipStream_t st, size_t bytes, void **out);
+
+#define MP_HIP(ctx, expr)                                                            \
+  do {                                                                               \
+    hipError_t e_ = (expr);                                                          \
+    if (e_ != hipSuccess)                                                            \
+      return mp::fail(ctx, MP_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                      __FILE__, __LINE__);                                           \
+  } while (0)
+
+// query.hip
+int launch_query(mp_ctx *ctx, const Mlp &m, const float *feat_hwc, int h, int w,
+                 const float *calib, float z_scale, const PointSrc &src, float *out,
+                 long long max_points, hipStream_t st);
+int launch_index(mp_ctx *ctx, const float *feat_hwc, int c, int h, int w, const float *uv,
+                 long long n, float *out, hipStream_t st);
+int launch_orthogonal(mp_ctx *ctx, const float *pts, long long n, const float *calib, float *out,
+                      hipStream_t st);
+// pack.hip
+int launch_pack_hwc(mp_ctx *ctx, const float *src, int c_src, int h, int w, float *dst, int c_dst,
+                    int c_off, hipStream_t st);
+int launch_pack_layer(mp_ctx *ctx, Mlp &m, int layer, const float *w, const float *b,
+                      hipStream_t st);
+// octree.hip
+size_t recon_scratch_bytes(const int *res, int n_levels);
+int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, const float *feat_hwc, int h, int w,
+                 const float *calib, float z_scale, const float *bmin, const float *bmax,
+                 const int *res, int n_levels, float balance, float *volume, int32_t *status,
+                 hipStream_t st);
+// vertices.hip
+int launch_forward_vertices(mp_ctx *ctx, void *scratch, const float *vol, int r, int dir, int64_t *x, int64_t *y,
+                            float *z, float *norm, int32_t *count, hipStream_t st);
+int launch_vertex_points(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *z,
+                         const int32_t *count, long long cap, int res, const float *mat16,
+                         float *pts, hipStream_t st);
+int launch_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *vals, int ch_major,
+                 const int32_t *count, long long cap, int res, float scale, float bias, float lo,
+                 float hi, float *image, hipStream_t st);
+
+}  // namespace mp

@@ -1,0 +1,265 @@
+// Coarse-to-fine occupancy reconstruction on the GPU: the replacement for
+// implicit_seg.functional.Seg3dLossless(faster=True) (un-vendored dependency of the reference:
+// requirements.txt:15; constructed at RTL/main.py:185-195, called at :392-394).
+//
+// Per level r -> 2r-1 (the scheme recalled in SURVEY.md section 5.7 and restated on the CPU in
+// oracle/pifu_oracle.py:seg3d_lossless, which this file must match bit for bit):
+//   1. upsample_classify: trilinear (align_corners=True) upsample of the previous level's
+//      occupancy into this level's volume, and a 1-bit "boundary" flag per node = the upsampled
+//      binary mask (occ > balance) is strictly between 0 and 1.  Flags are produced with a wave
+//      ballot: one 64-bit word per 64 consecutive x.
+//   2. select_compact: binary dilation of the flags by the level's box (9^3 / 7^3 / 3^3) as
+//      shift-OR on the 64-bit words, minus the nodes evaluated at earlier levels, popcount +
+//      wave prefix sum + one atomic per wave -> a packed (x | y<<10 | z<<20) point list.
+//   3. the fused query kernel (query.hip) reads the list and its device-side count, and scatters
+//      exact occupancies straight into the level volume.
+// No host synchronisation anywhere: counts stay on the device (`status`).
+#include <cstring>
+
+#include "mp_internal.h"
+
+// Reference parity is op-order parity: keep every a*b+c exactly as written (the HIP headers
+// define __fmul_rn & co. as plain operators, which hipcc would otherwise contract into FMAs).
+// Fused multiply-adds are requested explicitly (fmaf / MFMA) where they are wanted.
+#pragma clang fp contract(off)
+
+namespace mp {
+
+typedef unsigned long long u64;
+
+struct LevelBufs {
+  float *occ;   // [r][r][r]
+  u64 *bnd;     // boundary bits [r][r][w64]
+  u64 *ev;      // evaluated bits [r][r][w64]
+};
+
+static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+static inline int words64(int r) { return (r + 63) / 64; }
+
+size_t recon_scratch_bytes(const int *res, int n_levels) {
+  size_t total = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const size_t r = res[l];
+    if (l < n_levels - 1) total += align256(r * r * r * sizeof(float));
+    total += 2 * align256(r * r * words64(res[l]) * sizeof(u64));
+  }
+  const size_t rl = res[n_levels - 1];
+  total += align256(rl * rl * rl * sizeof(uint32_t));  // packed point list (worst case: every node)
+  return total + 4096;
+}
+
+// ---- level 0 ---------------------------------------------------------------------------------
+__global__ void iota_nodes_kernel(int r, uint32_t *__restrict__ packed, u64 *__restrict__ ev,
+                                  int w64, int32_t *__restrict__ count) {
+  const int total = r * r * r;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) *count = total;
+  if (t < total) {
+    const int x = t % r, y = (t / r) % r, z = t / (r * r);
+    packed[t] = (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20);
+  }
+  if (t < r * r * w64) {  // every node of level 0 is evaluated
+    const int w = t % w64;
+    const int nbits = min(64, r - 64 * w);
+    ev[t] = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+  }
+}
+
+__global__ void any_above_kernel(const float *__restrict__ occ, int n, float balance,
+                                 int32_t *__restrict__ flag) {
+  int hit = 0;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
+    hit |= occ[t] > balance;
+  if (__any(hit) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// ---- upsample + boundary flags ---------------------------------------------------------------
+// One wave per (z, y, 64-wide x span).  Interpolation order z, then y, then x with weights 0.5/0.5
+// -- the exact sequence of oracle upsample2x (axis 0 first), so values agree bit for bit.
+__global__ __launch_bounds__(256) void upsample_classify_kernel(const float *__restrict__ prev,
+                                                                int rp, float *__restrict__ cur,
+                                                                int r, float balance,
+                                                                u64 *__restrict__ bnd, int w64) {
+  const int lane = threadIdx.x & 63;
+  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long n_items = (long long)r * r * w64;
+  if (item >= n_items) return;
+  const int w = item % w64;
+  const int y = (item / w64) % r;
+  const int z = item / ((long long)w64 * r);
+  const int x = 64 * w + lane;
+  bool flag = false;
+  if (x < r) {
+    const int z0 = z >> 1, y0 = y >> 1, x0 = x >> 1;
+    const int oz = z & 1, oy = y & 1, ox = x & 1;
+    float vx[2];
+    int n_in = 0, n_all = 0;
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      float vy[2];
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const int xx = min(x0 + dx, rp - 1), yy = min(y0 + dy, rp - 1);
+        const float a = prev[((long long)z0 * rp + yy) * rp + xx];
+        const float b = prev[((long long)min(z0 + 1, rp - 1) * rp + yy) * rp + xx];
+        vy[dy] = oz ? 0.5f * a + 0.5f * b : a;
+        if (dx <= ox && dy <= oy) {  // corners with non-zero trilinear weight
+          n_all += 1 + oz;
+          n_in += (a > balance) + (oz ? (b > balance) : 0);
+        }
+      }
+      vx[dx] = oy ? 0.5f * vy[0] + 0.5f * vy[1] : vy[0];
+    }
+    const float v = ox ? 0.5f * vx[0] + 0.5f * vx[1] : vx[0];
+    cur[((long long)z * r + y) * r + x] = v;
+    flag = n_in > 0 && n_in < n_all;  // 0 < upsampled mask < 1
+  }
+  const u64 bits = __ballot(flag);
+  if (lane == 0) bnd[item] = bits;
+}
+
+// ---- dilate, drop evaluated nodes, compact ----------------------------------------------------
+__device__ __forceinline__ u64 spread32(u64 x) {  // bit i -> bit 2i
+  x &= 0xffffffffull;
+  x = (x | (x << 16)) & 0x0000ffff0000ffffull;
+  x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+  x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void select_compact_kernel(
+    const u64 *__restrict__ bnd, const u64 *__restrict__ ev_prev, int rp, int w64p,
+    u64 *__restrict__ ev, int r, int w64, int d, uint32_t *__restrict__ packed,
+    int32_t *__restrict__ count) {
+  const long long n_items = (long long)r * r * w64;
+  const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 sel = 0;
+  int w = 0, y = 0, z = 0;
+  if (item < n_items) {
+    w = item % w64;
+    y = (item / w64) % r;
+    z = item / ((long long)w64 * r);
+    u64 acc = 0;
+    for (int dz = -d; dz <= d; ++dz) {
+      const int zz = z + dz;
+      if (zz < 0 || zz >= r) continue;
+      for (int dy = -d; dy <= d; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= r) continue;
+        const u64 *row = bnd + ((long long)zz * r + yy) * w64;
+        const u64 c = row[w];
+        const u64 lo = w > 0 ? row[w - 1] : 0ull;
+        const u64 hi = w < w64 - 1 ? row[w + 1] : 0ull;
+        u64 hd = c;
+        for (int s = 1; s <= d; ++s) hd |= (c << s) | (lo >> (64 - s)) | (c >> s) | (hi << (64 - s));
+        acc |= hd;
+      }
+    }
+    // nodes already evaluated: even (z, y, x) that were evaluated one level up
+    u64 done = 0;
+    if (!(z & 1) && !(y & 1)) {
+      const u64 pw = ev_prev[((long long)(z >> 1) * rp + (y >> 1)) * w64p + (w >> 1)];
+      done = spread32(pw >> (32 * (w & 1)));
+    }
+    const int nbits = min(64, r - 64 * w);
+    const u64 in_range = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+    sel = acc & ~done & in_range;
+    ev[item] = done | sel;
+  }
+  // wave-level exclusive prefix of popcounts, one atomic per wave
+  const int lane = threadIdx.x & 63;
+  const int cnt = __popcll(sel);
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  const int total = __shfl(incl, 63);
+  int base = 0;
+  if (lane == 63 && total > 0) base = atomicAdd(count, total);
+  base = __shfl(base, 63);
+  int pos = base + incl - cnt;
+  const uint32_t yz = ((uint32_t)y << 10) | ((uint32_t)z << 20);
+  while (sel) {
+    const int b = __ffsll((long long)sel) - 1;
+    sel &= sel - 1;
+    packed[pos++] = (uint32_t)(64 * w + b) | yz;
+  }
+}
+
+// ---- driver ------------------------------------------------------------------------------------
+int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, const float *feat_hwc, int h, int w,
+                 const float *calib, float z_scale, const float *bmin, const float *bmax,
+                 const int *res, int n_levels, float balance, float *volume, int32_t *status,
+                 hipStream_t st) {
+  // carve the scratch arena
+  unsigned char *p = static_cast<unsigned char *>(scratch);
+  LevelBufs lv[8];
+  for (int l = 0; l < n_levels; ++l) {
+    const size_t r = res[l];
+    if (l < n_levels - 1) {
+      lv[l].occ = reinterpret_cast<float *>(p);
+      p += align256(r * r * r * sizeof(float));
+    } else {
+      lv[l].occ = volume;
+    }
+    const size_t wb = align256(r * r * words64(res[l]) * sizeof(u64));
+    lv[l].bnd = reinterpret_cast<u64 *>(p);
+    p += wb;
+    lv[l].ev = reinterpret_cast<u64 *>(p);
+    p += wb;
+  }
+  uint32_t *packed = reinterpret_cast<uint32_t *>(p);
+
+  const int rf = res[n_levels - 1];
+  PointSrc src;
+  std::memset(&src, 0, sizeof(src));
+  src.packed = packed;
+  src.res_final = (float)rf;
+  src.half_step = (1.0f / (float)rf) / 2.0f;
+  for (int i = 0; i < 3; ++i) {
+    src.bmin[i] = bmin[i];
+    src.blen[i] = bmax[i] - bmin[i];
+  }
+
+  MP_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * (1 + n_levels), st));
+
+  // level 0: every node
+  {
+    const int r = res[0], total = r * r * r;
+    hipLaunchKernelGGL(iota_nodes_kernel, dim3((total + 255) / 256), dim3(256), 0, st, r, packed,
+                       lv[0].ev, words64(r), status + 1);
+    src.stride = (rf - 1) / (r - 1);
+    src.level_res = r;
+    src.n_dev = nullptr;
+    src.n = total;
+    int rc = launch_query(ctx, m, feat_hwc, h, w, calib, z_scale, src, lv[0].occ, total, st);
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(any_above_kernel, dim3(min((total + 255) / 256, 256)), dim3(256), 0, st,
+                       lv[0].occ, total, balance, status);
+  }
+  for (int l = 1; l < n_levels; ++l) {
+    const int r = res[l], rp = res[l - 1], w64 = words64(r);
+    const long long items = (long long)r * r * w64;
+    hipLaunchKernelGGL(upsample_classify_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
+                       st, lv[l - 1].occ, rp, lv[l].occ, r, balance, lv[l].bnd, w64);
+    const int d = l == 1 ? 4 : (l == 2 ? 3 : 1);  // 9^3, 7^3, 3^3 boxes ("faster" mode)
+    hipLaunchKernelGGL(select_compact_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
+                       st, lv[l].bnd, lv[l - 1].ev, rp, words64(rp), lv[l].ev, r, w64, d, packed,
+                       status + 1 + l);
+    src.stride = (rf - 1) / (r - 1);
+    src.level_res = r;
+    src.n_dev = status + 1 + l;
+    src.n = 0;
+    int rc = launch_query(ctx, m, feat_hwc, h, w, calib, z_scale, src, lv[l].occ,
+                          (long long)r * r * r, st);
+    if (rc != MP_OK) return rc;
+  }
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+}  // namespace mp

@@ -1,0 +1,575 @@
+// Fused per-point PIFu query for gfx950 (MI355X):
+//   project -> in-image mask -> bilinear feature gather -> z concat -> skip-connected MLP -> mask
+// i.e. MonoPortNet.query in eval mode (monoport/lib/modeling/MonoPortNet.py:48-91) with
+// orthogonal (geometry.py:19-34), index (geometry.py:4-16), DepthNormalizer (normalizers/
+// DepthNormalizer.py:32) and SurfaceClassifier.forward (heads/SurfaceClassifier.py:39-71) in ONE
+// kernel.  Nothing per-point ever goes to HBM except 12 B of coordinates in and 4*Cout B out.
+//
+// Decomposition (one workgroup = 4 waves = one 64-point tile, 2 workgroups per CU for netG):
+//   * gather: each wave samples 16 points; a tap is one coalesced 16 B/lane read of a
+//     channels-last feature row; the blended feature vector lands in LDS, point-major, XOR
+//     swizzled in 16-byte slots so that both the gather's ds_write_b128 and the MFMA B-operand
+//     ds_read_b128 are bank-conflict free (MI355X_MICROARCH.md, LDS table).
+//   * MLP on v_mfma_f32_32x32x2_f32 (exact f32, 157 TF/s peak): M = output channels,
+//     N = points, K = [hidden | feature | z].  Weights stream straight from L2 in pre-packed
+//     fragment order (pack.hip) -- each wave owns distinct output rows, so there is no reuse to
+//     stage through LDS; activations are the shared operand and live in LDS / registers.
+//   * layer 0 (1024 x 257) is never materialised: it is produced in 64-row chunks that go
+//     through a 16 KB LDS buffer straight into layer 1's K loop, whose 512 x 64 accumulator tile
+//     is spread over the 4 waves' registers (128 VGPRs each).  Layers 2 and 3 consume their
+//     inputs the same way, chunk by chunk from the owning wave's registers.  The skip-concat
+//     (SurfaceClassifier.py:55) is just a second K segment read from the feature tile.
+//   * last layer (Cout x 385) and the activation run on the VALU.
+#include "mp_internal.h"
+
+// Reference parity is op-order parity: keep every a*b+c exactly as written (the HIP headers
+// define __fmul_rn & co. as plain operators, which hipcc would otherwise contract into FMAs).
+// Fused multiply-adds are requested explicitly (fmaf / MFMA) where they are wanted.
+#pragma clang fp contract(off)
+
+namespace mp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHbRowBytes = 64 * 4;                    // one point's 64-row hidden chunk
+constexpr int kHbBytes = kTilePts * kHbRowBytes;       // 16 KB
+
+// ---- point sources ---------------------------------------------------------------------------
+__device__ __forceinline__ float lattice_coord(int idx, const PointSrc &s, int axis) {
+  // Seg3dLossless.batch_eval (align_corners=False): ((c / R) + (1/R)/2) * (b_max-b_min) + b_min,
+  // each step rounded to f32 -- identical op sequence to oracle/pifu_oracle.py:lattice_points.
+  const float c = (float)(idx * s.stride);
+  const float u = __fadd_rn(__fdiv_rn(c, s.res_final), s.half_step);
+  return __fadd_rn(__fmul_rn(u, s.blen[axis]), s.bmin[axis]);
+}
+
+__device__ __forceinline__ void load_point(const PointSrc &s, long long n, float &px, float &py,
+                                           float &pz, uint32_t &code) {
+  if (s.packed) {
+    code = s.packed[n];
+    px = lattice_coord(code & 1023u, s, 0);
+    py = lattice_coord((code >> 10) & 1023u, s, 1);
+    pz = lattice_coord(code >> 20, s, 2);
+  } else {
+    code = 0;
+    px = s.pts[n * s.sn];
+    py = s.pts[n * s.sn + s.sc];
+    pz = s.pts[n * s.sn + 2 * s.sc];
+  }
+}
+
+// geometry.py:27-29: trans + rot @ p, unfused like the CPU oracle.
+__device__ __forceinline__ void project(const float *__restrict__ cal, float px, float py,
+                                        float pz, float &x, float &y, float &z) {
+  x = __fadd_rn(cal[3], __fadd_rn(__fadd_rn(__fmul_rn(cal[0], px), __fmul_rn(cal[1], py)),
+                                  __fmul_rn(cal[2], pz)));
+  y = __fadd_rn(cal[7], __fadd_rn(__fadd_rn(__fmul_rn(cal[4], px), __fmul_rn(cal[5], py)),
+                                  __fmul_rn(cal[6], pz)));
+  z = __fadd_rn(cal[11], __fadd_rn(__fadd_rn(__fmul_rn(cal[8], px), __fmul_rn(cal[9], py)),
+                                   __fmul_rn(cal[10], pz)));
+}
+
+__device__ __forceinline__ bool in_image(float x, float y) {  // MonoPortNet.py:74
+  return x >= -1.0f && x <= 1.0f && y >= -1.0f && y <= 1.0f;
+}
+
+// grid_sample(align_corners=True, padding zeros): 4 tap offsets (in floats) + weights.
+struct Taps {
+  long long o[4];
+  float w[4];
+};
+
+__device__ __forceinline__ Taps make_taps(float x, float y, int h, int w, int c, bool live) {
+  Taps t;
+  const float ix = __fmul_rn(__fmul_rn(__fadd_rn(x, 1.0f), 0.5f), (float)(w - 1));
+  const float iy = __fmul_rn(__fmul_rn(__fadd_rn(y, 1.0f), 0.5f), (float)(h - 1));
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const float wx1 = __fsub_rn(ix, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), ix);
+  const float wy1 = __fsub_rn(iy, fy0), wy0 = __fsub_rn(__fadd_rn(fy0, 1.0f), iy);
+  const int x0 = (int)fminf(fmaxf(fx0, -2.0f), (float)w);
+  const int y0 = (int)fminf(fmaxf(fy0, -2.0f), (float)h);
+  const int x1 = x0 + 1, y1 = y0 + 1;
+  const bool vx0 = x0 >= 0 && x0 < w, vx1 = x1 >= 0 && x1 < w;
+  const bool vy0 = y0 >= 0 && y0 < h, vy1 = y1 >= 0 && y1 < h;
+  const int cx0 = min(max(x0, 0), w - 1), cx1 = min(max(x1, 0), w - 1);
+  const int cy0 = min(max(y0, 0), h - 1), cy1 = min(max(y1, 0), h - 1);
+  t.o[0] = ((long long)cy0 * w + cx0) * c;
+  t.o[1] = ((long long)cy0 * w + cx1) * c;
+  t.o[2] = ((long long)cy1 * w + cx0) * c;
+  t.o[3] = ((long long)cy1 * w + cx1) * c;
+  t.w[0] = (live && vx0 && vy0) ? __fmul_rn(wx0, wy0) : 0.0f;
+  t.w[1] = (live && vx1 && vy0) ? __fmul_rn(wx1, wy0) : 0.0f;
+  t.w[2] = (live && vx0 && vy1) ? __fmul_rn(wx0, wy1) : 0.0f;
+  t.w[3] = (live && vx1 && vy1) ? __fmul_rn(wx1, wy1) : 0.0f;
+  return t;
+}
+
+__device__ __forceinline__ f32x4 blend(const f32x4 &a, const f32x4 &b, const f32x4 &c,
+                                       const f32x4 &d, const Taps &t) {
+  f32x4 r = a * t.w[0];
+  r += b * t.w[1];
+  r += c * t.w[2];
+  r += d * t.w[3];
+  return r;
+}
+
+// ---- MFMA building blocks ----------------------------------------------------------------------
+template <int MR, int NR>
+__device__ __forceinline__ void mma_group(f32x16 (&acc)[MR][NR], const f32x4 (&a)[MR],
+                                          const f32x4 (&b)[NR]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int n = 0; n < NR; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][i], b[n][i], acc[m][n], 0, 0, 0);
+}
+
+// acc[MR][NR] += A[rows of this wave][K segment] * B[K segment][points].
+//   a: fragment stream of row block 0 at group 0 for this lane (float4 units); row block m is
+//      a + m * rb_stride; group g is + g * 64.
+//   b: LDS byte address of this lane's point row for column block 0; column block n is
+//      + n * 32 * ROWB; group g lives in 16-byte slot (2g + h) ^ (p & 15) = (2g) ^ swz.
+// PF groups of A are kept in flight (ring of PF+1 fragments, statically indexed); the loop is
+// deliberately NOT unrolled further: hipcc clusters every load of a big unrolled block at its top
+// and spills the accumulators.
+template <int MR, int NR, int PF, int ROWB>
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[MR][NR], const f32x4 *__restrict__ a,
+                                         int rb_stride, int n_groups, const unsigned char *b,
+                                         int swz) {
+  constexpr int RS = PF + 1;
+  f32x4 ring[RS][MR];
+#pragma unroll
+  for (int d = 0; d < PF; ++d)
+#pragma unroll
+    for (int m = 0; m < MR; ++m) ring[d][m] = a[m * rb_stride + min(d, n_groups - 1) * 64];
+#pragma unroll 1
+  for (int g0 = 0; g0 < n_groups; g0 += RS) {
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+      const int g = g0 + r;
+      const int gp = min(g + PF, n_groups - 1);
+#pragma unroll
+      for (int m = 0; m < MR; ++m) ring[(r + PF) % RS][m] = a[m * rb_stride + gp * 64];
+      const int boff = ((2 * g) ^ swz) << 4;
+      f32x4 bf[NR];
+#pragma unroll
+      for (int n = 0; n < NR; ++n)
+        bf[n] = *reinterpret_cast<const f32x4 *>(b + n * 32 * ROWB + boff);
+      mma_group<MR, NR>(acc, ring[r % RS], bf);
+    }
+  }
+}
+
+// The z column: one k-step whose B operand is z_feat in lanes 0-31 and 0 in lanes 32-63.
+template <int MR, int NR>
+__device__ __forceinline__ void gemm_z(f32x16 (&acc)[MR][NR], const float *__restrict__ az,
+                                       const float (&zb)[NR]) {
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    const float a = az[m * 64];
+#pragma unroll
+    for (int n = 0; n < NR; ++n)
+      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, zb[n], acc[m][n], 0, 0, 0);
+  }
+}
+
+// bias + leaky_relu(0.01) in place on a C-layout tile: register t of lane (j, h) holds
+// row (t & 3) + 8 (t >> 2) + 4 h of the 32-row block (cdna_hip_programming.md section 3).
+__device__ __forceinline__ void bias_lrelu(f32x16 &v, const float *__restrict__ bias32, int h) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 bq = *reinterpret_cast<const f32x4 *>(bias32 + 8 * q + 4 * h);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float y = v[4 * q + i] + bq[i];
+      v[4 * q + i] = y > 0.0f ? y : y * 0.01f;  // F.leaky_relu default slope, SurfaceClassifier.py:58
+    }
+  }
+}
+
+// Store a C-layout 32x32 tile into the hidden-chunk buffer, point-major: rows 8q+4h..+3 of a
+// point are 4 consecutive floats = one 16-byte slot.
+__device__ __forceinline__ void store_hidden(unsigned char *hb, const f32x16 &v, int rb_local,
+                                             int cb, int j, int h) {
+  const int p = 32 * cb + j;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int slot = 8 * rb_local + 2 * q + h;
+    f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    *reinterpret_cast<f32x4 *>(hb + p * kHbRowBytes + ((slot ^ (p & 15)) << 4)) = o;
+  }
+}
+
+__device__ __forceinline__ float activate(float v, int act) {
+  if (act == MP_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  if (act == MP_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+// ---- the fused kernel ----------------------------------------------------------------------------
+template <int C, int COUT, int WPS>
+__global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
+    MlpPack mlp, const float *__restrict__ feat, int fh, int fw, const float *__restrict__ calib,
+    float z_scale, int act, PointSrc src, float *__restrict__ out) {
+  constexpr int ROWB = C * 4;
+  constexpr int NGX = C / 8;  // K groups of the feature segment
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *xs = smem;                    // [64 points][C] f32, swizzled 16-byte slots
+  unsigned char *hb = smem + kTilePts * ROWB;  // [64 points][64 rows] f32, swizzled
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+
+  const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
+  const long long n_tiles = (n_pts + kTilePts - 1) / kTilePts;
+
+  const int swz = h ^ (j & 15);  // this lane's 16-byte-slot swizzle (see gemm_seg)
+
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long n0 = tile * kTilePts;
+
+    // ---------------- gather: 16 points per wave ----------------
+    float zb[2];  // z_feat B operands of this wave's two column blocks
+    {
+    float cal[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) cal[i] = calib[i];
+#pragma unroll 2
+    for (int i = 0; i < 16; ++i) {
+      const int p = 16 * wv + i;
+      const long long n = n0 + p;
+      const bool live_n = n < n_pts;
+      float px = 0, py = 0, pz = 0, x, y, z;
+      uint32_t code;
+      if (live_n) load_point(src, n, px, py, pz, code);
+      project(cal, px, py, pz, x, y, z);
+      const bool live = live_n && in_image(x, y);
+      const Taps t = make_taps(x, y, fh, fw, C, live);
+#pragma unroll
+      for (int part = 0; part < C / 256; ++part) {
+        const int slot = lane + 64 * part;
+        f32x4 r = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (live) {
+          const f32x4 a = *reinterpret_cast<const f32x4 *>(feat + t.o[0] + 4 * slot);
+          const f32x4 b = *reinterpret_cast<const f32x4 *>(feat + t.o[1] + 4 * slot);
+          const f32x4 c = *reinterpret_cast<const f32x4 *>(feat + t.o[2] + 4 * slot);
+          const f32x4 d = *reinterpret_cast<const f32x4 *>(feat + t.o[3] + 4 * slot);
+          r = blend(a, b, c, d, t);
+        }
+        *reinterpret_cast<f32x4 *>(xs + p * ROWB + ((slot ^ (p & 15)) << 4)) = r;
+      }
+    }
+
+    // z_feat for the z k-step: lanes 0-31 carry it, lanes 32-63 supply 0
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const long long n = n0 + 32 * cb + j;
+      float px = 0, py = 0, pz = 0, x, y, z;
+      uint32_t code;
+      if (n < n_pts) load_point(src, n, px, py, pz, code);
+      project(cal, px, py, pz, x, y, z);
+      zb[cb] = (h == 0 && n < n_pts) ? __fmul_rn(z, z_scale) : 0.0f;
+    }
+    }
+    __syncthreads();
+
+    const unsigned char *xrow = xs + j * ROWB;       // this lane's point row, column block 0
+    const unsigned char *hrow = hb + j * kHbRowBytes;
+
+    // ---------------- layers 0 + 1, fused over 64-row chunks of layer 0 ----------------
+    f32x16 acc1[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc1[m][n][t] = 0.0f;
+
+    {
+      const int rb0 = wv >> 1, cb0 = wv & 1;  // this wave's tile inside a layer-0 chunk
+      const f32x4 *a1 = reinterpret_cast<const f32x4 *>((mlp.base + mlp.ah[1])) +
+                        (long long)(4 * wv) * (kHidden[0] / 8) * 64 + lane;
+      for (int ck = 0; ck < kHidden[0] / 64; ++ck) {
+        // layer-0 rows [64 ck + 32 rb0, +32) x points [32 cb0, +32)
+        f32x16 acc0[1][1];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc0[0][0][t] = 0.0f;
+        const int rb = 2 * ck + rb0;
+        gemm_seg<1, 1, 3, ROWB>(acc0,
+                                reinterpret_cast<const f32x4 *>((mlp.base + mlp.ax[0])) +
+                                    (long long)rb * NGX * 64 + lane,
+                                0, NGX, xrow + cb0 * 32 * ROWB, swz);
+        {
+          const float zz[1] = {zb[cb0]};
+          gemm_z<1, 1>(acc0, (mlp.base + mlp.az[0]) + rb * 64 + lane, zz);
+        }
+        bias_lrelu(acc0[0][0], (mlp.base + mlp.bias[0]) + 32 * rb, h);
+        store_hidden(hb, acc0[0][0], rb0, cb0, j, h);
+        __syncthreads();
+        // layer-1 rows [128 wv, +128) += W1[:, 64 ck .. +64) * chunk
+        gemm_seg<4, 2, 1, kHbRowBytes>(acc1, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8, hrow,
+                                       swz);
+        __syncthreads();
+      }
+      // skip segment of layer 1: W1[:, 1024 .. 1024 + C] * x, then the z column
+      gemm_seg<4, 2, 1, ROWB>(acc1,
+                              reinterpret_cast<const f32x4 *>((mlp.base + mlp.ax[1])) +
+                                  (long long)(4 * wv) * NGX * 64 + lane,
+                              NGX * 64, NGX, xrow, swz);
+      gemm_z<4, 2>(acc1, (mlp.base + mlp.az[1]) + (4 * wv) * 64 + lane, zb);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bias_lrelu(acc1[m][n], (mlp.base + mlp.bias[1]) + 32 * (4 * wv + m), h);
+    }
+
+    // ---------------- layer 2: rows [64 wv, +64), K = 512 hidden (8 chunks) + skip ----------------
+    f32x16 acc2[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc2[m][n][t] = 0.0f;
+    {
+      const f32x4 *a2 = reinterpret_cast<const f32x4 *>((mlp.base + mlp.ah[2])) +
+                        (long long)(2 * wv) * (kHidden[1] / 8) * 64 + lane;
+#pragma unroll
+      for (int ck = 0; ck < 8; ++ck) {
+        if (wv == (ck >> 1)) {  // owner of hidden rows [64 ck, +64): row blocks 2(ck&1), +1
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) store_hidden(hb, acc1[2 * (ck & 1) + mm][n], mm, n, j, h);
+        }
+        __syncthreads();
+        gemm_seg<2, 2, 1, kHbRowBytes>(acc2, a2 + ck * 8 * 64, (kHidden[1] / 8) * 64, 8, hrow,
+                                       swz);
+        __syncthreads();
+      }
+      gemm_seg<2, 2, 1, ROWB>(acc2,
+                              reinterpret_cast<const f32x4 *>((mlp.base + mlp.ax[2])) +
+                                  (long long)(2 * wv) * NGX * 64 + lane,
+                              NGX * 64, NGX, xrow, swz);
+      gemm_z<2, 2>(acc2, (mlp.base + mlp.az[2]) + (2 * wv) * 64 + lane, zb);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bias_lrelu(acc2[m][n], (mlp.base + mlp.bias[2]) + 32 * (2 * wv + m), h);
+    }
+
+    // ---------------- layer 3: rows [32 wv, +32), K = 256 hidden (4 chunks) + skip ----------------
+    f32x16 acc3[1][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc3[0][n][t] = 0.0f;
+    {
+      const f32x4 *a3 = reinterpret_cast<const f32x4 *>((mlp.base + mlp.ah[3])) +
+                        (long long)wv * (kHidden[2] / 8) * 64 + lane;
+#pragma unroll
+      for (int ck = 0; ck < 4; ++ck) {
+        if (wv == ck) {
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) store_hidden(hb, acc2[mm][n], mm, n, j, h);
+        }
+        __syncthreads();
+        gemm_seg<1, 2, 3, kHbRowBytes>(acc3, a3 + ck * 8 * 64, 0, 8, hrow, swz);
+        __syncthreads();
+      }
+      gemm_seg<1, 2, 3, ROWB>(acc3,
+                              reinterpret_cast<const f32x4 *>((mlp.base + mlp.ax[3])) +
+                                  (long long)wv * NGX * 64 + lane,
+                              0, NGX, xrow, swz);
+      gemm_z<1, 2>(acc3, (mlp.base + mlp.az[3]) + wv * 64 + lane, zb);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bias_lrelu(acc3[0][n], (mlp.base + mlp.bias[3]) + 32 * wv, h);
+    }
+
+    // ---------------- layer 4 (Cout x (128 + C + 1)) on the VALU ----------------
+    // red[part][o][p]: parts 0-3 = hidden rows of wave `part`, parts 4-7 = feature quarter
+    float *red = reinterpret_cast<float *>(hb);
+    constexpr int K4 = (kHidden[3] + C + 1 + 3) & ~3;  // padded row stride (pack.hip)
+    {
+      // hidden part: this lane holds rows 32 wv + 8q + 4h + i of points 32 cb + j
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) {
+        const float *w4 = (mlp.base + mlp.w4) + o * K4 + 32 * wv + 4 * h;
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 wq = *reinterpret_cast<const f32x4 *>(w4 + 8 * q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            s0 = fmaf(wq[i], acc3[0][0][4 * q + i], s0);
+            s1 = fmaf(wq[i], acc3[0][1][4 * q + i], s1);
+          }
+        }
+        s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 32);
+        if (h == 0) {
+          red[(wv * COUT + o) * kTilePts + j] = s0;
+          red[(wv * COUT + o) * kTilePts + 32 + j] = s1;
+        }
+      }
+      // feature part: lane = point, wave = quarter of the C channels
+      const int p = lane;
+      float sx[COUT];
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) sx[o] = 0.0f;
+      constexpr int SLOTS = C / 16;  // 16-byte slots per quarter
+      for (int s = 0; s < SLOTS; ++s) {
+        const int slot = wv * SLOTS + s;
+        const f32x4 xv =
+            *reinterpret_cast<const f32x4 *>(xs + p * ROWB + ((slot ^ (p & 15)) << 4));
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+          const f32x4 wq =
+              *reinterpret_cast<const f32x4 *>((mlp.base + mlp.w4) + o * K4 + kHidden[3] + 4 * slot);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sx[o] = fmaf(wq[i], xv[i], sx[o]);
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) red[((4 + wv) * COUT + o) * kTilePts + p] = sx[o];
+    }
+    __syncthreads();
+    if (tid < COUT * kTilePts) {
+      const int o = tid / kTilePts, p = tid % kTilePts;
+      const long long n = n0 + p;
+      if (n < n_pts) {
+        float cal[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cal[i] = calib[i];
+        float px, py, pz, x, y, z;
+        uint32_t code;
+        load_point(src, n, px, py, pz, code);
+        project(cal, px, py, pz, x, y, z);
+        float v = (mlp.base + mlp.bias[4])[o];
+#pragma unroll
+        for (int part = 0; part < 8; ++part) v += red[(part * COUT + o) * kTilePts + p];
+        v = fmaf((mlp.base + mlp.w4)[o * K4 + kHidden[3] + C], __fmul_rn(z, z_scale), v);
+        v = in_image(x, y) ? activate(v, act) : 0.0f;  // MonoPortNet.py:89
+        if (src.packed) {
+          const int ix = code & 1023u, iy = (code >> 10) & 1023u, iz = code >> 20;
+          out[((long long)iz * src.level_res + iy) * src.level_res + ix] = v;
+        } else {
+          out[o * src.out_stride + n] = v;
+        }
+      }
+    }
+    __syncthreads();  // red / xs are rewritten by the next tile
+  }
+}
+
+// ---- stand-alone index() and orthogonal() -------------------------------------------------------
+// geometry.py:4-16.  One wave per point and 256-channel slice; out is [C, N] like the reference.
+__global__ __launch_bounds__(256) void index_kernel(const float *__restrict__ feat, int c, int fh,
+                                                    int fw, const float *__restrict__ uv,
+                                                    long long n, float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+  const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const int slots = c / 4;
+  for (long long i = wave; i < n; i += n_waves) {
+    const float x = uv[i], y = uv[n + i];
+    const Taps t = make_taps(x, y, fh, fw, c, true);
+    for (int slot = lane; slot < slots; slot += 64) {
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(feat + t.o[0] + 4 * slot);
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(feat + t.o[1] + 4 * slot);
+      const f32x4 cc = *reinterpret_cast<const f32x4 *>(feat + t.o[2] + 4 * slot);
+      const f32x4 d = *reinterpret_cast<const f32x4 *>(feat + t.o[3] + 4 * slot);
+      const f32x4 r = blend(a, b, cc, d, t);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[(long long)(4 * slot + k) * n + i] = r[k];
+    }
+  }
+}
+
+__global__ void orthogonal_kernel(const float *__restrict__ pts, long long n,
+                                  const float *__restrict__ calib, float *__restrict__ out) {
+  float cal[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) cal[i] = calib[i];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float x, y, z;
+    project(cal, pts[i], pts[n + i], pts[2 * n + i], x, y, z);
+    out[i] = x;
+    out[n + i] = y;
+    out[2 * n + i] = z;
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+template <int C, int COUT, int WPS>
+static int launch_query_t(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w,
+                          const float *calib, float z_scale, const PointSrc &src, float *out,
+                          long long max_points, hipStream_t st) {
+  constexpr int lds = kTilePts * C * 4 + kHbBytes;
+  auto kern = pifu_query_kernel<C, COUT, WPS>;
+  static bool attr_set[16] = {};
+  if (!attr_set[ctx->device & 15]) {
+    MP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set[ctx->device & 15] = true;
+  }
+  long long tiles = (max_points + kTilePts - 1) / kTilePts;
+  if (tiles <= 0) return MP_OK;
+  const long long resident = (long long)ctx->n_cu * WPS;
+  // device-side counts: launch the resident grid and let it stride; host-side counts: one
+  // workgroup per tile up to a few waves of the machine
+  long long grid = src.n_dev ? (tiles < resident ? tiles : resident)
+                             : (tiles < 8 * resident ? tiles : 8 * resident);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kQueryThreads), lds, st, m.pack(), feat, h,
+                     w, calib, z_scale, m.act, src, out);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+int launch_query(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w, const float *calib,
+                 float z_scale, const PointSrc &src, float *out, long long max_points,
+                 hipStream_t st) {
+#define MP_QCASE(CC, CO, WP) \
+  if (m.c == CC && m.cout == CO) \
+    return launch_query_t<CC, CO, WP>(ctx, m, feat, h, w, calib, z_scale, src, out, max_points, st);
+  MP_QCASE(256, 1, 2)
+  MP_QCASE(256, 3, 2)
+  MP_QCASE(512, 1, 1)
+  MP_QCASE(512, 3, 1)
+#undef MP_QCASE
+  return fail(ctx, MP_ERR_UNSUPPORTED, "query kernels are built for C in {256,512}, Cout in {1,3}; got C=%d Cout=%d",
+              m.c, m.cout);
+}
+
+int launch_index(mp_ctx *ctx, const float *feat, int c, int h, int w, const float *uv, long long n,
+                 float *out, hipStream_t st) {
+  if (c % 4) return fail(ctx, MP_ERR_UNSUPPORTED, "index: C must be a multiple of 4, got %d", c);
+  if (n <= 0) return MP_OK;
+  long long blocks = (n + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(index_kernel, dim3((unsigned)blocks), dim3(256), 0, st, feat, c, h, w, uv, n,
+                     out);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+int launch_orthogonal(mp_ctx *ctx, const float *pts, long long n, const float *calib, float *out,
+                      hipStream_t st) {
+  if (n <= 0) return MP_OK;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(orthogonal_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pts, n, calib,
+                     out);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+}  // namespace mp

@@ -1,0 +1,205 @@
+// Visible-surface extraction and colour painting on the GPU.
+//   forward_vertices  RTL/recon.py:27-89   (first hit along the view axis, sub-voxel depth, normal)
+//   colorization      RTL/main.py:212-249  (vertex -> world points for netC.query; canvas scatter)
+// The reference materialises ten full-volume temporaries (flip, permute, ramp, max, nonzero ...);
+// here one pass walks each (x, y) column until its first occupied voxel and a single workgroup
+// turns the R*R hit map into the reference's x-major row order with a block scan.
+#include "mp_internal.h"
+
+// Reference parity is op-order parity: keep every a*b+c exactly as written (the HIP headers
+// define __fmul_rn & co. as plain operators, which hipcc would otherwise contract into FMAs).
+// Fused multiply-adds are requested explicitly (fmaf / MFMA) where they are wanted.
+#pragma clang fp contract(off)
+
+namespace mp {
+
+// s[x, y, z'] of RTL/recon.py:51-53 expressed on the original [z, y, x] volume, per direction
+// (front :39-40, left :41-42, back :43-45, right :46-49).
+__device__ __forceinline__ float view_sample(const float *__restrict__ v, int r, int dir, int x,
+                                             int y, int zp) {
+  long long zi, xi;
+  if (dir == MP_DIR_FRONT) {
+    zi = r - 1 - zp;
+    xi = x;
+  } else if (dir == MP_DIR_BACK) {
+    zi = zp;
+    xi = x;
+  } else if (dir == MP_DIR_LEFT) {
+    zi = x;
+    xi = r - 1 - zp;
+  } else {
+    zi = r - 1 - x;
+    xi = r - 1 - zp;
+  }
+  return v[(zi * r + y) * r + xi];
+}
+
+// hit[x * r + y] = first z' with s > 0.5 (recon.py:56-60), or -1.
+__global__ __launch_bounds__(256) void first_hit_kernel(const float *__restrict__ v, int r, int dir,
+                                                        int32_t *__restrict__ hit) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= r * r) return;
+  // lanes run along the memory-contiguous axis for front/back, along y for left/right
+  int x, y;
+  if (dir == MP_DIR_FRONT || dir == MP_DIR_BACK) {
+    x = t % r;
+    y = t / r;
+  } else {
+    y = t % r;
+    x = t / r;
+  }
+  int found = -1;
+  for (int zp = 0; zp < r; ++zp) {
+    if (view_sample(v, r, dir, x, y, zp) > 0.5f) {
+      found = zp;
+      break;
+    }
+  }
+  hit[x * r + y] = found;
+}
+
+// Single workgroup: exclusive scan of the hit map in x-major order (the row order of
+// keep.nonzero(), recon.py:62) and per-vertex outputs (recon.py:63-87).
+__global__ __launch_bounds__(1024) void emit_vertices_kernel(
+    const float *__restrict__ v, int r, int dir, const int32_t *__restrict__ hit,
+    int64_t *__restrict__ xo, int64_t *__restrict__ yo, float *__restrict__ zo,
+    float *__restrict__ no, int32_t *__restrict__ count) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  const int total = r * r;
+  for (int c0 = 0; c0 < total; c0 += 1024) {
+    const int idx = c0 + tid;
+    const int z1 = idx < total ? hit[idx] : -1;
+    const int flag = z1 >= 0;
+    const unsigned long long m = __ballot(flag);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wv] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int k = 0; k < wv; ++k) off += wave_tot[k];
+    if (flag) {
+      const int row = off + before;
+      const int x = idx / r, y = idx % r;
+      const int z2 = min(max(z1 - 2, 0), r), y2 = min(max(y - 2, 0), r), x2 = min(max(x - 2, 0), r);
+      const float v1 = view_sample(v, r, dir, x, y, z1);
+      const float v2 = view_sample(v, r, dir, x, y, z2);
+      const float v3 = view_sample(v, r, dir, x, y2, z1);
+      const float v4 = view_sample(v, r, dir, x2, y, z1);
+      // recon.py:77: p2z * (0.5 - v1) / (v2 - v1) + p1z * (v2 - 0.5) / (v2 - v1), left to right
+      const float den = __fsub_rn(v2, v1);
+      const float ta = __fdiv_rn(__fmul_rn((float)z2, __fsub_rn(0.5f, v1)), den);
+      const float tb = __fdiv_rn(__fmul_rn((float)z1, __fsub_rn(v2, 0.5f)), den);
+      float zz = __fadd_rn(ta, tb);
+      zz = zz < 0.0f ? 0.0f : (zz > (float)r ? (float)r : zz);  // clamp keeps NaN (hit at z'=0)
+      const float nx = __fsub_rn(v4, v1), ny = __fsub_rn(v3, v1), nz = den;
+      const float len = __fsqrt_rn(
+          __fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+      xo[row] = x;
+      yo[row] = y;
+      zo[row] = zz;
+      no[3 * row + 0] = __fdiv_rn(nx, len);
+      no[3 * row + 1] = __fdiv_rn(ny, len);
+      no[3 * row + 2] = __fdiv_rn(nz, len);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int s = base_s;
+      for (int k = 0; k < 16; ++k) s += wave_tot[k];
+      base_s = s;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *count = base_s;
+}
+
+int launch_forward_vertices(mp_ctx *ctx, void *scratch, const float *vol, int r, int dir, int64_t *x, int64_t *y,
+                            float *z, float *norm, int32_t *count, hipStream_t st) {
+  int32_t *hit = static_cast<int32_t *>(scratch);
+  hipLaunchKernelGGL(first_hit_kernel, dim3((r * r + 255) / 256), dim3(256), 0, st, vol, r, dir,
+                     hit);
+  hipLaunchKernelGGL(emit_vertices_kernel, dim3(1), dim3(1024), 0, st, vol, r, dir, hit, x, y, z,
+                     norm, count);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+// verts = (X, Y, res - Z) (main.py:231-233) through orthogonal(., mat_color) (main.py:237).
+struct Mat34 {
+  float m[12];
+};
+
+__global__ void vertex_points_kernel(const int64_t *__restrict__ x, const int64_t *__restrict__ y,
+                                     const float *__restrict__ z, const int32_t *__restrict__ count,
+                                     long long cap, int res, Mat34 mat, float *__restrict__ pts) {
+  const long long n = min((long long)*count, cap);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float vx = (float)x[i], vy = (float)y[i], vz = __fsub_rn((float)res, z[i]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      pts[k * cap + i] = __fadd_rn(
+          mat.m[4 * k + 3],
+          __fadd_rn(__fadd_rn(__fmul_rn(mat.m[4 * k], vx), __fmul_rn(mat.m[4 * k + 1], vy)),
+                    __fmul_rn(mat.m[4 * k + 2], vz)));
+  }
+}
+
+int launch_vertex_points(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *z,
+                         const int32_t *count, long long cap, int res, const float *mat16,
+                         float *pts, hipStream_t st) {
+  if (cap == 0) return MP_OK;
+  Mat34 m;
+  for (int i = 0; i < 12; ++i) m.m[i] = mat16[i];
+  long long blocks = (cap + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(vertex_points_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, z, count,
+                     cap, res, m, pts);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+__global__ void fill_kernel(float *__restrict__ p, long long n, float v) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+__global__ void paint_kernel(const int64_t *__restrict__ x, const int64_t *__restrict__ y,
+                             const float *__restrict__ vals, int ch_major,
+                             const int32_t *__restrict__ count, long long cap, int res, float scale,
+                             float bias, float lo, float hi, float *__restrict__ image) {
+  const long long n = min((long long)*count, cap);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long px = x[i], py = y[i];
+    if (px < 0 || px >= res || py < 0 || py >= res) continue;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = ch_major ? vals[c * cap + i] : vals[3 * i + c];
+      float o = __fadd_rn(__fmul_rn(v, scale), bias);
+      o = o < lo ? lo : (o > hi ? hi : o);
+      image[(px * res + py) * 3 + c] = o;
+    }
+  }
+}
+
+int launch_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *vals, int ch_major,
+                 const int32_t *count, long long cap, int res, float scale, float bias, float lo,
+                 float hi, float *image, hipStream_t st) {
+  const long long n_img = (long long)res * res * 3;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n_img + 255) / 256 > 1024 ? 1024 : (n_img + 255) / 256)),
+                     dim3(256), 0, st, image, n_img, 1.0f);  // canvas of ones, main.py:201-203
+  if (cap > 0) {
+    long long blocks = (cap + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(paint_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, vals, ch_major,
+                       count, cap, res, scale, bias, lo, hi, image);
+  }
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+}  // namespace mp

@@ -1,0 +1,267 @@
+"""Tensor-level entry points over the C-ABI (torch is only the allocator / stream provider).
+
+Every function here enqueues hand-written HIP kernels from libmonoport_hip.so on the caller's
+current HIP stream and returns ordinary ``torch.Tensor`` objects that outlive the call -- the
+ownership rule of the reference's stage pipeline (RTL/dataloader.py:1048-1054).
+"""
+import ctypes
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+from .synthetic import LAST_OP, MLP_DIMS  # noqa: F401  (re-exported for callers)
+
+DIRECTIONS = {"front": 0, "back": 1, "left": 2, "right": 3}  # RTL/recon.py:39-49
+
+_contexts = {}
+_contexts_lock = threading.Lock()
+
+
+class Context:
+    """One mp_ctx per HIP device, shared by all host threads (calls are serialised inside)."""
+
+    def __init__(self, device_index):
+        self.lib = _lib.load()
+        self.device_index = int(device_index)
+        handle = ctypes.c_void_p()
+        rc = self.lib.mp_create(self.device_index, ctypes.byref(handle))
+        if rc != 0:
+            msg = self.lib.mp_last_error(None)
+            raise _lib.MonoportError("mp_create(%d) failed (%d): %s"
+                                     % (device_index, rc, msg.decode() if msg else "?"))
+        self.handle = handle
+
+    def check(self, rc, what):
+        _lib.check(self.handle, rc, what)
+
+
+def get_context(device):
+    """Context for a torch device (``cuda:N``).  Raises on CPU tensors: no CPU fallback."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.MonoportError(
+            "monoport_amd runs on MI355X only (got device %s); there is no CPU path" % device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    with _contexts_lock:
+        ctx = _contexts.get(idx)
+        if ctx is None:
+            ctx = _contexts[idx] = Context(idx)
+    return ctx
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class PackedMLP:
+    """Device-resident SurfaceClassifier weights in MFMA fragment order."""
+
+    def __init__(self, ctx, channels, last_op):
+        self.ctx = ctx
+        self.channels = [int(c) for c in channels]
+        self.last_op = int(last_op)
+        n = len(self.channels) - 1
+        arr = (ctypes.c_int * (n + 1))(*self.channels)
+        mid = ctypes.c_int(-1)
+        ctx.check(ctx.lib.mp_mlp_create(ctx.handle, n, arr, self.last_op, ctypes.byref(mid)),
+                  "mp_mlp_create")
+        self.id = mid.value
+        self.c = self.channels[0] - 1
+        self.cout = self.channels[-1]
+
+    def load_layer(self, layer, weight, bias):
+        """weight [out,in] or [out,in,1] (Conv1d k=1), bias [out]; device tensors."""
+        w = _f32c(weight.reshape(weight.shape[0], -1))
+        b = _f32c(bias)
+        self.ctx.check(self.ctx.lib.mp_mlp_load(self.ctx.handle, self.id, layer, _ptr(w), _ptr(b),
+                                                w.shape[0], w.shape[1], _stream(w)), "mp_mlp_load")
+        # the pack kernels read w/b asynchronously: keep them alive until the stream drains
+        w.record_stream(torch.cuda.current_stream(w.device))
+        b.record_stream(torch.cuda.current_stream(b.device))
+
+    @classmethod
+    def from_layers(cls, device, layers, last_op):
+        """layers = [(W[out,in], b[out])] as numpy arrays or tensors (tests / bench fixtures)."""
+        ctx = get_context(device)
+        ws = [torch.as_tensor(np.asarray(w) if not torch.is_tensor(w) else w) for w, _ in layers]
+        dims = [ws[0].shape[1]] + [w.shape[0] for w in ws]
+        mlp = cls(ctx, dims, last_op)
+        for i, (w, b) in enumerate(layers):
+            mlp.load_layer(i, torch.as_tensor(w).to(device), torch.as_tensor(b).to(device))
+        return mlp
+
+    def __del__(self):
+        try:
+            self.ctx.lib.mp_mlp_destroy(self.ctx.handle, self.id)
+        except Exception:
+            pass
+
+
+def pack_features(feats, out=None):
+    """[1,Ci,H,W] NCHW maps -> one channels-last [H,W,sum Ci] map (concat order = list order,
+    i.e. MonoPortNet.py:44's cat([feat_prior, feat]) when given [prior, feat])."""
+    if torch.is_tensor(feats):
+        feats = [feats]
+    f0 = feats[0]
+    ctx = get_context(f0.device)
+    h, w = f0.shape[-2], f0.shape[-1]
+    total = 0
+    for f in feats:
+        if f.dim() != 4 or f.shape[0] != 1 or f.shape[-2:] != (h, w):
+            raise ValueError("pack_features wants [1,C,H,W] maps of one size, got %s"
+                             % (tuple(f.shape),))
+        total += f.shape[1]
+    if out is None:
+        out = torch.empty((h, w, total), dtype=torch.float32, device=f0.device)
+    off = 0
+    for f in feats:
+        fc = _f32c(f)
+        ctx.check(ctx.lib.mp_feat_pack_hwc(ctx.handle, _ptr(fc), fc.shape[1], h, w, _ptr(out),
+                                           total, off, _stream(out)), "mp_feat_pack_hwc")
+        off += fc.shape[1]
+    return out
+
+
+def _calib_dev(calib, device):
+    """[B,>=3,4] or [>=3,4] calibration -> contiguous f32 [rows,4] on device (rows 0-2 are read)."""
+    c = calib[0] if calib.dim() == 3 else calib
+    if c.shape[-1] != 4 or c.shape[0] < 3:
+        raise ValueError("calibration must be [>=3,4], got %s" % (tuple(c.shape),))
+    return _f32c(c.to(device))
+
+
+def index(feat_hwc, uv):
+    """geometry.py:4-16 on a channels-last map: uv [1,2,N] or [2,N] -> [1,C,N]."""
+    ctx = get_context(feat_hwc.device)
+    h, w, c = feat_hwc.shape
+    u = _f32c(uv.reshape(2, -1))
+    n = u.shape[1]
+    out = torch.empty((1, c, n), dtype=torch.float32, device=feat_hwc.device)
+    ctx.check(ctx.lib.mp_index(ctx.handle, _ptr(feat_hwc), c, h, w, _ptr(u), n, _ptr(out),
+                               _stream(out)), "mp_index")
+    return out
+
+
+def orthogonal(points, calib):
+    """geometry.py:19-34 (transforms=None): points [1,3,N] -> [1,3,N]."""
+    ctx = get_context(points.device)
+    p = _f32c(points.reshape(3, -1))
+    n = p.shape[1]
+    cal = _calib_dev(calib, points.device)
+    out = torch.empty((1, 3, n), dtype=torch.float32, device=points.device)
+    ctx.check(ctx.lib.mp_orthogonal(ctx.handle, _ptr(p), n, _ptr(cal), _ptr(out), _stream(out)),
+              "mp_orthogonal")
+    return out
+
+
+def query(mlp, feat_hwc, points, calib, z_scale):
+    """MonoPortNet.query (eval, one stage).  points [1,3,N] with ANY strides (the permuted view
+    query_func builds at RTL/main.py:176-177 is consumed in place) -> [1,Cout,N]."""
+    ctx = mlp.ctx
+    if points.dim() != 3 or points.shape[0] != 1 or points.shape[1] != 3:
+        raise ValueError("points must be [1,3,N], got %s" % (tuple(points.shape),))
+    if points.dtype != torch.float32:
+        points = points.float()
+    h, w, c = feat_hwc.shape
+    n = points.shape[2]
+    cal = _calib_dev(calib, feat_hwc.device)
+    out = torch.empty((1, mlp.cout, n), dtype=torch.float32, device=feat_hwc.device)
+    ctx.check(ctx.lib.mp_query(ctx.handle, mlp.id, _ptr(feat_hwc), c, h, w, _ptr(points), n,
+                               points.stride(2), points.stride(1), _ptr(cal), float(z_scale),
+                               _ptr(out), _stream(out)), "mp_query")
+    return out
+
+
+def query_counted(mlp, feat_hwc, points, count, calib, z_scale, out=None):
+    """mp_query_counted: points [3,cap] contiguous, count int32[1] on device -> [Cout,cap]."""
+    ctx = mlp.ctx
+    h, w, c = feat_hwc.shape
+    cap = points.shape[1]
+    cal = _calib_dev(calib, feat_hwc.device)
+    if out is None:
+        out = torch.zeros((mlp.cout, cap), dtype=torch.float32, device=feat_hwc.device)
+    ctx.check(ctx.lib.mp_query_counted(ctx.handle, mlp.id, _ptr(feat_hwc), c, h, w, _ptr(points),
+                                       cap, _ptr(count), _ptr(cal), float(z_scale), _ptr(out),
+                                       _stream(out)), "mp_query_counted")
+    return out
+
+
+def recon(mlp, feat_hwc, calib, z_scale, b_min, b_max, resolutions, balance=0.5, volume=None,
+          status=None):
+    """Coarse-to-fine occupancy volume (Seg3dLossless replacement).  Returns (volume [R,R,R]
+    f32, status int32[1+levels]) -- both on device, nothing synchronised."""
+    ctx = mlp.ctx
+    h, w, c = feat_hwc.shape
+    res = [int(r) for r in resolutions]
+    r_last = res[-1]
+    dev = feat_hwc.device
+    cal = _calib_dev(calib, dev)
+    if volume is None:
+        volume = torch.empty((r_last, r_last, r_last), dtype=torch.float32, device=dev)
+    if status is None:
+        status = torch.empty((1 + len(res),), dtype=torch.int32, device=dev)
+    bmin = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_min, np.float32).reshape(3)])
+    bmax = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_max, np.float32).reshape(3)])
+    res_c = (ctypes.c_int * len(res))(*res)
+    ctx.check(ctx.lib.mp_recon(ctx.handle, mlp.id, _ptr(feat_hwc), c, h, w, _ptr(cal),
+                               float(z_scale), bmin, bmax, res_c, len(res), float(balance),
+                               _ptr(volume), _ptr(status), _stream(volume)), "mp_recon")
+    return volume, status
+
+
+def forward_vertices_raw(volume, direction="front"):
+    """mp_forward_vertices: returns capacity-sized (X, Y, Z, norm, count) device tensors."""
+    vol = volume
+    while vol.dim() > 3:
+        vol = vol[0]
+    vol = _f32c(vol)
+    r = vol.shape[2]
+    if vol.shape != (r, r, r):
+        raise ValueError("forward_vertices wants a cubic volume, got %s" % (tuple(vol.shape),))
+    ctx = get_context(vol.device)
+    cap = r * r
+    dev = vol.device
+    x = torch.empty((cap,), dtype=torch.int64, device=dev)
+    y = torch.empty((cap,), dtype=torch.int64, device=dev)
+    z = torch.empty((cap,), dtype=torch.float32, device=dev)
+    nrm = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    ctx.check(ctx.lib.mp_forward_vertices(ctx.handle, _ptr(vol), r, DIRECTIONS[direction], _ptr(x),
+                                          _ptr(y), _ptr(z), _ptr(nrm), _ptr(count), _stream(vol)),
+              "mp_forward_vertices")
+    return x, y, z, nrm, count
+
+
+def vertex_points(x, y, z, count, res, mat):
+    """(X, Y, res - Z) through the voxel->world matrix (RTL/main.py:231-237) -> [3,cap]."""
+    ctx = get_context(x.device)
+    cap = x.shape[0]
+    m = (ctypes.c_float * 16)(*[float(v) for v in np.asarray(mat, np.float32).reshape(16)])
+    pts = torch.zeros((3, cap), dtype=torch.float32, device=x.device)
+    ctx.check(ctx.lib.mp_vertex_points(ctx.handle, _ptr(x), _ptr(y), _ptr(z), _ptr(count), cap,
+                                       int(res), m, _ptr(pts), _stream(pts)), "mp_vertex_points")
+    return pts
+
+
+def paint(x, y, values, channel_major, count, res, scale, bias, lo, hi):
+    """canvas of ones [res,res,3] with image[X,Y,:] = clamp(values*scale+bias) (main.py:220-248)."""
+    ctx = get_context(x.device)
+    cap = x.shape[0]
+    image = torch.empty((res, res, 3), dtype=torch.float32, device=x.device)
+    values = _f32c(values)
+    ctx.check(ctx.lib.mp_paint(ctx.handle, _ptr(x), _ptr(y), _ptr(values), int(channel_major),
+                               _ptr(count), cap, int(res), float(scale), float(bias), float(lo),
+                               float(hi), _ptr(image), _stream(image)), "mp_paint")
+    return image
