@@ -1,0 +1,126 @@
+"""GPU parity of the octree driver, forward_vertices and colorization kernels.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from monoport_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+DEV = "cuda:0"
+BMIN, BMAX = [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from monoport_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def body(ops, oracle):
+    layers = syn.body_mlp("G", noise=0.05, seed=1)
+    f = syn.body_feat(256, 128, 128, 2)
+    calib = oracle.pifu_calib(*syn.scene_camera(30))
+    mlp = ops.PackedMLP.from_layers(DEV, layers, 1)
+    fh = ops.pack_features(torch.from_numpy(f)[None].to(DEV))
+    cal = torch.from_numpy(calib).to(DEV)
+
+    def gpu_query(pts):  # [3,N] numpy -> [N] numpy through the HIP kernel
+        out = ops.query(mlp, fh, torch.from_numpy(np.ascontiguousarray(pts))[None].to(DEV), cal,
+                        syn.Z_SCALE)
+        return out[0, 0].cpu().numpy()
+
+    return dict(layers=layers, f=f, calib=calib, mlp=mlp, fh=fh, cal=cal, gpu_query=gpu_query)
+
+
+@pytest.mark.parametrize("res", [[9, 17, 33], [17, 33, 65], [17, 33, 65, 129]])
+def test_recon_bit_exact_vs_oracle_driver(ops, oracle, body, res):
+    """The HIP octree must make exactly the decisions of the CPU restatement.  Both sides get
+    their occupancies from the same HIP query kernel, so the volumes must be identical bits."""
+    vol, status = ops.recon(body["mlp"], body["fh"], body["cal"], syn.Z_SCALE, BMIN, BMAX, res)
+    torch.cuda.synchronize()
+    status = status.cpu().numpy()
+    stats = []
+    ref = oracle.seg3d_lossless(body["gpu_query"], BMIN, BMAX, res, stats=stats)
+    assert status[0] == 1
+    assert list(status[1:]) == stats
+    v = vol.cpu().numpy()
+    assert v.shape == ref.shape
+    assert np.array_equal(v, ref)
+
+
+def test_recon_matches_cpu_oracle_field(ops, oracle, body):
+    """... and against the all-CPU oracle (CPU query) the field agrees to 1e-4 and the
+    thresholded volume is identical (margin-checked)."""
+    res = [9, 17, 33, 65]
+    vol, status = ops.recon(body["mlp"], body["fh"], body["cal"], syn.Z_SCALE, BMIN, BMAX, res)
+    q = lambda p: oracle.query(body["f"], p, body["calib"][0], body["layers"], 1, syn.Z_SCALE,
+                               precision="f32")[0]
+    ref = oracle.seg3d_lossless(q, BMIN, BMAX, res)
+    v = vol.cpu().numpy()
+    assert np.abs(v - ref).max() <= 1e-4
+    safe = np.abs(ref - 0.5) > 1e-3
+    assert np.array_equal((v > 0.5)[safe], (ref > 0.5)[safe])
+
+
+def test_recon_empty_sets_status_zero(ops, body):
+    layers = syn.body_mlp("G", c=-3.0)  # occupancy < 0.5 everywhere
+    mlp = ops.PackedMLP.from_layers(DEV, layers, 1)
+    vol, status = ops.recon(mlp, body["fh"], body["cal"], syn.Z_SCALE, BMIN, BMAX, [9, 17, 33])
+    s = status.cpu().numpy()
+    assert s[0] == 0 and s[1] == 9 ** 3 and s[2] == 0 and s[3] == 0
+
+
+def test_recon_rejects_bad_resolutions(ops, body):
+    from monoport_amd._lib import MonoportError
+    with pytest.raises(MonoportError):
+        ops.recon(body["mlp"], body["fh"], body["cal"], syn.Z_SCALE, BMIN, BMAX, [9, 18])
+
+
+@pytest.mark.parametrize("res,seed", [(33, 51), (65, 52)])
+@pytest.mark.parametrize("direction", ["front", "back", "left", "right"])
+def test_forward_vertices_vs_reference(ops, res, seed, direction):
+    g = load_golden("forward_vertices")
+    vol = torch.from_numpy(syn.blob_volume(res, seed)).to(DEV)
+    x, y, z, n, count = ops.forward_vertices_raw(vol[None, None], direction)
+    c = int(count.item())
+    key = "r%d_%s_" % (res, direction)
+    assert c == g[key + "X"].shape[0]
+    assert np.array_equal(x[:c].cpu().numpy(), g[key + "X"])
+    assert np.array_equal(y[:c].cpu().numpy(), g[key + "Y"])
+    assert np.abs(z[:c].cpu().numpy() - g[key + "Z"]).max() <= 1e-4
+    assert np.abs(n[:c].cpu().numpy() - g[key + "norm"]).max() <= 1e-5
+
+
+def test_forward_vertices_nan_at_front_face(ops, oracle):
+    """A hit at z'=0 divides 0/0 in the reference: compare NaN for NaN."""
+    vol = syn.blob_volume(33, 77)
+    vol[-1, 10:14, 10:14] = 0.9  # occupied on the z' = 0 face
+    x, y, z, n, count = ops.forward_vertices_raw(torch.from_numpy(vol).to(DEV), "front")
+    c = int(count.item())
+    rx, ry, rz, rn = oracle.forward_vertices(vol, "front")
+    assert c == rx.shape[0] and np.array_equal(x[:c].cpu().numpy(), rx)
+    zz = z[:c].cpu().numpy()
+    assert np.isnan(rz).sum() > 0 and np.array_equal(np.isnan(zz), np.isnan(rz))
+    ok = ~np.isnan(rz)
+    assert np.abs(zz[ok] - rz[ok]).max() <= 1e-4
+
+
+def test_colorization_vs_reference(ops):
+    g = load_golden("colorization")
+    res = 33
+    vol = torch.from_numpy(syn.blob_volume(res, 63)).to(DEV)
+    x, y, z, n, count = ops.forward_vertices_raw(vol, "front")
+    img_n = ops.paint(x, y, n, 0, count, res, 0.5, 0.5, 0.0, 1.0)
+    assert np.abs(img_n.cpu().numpy() - g["norm_image"]).max() <= 1e-5
+    mlp = ops.PackedMLP.from_layers(DEV, syn.rand_mlp("C", 61, 2.0), 2)
+    fh = ops.pack_features(torch.from_numpy(syn.rand_feat(512, 128, 128, 62))[None].to(DEV))
+    mat = np.eye(4, dtype=np.float32)
+    for i in range(3):
+        mat[i, i] = np.float32(2.0) / np.float32(res)
+    mat[0:3, 3] = -1.0
+    pts = ops.vertex_points(x, y, z, count, res, mat)
+    preds = ops.query_counted(mlp, fh, pts, count, torch.from_numpy(g["calib"]).to(DEV), syn.Z_SCALE)
+    img_t = ops.paint(x, y, preds, 1, count, res, 0.5, 0.5, -np.inf, np.inf)
+    assert np.abs(img_t.cpu().numpy() - g["tex_image"]).max() <= 1e-4
