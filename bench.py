@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Headline benchmark: reconstructions/sec (512x512 image in, 256^3-effective octree grid out).
+
+One "step" = one full geometry reconstruction of one synthetic frame on one MI355X
+(BASELINE.json configs[1]): netG.filter (hourglass encoder, PyTorch-ROCm) -> channels-last pack
+-> coarse-to-fine octree 17..257 driving the fused HIP query kernel -> forward_vertices ->
+normal render.  Inputs are resident in HBM before the timed region.  With --gpus N every rank
+reconstructs its own frames (frame-parallel, weak scaling) and the renders are gathered to rank 0
+over RCCL.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  "roofline":     the fused query kernel against the f32 MFMA peak (HIP-event timed, live)
+  "cpu_baseline": the CPU oracle path timed on this box's host cores (rank 0, N=1 only)
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from monoport_amd import ops, synthetic as syn  # noqa: E402
+from monoport_amd.modeling import PIFuNetG  # noqa: E402
+from monoport_amd.recon import pifu_calib  # noqa: E402
+
+RESOLUTIONS = [17, 33, 65, 129, 257]  # RTL/main.py:187
+B_MIN, B_MAX = [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]  # RTL/main.py:185-186
+FLOP_PER_POINT = 2363906  # netG MLP, SURVEY.md section 8d / BASELINE.md section 2
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def build_netg(device):
+    """Random-init (seeded) encoder of the reference architecture + the analytic F-body head."""
+    net = PIFuNetG().eval()
+    shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
+    sd = syn.seeded_state_dict(shapes, 71)
+    net.image_filter.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    layers = syn.body_mlp("G", noise=0.05, seed=1)
+    net.surface_classifier.load_state_dict(
+        {**{"filters.%d.weight" % i: torch.from_numpy(w)[:, :, None] for i, (w, _) in enumerate(layers)},
+         **{"filters.%d.bias" % i: torch.from_numpy(b) for i, (_, b) in enumerate(layers)}})
+    return net.to(device), layers
+
+
+class FrameReconstructor:
+    """The per-frame stage chain of RTL/main.py:366-428 (geometry only), enqueued asynchronously."""
+
+    def __init__(self, device):
+        self.device = device
+        self.net, self.layers = build_netg(device)
+        self.mlp = self.net.surface_classifier.packed()
+        self.planes = torch.from_numpy(syn.body_feature_planes(128, 128)).to(device)
+        self.feat_hwc = torch.empty((128, 128, 256), dtype=torch.float32, device=device)
+        self.volume = torch.empty((257, 257, 257), dtype=torch.float32, device=device)
+        self.status = torch.zeros((1 + len(RESOLUTIONS),), dtype=torch.int32, device=device)
+
+    @torch.no_grad()
+    def step(self, image, calib):
+        feats = self.net.image_filter(image, last_only=True)  # eval reads the last stack only
+        feat = feats[-1][0]
+        # synthetic-data hook: the analytic F-body head reads channels 0/1 as depth planes; the
+        # other 254 channels are the encoder's output (consumed through the seeded-noise weights)
+        feat[0, 0:2] = self.planes
+        ops.pack_features(feat, out=self.feat_hwc)
+        ops.recon(self.mlp, self.feat_hwc, calib, syn.Z_SCALE, B_MIN, B_MAX, RESOLUTIONS, 0.5,
+                  volume=self.volume, status=self.status)
+        x, y, z, nrm, count = ops.forward_vertices_raw(self.volume, "front")
+        return ops.paint(x, y, nrm, 0, count, 257, 0.5, 0.5, 0.0, 1.0)  # normal render
+
+
+def cpu_baseline(threads):
+    """One reconstruction on the host cores: encoder (torch CPU, the reference's own op set) +
+    CPU oracle octree / query / forward_vertices.  Test infrastructure used as the baseline."""
+    from oracle import pifu_oracle as orc
+    torch.set_num_threads(threads)
+    net, layers = build_netg("cpu")
+    img = torch.from_numpy(syn.synthetic_image(0))[None]
+    calib = orc.pifu_calib(*syn.scene_camera(0))[0]
+    planes = syn.body_feature_planes(128, 128)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        feat = net.image_filter(img, last_only=True)[-1][0][0].numpy().copy()
+    feat[0:2] = planes
+    t1 = time.perf_counter()
+    stats = []
+    vol = orc.seg3d_lossless(
+        lambda p: orc.query(feat, p, calib, layers, 1, syn.Z_SCALE, precision="f32", threads=threads)[0],
+        B_MIN, B_MAX, RESOLUTIONS, stats=stats)
+    t2 = time.perf_counter()
+    orc.forward_vertices(vol, "front")
+    t3 = time.perf_counter()
+    total = t3 - t0
+    return {
+        "value": 1.0 / total, "unit": "recon/s", "cores": threads, "kind": "port",
+        "sample": "1 reconstruction: encoder %.2fs (torch CPU) + octree %.2fs (%d pts, C oracle f32, "
+                  "OpenMP) + forward_vertices %.2fs" % (t1 - t0, t2 - t1, sum(stats), t3 - t2),
+        "mpts_per_s": sum(stats) / (t2 - t1) / 1e6,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    fr = FrameReconstructor(device)
+    n_frames = args.steps + args.warmup
+    # distinct frames per rank: frame id = step * world + rank (frame-parallel sharding)
+    images = [torch.from_numpy(syn.synthetic_image(s * world + rank))[None].to(device)
+              for s in range(min(n_frames, 4))]
+    calibs = [pifu_calib(*syn.scene_camera(3 * (s * world + rank)), device=device)
+              for s in range(n_frames)]
+    gather_list = ([torch.empty((257, 257, 3), device=device) for _ in range(world)]
+                   if (dist is not None and rank == 0) else None)
+
+    def one_step(s):
+        render = fr.step(images[s % len(images)], calibs[s])
+        if dist is not None:
+            dist.gather(render, gather_list, dst=0)
+        return render
+
+    for s in range(args.warmup):
+        one_step(s)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    ops.profile_begin(device, max_records=8 * args.steps + 8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pts_total = 0
+    status_log = []
+    for s in range(args.warmup, n_frames):
+        one_step(s)
+        status_log.append(fr.status.clone())  # device-side copy, no sync
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    launch_ms = ops.profile_end(device, capacity=8 * args.steps + 8)
+
+    statuses = torch.stack(status_log).cpu().numpy()
+    assert (statuses[:, 0] == 1).all(), "synthetic body must be non-empty"
+    level_pts = statuses[:, 1:]
+    pts_total = int(level_pts.sum())
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    p = torch.tensor([pts_total], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    pts_all = float(p.item())
+
+    if rank == 0:
+        n_launch = min(len(launch_ms), level_pts.size)
+        flops = level_pts.reshape(-1)[:n_launch].astype(np.float64) * FLOP_PER_POINT
+        achieved = flops.sum() / (launch_ms[:n_launch].sum() * 1e-3) / 1e12 if n_launch else 0.0
+        out = {
+            "metric": "reconstructions/sec (512^2 in, 256^3 grid)",
+            "value": args.steps * world / elapsed,
+            "unit": "recon/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: single 512x512 image, netG (4-stack hourglass encoder "
+                            "fp32 + fused query), octree 17-33-65-129-257 on [-1,1]^3, geometry only "
+                            "(+forward_vertices, normal render)",
+                "frames_per_rank": args.steps,
+                "parallelism": "frame-parallel x%d" % world,
+                "fixture": "F-body analytic head, seeded encoder (monoport_amd/synthetic.py)",
+                "points_per_recon": pts_all / (args.steps * world),
+            },
+            "mpts_per_s": pts_all / elapsed / 1e6,
+            "roofline": {
+                "kernel": "pifu_query_kernel<256,1> (fused gather + MLP)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "launches": int(n_launch),
+                "avg_launch_ms": float(launch_ms[:n_launch].mean()) if n_launch else None,
+                "flop_per_point": FLOP_PER_POINT,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # bounded thread count: torch-CPU convs at batch 1 collapse when oversubscribed
+            out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,14 @@ int mp_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *value
              int channel_major, const int32_t *count, int64_t capacity, int res, float scale,
              float bias, float lo, float hi, float *image, mp_stream stream);
 
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* Brackets every fused-query kernel launch made through this context with a pair of HIP events
+ * recorded on the launch stream (bench.py's roofline leg).  mp_profile_end waits for the last
+ * event and writes the elapsed milliseconds of up to `capacity` launches, in launch order, to
+ * ms_out (host); *n_out = launches recorded. */
+int mp_profile_begin(mp_ctx *ctx, int max_records);
+int mp_profile_end(mp_ctx *ctx, float *ms_out /*host*/, int capacity, int *n_out /*host*/);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,8 @@ SIGNATURES = {
     "mp_vertex_points": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, _pf32, c_vp, c_vp]),
     "mp_paint": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_f32, c_f32, c_f32,
                          c_f32, c_vp, c_vp]),
+    "mp_profile_begin": (c_int, [c_vp, c_int]),
+    "mp_profile_end": (c_int, [c_vp, _pf32, c_int, _pint]),
 }
 
 _lib = None
@@ -52,6 +54,10 @@ def load():
             raise RuntimeError(
                 "monoport_amd: %s is missing -- build it with `python -m monoport_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # torch ships its own libamdhip64; it must be in the process BEFORE our library resolves
+        # the same SONAME, or two HIP runtimes coexist and device pointers / streams stop being
+        # interchangeable (symptom: "no HIP device visible" from mp_create)
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

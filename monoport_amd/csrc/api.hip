@@ -113,6 +113,7 @@ void mp_destroy(mp_ctx *ctx) {
     DeviceGuard g(ctx->device);
     for (auto &m : ctx->mlps)
       if (m.buf) (void)hipFree(m.buf);
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     for (auto &kv : ctx->arenas)
       if (kv.second.ptr) (void)hipFree(kv.second.ptr);
   }
@@ -348,6 +349,44 @@ int mp_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *value
   DeviceGuard g(ctx->device);
   return launch_paint(ctx, x, y, values, channel_major, count, capacity, res, scale, bias, lo, hi,
                       image, (hipStream_t)stream);
+}
+
+int mp_profile_begin(mp_ctx *ctx, int max_records) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (max_records < 1 || max_records > (1 << 20))
+    return fail(ctx, MP_ERR_ARG, "mp_profile_begin: bad max_records");
+  DeviceGuard g(ctx->device);
+  for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+  ctx->prof_events.clear();
+  ctx->prof_used = 0;
+  ctx->prof_events.resize(2 * (size_t)max_records);
+  for (auto &e : ctx->prof_events) MP_HIP(ctx, hipEventCreate(&e));
+  return MP_OK;
+}
+
+int mp_profile_end(mp_ctx *ctx, float *ms_out, int capacity, int *n_out) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ms_out || !n_out || capacity < 0) return fail(ctx, MP_ERR_ARG, "mp_profile_end: bad argument");
+  DeviceGuard g(ctx->device);
+  const int n = ctx->prof_used;
+  int rc = MP_OK;
+  for (int i = 0; i < n && rc == MP_OK; ++i) {
+    if (hipEventSynchronize(ctx->prof_events[2 * i + 1]) != hipSuccess) {
+      rc = fail(ctx, MP_ERR_HIP, "mp_profile_end: hipEventSynchronize failed");
+      break;
+    }
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]) != hipSuccess)
+      rc = fail(ctx, MP_ERR_HIP, "mp_profile_end: hipEventElapsedTime failed");
+    if (i < capacity) ms_out[i] = ms;
+  }
+  *n_out = n;
+  for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+  ctx->prof_events.clear();
+  ctx->prof_used = 0;
+  return rc;
 }
 
 }  // extern "C"

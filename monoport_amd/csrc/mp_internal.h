@@ -72,6 +72,9 @@ struct mp_ctx {
     size_t bytes = 0;
   };
   std::unordered_map<void *, Arena> arenas;
+  // optional event bracketing of query launches (mp_profile_begin / mp_profile_end)
+  std::vector<hipEvent_t> prof_events;  // start/stop pairs
+  int prof_used = 0;                    // pairs recorded
 };
 
 namespace mp {

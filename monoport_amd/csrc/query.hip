@@ -528,8 +528,14 @@ static int launch_query_t(mp_ctx *ctx, const Mlp &m, const float *feat, int h, i
   // workgroup per tile up to a few waves of the machine
   long long grid = src.n_dev ? (tiles < resident ? tiles : resident)
                              : (tiles < 8 * resident ? tiles : 8 * resident);
+  const bool prof = 2 * (ctx->prof_used + 1) <= (int)ctx->prof_events.size();
+  if (prof) MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], st));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kQueryThreads), lds, st, m.pack(), feat, h,
                      w, calib, z_scale, m.act, src, out);
+  if (prof) {
+    MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], st));
+    ++ctx->prof_used;
+  }
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
 }

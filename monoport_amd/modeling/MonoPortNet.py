@@ -1,0 +1,174 @@
+"""MonoPortNet: the PIFu geometry / colour network wrapper (mirror of
+monoport/lib/modeling/MonoPortNet.py, same constructor, attributes and method signatures).
+
+``filter`` runs the image encoder under PyTorch-ROCm once per frame.  ``query`` -- the hot path,
+called once per octree level on 10^4..10^5 points -- is ONE hand-written HIP kernel
+(csrc/query.hip): projection, in-image mask, depth feature, bilinear feature gather, the
+skip-connected MLP on f32 MFMA, final activation and mask.
+"""
+import threading
+import weakref
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .backbones import PIFuHGFilters, PIFuResBlkFilters
+from .geometry import index, orthogonal, perspective  # noqa: F401
+from .heads import PIFuNetCMLP, PIFuNetGMLP
+from .normalizers import PIFuNomalizer
+
+# the reference resolves these names through globals() (MonoPortNet.py:23-28)
+_REGISTRY = {
+    "PIFuHGFilters": PIFuHGFilters,
+    "PIFuResBlkFilters": PIFuResBlkFilters,
+    "PIFuNetGMLP": PIFuNetGMLP,
+    "PIFuNetCMLP": PIFuNetCMLP,
+    "PIFuNomalizer": PIFuNomalizer,
+    "orthogonal": orthogonal,
+    "perspective": perspective,
+}
+
+_tls = threading.local()
+
+
+class QueryBinding:
+    """What one ``MonoPortNet.query`` call binds together: packed MLP + channels-last features +
+    calibration.  The octree engine records it once per frame and drives all levels natively."""
+
+    def __init__(self, net, mlp, feat_hwc, calib, z_scale):
+        self.net, self.mlp, self.feat_hwc, self.calib, self.z_scale = net, mlp, feat_hwc, calib, z_scale
+
+
+class capture_query:
+    """Context manager: inside it, the first ``MonoPortNet.query`` records its QueryBinding in
+    ``.binding`` and returns zeros instead of launching (used by Seg3dLossless to see through an
+    opaque ``query_func`` closure such as RTL/main.py:169-183)."""
+
+    def __enter__(self):
+        self.binding = None
+        self._prev = getattr(_tls, "capture", None)
+        _tls.capture = self
+        return self
+
+    def __exit__(self, *exc):
+        _tls.capture = self._prev
+        return False
+
+
+class _AttrDict(dict):
+    """yacs-free stand-in for CfgNode in the factories below."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class MonoPortNet(nn.Module):
+    def __init__(self, opt_net):
+        super().__init__()
+        self.opt = opt_net
+        assert opt_net.projection in ["orthogonal", "perspective"]
+        self.image_filter = _REGISTRY[opt_net.backbone.IMF](opt_net.backbone)
+        self.surface_classifier = _REGISTRY[opt_net.head.IMF](opt_net.head)
+        self.projection = _REGISTRY[opt_net.projection]
+        self.normalizer = _REGISTRY[opt_net.normalizer.IMF](opt_net.normalizer)
+        self._hwc_cache = None  # (weakrefs of source maps, versions, packed map)
+
+    # ---- encoder ---------------------------------------------------------------------------------
+    def filter(self, images, feat_prior=None):
+        """images [B,3,512,512] -> list(stages) of list(levels) of [B,C,128,128]
+        (MonoPortNet.py:31-46).  With ``feat_prior`` (netC) the prior is nearest-resized to
+        128x128 and concatenated FIRST (:42-44)."""
+        feats_stages = self.image_filter(images)
+        if feat_prior is not None:
+            feat_prior = F.interpolate(feat_prior, size=(128, 128))
+            feats_stages = [[torch.cat([feat_prior, f], dim=1) for f in feats]
+                            for feats in feats_stages]
+        return feats_stages
+
+    # ---- hot path --------------------------------------------------------------------------------
+    def _packed_features(self, feats):
+        """Channels-last copy of this stage's maps, cached per source tensors so the five octree
+        levels of one frame (and repeated calls) pack once."""
+        key = tuple((f.data_ptr(), f._version, tuple(f.shape)) for f in feats)
+        c = self._hwc_cache
+        if c is not None and c[0] == key and all(r() is f for r, f in zip(c[1], feats)):
+            return c[2]
+        packed = ops.pack_features(list(feats))
+        self._hwc_cache = (key, [weakref.ref(f) for f in feats], packed)
+        return packed
+
+    def bind(self, feats_stages, calibs):
+        """QueryBinding for eval-mode queries against ``feats_stages`` / ``calibs``."""
+        if self.training:
+            raise NotImplementedError("monoport_amd implements the inference path (net.eval())")
+        if self.projection is not orthogonal:
+            raise NotImplementedError("only the orthogonal projection of the PIFu configs is built")
+        feats = list(feats_stages[-1])  # eval keeps the last stage only (MonoPortNet.py:63-64)
+        dev = feats[0].device
+        if calibs is None:
+            calibs = torch.eye(4, device=dev)[None]  # xyz = points (MonoPortNet.py:66-67)
+        mlp = self.surface_classifier.packed()
+        if mlp.ctx.device_index != (dev.index if dev.index is not None else torch.cuda.current_device()):
+            raise RuntimeError("surface_classifier and the feature maps must be on one GPU "
+                               "(RTL/main.py:382-387 moves the features first)")
+        return QueryBinding(self, mlp, self._packed_features(feats), calibs, self.normalizer.scale)
+
+    def query(self, feats_stages, points, calibs=None, transforms=None):
+        """points [B,3,N] world coords -> [ [B,Cout,N] ] (MonoPortNet.py:48-91, eval mode).
+        Out-of-image points come back as exactly 0 (:89)."""
+        if transforms is not None:
+            raise NotImplementedError("query(transforms=...) is a training-time option")
+        binding = self.bind(feats_stages, calibs)
+        cap = getattr(_tls, "capture", None)
+        if cap is not None and cap.binding is None:
+            cap.binding = binding
+            return [torch.zeros((points.shape[0], binding.mlp.cout, points.shape[2]),
+                                dtype=torch.float32, device=points.device)]
+        if points.shape[0] != 1:
+            raise NotImplementedError("batch size 1 (RTL/main.py:175 asserts the same)")
+        return [ops.query(binding.mlp, binding.feat_hwc, points, binding.calib, binding.z_scale)]
+
+    def get_loss(self, pred_stages, labels):
+        """Average MSE / L1 over stages (MonoPortNet.py:93-117); plain tensor ops."""
+        kind = self.opt.loss.IMF
+        if kind not in ("MSE", "L1"):
+            raise NotImplementedError(kind)
+        fn = F.mse_loss if kind == "MSE" else F.l1_loss
+        return sum(fn(p, labels) for p in pred_stages) / len(pred_stages)
+
+    def forward(self, images, points, calibs, transforms=None, labels=None, feat_prior=None):
+        feats_stages = self.filter(images, feat_prior)
+        pred_stages = self.query(feats_stages, points, calibs, transforms)
+        if labels is not None:
+            return pred_stages[-1], self.get_loss(pred_stages, labels)
+        return pred_stages[-1]
+
+    def load_legacy_pifu(self, ckpt_path):
+        """Flat legacy PIFu checkpoints: ``image_filter.*`` and ``surface_classifier.conv{i}.*``
+        (renamed to ``filters.{i}.*``) -- MonoPortNet.py:153-160."""
+        ckpt = torch.load(ckpt_path, map_location="cpu")
+        self.image_filter.load_state_dict(
+            {k.replace("image_filter.", ""): v for k, v in ckpt.items() if "image_filter" in k})
+        self.surface_classifier.load_state_dict(
+            {k.replace("surface_classifier.conv", "filters."): v
+             for k, v in ckpt.items() if "surface_classifier" in k})
+
+
+def _options(backbone, head, loss):
+    opt = _AttrDict(projection="orthogonal")
+    opt.backbone = _AttrDict(IMF=backbone)
+    opt.normalizer = _AttrDict(IMF="PIFuNomalizer")
+    opt.head = _AttrDict(IMF=head)
+    opt.loss = _AttrDict(IMF=loss)
+    return opt
+
+
+def PIFuNetG():
+    """netG: hourglass encoder + [257,1024,512,256,128,1] sigmoid head (MonoPortNet.py:163-184)."""
+    return MonoPortNet(_options("PIFuHGFilters", "PIFuNetGMLP", "MSE"))
+
+
+def PIFuNetC():
+    """netC: ResNet encoder + [513,1024,512,256,128,3] tanh head (MonoPortNet.py:187-208)."""
+    return MonoPortNet(_options("PIFuResBlkFilters", "PIFuNetCMLP", "L1"))

@@ -1,0 +1,158 @@
+"""Image encoders of the PIFu networks, run once per frame under PyTorch-ROCm (MIOpen convs).
+
+Only the two encoders the reference's configs select are provided:
+
+* ``HGFilter`` / ``PIFuHGFilters``      -- 4-stack hourglass, netG  (backbones/HGFilters.py:117-216)
+* ``ResnetFilter`` / ``PIFuResBlkFilters`` -- 6 residual blocks, netC (backbones/ResBlkFilters.py:87-147)
+
+Parameter names and shapes follow the reference's state dicts exactly, so ``load_state_dict`` /
+``load_legacy_pifu`` accept the published checkpoints.  The modules are written for inference:
+the forward passes avoid in-place aliasing tricks and keep activations in whatever memory format
+the caller chose (``.to(memory_format=torch.channels_last)`` is honoured end to end).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_GROUPS = 32  # GroupNorm(32, C) everywhere (HGFilters.py:23-27, ResBlkFilters.py:19)
+
+
+def _gn(channels):
+    return nn.GroupNorm(_GROUPS, channels)
+
+
+class ConvBlock(nn.Module):
+    """Pre-activation pyramid block: three GN-ReLU-3x3 convs of widths C/2, C/4, C/4 whose
+    outputs are concatenated and added to a (projected) shortcut (HGFilters.py:12-62)."""
+
+    def __init__(self, c_in, c_out):
+        super().__init__()
+        half, quarter = c_out // 2, c_out // 4
+        self.conv1 = nn.Conv2d(c_in, half, 3, 1, 1, bias=False)
+        self.conv2 = nn.Conv2d(half, quarter, 3, 1, 1, bias=False)
+        self.conv3 = nn.Conv2d(quarter, quarter, 3, 1, 1, bias=False)
+        self.bn1 = _gn(c_in)
+        self.bn2 = _gn(half)
+        self.bn3 = _gn(quarter)
+        self.bn4 = _gn(c_in)  # always present in the checkpoints, used only by the projection
+        if c_in != c_out:
+            # indices 0 / 2 carry parameters: "downsample.0.*" aliases bn4, "downsample.2.weight"
+            self.downsample = nn.Sequential(self.bn4, nn.ReLU(), nn.Conv2d(c_in, c_out, 1, bias=False))
+        else:
+            self.downsample = None
+
+    def forward(self, x):
+        a = self.conv1(F.relu(self.bn1(x)))
+        b = self.conv2(F.relu(self.bn2(a)))
+        c = self.conv3(F.relu(self.bn3(b)))
+        shortcut = x if self.downsample is None else self.downsample(x)
+        return torch.cat((a, b, c), 1) + shortcut
+
+
+class HourGlass(nn.Module):
+    """Recursive hourglass of ``depth`` levels; children are named b1_k / b2_k / b3_k (+ b2_plus_1
+    at the bottom) as in HGFilters.py:75-86."""
+
+    def __init__(self, depth, channels):
+        super().__init__()
+        self.depth = depth
+        for level in range(depth, 0, -1):
+            self.add_module("b1_%d" % level, ConvBlock(channels, channels))
+            self.add_module("b2_%d" % level, ConvBlock(channels, channels))
+        self.add_module("b2_plus_1", ConvBlock(channels, channels))
+        for level in range(1, depth + 1):
+            self.add_module("b3_%d" % level, ConvBlock(channels, channels))
+
+    def _level(self, level, x):
+        skip = getattr(self, "b1_%d" % level)(x)
+        y = getattr(self, "b2_%d" % level)(F.avg_pool2d(x, 2, stride=2))
+        y = self._level(level - 1, y) if level > 1 else self.b2_plus_1(y)
+        y = getattr(self, "b3_%d" % level)(y)
+        # bicubic x2, align_corners=True (HGFilters.py:108)
+        y = F.interpolate(y, scale_factor=2, mode="bicubic", align_corners=True)
+        return skip + y
+
+    def forward(self, x):
+        return self._level(self.depth, x)
+
+
+class HGFilter(nn.Module):
+    """Stacked-hourglass encoder: [B,3,512,512] -> num_stack x ([B,256,128,128],)
+    (HGFilters.py:117-204 with the PIFu settings of :207-216: group norm, ave_pool down)."""
+
+    def __init__(self, num_stack=4, depth=2, dim=256):
+        super().__init__()
+        self.num_stack = num_stack
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3)
+        self.bn1 = _gn(64)
+        self.conv2 = ConvBlock(64, 128)
+        self.conv3 = ConvBlock(128, 128)
+        self.conv4 = ConvBlock(128, 256)
+        for i in range(num_stack):
+            self.add_module("m%d" % i, HourGlass(depth, 256))
+            self.add_module("top_m_%d" % i, ConvBlock(256, 256))
+            self.add_module("conv_last%d" % i, nn.Conv2d(256, 256, 1))
+            self.add_module("bn_end%d" % i, _gn(256))
+            self.add_module("l%d" % i, nn.Conv2d(256, dim, 1))
+            if i < num_stack - 1:
+                self.add_module("bl%d" % i, nn.Conv2d(256, 256, 1))
+                self.add_module("al%d" % i, nn.Conv2d(dim, 256, 1))
+
+    def forward(self, x, last_only=False):
+        """``last_only=True`` skips materialising the per-stack outputs nobody reads in eval mode
+        (MonoPortNet.py:63-64 keeps feats_stages[-1] only); the default matches the reference."""
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.avg_pool2d(self.conv2(x), 2, stride=2)
+        x = self.conv4(self.conv3(x))
+        outputs = []
+        for i in range(self.num_stack):
+            y = getattr(self, "top_m_%d" % i)(getattr(self, "m%d" % i)(x))
+            y = F.relu(getattr(self, "bn_end%d" % i)(getattr(self, "conv_last%d" % i)(y)))
+            out = getattr(self, "l%d" % i)(y)
+            outputs.append((out,))
+            if i < self.num_stack - 1:
+                x = x + getattr(self, "bl%d" % i)(y) + getattr(self, "al%d" % i)(out)
+        return outputs[-1:] if last_only else outputs
+
+
+def PIFuHGFilters(*args, **kwargs):
+    return HGFilter(num_stack=4, depth=2, dim=256)
+
+
+class _ResBlock(nn.Module):
+    """x + conv_block(x) with reflect padding (ResBlkFilters.py:28-84); children sit in a
+    Sequential named conv_block so that checkpoint keys line up (indices 1, 2, 5, 6)."""
+
+    def __init__(self, dim, last=False):
+        super().__init__()
+        layers = [nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3, bias=False), _gn(dim), nn.ReLU(),
+                  nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3, bias=False)]
+        if not last:
+            layers.append(_gn(dim))
+        self.conv_block = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return x + self.conv_block(x)
+
+
+class ResnetFilter(nn.Module):
+    """netC encoder: reflect-pad 7x7, two stride-2 convs, six residual blocks ->
+    [([B,256,128,128],)] (ResBlkFilters.py:87-139 with group norm, no tanh: :142-147)."""
+
+    def __init__(self, input_nc=3, ngf=64, n_blocks=6):
+        super().__init__()
+        layers = [nn.ReflectionPad2d(3), nn.Conv2d(input_nc, ngf, 7, bias=False), _gn(ngf), nn.ReLU()]
+        ch = ngf
+        for _ in range(2):
+            layers += [nn.Conv2d(ch, 2 * ch, 3, 2, 1, bias=False), _gn(2 * ch), nn.ReLU()]
+            ch *= 2
+        for i in range(n_blocks):
+            layers.append(_ResBlock(ch, last=(i == n_blocks - 1)))
+        self.model = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return [(self.model(x),)]
+
+
+def PIFuResBlkFilters(*args, **kwargs):
+    return ResnetFilter()

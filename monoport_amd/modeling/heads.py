@@ -1,0 +1,77 @@
+"""SurfaceClassifier: the skip-connected per-point MLP (mirror of
+monoport/lib/modeling/heads/SurfaceClassifier.py).
+
+The parameters live in ``filters.{i}`` Conv1d(k=1) modules so checkpoints load unchanged
+(weight [out, in, 1]); the arithmetic runs in the fused HIP query kernel, which reads a copy of
+the weights re-packed into MFMA fragment order.  The copy is refreshed automatically whenever a
+parameter tensor is replaced or modified in place.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+_ACT_CODES = {None: 0, "sigmoid": 1, "tanh": 2}
+
+
+class SurfaceClassifier(nn.Module):
+    def __init__(self, filter_channels, num_views=1, no_residual=False, last_op=None):
+        super().__init__()
+        if num_views != 1:
+            raise NotImplementedError("multi-view averaging (SurfaceClassifier.py:60-66) is unused "
+                                      "by the PIFu configs")
+        if no_residual:
+            raise NotImplementedError("only the skip-concat variant (no_residual=False) is used")
+        self.filter_channels = list(filter_channels)
+        self.num_views = num_views
+        self.no_residual = no_residual
+        if isinstance(last_op, nn.Sigmoid):
+            last_op = "sigmoid"
+        elif isinstance(last_op, nn.Tanh):
+            last_op = "tanh"
+        if last_op not in _ACT_CODES:
+            raise ValueError("last_op must be None, 'sigmoid' or 'tanh'")
+        self.last_op = last_op
+        c0 = self.filter_channels[0]
+        self.filters = nn.ModuleList()
+        for l in range(len(self.filter_channels) - 1):
+            c_in = self.filter_channels[l] + (c0 if l > 0 else 0)  # SurfaceClassifier.py:26-31
+            self.filters.append(nn.Conv1d(c_in, self.filter_channels[l + 1], 1))
+        self._packed = None
+        self._packed_key = None
+
+    # ---- packed-weight cache ------------------------------------------------------------------
+    def _weights_key(self):
+        key = []
+        for f in self.filters:
+            for p in (f.weight, f.bias):
+                key.append((p.data_ptr(), p._version, str(p.device)))
+        return tuple(key)
+
+    def packed(self):
+        """PackedMLP on the parameters' device, rebuilt if the weights changed."""
+        key = self._weights_key()
+        if self._packed is None or key != self._packed_key:
+            dev = self.filters[0].weight.device
+            ctx = ops.get_context(dev)
+            if self._packed is None or self._packed.ctx is not ctx:
+                self._packed = ops.PackedMLP(ctx, self.filter_channels, _ACT_CODES[self.last_op])
+            for i, f in enumerate(self.filters):
+                self._packed.load_layer(i, f.weight.detach(), f.bias.detach())
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, feature):
+        """[1, C_in, N] -> [1, C_out, N] on explicit features (SurfaceClassifier.py:39-71).
+        The reconstruction path never materialises this tensor -- see MonoPortNet.query."""
+        raise NotImplementedError(
+            "SurfaceClassifier.forward on explicit [B,C,N] features is not part of the "
+            "reconstruction path; use MonoPortNet.query (fused gather + MLP)")
+
+
+def PIFuNetGMLP(*args, **kwargs):
+    return SurfaceClassifier([257, 1024, 512, 256, 128, 1], 1, False, "sigmoid")
+
+
+def PIFuNetCMLP(*args, **kwargs):
+    return SurfaceClassifier([513, 1024, 512, 256, 128, 3], 1, False, "tanh")

@@ -265,3 +265,18 @@ def paint(x, y, values, channel_major, count, res, scale, bias, lo, hi):
                                _ptr(count), cap, int(res), float(scale), float(bias), float(lo),
                                float(hi), _ptr(image), _stream(image)), "mp_paint")
     return image
+
+
+def profile_begin(device, max_records=4096):
+    """Start bracketing fused-query launches on ``device`` with HIP events (bench.py roofline)."""
+    ctx = get_context(device)
+    ctx.check(ctx.lib.mp_profile_begin(ctx.handle, int(max_records)), "mp_profile_begin")
+
+
+def profile_end(device, capacity=4096):
+    """Stop and return the per-launch durations (ms, launch order) as a numpy array."""
+    ctx = get_context(device)
+    buf = (ctypes.c_float * capacity)()
+    n = ctypes.c_int(0)
+    ctx.check(ctx.lib.mp_profile_end(ctx.handle, buf, capacity, ctypes.byref(n)), "mp_profile_end")
+    return np.array(buf[:min(n.value, capacity)], dtype=np.float64)

@@ -1,0 +1,69 @@
+"""Drop-ins for RTL/recon.py (``pifu_calib``, ``forward_vertices``) and for the colorization
+closure of RTL/main.py:201-249, on top of the HIP kernels in csrc/vertices.hip."""
+import numpy as np
+import torch
+
+from . import ops
+from .modeling.MonoPortNet import capture_query
+
+_FLIP_Y = np.diag([1.0, -1.0, 1.0, 1.0])  # RTL/recon.py:6-11
+
+
+@torch.no_grad()
+def pifu_calib(extrinsic, intrinsic, device="cuda:0"):
+    """Calibration tensor [1,4,4] f32 = inv(K' E' diag(1,-1,1,1)) with the orthographic tweaks
+    K'[2,2]=K[0,0], K'[2,3]=0, E'[2,3]=0 (RTL/recon.py:4-25).  Host-side float64 numpy; inputs are
+    not modified."""
+    k = np.array(intrinsic, copy=True)
+    k[2, 2] = k[0, 0]
+    k[2, 3] = 0
+    e = np.array(extrinsic, copy=True)
+    e[2, 3] = 0
+    calib = np.linalg.inv(k @ e @ _FLIP_Y)
+    return torch.from_numpy(calib).unsqueeze(0).float().to(device)
+
+
+@torch.no_grad()
+def forward_vertices(sdf, direction="front"):
+    """Visible-surface vertices of an occupancy volume [1,1,D,H,W] (RTL/recon.py:27-89):
+    X, Y int64 [N], Z f32 [N] (sub-voxel depth), norm f32 [N,3]; four Nones for ``sdf is None``.
+    One host sync (N), like the reference's ``nonzero``."""
+    if sdf is None:
+        return None, None, None, None
+    x, y, z, n, count = ops.forward_vertices_raw(sdf, direction)
+    c = int(count.item())
+    return x[:c], y[:c], z[:c], n[:c]
+
+
+def color_matrix(b_min, b_max, resolution):
+    """voxel -> world matrix of RTL/main.py:204-210."""
+    mat = np.eye(4, dtype=np.float32)
+    length = np.asarray(b_max, np.float32).reshape(3) - np.asarray(b_min, np.float32).reshape(3)
+    for i in range(3):
+        mat[i, i] = length[i] / np.float32(resolution)
+    mat[0:3, 3] = np.asarray(b_min, np.float32).reshape(3)
+    return mat
+
+
+@torch.no_grad()
+def colorization(netC, feat_tensor_C, X, Y, Z, calib_tensor, norm=None, resolution=257,
+                 mat_color=None):
+    """[res,res,3] f32 render (RTL/main.py:212-249): normals as colour when ``norm`` is given,
+    else netC.query on the vertices mapped to world space; ``None`` passes through (:214-215)."""
+    if X is None:
+        return None
+    count = torch.tensor([X.shape[0]], dtype=torch.int32, device=X.device)
+    if norm is not None:
+        return ops.paint(X, Y, norm, 0, count, resolution, 0.5, 0.5, 0.0, 1.0)
+    if mat_color is None:
+        mat_color = color_matrix([-1, -1, -1], [1, 1, 1], resolution)
+    if torch.is_tensor(mat_color):
+        mat_color = mat_color.detach().cpu().numpy()
+    device = calib_tensor.device
+    feat_tensor_C = [[f.to(device) for f in feats] for feats in feat_tensor_C]  # main.py:229-230
+    X, Y, Z = X.to(device), Y.to(device), Z.to(device)
+    pts = ops.vertex_points(X, Y, Z.float(), count.to(device), resolution, mat_color)
+    binding = netC.bind(feat_tensor_C, calib_tensor)
+    preds = ops.query_counted(binding.mlp, binding.feat_hwc, pts, count.to(device), binding.calib,
+                              binding.z_scale)
+    return ops.paint(X, Y, preds, 1, count.to(device), resolution, 0.5, 0.5, -np.inf, np.inf)

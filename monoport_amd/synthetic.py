@@ -211,3 +211,28 @@ def blob_volume(res, seed, n_blobs=6, sharp=6.0):
     edge[[0, -1], :, :] = edge[:, [0, -1], :] = edge[:, :, [0, -1]] = True
     vol[edge] = 0.01
     return vol.astype(np.float32)
+
+
+def seeded_state_dict(shapes, seed):
+    """Deterministic weights for an encoder: ``shapes`` = {state_dict key: shape}.
+
+    Each tensor is drawn from a RandomState seeded by (seed, crc32(key)), so the result does not
+    depend on key order.  Keys that alias one parameter in the reference (``downsample.0.*`` is
+    ``bn4.*``, HGFilters.py:29-35) get identical values.  Conv weights ~ N(0, 2/fan_in), norm
+    scales ~ 1 + 0.1 N, biases ~ 0.1 N.
+    """
+    import zlib
+    out = {}
+    for key, shape in shapes.items():
+        canon = key.replace("downsample.0.", "bn4.")
+        rs = np.random.RandomState((seed * 1000003 + zlib.crc32(canon.encode())) % (2 ** 32))
+        shape = tuple(shape)
+        if len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            v = rs.standard_normal(shape) * math.sqrt(2.0 / fan_in)
+        elif key.endswith("weight"):
+            v = 1.0 + 0.1 * rs.standard_normal(shape)
+        else:
+            v = 0.1 * rs.standard_normal(shape)
+        out[key] = v.astype(np.float32)
+    return out

@@ -156,9 +156,65 @@ def gen_colorization():
     print("colorization", int(X.shape[0]), "verts")
 
 
+@torch.no_grad()
+def gen_encoders():
+    """netG.filter / netC.filter (MonoPortNet.py:31-46) under seeded weights; stores a strided
+    slice of every output (the full maps are 16-33 MB)."""
+    store = {}
+    netg, netc = ref_net("G"), ref_net("C")
+    for name, net in (("G", netg), ("C", netc)):
+        shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
+        sd = syn.seeded_state_dict(shapes, 71 if name == "G" else 72)
+        net.image_filter.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    img = torch.from_numpy(syn.synthetic_image(73))[None]
+    feats_g = netg.filter(img)
+    feats_c = netc.filter(img, feat_prior=feats_g[-1][-1])
+    assert len(feats_g) == 4 and len(feats_c) == 1
+    for i, st in enumerate(feats_g):
+        store["G%d" % i] = st[0][0, ::8, ::8, ::8].numpy()
+        store["G%d_stats" % i] = np.array([st[0].mean().item(), st[0].std().item()], np.float64)
+    store["C0"] = feats_c[0][0][0, ::8, ::8, ::8].numpy()
+    store["C0_stats"] = np.array([feats_c[0][0].mean().item(), feats_c[0][0].std().item()])
+    store["meta"] = np.array(["img=synthetic_image(73); seeds 71 (G) / 72 (C); slice [::8,::8,::8]"])
+    np.savez_compressed(os.path.join(OUT, "encoders.npz"), **store)
+    print("encoders", store["G3"].shape, store["C0"].shape, store["G3_stats"], store["C0_stats"])
+
+
+@torch.no_grad()
+def gen_pipeline():
+    """The per-frame call sequence of RTL/main.py:389-428 with the reference's netG.query as
+    query_func; the octree driver is OUR restatement (implicit_seg is not vendored)."""
+    import recon as ref_recon
+    from oracle import pifu_oracle as orc
+    net = ref_net("G")
+    load_mlp(net, syn.body_mlp("G", noise=0.05, seed=81))
+    f = syn.body_feat(256, 128, 128, 82)
+    feats = [[torch.zeros(1, 256, 2, 2)]] * 3 + [[torch.from_numpy(f)[None]]]
+    ext, intr = syn.scene_camera(24)
+    calib = ref_recon.pifu_calib(ext, intr, device="cpu")
+
+    def query_func(points):  # RTL/main.py:169-183 on [3,N] numpy
+        p = torch.from_numpy(points.T.copy())[None]          # [1,N,3]
+        samples = p.repeat(1, 1, 1).permute(0, 2, 1)        # [1,3,N]
+        return net.query(feats, points=samples, calibs=calib)[0][0, 0].numpy()
+
+    res = [9, 17, 33]
+    stats = []
+    sdf = orc.seg3d_lossless(query_func, [-1, -1, -1], [1, 1, 1], res, stats=stats)
+    X, Y, Z, norm = ref_recon.forward_vertices(torch.from_numpy(sdf)[None, None], "front")
+    img = torch.ones((res[-1], res[-1], 3))
+    img[X, Y, :] = ((norm + 1) / 2).clamp(0, 1)
+    np.savez_compressed(os.path.join(OUT, "pipeline.npz"), sdf=sdf, X=X.numpy(), Y=Y.numpy(),
+                        Z=Z.numpy(), norm=norm.numpy(), render_norm=img.numpy(),
+                        stats=np.array(stats), calib=calib.numpy(),
+                        meta=np.array(["mlp=body_mlp(G,noise=.05,seed=81) feat=body_feat(256,128,128,82) "
+                                       "scene_camera(24) res=[9,17,33]"]))
+    print("pipeline", stats, int(X.shape[0]), "verts; margin", float(np.abs(sdf - 0.5).min()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["query", "misc", "vertices", "color"]
+    which = sys.argv[1:] or ["query", "misc", "vertices", "color", "encoders", "pipeline"]
     if "query" in which:
         gen_query()
     if "misc" in which:
@@ -167,3 +223,7 @@ if __name__ == "__main__":
         gen_forward_vertices()
     if "color" in which:
         gen_colorization()
+    if "encoders" in which:
+        gen_encoders()
+    if "pipeline" in which:
+        gen_pipeline()
