@@ -27,7 +27,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from monoport_amd import ops, synthetic as syn  # noqa: E402
+from monoport_amd import ops, parallel, synthetic as syn  # noqa: E402
 from monoport_amd.modeling import PIFuNetG  # noqa: E402
 from monoport_amd.recon import pifu_calib  # noqa: E402
 
@@ -114,20 +114,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if int(os.environ.get("WORLD_SIZE", "1")) not in (1, args.gpus):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ["WORLD_SIZE"]))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    rank, world = parallel.init_from_env(backend="nccl", device=device)  # nccl = RCCL on ROCm
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     fr = FrameReconstructor(device)
     n_frames = args.steps + args.warmup
@@ -136,13 +133,11 @@ def main():
               for s in range(min(n_frames, 4))]
     calibs = [pifu_calib(*syn.scene_camera(3 * (s * world + rank)), device=device)
               for s in range(n_frames)]
-    gather_list = ([torch.empty((257, 257, 3), device=device) for _ in range(world)]
-                   if (dist is not None and rank == 0) else None)
+    gather = parallel.FrameGather((257, 257, 3), device=device, store=False)
 
     def one_step(s):
         render = fr.step(images[s % len(images)], calibs[s])
-        if dist is not None:
-            dist.gather(render, gather_list, dst=0)
+        gather.push(s, render)  # fixed-size per-frame result to rank 0 (no-op on one GPU)
         return render
 
     for s in range(args.warmup):
