@@ -127,24 +127,36 @@ __device__ __forceinline__ void mma_group(f32x16 (&acc)[MR][NR], const f32x4 (&a
         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][i], b[n][i], acc[m][n], 0, 0, 0);
 }
 
-// acc[MR][NR] += A[rows of this wave][K segment] * B[K segment][points].
+// acc[MR][NR] += A[rows of this wave][K segment] * B[K segment][points], in two calls:
+//   seg_prefetch : issue the first PF groups of A into the ring -- placed EARLY by the caller
+//                  (before the previous segment's epilogue / barrier) so L2 latency is hidden;
+//   seg_main     : the K loop.  Every iteration issues the A fragment PF groups ahead and the B
+//                  operand one group ahead, then the 4*MR*NR MFMAs of the current group.
 //   a: fragment stream of row block 0 at group 0 for this lane (float4 units); row block m is
 //      a + m * rb_stride; group g is + g * 64.
 //   b: LDS byte address of this lane's point row for column block 0; column block n is
 //      + n * 32 * ROWB; group g lives in 16-byte slot (2g + h) ^ (p & 15) = (2g) ^ swz.
-// PF groups of A are kept in flight (ring of PF+1 fragments, statically indexed); the loop is
-// deliberately NOT unrolled further: hipcc clusters every load of a big unrolled block at its top
-// and spills the accumulators.
-template <int MR, int NR, int PF, int ROWB>
-__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[MR][NR], const f32x4 *__restrict__ a,
-                                         int rb_stride, int n_groups, const unsigned char *b,
-                                         int swz) {
-  constexpr int RS = PF + 1;
-  f32x4 ring[RS][MR];
+// The loop is deliberately NOT unrolled beyond the ring size: hipcc clusters every load of a
+// big unrolled block at its top and spills the accumulators.
+template <int MR, int PF>
+__device__ __forceinline__ void seg_prefetch(f32x4 (&ring)[PF + 1][MR],
+                                             const f32x4 *__restrict__ a, int rb_stride,
+                                             int n_groups) {
 #pragma unroll
   for (int d = 0; d < PF; ++d)
 #pragma unroll
     for (int m = 0; m < MR; ++m) ring[d][m] = a[m * rb_stride + min(d, n_groups - 1) * 64];
+}
+
+template <int MR, int NR, int PF, int ROWB>
+__device__ __forceinline__ void seg_main(f32x16 (&acc)[MR][NR], f32x4 (&ring)[PF + 1][MR],
+                                         const f32x4 *__restrict__ a, int rb_stride, int n_groups,
+                                         const unsigned char *b, int swz) {
+  constexpr int RS = PF + 1;
+  f32x4 bcur[NR];
+#pragma unroll
+  for (int n = 0; n < NR; ++n)
+    bcur[n] = *reinterpret_cast<const f32x4 *>(b + n * 32 * ROWB + (swz << 4));
 #pragma unroll 1
   for (int g0 = 0; g0 < n_groups; g0 += RS) {
 #pragma unroll
@@ -153,41 +165,48 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[MR][NR], const f32x4 *__r
       const int gp = min(g + PF, n_groups - 1);
 #pragma unroll
       for (int m = 0; m < MR; ++m) ring[(r + PF) % RS][m] = a[m * rb_stride + gp * 64];
-      const int boff = ((2 * g) ^ swz) << 4;
-      f32x4 bf[NR];
+      const int boff = ((2 * min(g + 1, n_groups - 1)) ^ swz) << 4;
+      f32x4 bnxt[NR];
 #pragma unroll
       for (int n = 0; n < NR; ++n)
-        bf[n] = *reinterpret_cast<const f32x4 *>(b + n * 32 * ROWB + boff);
-      mma_group<MR, NR>(acc, ring[r % RS], bf);
+        bnxt[n] = *reinterpret_cast<const f32x4 *>(b + n * 32 * ROWB + boff);
+      // keep the prefetches ABOVE this group's MFMAs: left alone, hipcc sinks them to the end of
+      // the group (to recycle registers) and every group then starts with a full L2 round trip
+      __builtin_amdgcn_sched_barrier(0);
+      mma_group<MR, NR>(acc, ring[r % RS], bcur);
+#pragma unroll
+      for (int n = 0; n < NR; ++n) bcur[n] = bnxt[n];
     }
   }
 }
 
 // The z column: one k-step whose B operand is z_feat in lanes 0-31 and 0 in lanes 32-63.
 template <int MR, int NR>
-__device__ __forceinline__ void gemm_z(f32x16 (&acc)[MR][NR], const float *__restrict__ az,
+__device__ __forceinline__ void gemm_z(f32x16 (&acc)[MR][NR], const float (&az)[MR],
                                        const float (&zb)[NR]) {
 #pragma unroll
-  for (int m = 0; m < MR; ++m) {
-    const float a = az[m * 64];
+  for (int m = 0; m < MR; ++m)
 #pragma unroll
     for (int n = 0; n < NR; ++n)
-      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, zb[n], acc[m][n], 0, 0, 0);
-  }
+      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(az[m], zb[n], acc[m][n], 0, 0, 0);
 }
 
-// bias + leaky_relu(0.01) in place on a C-layout tile: register t of lane (j, h) holds
-// row (t & 3) + 8 (t >> 2) + 4 h of the 32-row block (cdna_hip_programming.md section 3).
-__device__ __forceinline__ void bias_lrelu(f32x16 &v, const float *__restrict__ bias32, int h) {
+// Accumulators start from the bias: register t of lane (j, h) of a C-layout tile holds row
+// (t & 3) + 8 (t >> 2) + 4 h of the 32-row block (cdna_hip_programming.md section 3), so the 16
+// registers are four 16-byte pieces of the bias vector.
+__device__ __forceinline__ void init_from_bias(f32x16 &v, const float *__restrict__ bias32, int h) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const f32x4 bq = *reinterpret_cast<const f32x4 *>(bias32 + 8 * q + 4 * h);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float y = v[4 * q + i] + bq[i];
-      v[4 * q + i] = y > 0.0f ? y : y * 0.01f;  // F.leaky_relu default slope, SurfaceClassifier.py:58
-    }
+    for (int i = 0; i < 4; ++i) v[4 * q + i] = bq[i];
   }
+}
+
+__device__ __forceinline__ void lrelu(f32x16 &v) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    v[t] = v[t] > 0.0f ? v[t] : v[t] * 0.01f;  // F.leaky_relu default slope, SurfaceClassifier.py:58
 }
 
 // Store a C-layout 32x32 tile into the hidden-chunk buffer, point-major: rows 8q+4h..+3 of a
@@ -239,29 +258,41 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
     float cal[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) cal[i] = calib[i];
-#pragma unroll 2
-    for (int i = 0; i < 16; ++i) {
-      const int p = 16 * wv + i;
-      const long long n = n0 + p;
-      const bool live_n = n < n_pts;
-      float px = 0, py = 0, pz = 0, x, y, z;
-      uint32_t code;
-      if (live_n) load_point(src, n, px, py, pz, code);
-      project(cal, px, py, pz, x, y, z);
-      const bool live = live_n && in_image(x, y);
-      const Taps t = make_taps(x, y, fh, fw, C, live);
+    // 4 points per batch: 16 (C=256) / 32 (C=512) independent 16-byte loads in flight per lane.
+    // Dead points (past the end / out of image) read a clamped in-bounds tap with weight 0, so
+    // the loads need no branch and the compiler can issue the whole batch back to back.
+    constexpr int GB = 4;
+#pragma unroll 1
+    for (int i0 = 0; i0 < 16; i0 += GB) {
+      Taps t[GB];
 #pragma unroll
-      for (int part = 0; part < C / 256; ++part) {
-        const int slot = lane + 64 * part;
-        f32x4 r = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (live) {
-          const f32x4 a = *reinterpret_cast<const f32x4 *>(feat + t.o[0] + 4 * slot);
-          const f32x4 b = *reinterpret_cast<const f32x4 *>(feat + t.o[1] + 4 * slot);
-          const f32x4 c = *reinterpret_cast<const f32x4 *>(feat + t.o[2] + 4 * slot);
-          const f32x4 d = *reinterpret_cast<const f32x4 *>(feat + t.o[3] + 4 * slot);
-          r = blend(a, b, c, d, t);
+      for (int u = 0; u < GB; ++u) {
+        const long long n = n0 + 16 * wv + i0 + u;
+        const bool live_n = n < n_pts;
+        float px = 0, py = 0, pz = 0, x, y, z;
+        uint32_t code;
+        if (live_n) load_point(src, n, px, py, pz, code);
+        project(cal, px, py, pz, x, y, z);
+        t[u] = make_taps(x, y, fh, fw, C, live_n && in_image(x, y));
+      }
+      f32x4 v[GB][C / 256][4];
+#pragma unroll
+      for (int u = 0; u < GB; ++u)
+#pragma unroll
+        for (int part = 0; part < C / 256; ++part)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            v[u][part][k] =
+                *reinterpret_cast<const f32x4 *>(feat + t[u].o[k] + 4 * (lane + 64 * part));
+#pragma unroll
+      for (int u = 0; u < GB; ++u) {
+        const int p = 16 * wv + i0 + u;
+#pragma unroll
+        for (int part = 0; part < C / 256; ++part) {
+          const int slot = lane + 64 * part;
+          const f32x4 r = blend(v[u][part][0], v[u][part][1], v[u][part][2], v[u][part][3], t[u]);
+          *reinterpret_cast<f32x4 *>(xs + p * ROWB + ((slot ^ (p & 15)) << 4)) = r;
         }
-        *reinterpret_cast<f32x4 *>(xs + p * ROWB + ((slot ^ (p & 15)) << 4)) = r;
       }
     }
 
@@ -282,63 +313,76 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
     const unsigned char *hrow = hb + j * kHbRowBytes;
 
     // ---------------- layers 0 + 1, fused over 64-row chunks of layer 0 ----------------
+    const float *wbase = mlp.base;
     f32x16 acc1[4][2];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc1[m][n][t] = 0.0f;
-
+    for (int m = 0; m < 4; ++m) {
+      init_from_bias(acc1[m][0], wbase + mlp.bias[1] + 32 * (4 * wv + m), h);
+      acc1[m][1] = acc1[m][0];
+    }
     {
       const int rb0 = wv >> 1, cb0 = wv & 1;  // this wave's tile inside a layer-0 chunk
-      const f32x4 *a1 = reinterpret_cast<const f32x4 *>((mlp.base + mlp.ah[1])) +
+      const f32x4 *a0 = reinterpret_cast<const f32x4 *>(wbase + mlp.ax[0]) + lane;
+      const f32x4 *a1 = reinterpret_cast<const f32x4 *>(wbase + mlp.ah[1]) +
                         (long long)(4 * wv) * (kHidden[0] / 8) * 64 + lane;
+      const float zz[1] = {zb[cb0]};
+      f32x4 ring0[4][1];
+      f32x16 acc0[1][1];
+      float az0[1];
+      seg_prefetch<1, 3>(ring0, a0 + (long long)rb0 * NGX * 64, 0, NGX);
+      init_from_bias(acc0[0][0], wbase + mlp.bias[0] + 32 * rb0, h);
+      az0[0] = (wbase + mlp.az[0])[rb0 * 64 + lane];
+#pragma unroll 1
       for (int ck = 0; ck < kHidden[0] / 64; ++ck) {
         // layer-0 rows [64 ck + 32 rb0, +32) x points [32 cb0, +32)
-        f32x16 acc0[1][1];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc0[0][0][t] = 0.0f;
         const int rb = 2 * ck + rb0;
-        gemm_seg<1, 1, 3, ROWB>(acc0,
-                                reinterpret_cast<const f32x4 *>((mlp.base + mlp.ax[0])) +
-                                    (long long)rb * NGX * 64 + lane,
-                                0, NGX, xrow + cb0 * 32 * ROWB, swz);
-        {
-          const float zz[1] = {zb[cb0]};
-          gemm_z<1, 1>(acc0, (mlp.base + mlp.az[0]) + rb * 64 + lane, zz);
-        }
-        bias_lrelu(acc0[0][0], (mlp.base + mlp.bias[0]) + 32 * rb, h);
+        seg_main<1, 1, 3, ROWB>(acc0, ring0, a0 + (long long)rb * NGX * 64, 0, NGX,
+                                xrow + cb0 * 32 * ROWB, swz);
+        // layer-1 weights of this chunk start streaming before the chunk is even stored
+        f32x4 ring1[2][4];
+        seg_prefetch<4, 1>(ring1, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8);
+        gemm_z<1, 1>(acc0, az0, zz);
+        lrelu(acc0[0][0]);
         store_hidden(hb, acc0[0][0], rb0, cb0, j, h);
+        // next chunk's layer-0 operands
+        const int rbn = min(rb + 2, kHidden[0] / 32 - 2 + rb0);
+        seg_prefetch<1, 3>(ring0, a0 + (long long)rbn * NGX * 64, 0, NGX);
+        init_from_bias(acc0[0][0], wbase + mlp.bias[0] + 32 * rbn, h);
+        az0[0] = (wbase + mlp.az[0])[rbn * 64 + lane];
         __syncthreads();
         // layer-1 rows [128 wv, +128) += W1[:, 64 ck .. +64) * chunk
-        gemm_seg<4, 2, 1, kHbRowBytes>(acc1, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8, hrow,
-                                       swz);
+        seg_main<4, 2, 1, kHbRowBytes>(acc1, ring1, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8,
+                                       hrow, swz);
         __syncthreads();
       }
       // skip segment of layer 1: W1[:, 1024 .. 1024 + C] * x, then the z column
-      gemm_seg<4, 2, 1, ROWB>(acc1,
-                              reinterpret_cast<const f32x4 *>((mlp.base + mlp.ax[1])) +
-                                  (long long)(4 * wv) * NGX * 64 + lane,
-                              NGX * 64, NGX, xrow, swz);
-      gemm_z<4, 2>(acc1, (mlp.base + mlp.az[1]) + (4 * wv) * 64 + lane, zb);
+      const f32x4 *a1x = reinterpret_cast<const f32x4 *>(wbase + mlp.ax[1]) +
+                         (long long)(4 * wv) * NGX * 64 + lane;
+      f32x4 ring1[2][4];
+      float az1[4];
+      seg_prefetch<4, 1>(ring1, a1x, NGX * 64, NGX);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) az1[m] = (wbase + mlp.az[1])[(4 * wv + m) * 64 + lane];
+      seg_main<4, 2, 1, ROWB>(acc1, ring1, a1x, NGX * 64, NGX, xrow, swz);
+      gemm_z<4, 2>(acc1, az1, zb);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) bias_lrelu(acc1[m][n], (mlp.base + mlp.bias[1]) + 32 * (4 * wv + m), h);
+        for (int n = 0; n < 2; ++n) lrelu(acc1[m][n]);
     }
 
     // ---------------- layer 2: rows [64 wv, +64), K = 512 hidden (8 chunks) + skip ----------------
     f32x16 acc2[2][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc2[m][n][t] = 0.0f;
+    for (int m = 0; m < 2; ++m) {
+      init_from_bias(acc2[m][0], wbase + mlp.bias[2] + 32 * (2 * wv + m), h);
+      acc2[m][1] = acc2[m][0];
+    }
     {
-      const f32x4 *a2 = reinterpret_cast<const f32x4 *>((mlp.base + mlp.ah[2])) +
+      const f32x4 *a2 = reinterpret_cast<const f32x4 *>(wbase + mlp.ah[2]) +
                         (long long)(2 * wv) * (kHidden[1] / 8) * 64 + lane;
+      f32x4 ring2[2][2];
+      seg_prefetch<2, 1>(ring2, a2, (kHidden[1] / 8) * 64, 8);
 #pragma unroll
       for (int ck = 0; ck < 8; ++ck) {
         if (wv == (ck >> 1)) {  // owner of hidden rows [64 ck, +64): row blocks 2(ck&1), +1
@@ -348,30 +392,34 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
             for (int n = 0; n < 2; ++n) store_hidden(hb, acc1[2 * (ck & 1) + mm][n], mm, n, j, h);
         }
         __syncthreads();
-        gemm_seg<2, 2, 1, kHbRowBytes>(acc2, a2 + ck * 8 * 64, (kHidden[1] / 8) * 64, 8, hrow,
-                                       swz);
+        seg_main<2, 2, 1, kHbRowBytes>(acc2, ring2, a2 + ck * 8 * 64, (kHidden[1] / 8) * 64, 8,
+                                       hrow, swz);
+        if (ck < 7) seg_prefetch<2, 1>(ring2, a2 + (ck + 1) * 8 * 64, (kHidden[1] / 8) * 64, 8);
         __syncthreads();
       }
-      gemm_seg<2, 2, 1, ROWB>(acc2,
-                              reinterpret_cast<const f32x4 *>((mlp.base + mlp.ax[2])) +
-                                  (long long)(2 * wv) * NGX * 64 + lane,
-                              NGX * 64, NGX, xrow, swz);
-      gemm_z<2, 2>(acc2, (mlp.base + mlp.az[2]) + (2 * wv) * 64 + lane, zb);
+      const f32x4 *a2x = reinterpret_cast<const f32x4 *>(wbase + mlp.ax[2]) +
+                         (long long)(2 * wv) * NGX * 64 + lane;
+      float az2[2];
+      seg_prefetch<2, 1>(ring2, a2x, NGX * 64, NGX);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) az2[m] = (wbase + mlp.az[2])[(2 * wv + m) * 64 + lane];
+      seg_main<2, 2, 1, ROWB>(acc2, ring2, a2x, NGX * 64, NGX, xrow, swz);
+      gemm_z<2, 2>(acc2, az2, zb);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) bias_lrelu(acc2[m][n], (mlp.base + mlp.bias[2]) + 32 * (2 * wv + m), h);
+        for (int n = 0; n < 2; ++n) lrelu(acc2[m][n]);
     }
 
     // ---------------- layer 3: rows [32 wv, +32), K = 256 hidden (4 chunks) + skip ----------------
     f32x16 acc3[1][2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int t = 0; t < 16; ++t) acc3[0][n][t] = 0.0f;
+    init_from_bias(acc3[0][0], wbase + mlp.bias[3] + 32 * wv, h);
+    acc3[0][1] = acc3[0][0];
     {
-      const f32x4 *a3 = reinterpret_cast<const f32x4 *>((mlp.base + mlp.ah[3])) +
+      const f32x4 *a3 = reinterpret_cast<const f32x4 *>(wbase + mlp.ah[3]) +
                         (long long)wv * (kHidden[2] / 8) * 64 + lane;
+      f32x4 ring3[4][1];
+      seg_prefetch<1, 3>(ring3, a3, 0, 8);
 #pragma unroll
       for (int ck = 0; ck < 4; ++ck) {
         if (wv == ck) {
@@ -381,16 +429,19 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
             for (int n = 0; n < 2; ++n) store_hidden(hb, acc2[mm][n], mm, n, j, h);
         }
         __syncthreads();
-        gemm_seg<1, 2, 3, kHbRowBytes>(acc3, a3 + ck * 8 * 64, 0, 8, hrow, swz);
+        seg_main<1, 2, 3, kHbRowBytes>(acc3, ring3, a3 + ck * 8 * 64, 0, 8, hrow, swz);
+        if (ck < 3) seg_prefetch<1, 3>(ring3, a3 + (ck + 1) * 8 * 64, 0, 8);
         __syncthreads();
       }
-      gemm_seg<1, 2, 3, ROWB>(acc3,
-                              reinterpret_cast<const f32x4 *>((mlp.base + mlp.ax[3])) +
-                                  (long long)wv * NGX * 64 + lane,
-                              0, NGX, xrow, swz);
-      gemm_z<1, 2>(acc3, (mlp.base + mlp.az[3]) + wv * 64 + lane, zb);
+      const f32x4 *a3x = reinterpret_cast<const f32x4 *>(wbase + mlp.ax[3]) +
+                         (long long)wv * NGX * 64 + lane;
+      float az3[1];
+      seg_prefetch<1, 3>(ring3, a3x, 0, NGX);
+      az3[0] = (wbase + mlp.az[3])[wv * 64 + lane];
+      seg_main<1, 2, 3, ROWB>(acc3, ring3, a3x, 0, NGX, xrow, swz);
+      gemm_z<1, 2>(acc3, az3, zb);
 #pragma unroll
-      for (int n = 0; n < 2; ++n) bias_lrelu(acc3[0][n], (mlp.base + mlp.bias[3]) + 32 * wv, h);
+      for (int n = 0; n < 2; ++n) lrelu(acc3[0][n]);
     }
 
     // ---------------- layer 4 (Cout x (128 + C + 1)) on the VALU ----------------
@@ -425,6 +476,7 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
 #pragma unroll
       for (int o = 0; o < COUT; ++o) sx[o] = 0.0f;
       constexpr int SLOTS = C / 16;  // 16-byte slots per quarter
+#pragma unroll 4
       for (int s = 0; s < SLOTS; ++s) {
         const int slot = wv * SLOTS + s;
         const f32x4 xv =

@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0,'.')
+sys.path.insert(0,__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from monoport_amd import synthetic as syn, ops
 dev="cuda:0"
 layers=syn.body_mlp("G",noise=0.05,seed=1); f=syn.body_feat(256,128,128,2)
