@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 from monoport_amd import ops, parallel, synthetic as syn  # noqa: E402
 from monoport_amd.modeling import PIFuNetG  # noqa: E402
+from monoport_amd.pipeline import FramePipeline  # noqa: E402
 from monoport_amd.recon import pifu_calib  # noqa: E402
 
 RESOLUTIONS = [17, 33, 65, 129, 257]  # RTL/main.py:187
@@ -50,30 +51,22 @@ def build_netg(device):
     return net.to(device), layers
 
 
-class FrameReconstructor:
-    """The per-frame stage chain of RTL/main.py:366-428 (geometry only), enqueued asynchronously."""
+def make_pipeline(device, depth, use_graph):
+    """`depth` frames in flight, each the stage chain of RTL/main.py:366-428 (geometry only)
+    captured in a hipGraph on its own stream (monoport_amd/pipeline.py)."""
+    net, _ = build_netg(device)
+    planes = torch.from_numpy(syn.body_feature_planes(128, 128)).to(device)
 
-    def __init__(self, device):
-        self.device = device
-        self.net, self.layers = build_netg(device)
-        self.mlp = self.net.surface_classifier.packed()
-        self.planes = torch.from_numpy(syn.body_feature_planes(128, 128)).to(device)
-        self.feat_hwc = torch.empty((128, 128, 256), dtype=torch.float32, device=device)
-        self.volume = torch.empty((257, 257, 257), dtype=torch.float32, device=device)
-        self.status = torch.zeros((1 + len(RESOLUTIONS),), dtype=torch.int32, device=device)
-
-    @torch.no_grad()
-    def step(self, image, calib):
-        feats = self.net.image_filter(image, last_only=True)  # eval reads the last stack only
-        feat = feats[-1][0]
+    def body_planes_hook(feat):
         # synthetic-data hook: the analytic F-body head reads channels 0/1 as depth planes; the
         # other 254 channels are the encoder's output (consumed through the seeded-noise weights)
-        feat[0, 0:2] = self.planes
-        ops.pack_features(feat, out=self.feat_hwc)
-        ops.recon(self.mlp, self.feat_hwc, calib, syn.Z_SCALE, B_MIN, B_MAX, RESOLUTIONS, 0.5,
-                  volume=self.volume, status=self.status)
-        x, y, z, nrm, count = ops.forward_vertices_raw(self.volume, "front")
-        return ops.paint(x, y, nrm, 0, count, 257, 0.5, 0.5, 0.0, 1.0)  # normal render
+        feat[0, 0:2].copy_(planes)
+
+    pipe = FramePipeline(net, device, depth=depth, resolutions=RESOLUTIONS, b_min=B_MIN,
+                         b_max=B_MAX, balance=0.5, feature_hook=body_planes_hook,
+                         use_graph=use_graph)
+    pipe.prepare()
+    return pipe
 
 
 def cpu_baseline(threads):
@@ -111,6 +104,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--depth", type=int, default=3, help="frames in flight per GPU")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay each frame as a hipGraph (experimental: faults on ROCm 7.2 when "
+                         "tensors are allocated after capture; eager launches are within ~4%%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -126,7 +123,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-    fr = FrameReconstructor(device)
+    pipe = make_pipeline(device, args.depth, args.graph)
     n_frames = args.steps + args.warmup
     # distinct frames per rank: frame id = step * world + rank (frame-parallel sharding)
     images = [torch.from_numpy(syn.synthetic_image(s * world + rank))[None].to(device)
@@ -134,30 +131,45 @@ def main():
     calibs = [pifu_calib(*syn.scene_camera(3 * (s * world + rank)), device=device)
               for s in range(n_frames)]
     gather = parallel.FrameGather((257, 257, 3), device=device, store=False)
+    status_log = []
 
-    def one_step(s):
-        render = fr.step(images[s % len(images)], calibs[s])
-        gather.push(s, render)  # fixed-size per-frame result to rank 0 (no-op on one GPU)
-        return render
+    def one_step(s, log):
+        slot = pipe.submit(images[s % len(images)], calibs[s])
+        with torch.cuda.stream(slot.stream):
+            gather.push(s, slot.render)  # fixed-size per-frame result to rank 0 (no-op on one GPU)
+            if log:
+                status_log.append(slot.status.clone())  # device-side copy, no sync
 
     for s in range(args.warmup):
-        one_step(s)
+        one_step(s, False)
+    pipe.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    ops.profile_begin(device, max_records=8 * args.steps + 8)
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pts_total = 0
-    status_log = []
     for s in range(args.warmup, n_frames):
-        one_step(s)
-        status_log.append(fr.status.clone())  # device-side copy, no sync
+        one_step(s, True)
+    pipe.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+
+    # roofline leg: the same frames again on ONE stream, eagerly, with every fused-query launch
+    # bracketed by HIP events on its launch stream (hipGraph replays cannot be bracketed, and
+    # concurrent frames would share CUs) -> per-launch durations of the dominant kernel
+    prof_slot = pipe.slots[0]
+    prof_status = []
+    ops.profile_begin(device, max_records=8 * args.steps + 8)
+    with torch.cuda.stream(prof_slot.stream):
+        for s in range(args.warmup, n_frames):
+            prof_slot.image.copy_(images[s % len(images)])
+            prof_slot.calib.copy_(calibs[s])
+            prof_slot._chain()
+            prof_status.append(prof_slot.status.clone())
+    prof_slot.stream.synchronize()
     launch_ms = ops.profile_end(device, capacity=8 * args.steps + 8)
+    prof_pts = torch.stack(prof_status).cpu().numpy()[:, 1:]
 
     statuses = torch.stack(status_log).cpu().numpy()
     assert (statuses[:, 0] == 1).all(), "synthetic body must be non-empty"
@@ -172,8 +184,8 @@ def main():
     pts_all = float(p.item())
 
     if rank == 0:
-        n_launch = min(len(launch_ms), level_pts.size)
-        flops = level_pts.reshape(-1)[:n_launch].astype(np.float64) * FLOP_PER_POINT
+        n_launch = min(len(launch_ms), prof_pts.size)
+        flops = prof_pts.reshape(-1)[:n_launch].astype(np.float64) * FLOP_PER_POINT
         achieved = flops.sum() / (launch_ms[:n_launch].sum() * 1e-3) / 1e12 if n_launch else 0.0
         out = {
             "metric": "reconstructions/sec (512^2 in, 256^3 grid)",
@@ -193,7 +205,8 @@ def main():
                             "fp32 + fused query), octree 17-33-65-129-257 on [-1,1]^3, geometry only "
                             "(+forward_vertices, normal render)",
                 "frames_per_rank": args.steps,
-                "parallelism": "frame-parallel x%d" % world,
+                "parallelism": "frame-parallel x%d, %d frames in flight per GPU%s"
+                               % (world, args.depth, " (hipGraph replay)" if args.graph else ""),
                 "fixture": "F-body analytic head, seeded encoder (monoport_amd/synthetic.py)",
                 "points_per_recon": pts_all / (args.steps * world),
             },
