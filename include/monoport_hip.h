@@ -132,6 +132,18 @@ int mp_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *value
              int channel_major, const int32_t *count, int64_t capacity, int res, float scale,
              float bias, float lo, float hi, float *image, mp_stream stream);
 
+/* ---- triangle mesh (north star; no counterpart in the reference) ----------------- */
+/* Marching cubes of volume [R,R,R] at `level` (inside = value > level) with the face-consistent
+ * case table of tools/gen_mc_tables.py.  One welded vertex per crossing lattice edge, in edge-id
+ * order ((z*R+y)*R+x)*3 + axis, positioned at the linear crossing and mapped to world space like
+ * the octree lattice; triangles in cell order, wound counter-clockwise seen from the outside.
+ * verts f32 [max_verts,3], faces int32 [max_faces,3]; counts (device int32[2]) = vertices and
+ * faces NEEDED (compare with the capacities to detect truncation). */
+int mp_marching_cubes(mp_ctx *ctx, const float *volume, int r, float level,
+                      const float *b_min /*host[3]*/, const float *b_max /*host[3]*/, float *verts,
+                      int64_t max_verts, int32_t *faces, int64_t max_faces, int32_t *counts,
+                      mp_stream stream);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Brackets every fused-query kernel launch made through this context with a pair of HIP events
  * recorded on the launch stream (bench.py's roofline leg).  mp_profile_end waits for the last

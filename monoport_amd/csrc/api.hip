@@ -351,6 +351,22 @@ int mp_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *value
                       image, (hipStream_t)stream);
 }
 
+int mp_marching_cubes(mp_ctx *ctx, const float *volume, int r, float level, const float *b_min,
+                      const float *b_max, float *verts, int64_t max_verts, int32_t *faces,
+                      int64_t max_faces, int32_t *counts, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!volume || !b_min || !b_max || !counts || r < 2 || r > 1023 || max_verts < 0 ||
+      max_faces < 0 || (max_verts > 0 && !verts) || (max_faces > 0 && !faces))
+    return fail(ctx, MP_ERR_ARG, "mp_marching_cubes: bad argument");
+  DeviceGuard g(ctx->device);
+  void *scratch = nullptr;
+  int rc = ensure_scratch(ctx, (hipStream_t)stream, mc_scratch_bytes(r), &scratch);
+  if (rc != MP_OK) return rc;
+  return launch_marching_cubes(ctx, scratch, volume, r, level, b_min, b_max, verts, max_verts,
+                               faces, max_faces, counts, (hipStream_t)stream);
+}
+
 int mp_profile_begin(mp_ctx *ctx, int max_records) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);

@@ -57,6 +57,12 @@ struct Mlp {
   MlpPack pack() const;
 };
 
+// mcubes.hip
+size_t mc_scratch_bytes(int r);
+int launch_marching_cubes(mp_ctx *ctx, void *scratch, const float *vol, int r, float level,
+                          const float *bmin, const float *bmax, float *verts, long long max_v,
+                          int32_t *faces, long long max_f, int32_t *counts, hipStream_t st);
+
 }  // namespace mp
 
 struct mp_ctx {
@@ -118,5 +124,11 @@ int launch_vertex_points(mp_ctx *ctx, const int64_t *x, const int64_t *y, const 
 int launch_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *vals, int ch_major,
                  const int32_t *count, long long cap, int res, float scale, float bias, float lo,
                  float hi, float *image, hipStream_t st);
+
+// mcubes.hip
+size_t mc_scratch_bytes(int r);
+int launch_marching_cubes(mp_ctx *ctx, void *scratch, const float *vol, int r, float level,
+                          const float *bmin, const float *bmax, float *verts, long long max_v,
+                          int32_t *faces, long long max_f, int32_t *counts, hipStream_t st);
 
 }  // namespace mp

@@ -267,6 +267,32 @@ def paint(x, y, values, channel_major, count, res, scale, bias, lo, hi):
     return image
 
 
+def marching_cubes_raw(volume, level=0.5, b_min=(-1, -1, -1), b_max=(1, 1, 1), max_verts=None,
+                       max_faces=None):
+    """mp_marching_cubes: capacity-sized (verts [max_v,3] f32, faces [max_f,3] int32,
+    counts int32[2] = needed vertices / faces) on device, no host sync."""
+    vol = volume
+    while vol.dim() > 3:
+        vol = vol[0]
+    vol = _f32c(vol)
+    r = vol.shape[0]
+    ctx = get_context(vol.device)
+    if max_verts is None:
+        max_verts = 12 * r * r  # a closed body at resolution r has O(r^2) surface cells
+    if max_faces is None:
+        max_faces = 2 * max_verts
+    dev = vol.device
+    verts = torch.empty((max_verts, 3), dtype=torch.float32, device=dev)
+    faces = torch.empty((max_faces, 3), dtype=torch.int32, device=dev)
+    counts = torch.empty((2,), dtype=torch.int32, device=dev)
+    bmin = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_min, np.float32).reshape(3)])
+    bmax = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_max, np.float32).reshape(3)])
+    ctx.check(ctx.lib.mp_marching_cubes(ctx.handle, _ptr(vol), r, float(level), bmin, bmax,
+                                        _ptr(verts), max_verts, _ptr(faces), max_faces,
+                                        _ptr(counts), _stream(vol)), "mp_marching_cubes")
+    return verts, faces, counts
+
+
 def profile_begin(device, max_records=4096):
     """Start bracketing fused-query launches on ``device`` with HIP events (bench.py roofline)."""
     ctx = get_context(device)

@@ -67,3 +67,19 @@ def colorization(netC, feat_tensor_C, X, Y, Z, calib_tensor, norm=None, resoluti
     preds = ops.query_counted(binding.mlp, binding.feat_hwc, pts, count.to(device), binding.calib,
                               binding.z_scale)
     return ops.paint(X, Y, preds, 1, count.to(device), resolution, 0.5, 0.5, -np.inf, np.inf)
+
+
+@torch.no_grad()
+def marching_cubes(sdf, level=0.5, b_min=(-1, -1, -1), b_max=(1, 1, 1)):
+    """Triangle mesh of an occupancy volume [1,1,D,H,W] (or [D,H,W]): (verts [V,3] f32 world
+    coordinates, faces [F,3] int32), or (None, None) for ``sdf is None``.  Not part of the
+    reference (it renders from the volume directly); the mesh output the north star asks for.
+    One host sync (the two counts); retried once with exact capacities if the guess was short."""
+    if sdf is None:
+        return None, None
+    verts, faces, counts = ops.marching_cubes_raw(sdf, level, b_min, b_max)
+    nv, nf = (int(c) for c in counts.cpu())
+    if nv > verts.shape[0] or nf > faces.shape[0]:
+        verts, faces, counts = ops.marching_cubes_raw(sdf, level, b_min, b_max, max_verts=nv,
+                                                      max_faces=nf)
+    return verts[:nv], faces[:nf]

@@ -316,3 +316,77 @@ def dense_volume(query_func, b_min, b_max, res, res_final=None):
                    -1).reshape(-1, 3)
     return np.asarray(query_func(lattice_points(idx, stride, rf, b_min, b_max)),
                       np.float32).reshape(res, res, res)
+
+
+# ------------------------------------------------------------------------------------------
+# marching cubes (OUR variant -- the reference has none; table from tools/gen_mc_tables.py)
+# ------------------------------------------------------------------------------------------
+_mc = None
+
+
+def _mc_tables():
+    global _mc
+    if _mc is None:
+        t = np.load(os.path.join(_HERE, "mc_tables.npz"))
+        _mc = {k: t[k] for k in t.files}
+    return _mc
+
+
+def marching_cubes(vol, level=0.5, b_min=(-1, -1, -1), b_max=(1, 1, 1)):
+    """Mesh of volume [R,R,R] (z,y,x): verts [V,3] f32 world coords, faces [F,3] int32.
+
+    One welded vertex per lattice edge whose endpoints straddle ``level`` (inside = value >
+    level), ordered by edge id = ((z*R+y)*R+x)*3 + axis (axis 0 = x); placed at the linear crossing
+    t = (level - va)/(vb - va) and mapped to world space with the octree lattice convention
+    ((p/R) + (1/R)/2) * (b_max-b_min) + b_min.  Triangles: cells in (z,y,x) order, table order
+    within a cell, counter-clockwise seen from outside.
+    """
+    t = _mc_tables()
+    vol = np.asarray(vol, np.float32)
+    r = vol.shape[0]
+    lvl = np.float32(level)
+    inside = vol > lvl
+    vidx = -np.ones((r, r, r, 3), np.int64)
+    cross = np.zeros((r, r, r, 3), bool)
+    cross[:, :, :-1, 0] = inside[:, :, :-1] != inside[:, :, 1:]
+    cross[:, :-1, :, 1] = inside[:, :-1, :] != inside[:, 1:, :]
+    cross[:-1, :, :, 2] = inside[:-1, :, :] != inside[1:, :, :]
+    flat = cross.reshape(-1)
+    vidx.reshape(-1)[flat] = np.arange(int(flat.sum()))
+    zz, yy, xx, aa = np.nonzero(cross)  # ascending edge id
+    va = vol[zz, yy, xx]
+    vb = vol[zz + (aa == 2), yy + (aa == 1), xx + (aa == 0)]
+    tt = ((lvl - va) / (vb - va)).astype(np.float32)
+    pos = np.stack([xx, yy, zz], 1).astype(np.float32)
+    pos[np.arange(pos.shape[0]), aa] = pos[np.arange(pos.shape[0]), aa] + tt
+    rf = np.float32(r)
+    half_step = np.float32(np.float32(1.0) / rf) / np.float32(2)
+    bmin = np.asarray(b_min, np.float32).reshape(3)
+    blen = np.asarray(b_max, np.float32).reshape(3) - bmin
+    verts = ((pos / rf + half_step).astype(np.float32) * blen + bmin).astype(np.float32)
+
+    case = np.zeros((r - 1, r - 1, r - 1), np.int32)
+    for i in range(8):
+        dx, dy, dz = i & 1, (i >> 1) & 1, (i >> 2) & 1
+        case |= inside[dz:r - 1 + dz, dy:r - 1 + dy, dx:r - 1 + dx].astype(np.int32) << i
+    cz, cy, cx = np.nonzero(t["count"][case] > 0)
+    cc = case[cz, cy, cx]
+    faces = []
+    for k in range(t["tri"].shape[1]):
+        sel = t["count"][cc] > k
+        if not sel.any():
+            break
+        tri = t["tri"][cc[sel], k]  # [n,3] edge ids
+        own = t["owner"][tri]       # [n,3,4]: dx,dy,dz,axis
+        f = vidx[cz[sel, None] + own[..., 2], cy[sel, None] + own[..., 1],
+                 cx[sel, None] + own[..., 0], own[..., 3]]
+        order = np.nonzero(sel)[0] * 8 + k  # cell-major, then table order
+        faces.append((order, f))
+    if faces:
+        order = np.concatenate([o for o, _ in faces])
+        f = np.concatenate([f for _, f in faces])
+        f = f[np.argsort(order, kind="stable")]
+    else:
+        f = np.zeros((0, 3), np.int64)
+    assert (f >= 0).all()
+    return verts, f.astype(np.int32)

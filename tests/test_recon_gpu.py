@@ -124,3 +124,44 @@ def test_colorization_vs_reference(ops):
     preds = ops.query_counted(mlp, fh, pts, count, torch.from_numpy(g["calib"]).to(DEV), syn.Z_SCALE)
     img_t = ops.paint(x, y, preds, 1, count, res, 0.5, 0.5, -np.inf, np.inf)
     assert np.abs(img_t.cpu().numpy() - g["tex_image"]).max() <= 1e-4
+
+
+def _sphere(r, radius=0.6, sharp=8.0):
+    g = ((np.arange(r) + 0.5) / r) * 2 - 1
+    z, y, x = np.meshgrid(g, g, g, indexing="ij")
+    d = np.sqrt(x * x + y * y + z * z)
+    return (1.0 / (1.0 + np.exp(-sharp * (radius - d) / radius))).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["blob33", "sphere65", "empty9", "recon129"])
+def test_marching_cubes_identical_connectivity(ops, oracle, body, name):
+    """Triangle connectivity identical to the CPU oracle, vertices to 1e-6 (self-parity: the
+    reference has no marching cubes)."""
+    from monoport_amd.recon import marching_cubes
+    if name == "blob33":
+        vol = syn.blob_volume(33, 5)
+    elif name == "sphere65":
+        vol = _sphere(65)
+    elif name == "empty9":
+        vol = np.zeros((9, 9, 9), np.float32)
+    else:
+        v, _ = ops.recon(body["mlp"], body["fh"], body["cal"], syn.Z_SCALE, BMIN, BMAX,
+                         [17, 33, 65, 129])
+        vol = v.cpu().numpy()
+    verts, faces = marching_cubes(torch.from_numpy(vol).to(DEV)[None, None], 0.5, BMIN, BMAX)
+    rv, rf = oracle.marching_cubes(vol, 0.5, BMIN, BMAX)
+    assert tuple(verts.shape) == rv.shape and tuple(faces.shape) == rf.shape
+    assert faces.dtype == torch.int32 and np.array_equal(faces.cpu().numpy(), rf)
+    if len(rv):
+        assert np.abs(verts.cpu().numpy() - rv).max() <= 1e-6
+
+
+def test_marching_cubes_capacity_retry_and_none(ops, oracle):
+    from monoport_amd.recon import marching_cubes
+    assert marching_cubes(None) == (None, None)
+    vol = torch.from_numpy(_sphere(33)).to(DEV)
+    v, f, counts = ops.marching_cubes_raw(vol, max_verts=10, max_faces=10)
+    nv, nf = counts.cpu().tolist()
+    rv, rf = oracle.marching_cubes(_sphere(33))
+    assert (nv, nf) == (len(rv), len(rf))  # needed sizes are reported even when truncated
+    assert np.array_equal(f.cpu().numpy(), rf[:10])
