@@ -1,0 +1,174 @@
+// Memory-bound helper kernels for the image encoders.  The encoders stay
+// under PyTorch-ROCm (MIOpen convolutions); what PyTorch does badly at batch 1 on a 256-CU part
+// is everything between the convolutions:
+//   * GroupNorm(32, C) (+ReLU): torch launches RowwiseMoments on 32 workgroups (one per group,
+//     12 % of the CUs), a parameter kernel, an affine kernel and a ReLU kernel -- 4.6 ms / frame.
+//     Here: a split reduction over (group, slice) workgroups + one fused normalise/affine/ReLU pass.
+//   * bicubic x2 upsample (align_corners=True) + the hourglass skip add (HGFilters.py:108-111):
+//     one pass, 16 taps from L1/L2, instead of upsample + add.
+// Both are HBM-bound: bytes moved = 3x (GroupNorm: two reads + one write) resp. ~2.5x
+// (upsample-add) the tensor size; measured against the ~6.3 TB/s achievable HBM rate.
+#include "mp_internal.h"
+
+namespace mp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kGnSlices = 16;   // slices per group for the split reduction
+constexpr int kGnThreads = 256;
+
+// partial[(g * kGnSlices + s) * 2 + {0,1}] = sum, sum of squares (double) of slice s of group g
+__global__ __launch_bounds__(kGnThreads) void gn_partial_kernel(const float *__restrict__ x,
+                                                                long long group_elems,
+                                                                double *__restrict__ partial) {
+  const int g = blockIdx.x / kGnSlices, s = blockIdx.x % kGnSlices;
+  const long long per = (group_elems / 4 + kGnSlices - 1) / kGnSlices;  // float4 per slice
+  const long long v0 = s * per, v1 = min(v0 + per, group_elems / 4);
+  const f32x4 *xp = reinterpret_cast<const f32x4 *>(x + g * group_elems);
+  float s1 = 0.f, s2 = 0.f;  // per-thread f32 partials over <= a few hundred values
+  double d1 = 0.0, d2 = 0.0;
+  int k = 0;
+  for (long long i = v0 + threadIdx.x; i < v1; i += kGnThreads) {
+    const f32x4 v = xp[i];
+    s1 += (v[0] + v[1]) + (v[2] + v[3]);
+    s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    if (++k == 64) {  // flush to double regularly: keeps the f32 running sums short
+      d1 += s1;
+      d2 += s2;
+      s1 = s2 = 0.f;
+      k = 0;
+    }
+  }
+  d1 += s1;
+  d2 += s2;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    d1 += __shfl_down(d1, o);
+    d2 += __shfl_down(d2, o);
+  }
+  __shared__ double w1[kGnThreads / 64], w2[kGnThreads / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+    w1[wv] = d1;
+    w2[wv] = d2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0;
+    for (int i = 0; i < kGnThreads / 64; ++i) {
+      a += w1[i];
+      b += w2[i];
+    }
+    partial[2 * blockIdx.x] = a;
+    partial[2 * blockIdx.x + 1] = b;
+  }
+}
+
+// y = relu?((x - mean) * rstd * gamma[c] + beta[c]); one workgroup per (group, slice)
+__global__ __launch_bounds__(kGnThreads) void gn_apply_kernel(
+    const float *__restrict__ x, long long group_elems, int ch_per_group, long long hw,
+    const double *__restrict__ partial, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float eps, int relu, float *__restrict__ y) {
+  const int g = blockIdx.x / kGnSlices, s = blockIdx.x % kGnSlices;
+  double a = 0, b = 0;
+#pragma unroll
+  for (int i = 0; i < kGnSlices; ++i) {
+    a += partial[2 * (g * kGnSlices + i)];
+    b += partial[2 * (g * kGnSlices + i) + 1];
+  }
+  const double mean_d = a / (double)group_elems;
+  const double var_d = fmax(b / (double)group_elems - mean_d * mean_d, 0.0);
+  const float mean = (float)mean_d;
+  const float rstd = (float)(1.0 / sqrt(var_d + (double)eps));
+  const long long per = (group_elems / 4 + kGnSlices - 1) / kGnSlices;
+  const long long v0 = s * per, v1 = min(v0 + per, group_elems / 4);
+  const f32x4 *xp = reinterpret_cast<const f32x4 *>(x + g * group_elems);
+  f32x4 *yp = reinterpret_cast<f32x4 *>(y + g * group_elems);
+  for (long long i = v0 + threadIdx.x; i < v1; i += kGnThreads) {
+    const int c = g * ch_per_group + (int)((4 * i) / hw);  // hw % 4 == 0: one channel per float4
+    const float sc = rstd * gamma[c];
+    const float sh = beta[c] - mean * sc;
+    f32x4 v = xp[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float o = v[k] * sc + sh;
+      v[k] = (relu && o < 0.f) ? 0.f : o;
+    }
+    yp[i] = v;
+  }
+}
+
+size_t gn_scratch_bytes(int groups) { return (size_t)groups * kGnSlices * 2 * sizeof(double); }
+
+int launch_group_norm(mp_ctx *ctx, void *scratch, const float *x, int c, long long hw, int groups,
+                      const float *gamma, const float *beta, float eps, int relu, float *y,
+                      hipStream_t st) {
+  const int cpg = c / groups;
+  const long long ge = (long long)cpg * hw;
+  double *partial = static_cast<double *>(scratch);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(groups * kGnSlices), dim3(kGnThreads), 0, st, x, ge,
+                     partial);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(groups * kGnSlices), dim3(kGnThreads), 0, st, x, ge, cpg,
+                     hw, partial, gamma, beta, eps, relu, y);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+// ---- bicubic x2, align_corners=True, optional fused add ------------------------------------------
+// torch.nn.functional.interpolate(mode="bicubic", align_corners=True): source coordinate
+// = dst * (in-1)/(out-1); cubic convolution with A = -0.75; taps clamped to the border.
+__device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = 2.0f - t;
+  w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+  w[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+  w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+  w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+__global__ __launch_bounds__(256) void upsample_bicubic2x_kernel(const float *__restrict__ x, int c,
+                                                                 int h, int w,
+                                                                 const float *__restrict__ add,
+                                                                 float *__restrict__ y) {
+  const int ho = 2 * h, wo = 2 * w;
+  const long long total = (long long)c * ho * wo;
+  const float sy = (float)(h - 1) / (float)(ho - 1), sx = (float)(w - 1) / (float)(wo - 1);
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(t % wo), oy = (int)((t / wo) % ho);
+    const long long ch = t / ((long long)wo * ho);
+    const float ry = sy * oy, rx = sx * ox;
+    const float fy = floorf(ry), fx = floorf(rx);
+    const int iy = (int)fy, ix = (int)fx;
+    float wy[4], wx[4];
+    cubic_coeffs(ry - fy, wy);
+    cubic_coeffs(rx - fx, wx);
+    const float *src = x + ch * (long long)h * w;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int yy = min(max(iy - 1 + j, 0), h - 1);
+      float row = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int xx = min(max(ix - 1 + i, 0), w - 1);
+        row += src[yy * w + xx] * wx[i];
+      }
+      acc += row * wy[j];
+    }
+    y[t] = add ? add[t] + acc : acc;
+  }
+}
+
+int launch_upsample_bicubic2x(mp_ctx *ctx, const float *x, int c, int h, int w, const float *add,
+                              float *y, hipStream_t st) {
+  const long long total = (long long)c * 4 * h * w;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(upsample_bicubic2x_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, c, h, w,
+                     add, y);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+}  // namespace mp

@@ -14,11 +14,56 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+
 _GROUPS = 32  # GroupNorm(32, C) everywhere (HGFilters.py:23-27, ResBlkFilters.py:19)
 
 
+class _GroupNorm(nn.GroupNorm):
+    """nn.GroupNorm (same parameters / state-dict keys) whose inference forward on the GPU is the
+    split-reduction HIP kernel of csrc/encoder_ops.hip, optionally fused with the ReLU that
+    follows every norm but one in these encoders.  CPU tensors, training mode and unusual shapes
+    take the stock PyTorch op."""
+
+    def forward(self, x, relu=False):
+        if not self.training and ops.group_norm_supported(x):
+            return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, relu)
+        y = super().forward(x)
+        return F.relu(y) if relu else y
+
+
+class _GNReLU(nn.Module):
+    """ReLU placeholder used inside nn.Sequential right after a _GroupNorm: the pair is executed
+    as one fused call by _run_sequential."""
+
+    def forward(self, x):
+        return F.relu(x)
+
+
 def _gn(channels):
-    return nn.GroupNorm(_GROUPS, channels)
+    return _GroupNorm(_GROUPS, channels)
+
+
+def _run_sequential(seq, x):
+    """nn.Sequential forward that fuses each (_GroupNorm, ReLU) pair."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, _GroupNorm) and i + 1 < len(mods) and isinstance(mods[i + 1], (nn.ReLU, _GNReLU)):
+            x = m(x, relu=True)
+            i += 2
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
+def _upsample2x_add(low, skip):
+    """skip + bicubic x2 (align_corners=True) of ``low`` (HGFilters.py:108-111)."""
+    if low.is_cuda and low.shape[0] == 1 and low.dtype == torch.float32:
+        return ops.upsample_bicubic2x(low.contiguous(), add=skip.contiguous())
+    return skip + F.interpolate(low, scale_factor=2, mode="bicubic", align_corners=True)
 
 
 class ConvBlock(nn.Module):
@@ -42,10 +87,10 @@ class ConvBlock(nn.Module):
             self.downsample = None
 
     def forward(self, x):
-        a = self.conv1(F.relu(self.bn1(x)))
-        b = self.conv2(F.relu(self.bn2(a)))
-        c = self.conv3(F.relu(self.bn3(b)))
-        shortcut = x if self.downsample is None else self.downsample(x)
+        a = self.conv1(self.bn1(x, relu=True))
+        b = self.conv2(self.bn2(a, relu=True))
+        c = self.conv3(self.bn3(b, relu=True))
+        shortcut = x if self.downsample is None else _run_sequential(self.downsample, x)
         return torch.cat((a, b, c), 1) + shortcut
 
 
@@ -68,9 +113,8 @@ class HourGlass(nn.Module):
         y = getattr(self, "b2_%d" % level)(F.avg_pool2d(x, 2, stride=2))
         y = self._level(level - 1, y) if level > 1 else self.b2_plus_1(y)
         y = getattr(self, "b3_%d" % level)(y)
-        # bicubic x2, align_corners=True (HGFilters.py:108)
-        y = F.interpolate(y, scale_factor=2, mode="bicubic", align_corners=True)
-        return skip + y
+        # bicubic x2, align_corners=True, plus the skip (HGFilters.py:108-111) in one kernel
+        return _upsample2x_add(y, skip)
 
     def forward(self, x):
         return self._level(self.depth, x)
@@ -101,13 +145,13 @@ class HGFilter(nn.Module):
     def forward(self, x, last_only=False):
         """``last_only=True`` skips materialising the per-stack outputs nobody reads in eval mode
         (MonoPortNet.py:63-64 keeps feats_stages[-1] only); the default matches the reference."""
-        x = F.relu(self.bn1(self.conv1(x)))
+        x = self.bn1(self.conv1(x), relu=True)
         x = F.avg_pool2d(self.conv2(x), 2, stride=2)
         x = self.conv4(self.conv3(x))
         outputs = []
         for i in range(self.num_stack):
             y = getattr(self, "top_m_%d" % i)(getattr(self, "m%d" % i)(x))
-            y = F.relu(getattr(self, "bn_end%d" % i)(getattr(self, "conv_last%d" % i)(y)))
+            y = getattr(self, "bn_end%d" % i)(getattr(self, "conv_last%d" % i)(y), relu=True)
             out = getattr(self, "l%d" % i)(y)
             outputs.append((out,))
             if i < self.num_stack - 1:
@@ -132,7 +176,7 @@ class _ResBlock(nn.Module):
         self.conv_block = nn.Sequential(*layers)
 
     def forward(self, x):
-        return x + self.conv_block(x)
+        return x + _run_sequential(self.conv_block, x)
 
 
 class ResnetFilter(nn.Module):
@@ -151,7 +195,7 @@ class ResnetFilter(nn.Module):
         self.model = nn.Sequential(*layers)
 
     def forward(self, x):
-        return [(self.model(x),)]
+        return [(_run_sequential(self.model, x),)]
 
 
 def PIFuResBlkFilters(*args, **kwargs):

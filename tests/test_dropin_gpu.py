@@ -119,3 +119,26 @@ def test_encoder_on_gpu_close_to_reference():
     with torch.no_grad():
         fg = net.filter(img)
     assert np.abs(fg[3][0][0, ::8, ::8, ::8].cpu().numpy() - g["G3"]).max() <= 5e-3
+
+
+def test_group_norm_and_bicubic_kernels_match_torch():
+    """csrc/encoder_ops.hip against the stock PyTorch ops they replace inside the encoders."""
+    from monoport_amd import ops
+    torch.manual_seed(3)
+    for c, h, w in ((64, 256, 256), (256, 128, 128), (128, 64, 64), (256, 32, 32)):
+        x = (torch.randn(1, c, h, w, device=DEV) * 3 + 1.5)
+        gn = torch.nn.GroupNorm(32, c).to(DEV)
+        with torch.no_grad():
+            gn.weight.uniform_(0.5, 1.5)
+            gn.bias.uniform_(-0.5, 0.5)
+            ref = gn(x)
+            out = ops.group_norm(x, 32, gn.weight, gn.bias, gn.eps, relu=False)
+            out_r = ops.group_norm(x, 32, gn.weight, gn.bias, gn.eps, relu=True)
+        assert (out - ref).abs().max().item() <= 2e-5
+        assert torch.equal(out_r, torch.relu(out))
+    for c, h, w in ((256, 64, 64), (256, 32, 32), (8, 5, 7)):
+        x = torch.randn(1, c, h, w, device=DEV)
+        skip = torch.randn(1, c, 2 * h, 2 * w, device=DEV)
+        ref = torch.nn.functional.interpolate(x, scale_factor=2, mode="bicubic", align_corners=True)
+        assert (ops.upsample_bicubic2x(x) - ref).abs().max().item() <= 2e-5
+        assert (ops.upsample_bicubic2x(x, add=skip) - (skip + ref)).abs().max().item() <= 2e-5
