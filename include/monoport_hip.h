@@ -92,6 +92,12 @@ int mp_query(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w,
              const float *points, int64_t n, int64_t stride_n, int64_t stride_c,
              const float *calib, float z_scale, float *out, mp_stream stream);
 
+/* SurfaceClassifier.forward on explicit features (heads/SurfaceClassifier.py:39-71; the shape of
+ * the reference's own micro-benchmark, :95-116): feature [C+1,N] (sampled features + z_feat as
+ * the last row, MonoPortNet.py:82-83) -> out [Cout,N] with the last_op applied. */
+int mp_mlp_forward(mp_ctx *ctx, int mlp, const float *feature, int64_t n, float *out,
+                   mp_stream stream);
+
 /* Same, with the point count read from device memory at run time (netC.query over the vertices
  * forward_vertices found, RTL/main.py:239-242, without a host round trip).  points [3,capacity],
  * out [Cout,capacity]; only the first *count columns are read / written. */

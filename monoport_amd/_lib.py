@@ -31,6 +31,7 @@ SIGNATURES = {
     "mp_orthogonal": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "mp_query": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_i64, c_vp,
                          c_f32, c_vp, c_vp]),
+    "mp_mlp_forward": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp]),
     "mp_query_counted": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp,
                                  c_f32, c_vp, c_vp]),
     "mp_recon": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_f32, _pf32, _pf32, _pint,

@@ -259,6 +259,28 @@ int mp_query(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, c
   return launch_query(ctx, *m, feat_hwc, h, w, calib, z_scale, src, out, n, (hipStream_t)stream);
 }
 
+int mp_mlp_forward(mp_ctx *ctx, int mlp, const float *feature, int64_t n, float *out,
+                   mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const Mlp *m = get_mlp(ctx, mlp);
+  if (!m) return fail(ctx, MP_ERR_ARG, "mp_mlp_forward: unknown mlp id %d", mlp);
+  int rc = check_ready(ctx, m, m->c);
+  if (rc != MP_OK) return rc;
+  if (n < 0 || (n > 0 && (!feature || !out))) return fail(ctx, MP_ERR_ARG, "mp_mlp_forward: bad argument");
+  if (n == 0) return MP_OK;
+  PointSrc src;
+  std::memset(&src, 0, sizeof(src));
+  src.pts = feature;
+  src.sn = 1;
+  src.sc = n;
+  src.n = n;
+  src.out_stride = n;
+  DeviceGuard g(ctx->device);
+  return launch_query(ctx, *m, /*feat_hwc=*/nullptr, 0, 0, /*calib=*/nullptr, 0.0f, src, out, n,
+                      (hipStream_t)stream);
+}
+
 int mp_query_counted(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w,
                      const float *points, int64_t capacity, const int32_t *count,
                      const float *calib, float z_scale, float *out, mp_stream stream) {

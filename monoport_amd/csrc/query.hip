@@ -229,7 +229,10 @@ __device__ __forceinline__ float activate(float v, int act) {
 }
 
 // ---- the fused kernel ----------------------------------------------------------------------------
-template <int C, int COUT, int WPS>
+// DIRECT = true: SurfaceClassifier.forward on explicit features (SurfaceClassifier.py:39-71): the
+// "points" are columns of a [C+1, N] tensor (src.pts, row stride src.sc) that already holds the
+// sampled features and z_feat; no projection, no sampling, no mask.
+template <int C, int COUT, int WPS, bool DIRECT>
 __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
     MlpPack mlp, const float *__restrict__ feat, int fh, int fw, const float *__restrict__ calib,
     float z_scale, int act, PointSrc src, float *__restrict__ out) {
@@ -254,6 +257,26 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
 
     // ---------------- gather: 16 points per wave ----------------
     float zb[2];  // z_feat B operands of this wave's two column blocks
+    if constexpr (DIRECT) {
+      // lane = point; each wave moves C/16 four-channel slots: 4 coalesced 256-byte row loads,
+      // one conflict-free ds_write_b128
+      const long long n = n0 + lane;
+      const bool live = n < n_pts;
+      for (int s0 = wv; s0 < C / 4; s0 += 4) {
+        f32x4 r = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (live) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) r[k] = src.pts[(long long)(4 * s0 + k) * src.sc + n];
+        }
+        *reinterpret_cast<f32x4 *>(xs + lane * ROWB + ((s0 ^ (lane & 15)) << 4)) = r;
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const long long m = n0 + 32 * cb + j;
+        zb[cb] = (h == 0 && m < n_pts) ? src.pts[(long long)C * src.sc + m] : 0.0f;
+      }
+    } else {
+    // ---------------- gather: 16 points per wave ----------------
     {
     float cal[12];
 #pragma unroll
@@ -305,6 +328,7 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
       if (n < n_pts) load_point(src, n, px, py, pz, code);
       project(cal, px, py, pz, x, y, z);
       zb[cb] = (h == 0 && n < n_pts) ? __fmul_rn(z, z_scale) : 0.0f;
+    }
     }
     }
     __syncthreads();
@@ -497,23 +521,29 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
       const int o = tid / kTilePts, p = tid % kTilePts;
       const long long n = n0 + p;
       if (n < n_pts) {
-        float cal[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) cal[i] = calib[i];
-        float px, py, pz, x, y, z;
-        uint32_t code;
-        load_point(src, n, px, py, pz, code);
-        project(cal, px, py, pz, x, y, z);
         float v = (mlp.base + mlp.bias[4])[o];
 #pragma unroll
         for (int part = 0; part < 8; ++part) v += red[(part * COUT + o) * kTilePts + p];
-        v = fmaf((mlp.base + mlp.w4)[o * K4 + kHidden[3] + C], __fmul_rn(z, z_scale), v);
-        v = in_image(x, y) ? activate(v, act) : 0.0f;  // MonoPortNet.py:89
-        if (src.packed) {
-          const int ix = code & 1023u, iy = (code >> 10) & 1023u, iz = code >> 20;
-          out[((long long)iz * src.level_res + iy) * src.level_res + ix] = v;
+        const float wz = (mlp.base + mlp.w4)[o * K4 + kHidden[3] + C];
+        if constexpr (DIRECT) {
+          v = fmaf(wz, src.pts[(long long)C * src.sc + n], v);
+          out[o * src.out_stride + n] = activate(v, act);
         } else {
-          out[o * src.out_stride + n] = v;
+          float cal[12];
+#pragma unroll
+          for (int i = 0; i < 12; ++i) cal[i] = calib[i];
+          float px, py, pz, x, y, z;
+          uint32_t code;
+          load_point(src, n, px, py, pz, code);
+          project(cal, px, py, pz, x, y, z);
+          v = fmaf(wz, __fmul_rn(z, z_scale), v);
+          v = in_image(x, y) ? activate(v, act) : 0.0f;  // MonoPortNet.py:89
+          if (src.packed) {
+            const int ix = code & 1023u, iy = (code >> 10) & 1023u, iz = code >> 20;
+            out[((long long)iz * src.level_res + iy) * src.level_res + ix] = v;
+          } else {
+            out[o * src.out_stride + n] = v;
+          }
         }
       }
     }
@@ -561,12 +591,12 @@ __global__ void orthogonal_kernel(const float *__restrict__ pts, long long n,
 }
 
 // ---- host side -----------------------------------------------------------------------------------
-template <int C, int COUT, int WPS>
+template <int C, int COUT, int WPS, bool DIRECT>
 static int launch_query_t(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w,
                           const float *calib, float z_scale, const PointSrc &src, float *out,
                           long long max_points, hipStream_t st) {
   constexpr int lds = kTilePts * C * 4 + kHbBytes;
-  auto kern = pifu_query_kernel<C, COUT, WPS>;
+  auto kern = pifu_query_kernel<C, COUT, WPS, DIRECT>;
   static bool attr_set[16] = {};
   if (!attr_set[ctx->device & 15]) {
     MP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -595,9 +625,14 @@ static int launch_query_t(mp_ctx *ctx, const Mlp &m, const float *feat, int h, i
 int launch_query(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w, const float *calib,
                  float z_scale, const PointSrc &src, float *out, long long max_points,
                  hipStream_t st) {
-#define MP_QCASE(CC, CO, WP) \
-  if (m.c == CC && m.cout == CO) \
-    return launch_query_t<CC, CO, WP>(ctx, m, feat, h, w, calib, z_scale, src, out, max_points, st);
+#define MP_QCASE(CC, CO, WP)                                                                    \
+  if (m.c == CC && m.cout == CO) {                                                              \
+    if (feat == nullptr)                                                                        \
+      return launch_query_t<CC, CO, WP, true>(ctx, m, feat, h, w, calib, z_scale, src, out,     \
+                                              max_points, st);                                  \
+    return launch_query_t<CC, CO, WP, false>(ctx, m, feat, h, w, calib, z_scale, src, out,      \
+                                             max_points, st);                                   \
+  }
   MP_QCASE(256, 1, 2)
   MP_QCASE(256, 3, 2)
   MP_QCASE(512, 1, 1)

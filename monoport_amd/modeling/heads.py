@@ -62,11 +62,11 @@ class SurfaceClassifier(nn.Module):
         return self._packed
 
     def forward(self, feature):
-        """[1, C_in, N] -> [1, C_out, N] on explicit features (SurfaceClassifier.py:39-71).
-        The reconstruction path never materialises this tensor -- see MonoPortNet.query."""
-        raise NotImplementedError(
-            "SurfaceClassifier.forward on explicit [B,C,N] features is not part of the "
-            "reconstruction path; use MonoPortNet.query (fused gather + MLP)")
+        """[B, C_in, N] -> [B, C_out, N] on explicit features (SurfaceClassifier.py:39-71): the same
+        fused MFMA kernel as MonoPortNet.query with the gather stage reading the given features
+        (the reconstruction path itself never materialises this tensor)."""
+        mlp = self.packed()
+        return torch.cat([ops.mlp_forward(mlp, feature[b:b + 1]) for b in range(feature.shape[0])], 0)
 
 
 def PIFuNetGMLP(*args, **kwargs):

@@ -184,6 +184,19 @@ def query(mlp, feat_hwc, points, calib, z_scale):
     return out
 
 
+def mlp_forward(mlp, feature):
+    """SurfaceClassifier.forward: feature [1,C+1,N] -> [1,Cout,N] (mp_mlp_forward)."""
+    ctx = mlp.ctx
+    if feature.dim() != 3 or feature.shape[0] != 1 or feature.shape[1] != mlp.c + 1:
+        raise ValueError("feature must be [1,%d,N], got %s" % (mlp.c + 1, tuple(feature.shape)))
+    f = _f32c(feature)
+    n = f.shape[2]
+    out = torch.empty((1, mlp.cout, n), dtype=torch.float32, device=f.device)
+    ctx.check(ctx.lib.mp_mlp_forward(ctx.handle, mlp.id, _ptr(f), n, _ptr(out), _stream(f)),
+              "mp_mlp_forward")
+    return out
+
+
 def query_counted(mlp, feat_hwc, points, count, calib, z_scale, out=None):
     """mp_query_counted: points [3,cap] contiguous, count int32[1] on device -> [Cout,cap]."""
     ctx = mlp.ctx

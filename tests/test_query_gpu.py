@@ -136,3 +136,28 @@ def test_unsupported_shapes_fail_loudly(ops):
         ops.PackedMLP(ops.get_context("cuda:0"), [129, 1024, 512, 256, 128, 1], 1)
     with pytest.raises(MonoportError):
         ops.get_context("cpu")
+
+
+@pytest.mark.parametrize("kind,n", [("G", 5000), ("C", 777), ("G", 64), ("G", 1)])
+def test_surface_classifier_forward_on_explicit_features(ops, oracle, kind, n):
+    """SurfaceClassifier.forward (the reference's __main__ micro-benchmark shape,
+    heads/SurfaceClassifier.py:95-116) against a float64 numpy restatement of :47-69."""
+    from monoport_amd.modeling.heads import PIFuNetCMLP, PIFuNetGMLP
+    layers = syn.rand_mlp(kind, 23, 2.0)
+    head = (PIFuNetGMLP if kind == "G" else PIFuNetCMLP)()
+    head.load_state_dict({**{"filters.%d.weight" % i: torch.from_numpy(w)[:, :, None] for i, (w, _) in enumerate(layers)},
+                          **{"filters.%d.bias" % i: torch.from_numpy(b) for i, (_, b) in enumerate(layers)}})
+    head.to("cuda:0").eval()
+    rs = np.random.RandomState(n)
+    x = rs.standard_normal((syn.MLP_DIMS[kind][0], n)).astype(np.float32)
+    out = head(torch.from_numpy(x)[None].to("cuda:0"))[0].cpu().numpy()
+    y = x.astype(np.float64)
+    x64 = y
+    for i, (w, b) in enumerate(layers):
+        inp = y if i == 0 else np.concatenate([y, x64], 0)  # SurfaceClassifier.py:55
+        y = w.astype(np.float64) @ inp + b.astype(np.float64)[:, None]
+        if i != len(layers) - 1:
+            y = np.where(y > 0, y, 0.01 * y)
+    ref = 1 / (1 + np.exp(-y)) if kind == "G" else np.tanh(y)
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 2e-5
