@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from monoport_amd import ops, parallel, synthetic as syn  # noqa: E402
-from monoport_amd.modeling import PIFuNetG  # noqa: E402
+from monoport_amd.modeling import PIFuNetC, PIFuNetG  # noqa: E402
 from monoport_amd.pipeline import FramePipeline  # noqa: E402
 from monoport_amd.recon import pifu_calib  # noqa: E402
 
@@ -51,7 +51,20 @@ def build_netg(device):
     return net.to(device), layers
 
 
-def make_pipeline(device, depth, use_graph):
+def build_netc(device):
+    """netC with seeded random weights of the reference architecture (config 3)."""
+    net = PIFuNetC().eval()
+    shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
+    sd = syn.seeded_state_dict(shapes, 72)
+    net.image_filter.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    layers = syn.rand_mlp("C", 61, 2.0)
+    net.surface_classifier.load_state_dict(
+        {**{"filters.%d.weight" % i: torch.from_numpy(w)[:, :, None] for i, (w, _) in enumerate(layers)},
+         **{"filters.%d.bias" % i: torch.from_numpy(b) for i, (_, b) in enumerate(layers)}})
+    return net.to(device)
+
+
+def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False):
     """`depth` frames in flight, each the stage chain of RTL/main.py:366-428 (geometry only)
     captured in a hipGraph on its own stream (monoport_amd/pipeline.py)."""
     net, _ = build_netg(device)
@@ -62,11 +75,23 @@ def make_pipeline(device, depth, use_graph):
         # other 254 channels are the encoder's output (consumed through the seeded-noise weights)
         feat[0, 0:2].copy_(planes)
 
-    pipe = FramePipeline(net, device, depth=depth, resolutions=RESOLUTIONS, b_min=B_MIN,
-                         b_max=B_MAX, balance=0.5, feature_hook=body_planes_hook,
-                         use_graph=use_graph)
+    pipe = FramePipeline(net, device, depth=depth, resolutions=resolutions or RESOLUTIONS,
+                         b_min=B_MIN, b_max=B_MAX, balance=0.5, feature_hook=body_planes_hook,
+                         use_graph=use_graph, netC=build_netc(device) if with_color else None)
     pipe.prepare()
     return pipe
+
+
+def traffic_from_profile():
+    """HBM-side bytes per fused-query launch from the committed PMC pass (separate rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, corrected as MI355X_MICROARCH.md
+    prescribes); None if the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_query_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["bytes_per_launch_avg"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(threads):
@@ -108,6 +133,10 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay each frame as a hipGraph (experimental: faults on ROCm 7.2 when "
                          "tensors are allocated after capture; eager launches are within ~4%%)")
+    ap.add_argument("--with-color", action="store_true",
+                    help="BASELINE configs[2]: add netC (ResNet encoder + per-vertex colour MLP)")
+    ap.add_argument("--levels", type=int, default=5, choices=[5, 6],
+                    help="6 = octree to 513^3 (BASELINE configs[4] grid, f32 weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -123,20 +152,23 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-    pipe = make_pipeline(device, args.depth, args.graph)
+    resolutions = RESOLUTIONS + ([513] if args.levels == 6 else [])
+    pipe = make_pipeline(device, args.depth, args.graph, resolutions, args.with_color)
     n_frames = args.steps + args.warmup
     # distinct frames per rank: frame id = step * world + rank (frame-parallel sharding)
     images = [torch.from_numpy(syn.synthetic_image(s * world + rank))[None].to(device)
               for s in range(min(n_frames, 4))]
     calibs = [pifu_calib(*syn.scene_camera(3 * (s * world + rank)), device=device)
               for s in range(n_frames)]
-    gather = parallel.FrameGather((257, 257, 3), device=device, store=False)
+    r_last = resolutions[-1]
+    gather = parallel.FrameGather((r_last, r_last, 3), device=device, store=False)
     status_log = []
 
     def one_step(s, log):
         slot = pipe.submit(images[s % len(images)], calibs[s])
         with torch.cuda.stream(slot.stream):
-            gather.push(s, slot.render)  # fixed-size per-frame result to rank 0 (no-op on one GPU)
+            # fixed-size per-frame result to rank 0 (no-op on one GPU)
+            gather.push(s, slot.render_tex if args.with_color else slot.render)
             if log:
                 status_log.append(slot.status.clone())  # device-side copy, no sync
 
@@ -201,9 +233,13 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: single 512x512 image, netG (4-stack hourglass encoder "
-                            "fp32 + fused query), octree 17-33-65-129-257 on [-1,1]^3, geometry only "
-                            "(+forward_vertices, normal render)",
+                "workload": ("BASELINE configs[%d]: single 512x512 image, netG (4-stack hourglass encoder "
+                             "fp32 + fused query), octree %s on [-1,1]^3, %s"
+                             % (2 if args.with_color else (4 if args.levels == 6 else 1),
+                                "-".join(str(r) for r in resolutions),
+                                "geometry + netC per-vertex colour (ResNet encoder + colour MLP)"
+                                if args.with_color else
+                                "geometry only (+forward_vertices, normal render)")),
                 "frames_per_rank": args.steps,
                 "parallelism": "frame-parallel x%d, %d frames in flight per GPU%s"
                                % (world, args.depth, " (hipGraph replay)" if args.graph else ""),
@@ -218,13 +254,13 @@ def main():
                 "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic_from_profile(),
                 "launches": int(n_launch),
                 "avg_launch_ms": float(launch_ms[:n_launch].mean()) if n_launch else None,
                 "flop_per_point": FLOP_PER_POINT,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.with_color and args.levels == 5:
             # bounded thread count: torch-CPU convs at batch 1 collapse when oversubscribed
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))
         print(json.dumps(out), flush=True)

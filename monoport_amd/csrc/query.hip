@@ -337,6 +337,10 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
     const unsigned char *hrow = hb + j * kHbRowBytes;
 
     // ---------------- layers 0 + 1, fused over 64-row chunks of layer 0 ----------------
+    // NB: hipcc hoists ~70 lane-dependent weight addresses out of the tile loop and spills them in
+    // the workgroup prologue (139 KB of scratch per workgroup, visible as WRITE_SIZE).  Making the
+    // base opaque per tile removes the spills but measured 2 % SLOWER (address recomputation sits
+    // on the MFMA issue path), so the hoist stays.
     const float *wbase = mlp.base;
     f32x16 acc1[4][2];
 #pragma unroll

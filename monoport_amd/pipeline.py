@@ -25,8 +25,9 @@ class FrameSlot:
     RTL/main.py:366-428)."""
 
     def __init__(self, netG, device, resolutions=RESOLUTIONS, b_min=(-1, -1, -1), b_max=(1, 1, 1),
-                 balance=0.5, feature_hook=None, use_graph=False):
+                 balance=0.5, feature_hook=None, use_graph=False, netC=None):
         self.net = netG
+        self.netC = netC  # optional colour network: adds the texture stages of RTL/main.py:373-441
         self.device = torch.device(device)
         self.res = [int(r) for r in resolutions]
         self.b_min, self.b_max, self.balance = b_min, b_max, float(balance)
@@ -40,7 +41,13 @@ class FrameSlot:
         self.volume = torch.empty((r, r, r), dtype=torch.float32, device=dev)
         self.status = torch.zeros((1 + len(self.res),), dtype=torch.int32, device=dev)
         self.render = None
+        self.render_tex = None
         self.vertices = None
+        if netC is not None:
+            from .recon import color_matrix
+            self.feat_hwc_c = torch.empty((128, 128, 512), dtype=torch.float32, device=dev)
+            self.mat_color = color_matrix(b_min, b_max, r)
+            self.image_c = torch.zeros((1, 3, 512, 512), dtype=torch.float32, device=dev)
         self.graph = None
         self.use_graph = use_graph
         self.done = torch.cuda.Event()  # recorded after each frame's last kernel
@@ -58,6 +65,16 @@ class FrameSlot:
         x, y, z, nrm, count = ops.forward_vertices_raw(self.volume, "front")
         self.vertices = (x, y, z, nrm, count)
         self.render = ops.paint(x, y, nrm, 0, count, self.res[-1], 0.5, 0.5, 0.0, 1.0)
+        if self.netC is not None:
+            # netC.filter(image_c, feat_prior=featG_last) -> cat([prior, featC]) (MonoPortNet.py:41-45)
+            # packed straight into one channels-last map, then netC.query on the visible vertices
+            mlp_c = self.netC.surface_classifier.packed()
+            feat_c = self.netC.image_filter(self.image_c)[-1][0]
+            ops.pack_features([feat, feat_c], out=self.feat_hwc_c)
+            pts = ops.vertex_points(x, y, z, count, self.res[-1], self.mat_color)
+            preds = ops.query_counted(mlp_c, self.feat_hwc_c, pts, count, self.calib, Z_SCALE)
+            self.render_tex = ops.paint(x, y, preds, 1, count, self.res[-1], 0.5, 0.5,
+                                        -np.inf, np.inf)
 
     def prepare(self, warmup=2):
         """Warm up (MIOpen find, scratch arenas) and capture the chain into a hipGraph."""
@@ -71,7 +88,7 @@ class FrameSlot:
                 self._chain()
             self.stream.synchronize()
 
-    def submit(self, image, calib):
+    def submit(self, image, calib, image_c=None):
         """Enqueue one reconstruction of ``image`` [1,3,512,512] with ``calib`` [1,4,4]; returns
         immediately.  Results (``render``, ``volume``, ``status``, ``vertices``) are valid after
         ``stream.synchronize()`` and until the next submit on this slot."""
@@ -79,6 +96,8 @@ class FrameSlot:
         with torch.cuda.stream(self.stream):
             self.image.copy_(image, non_blocking=True)
             self.calib.copy_(calib, non_blocking=True)
+            if self.netC is not None:
+                self.image_c.copy_(image if image_c is None else image_c, non_blocking=True)
             if self.graph is not None:
                 self.graph.replay()
             else:
@@ -105,9 +124,9 @@ class FramePipeline:
         for s in self.slots:
             s.prepare()
 
-    def submit(self, image, calib):
+    def submit(self, image, calib, image_c=None):
         slot = self.slots[self.n_submitted % len(self.slots)]
-        slot.submit(image, calib)
+        slot.submit(image, calib, image_c)
         self.n_submitted += 1
         return slot
 

@@ -165,3 +165,37 @@ def test_marching_cubes_capacity_retry_and_none(ops, oracle):
     rv, rf = oracle.marching_cubes(_sphere(33))
     assert (nv, nf) == (len(rv), len(rf))  # needed sizes are reported even when truncated
     assert np.array_equal(f.cpu().numpy(), rf[:10])
+
+
+@pytest.mark.parametrize("res", [[17, 33, 65, 129, 257], [17, 33, 65, 129, 257, 513]])
+def test_full_size_properties(ops, oracle, body, res):
+    """BASELINE sizes (257^3 and 513^3): too large for the CPU oracle in a test, so check
+    size-independent properties of the coarse-to-fine volume."""
+    vol, status = ops.recon(body["mlp"], body["fh"], body["cal"], syn.Z_SCALE, BMIN, BMAX, res)
+    st = status.cpu().numpy()
+    r = res[-1]
+    assert st[0] == 1 and st[1] == res[0] ** 3
+    assert 0 < st[-1] < 0.05 * r ** 3  # the last level stays sparse
+    # (1) "lossless": on a random sample of ALL nodes the thresholded octree volume equals the
+    #     thresholded direct evaluation (dense evaluation of r^3 nodes is 40+ TFLOP)
+    rs = np.random.RandomState(r)
+    allpick = rs.randint(0, r, size=(50000, 3))
+    direct_all = body["gpu_query"](oracle.lattice_points(allpick, 1, r, BMIN, BMAX))
+    got_all = vol[allpick[:, 0], allpick[:, 1], allpick[:, 2]].cpu().numpy()
+    assert np.array_equal(got_all > 0.5, direct_all > 0.5)
+    # (2) surface voxels carry exact network values: the first-hit voxels of forward_vertices are
+    #     occupied nodes with an empty neighbour in front; re-query them directly
+    xf, yf, zf, _, cf = ops.forward_vertices_raw(vol, "front")
+    nf = int(cf.item())
+    z1 = (r - 1) - torch.ceil(zf[:nf]).long().clamp(0, r - 1)  # Z interpolates between z'-2 and z'
+    pick = torch.stack([z1, yf[:nf], xf[:nf]], 1)[:20000].cpu().numpy()
+    direct = body["gpu_query"](oracle.lattice_points(pick, 1, r, BMIN, BMAX))
+    got = vol[pick[:, 0], pick[:, 1], pick[:, 2]].cpu().numpy()
+    assert (got == direct).mean() >= 0.99 and np.abs(got - direct).max() < 0.5
+    # (3) idempotence: the same call again gives the same bits
+    vol2, _ = ops.recon(body["mlp"], body["fh"], body["cal"], syn.Z_SCALE, BMIN, BMAX, res)
+    assert torch.equal(vol, vol2)
+    # (4) a closed surface: forward_vertices from front and back see the same silhouette
+    xb, yb, _, _, cb = ops.forward_vertices_raw(vol, "back")
+    nb = int(cb.item())
+    assert nf == nb and torch.equal(xf[:nf], xb[:nb]) and torch.equal(yf[:nf], yb[:nb])
