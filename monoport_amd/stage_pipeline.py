@@ -1,0 +1,139 @@
+"""Thread-per-stage frame pipeline: the ``processors=[...]`` contract of the reference's forked
+DataLoader (RTL/dataloader.py:112-131, :734-751, :1026-1053) for torch 2.x.
+
+The reference file cannot even be imported on torch >= 1.9 (``torch._six``, RTL/dataloader.py:15),
+so this module re-creates the part of it the reconstruction demo relies on (RTL/main.py:326-464):
+
+* ``processors`` is a list of callables; stage k runs on its own daemon thread, fed by a FIFO
+  queue from stage k-1 (dataloader.py:734-751); different frames occupy different stages at the
+  same time and come out in submission order;
+* every stage thread starts with ``torch.set_num_threads(1)`` and ``torch.cuda.set_device``
+  (dataloader.py:1029-1031);
+* an exception inside a stage is captured, travels down the remaining queues untouched and is
+  re-raised in the consumer (``ExceptionWrapper``, dataloader.py:1042-1047, :909-914);
+* at most ``max_in_flight`` frames are admitted at once (the reference primes ``2 * num_workers``,
+  dataloader.py:776-777, :891).
+
+MI355X-specific addition: each stage thread owns a HIP stream; a frame is handed to the next
+stage together with an event recorded on the producer's stream, and the consumer's stream waits
+on it.  Stages therefore overlap on the GPU (not only on the host) without any
+``synchronize`` call.
+"""
+import queue
+import sys
+import threading
+
+import torch
+
+_END = object()
+
+
+def _record_streams(obj, stream, depth=0):
+    """Tell the caching allocator that ``stream`` uses every CUDA tensor reachable from ``obj``
+    (dict / list / tuple nesting as in the data_dict of RTL/main.py:326-452): a tensor allocated
+    on the producer stage's stream must not be recycled while a later stage still reads it."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif depth < 4:
+        if isinstance(obj, dict):
+            for v in obj.values():
+                _record_streams(v, stream, depth + 1)
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                _record_streams(v, stream, depth + 1)
+
+
+class StageError:
+    """An exception raised inside a stage, re-raised by the consumer with its stage index."""
+
+    def __init__(self, stage, exc_info):
+        self.stage = stage
+        self.exc_type, self.exc, self.tb = exc_info
+
+    def reraise(self):
+        raise RuntimeError("stage %d failed: %s: %s"
+                           % (self.stage, self.exc_type.__name__, self.exc)) from self.exc
+
+
+class StagePipeline:
+    def __init__(self, source, processors, device=None, max_in_flight=2, stage_streams=True):
+        """``source``: iterable of input items (the reference's data stream);
+        ``processors``: list of callables ``item -> item`` (e.g. the lambdas of RTL/main.py:326-452);
+        ``device``: torch device of the stage threads (None = CPU only, no streams)."""
+        self.source = source
+        self.processors = list(processors)
+        self.device = torch.device(device) if device is not None else None
+        self.max_in_flight = max(1, int(max_in_flight))
+        self.use_streams = bool(stage_streams and self.device is not None
+                                and self.device.type == "cuda")
+        self._threads = []
+
+    # ---- worker bodies ------------------------------------------------------------------------
+    def _stage_loop(self, idx, fn, q_in, q_out):
+        torch.set_num_threads(1)
+        stream = None
+        if self.device is not None and self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+            if self.use_streams:
+                stream = torch.cuda.Stream(device=self.device)
+        while True:
+            item = q_in.get()
+            if item is _END:
+                q_out.put(_END)
+                return
+            payload, event = item
+            if isinstance(payload, StageError):
+                q_out.put((payload, None))
+                continue
+            try:
+                if stream is not None:
+                    with torch.cuda.stream(stream):
+                        if event is not None:
+                            stream.wait_event(event)
+                        _record_streams(payload, stream)
+                        result = fn(payload)
+                        done = torch.cuda.Event()
+                        done.record(stream)
+                    q_out.put((result, done))
+                else:
+                    q_out.put((fn(payload), None))
+            except Exception:  # noqa: BLE001 -- forwarded to the consumer like ExceptionWrapper
+                q_out.put((StageError(idx, sys.exc_info()), None))
+
+    def _feeder(self, q0, slots):
+        try:
+            for item in self.source:
+                slots.acquire()
+                q0.put((item, None))
+        except Exception:  # noqa: BLE001
+            q0.put((StageError(-1, sys.exc_info()), None))
+        q0.put(_END)
+
+    # ---- consumer ---------------------------------------------------------------------------------
+    def __iter__(self):
+        queues = [queue.Queue() for _ in range(len(self.processors) + 1)]
+        slots = threading.Semaphore(self.max_in_flight)
+        self._threads = [threading.Thread(target=self._feeder, args=(queues[0], slots), daemon=True)]
+        for i, fn in enumerate(self.processors):
+            self._threads.append(threading.Thread(target=self._stage_loop,
+                                                  args=(i, fn, queues[i], queues[i + 1]),
+                                                  daemon=True))
+        for t in self._threads:
+            t.start()
+        while True:
+            item = queues[-1].get()
+            if item is _END:
+                break
+            payload, event = item
+            slots.release()
+            if isinstance(payload, StageError):
+                payload.reraise()
+            if event is not None:
+                # the consumer reads the result on its own current stream
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(event)
+                _record_streams(payload, cur)
+            yield payload
+        for t in self._threads:
+            t.join(timeout=5)

@@ -142,3 +142,79 @@ def test_group_norm_and_bicubic_kernels_match_torch():
         ref = torch.nn.functional.interpolate(x, scale_factor=2, mode="bicubic", align_corners=True)
         assert (ops.upsample_bicubic2x(x) - ref).abs().max().item() <= 2e-5
         assert (ops.upsample_bicubic2x(x, add=skip) - (skip + ref)).abs().max().item() <= 2e-5
+
+
+def test_processors_list_through_stage_pipeline():
+    """The hot-path stages of RTL/main.py:326-452 as a processors=[...] list on the torch-2.x
+    stage pipeline (thread + HIP stream per stage): results must equal sequential execution."""
+    from monoport_amd.implicit_seg.functional import Seg3dLossless
+    from monoport_amd.modeling import PIFuNetG
+    from monoport_amd.recon import colorization, forward_vertices, pifu_calib
+    from monoport_amd.stage_pipeline import StagePipeline
+
+    netG = PIFuNetG()
+    _load_mlp(netG, syn.body_mlp("G", noise=0.05, seed=81))
+    shapes = {k: tuple(v.shape) for k, v in netG.image_filter.state_dict().items()}
+    netG.image_filter.load_state_dict(
+        {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, 71).items()})
+    netG.to(DEV).eval()
+    planes = torch.from_numpy(syn.body_feature_planes(128, 128)).to(DEV)
+
+    def query_func(points, im_feat_list, calib_tensor):
+        return netG.query(im_feat_list, points=points.permute(0, 2, 1), calibs=calib_tensor)[0]
+
+    res = [9, 17, 33, 65]
+    reconEngine = Seg3dLossless(query_func=query_func, b_min=np.array([[-1., -1., -1.]]),
+                                b_max=np.array([[1., 1., 1.]]), resolutions=res, faster=True).to(DEV)
+    mean, std = 0.5, 0.5
+    step = [0]
+
+    def update_camera():
+        ext, intr = syn.scene_camera(step[0])
+        step[0] += 3
+        return ext, intr
+
+    def filt(d):
+        feats = netG.filter(d["input_netG"])
+        feats[-1][0][0, 0:2].copy_(planes)  # synthetic body planes (see bench.py)
+        return {**d, "feat_tensor_G": feats}
+
+    processors = [
+        lambda data: {"input": data.to(DEV, non_blocking=True)},                      # main.py:327
+        lambda d: {**d, **dict(zip(["extrinsic", "intrinsic"], update_camera()))},      # :330-336
+        lambda d: {**d, "calib_tensor": pifu_calib(d["extrinsic"], d["intrinsic"], device=DEV)},
+        lambda d: {**d, "input_netG": (((d["input"][:, 0:3] * 0.5 + 0.5) - mean) / std)
+                   * d["input"][:, 3:4]},                                             # :353-357
+        filt,                                                                          # :367-370
+        lambda d: {**d, "sdf": reconEngine(im_feat_list=d["feat_tensor_G"],
+                                           calib_tensor=d["calib_tensor"])},           # :390-395
+        lambda d: {**d, **dict(zip(["X", "Y", "Z", "norm"],
+                                   forward_vertices(d["sdf"], direction="front")))},   # :401-406
+        lambda d: {**d, "render_norm": colorization(None, None, d["X"], d["Y"], d["Z"],
+                                                    d["calib_tensor"], d["norm"],
+                                                    resolution=res[-1])},              # :418-428
+    ]
+    frames = []
+    for i in range(5):
+        img = torch.from_numpy(syn.synthetic_image(i))
+        mask = (img.abs().sum(0, keepdim=True) > 0).float()
+        frames.append(torch.cat([img, mask], 0)[None])
+
+    step[0] = 0
+    sequential = []
+    for f in frames:
+        d = f
+        for p in processors:
+            d = p(d)
+        sequential.append(d)
+    torch.cuda.synchronize()
+    step[0] = 0
+    piped = list(StagePipeline(frames, processors, device=DEV, max_in_flight=2))
+    torch.cuda.synchronize()
+    assert len(piped) == len(sequential) == 5
+    for a, b in zip(piped, sequential):
+        assert torch.equal(a["calib_tensor"], b["calib_tensor"])
+        assert torch.equal(a["sdf"], b["sdf"])
+        assert torch.equal(a["X"], b["X"]) and torch.equal(a["Z"], b["Z"])
+        assert torch.equal(a["render_norm"], b["render_norm"])
+    assert piped[0]["X"].shape[0] > 100
