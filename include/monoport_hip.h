@@ -138,6 +138,12 @@ int mp_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *value
              int channel_major, const int32_t *count, int64_t capacity, int res, float scale,
              float bias, float lo, float hi, float *image, mp_stream stream);
 
+/* visulization (sic, RTL/main.py:252-281) for one render: out[i,j,:] = 255 * image[rot90, nearest
+ * resized res -> size]; image [res,res,3] f32 in [0,1], out [size,size,3] f32, mask [size,size]
+ * uint8 = 0 where all three channels are exactly 255 (the white background), else 1. */
+int mp_visualize(mp_ctx *ctx, const float *image, int res, int size, float *out, uint8_t *mask,
+                 mp_stream stream);
+
 /* ---- triangle mesh (north star; no counterpart in the reference) ----------------- */
 /* Marching cubes of volume [R,R,R] at `level` (inside = value > level) with the face-consistent
  * case table of tools/gen_mc_tables.py.  One welded vertex per crossing lattice edge, in edge-id

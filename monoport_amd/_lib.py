@@ -40,6 +40,7 @@ SIGNATURES = {
     "mp_vertex_points": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, _pf32, c_vp, c_vp]),
     "mp_paint": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_f32, c_f32, c_f32,
                          c_f32, c_vp, c_vp]),
+    "mp_visualize": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "mp_marching_cubes": (c_int, [c_vp, c_vp, c_int, c_f32, _pf32, _pf32, c_vp, c_i64, c_vp, c_i64,
                                   c_vp, c_vp]),
     "mp_group_norm": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_f32, c_int, c_vp, c_vp]),

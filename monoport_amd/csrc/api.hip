@@ -373,6 +373,16 @@ int mp_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *value
                       image, (hipStream_t)stream);
 }
 
+int mp_visualize(mp_ctx *ctx, const float *image, int res, int size, float *out, uint8_t *mask,
+                 mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!image || !out || !mask || res < 1 || size < 1 || size > 16384)
+    return fail(ctx, MP_ERR_ARG, "mp_visualize: bad argument");
+  DeviceGuard g(ctx->device);
+  return launch_visualize(ctx, image, res, size, out, mask, (hipStream_t)stream);
+}
+
 int mp_marching_cubes(mp_ctx *ctx, const float *volume, int r, float level, const float *b_min,
                       const float *b_max, float *verts, int64_t max_verts, int32_t *faces,
                       int64_t max_faces, int32_t *counts, mp_stream stream) {

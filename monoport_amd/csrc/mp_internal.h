@@ -125,6 +125,8 @@ int launch_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *v
                  const int32_t *count, long long cap, int res, float scale, float bias, float lo,
                  float hi, float *image, hipStream_t st);
 
+int launch_visualize(mp_ctx *ctx, const float *image, int res, int size, float *out, uint8_t *mask,
+                     hipStream_t st);
 // mcubes.hip
 size_t mc_scratch_bytes(int r);
 int launch_marching_cubes(mp_ctx *ctx, void *scratch, const float *vol, int r, float level,

@@ -202,4 +202,34 @@ int launch_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *v
   return MP_OK;
 }
 
+// RTL/main.py:259-281: *255, torch.rot90(k=1, dims [0,1]) (out[i][j] = in[j][res-1-i]), nearest
+// resize to `size` (src = floor(dst * res / size), the legacy 'nearest' rule) and the white-
+// background mask, in one pass; the caller does the single D2H copy.
+__global__ void visualize_kernel(const float *__restrict__ image, int res, int size,
+                                 float *__restrict__ out, uint8_t *__restrict__ mask) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= size * size) return;
+  const int i = t / size, j = t % size;
+  const float scale = (float)res / (float)size;
+  const int si = min((int)floorf((float)i * scale), res - 1);
+  const int sj = min((int)floorf((float)j * scale), res - 1);
+  const float *src = image + ((long long)sj * res + (res - 1 - si)) * 3;
+  bool white = true;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = src[c] * 255.0f;
+    out[3 * (long long)t + c] = v;
+    white = white && v == 255.0f;
+  }
+  mask[t] = white ? 0 : 1;
+}
+
+int launch_visualize(mp_ctx *ctx, const float *image, int res, int size, float *out, uint8_t *mask,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(visualize_kernel, dim3((size * size + 255) / 256), dim3(256), 0, st, image, res,
+                     size, out, mask);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
 }  // namespace mp

@@ -280,6 +280,19 @@ def paint(x, y, values, channel_major, count, res, scale, bias, lo, hi):
     return image
 
 
+def visualize(image, size=256):
+    """mp_visualize: ([size,size,3] f32 = 255 * rot90 + nearest resize of ``image`` [res,res,3],
+    [size,size] uint8 foreground mask) on device."""
+    ctx = get_context(image.device)
+    img = _f32c(image)
+    res = img.shape[0]
+    out = torch.empty((size, size, 3), dtype=torch.float32, device=img.device)
+    mask = torch.empty((size, size), dtype=torch.uint8, device=img.device)
+    ctx.check(ctx.lib.mp_visualize(ctx.handle, _ptr(img), res, int(size), _ptr(out), _ptr(mask),
+                                   _stream(img)), "mp_visualize")
+    return out, mask
+
+
 def marching_cubes_raw(volume, level=0.5, b_min=(-1, -1, -1), b_max=(1, 1, 1), max_verts=None,
                        max_faces=None):
     """mp_marching_cubes: capacity-sized (verts [max_v,3] f32, faces [max_f,3] int32,

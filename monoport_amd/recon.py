@@ -83,3 +83,21 @@ def marching_cubes(sdf, level=0.5, b_min=(-1, -1, -1), b_max=(1, 1, 1)):
         verts, faces, counts = ops.marching_cubes_raw(sdf, level, b_min, b_max, max_verts=nv,
                                                       max_faces=nf)
     return verts[:nv], faces[:nf]
+
+
+@torch.no_grad()
+def visulization(render_norm, render_tex=None, render_size=256):
+    """(sic) RTL/main.py:252-281: both renders scaled to 0..255, rotated by 90 degrees,
+    nearest-resized to 256x256 and moved to the host as [256,256,3] numpy arrays, plus the
+    foreground mask (pixels that are not pure white) of the last render present."""
+    if render_norm is None and render_tex is None:
+        return None, None, None
+    outs, mask = [], None
+    for img in (render_norm, render_tex):
+        if img is None:
+            outs.append(None)
+            continue
+        out, m = ops.visualize(img.detach(), render_size)
+        outs.append(out.cpu().numpy())
+        mask = m
+    return outs[0], outs[1], mask.cpu().numpy().astype(bool).reshape(render_size, render_size, 1)

@@ -218,3 +218,46 @@ def test_processors_list_through_stage_pipeline():
         assert torch.equal(a["X"], b["X"]) and torch.equal(a["Z"], b["Z"])
         assert torch.equal(a["render_norm"], b["render_norm"])
     assert piped[0]["X"].shape[0] > 100
+
+
+def test_visulization_matches_reference_formula():
+    """RTL/main.py:252-281 restated with stock tensor ops on the CPU vs the one-pass kernel."""
+    import torch.nn.functional as F
+    from monoport_amd.recon import visulization
+    assert visulization(None, None) == (None, None, None)
+    rs = np.random.RandomState(0)
+    img = np.ones((257, 257, 3), np.float32)
+    idx = rs.randint(0, 257, size=(5000, 2))
+    img[idx[:, 0], idx[:, 1]] = rs.rand(5000, 3).astype(np.float32)
+    t = torch.from_numpy(img)
+    ref = torch.rot90(t * 255.0, 1, [0, 1]).permute(2, 0, 1).unsqueeze(0)
+    ref = F.interpolate(ref, size=(256, 256))[0].numpy().transpose(1, 2, 0)
+    bg = np.logical_and(np.logical_and(ref[:, :, 0] == 255, ref[:, :, 1] == 255), ref[:, :, 2] == 255)
+    n, tex, mask = visulization(t.to(DEV), None)
+    assert tex is None and np.array_equal(n, ref)
+    assert np.array_equal(mask, ~bg.reshape(256, 256, 1))
+
+
+def test_obj_export_and_vertex_colors(tmp_path):
+    from monoport_amd.mesh_util import save_obj_mesh, save_obj_mesh_with_color, vertex_colors
+    from monoport_amd.modeling import PIFuNetC
+    from monoport_amd.recon import marching_cubes
+    vol = torch.from_numpy(syn.blob_volume(33, 5)).to(DEV)
+    verts, faces = marching_cubes(vol[None, None])
+    netC = PIFuNetC()
+    _load_mlp(netC, syn.rand_mlp("C", 61, 2.0))
+    netC.surface_classifier.to(DEV)
+    netC.eval()
+    feat_C = [[torch.from_numpy(syn.rand_feat(512, 128, 128, 62))[None].to(DEV)]]
+    colors = vertex_colors(netC, feat_C, verts, torch.eye(4, device=DEV)[None])
+    assert colors.shape == verts.shape and float(colors.min()) >= 0 and float(colors.max()) <= 1
+    p1, p2 = tmp_path / "m.obj", tmp_path / "mc.obj"
+    save_obj_mesh(str(p1), verts, faces)
+    save_obj_mesh_with_color(str(p2), verts, faces, colors)
+    lines = open(p2).read().splitlines()
+    nv, nf = verts.shape[0], faces.shape[0]
+    assert len(lines) == nv + nf and len(open(p1).read().splitlines()) == nv + nf
+    v0 = lines[0].split()
+    assert v0[0] == "v" and len(v0) == 7 and abs(float(v0[1]) - float(verts[0, 0])) < 1e-4
+    f0 = lines[nv].split()
+    assert f0[0] == "f" and [int(a) for a in f0[1:]] == [int(a) + 1 for a in faces[0].tolist()]
