@@ -117,6 +117,23 @@ int mp_recon(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, c
              const int *resolutions /*host*/, int n_levels, float balance, float *volume,
              int32_t *status, mp_stream stream);
 
+/* The same engine one level at a time, for an arbitrary Python ``query_func`` (the general
+ * Seg3dLossless contract, RTL/main.py:169-195): the caller evaluates the selected nodes itself.
+ *   mp_octree_select: level 0 (prev == NULL) selects every node; otherwise upsamples prev [rp^3]
+ *     into cur [r^3] (r = 2 rp - 1), flags boundary nodes, dilates by the level's box, drops nodes
+ *     evaluated earlier.  ev_prev / ev_cur / bnd are u64 bitsets of r*r*ceil(r/64) words (rp for
+ *     ev_prev); packed (u32 [r^3]) receives x | y<<10 | z<<20, count (device int32) their number.
+ *   mp_lattice_points: packed nodes -> world points [capacity,3] (row i = x,y,z of node i).
+ *   mp_scatter_nodes: volume[z,y,x] = values[i] for the first *count nodes. */
+int mp_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
+                     const uint64_t *ev_prev, uint64_t *ev_cur, uint64_t *bnd, int level,
+                     float balance, uint32_t *packed, int32_t *count, mp_stream stream);
+int mp_lattice_points(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, int64_t capacity,
+                      int stride, int res_final, const float *b_min /*host[3]*/,
+                      const float *b_max /*host[3]*/, float *points, mp_stream stream);
+int mp_scatter_nodes(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, int64_t capacity,
+                     int r, const float *values, float *volume, mp_stream stream);
+
 /* ---- visible-surface extraction ------------------------------------------------------------ */
 /* forward_vertices (RTL/recon.py:27-89).  volume [R,R,R]; outputs sized for R*R rows:
  * X, Y int64 [R*R]; Z f32 [R*R]; norm f32 [R*R,3]; count (device int32[1]) = rows written,

@@ -335,6 +335,46 @@ int mp_recon(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, c
                       balance, volume, status, (hipStream_t)stream);
 }
 
+int mp_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
+                     const uint64_t *ev_prev, uint64_t *ev_cur, uint64_t *bnd, int level,
+                     float balance, uint32_t *packed, int32_t *count, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ev_cur || !packed || !count || r < 2 || r > 1023 || level < 0)
+    return fail(ctx, MP_ERR_ARG, "mp_octree_select: bad argument");
+  if (prev && (!cur || !ev_prev || !bnd || r != 2 * rp - 1 || level < 1))
+    return fail(ctx, MP_ERR_ARG, "mp_octree_select: refinement needs cur, ev_prev, bnd and r == 2 rp - 1");
+  DeviceGuard g(ctx->device);
+  return launch_octree_select(ctx, prev, rp, cur, r,
+                              reinterpret_cast<const unsigned long long *>(ev_prev),
+                              reinterpret_cast<unsigned long long *>(ev_cur),
+                              reinterpret_cast<unsigned long long *>(bnd), level, balance, packed,
+                              count, (hipStream_t)stream);
+}
+
+int mp_lattice_points(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, int64_t capacity,
+                      int stride, int res_final, const float *b_min, const float *b_max,
+                      float *points, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!packed || !count || capacity < 0 || stride < 1 || res_final < 2 || !b_min || !b_max ||
+      (capacity > 0 && !points))
+    return fail(ctx, MP_ERR_ARG, "mp_lattice_points: bad argument");
+  DeviceGuard g(ctx->device);
+  return launch_lattice_points(ctx, packed, count, capacity, stride, res_final, b_min, b_max,
+                               points, (hipStream_t)stream);
+}
+
+int mp_scatter_nodes(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, int64_t capacity,
+                     int r, const float *values, float *volume, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!packed || !count || capacity < 0 || r < 2 || !volume || (capacity > 0 && !values))
+    return fail(ctx, MP_ERR_ARG, "mp_scatter_nodes: bad argument");
+  DeviceGuard g(ctx->device);
+  return launch_scatter_nodes(ctx, packed, count, capacity, r, values, volume, (hipStream_t)stream);
+}
+
 int mp_forward_vertices(mp_ctx *ctx, const float *volume, int r, int direction, int64_t *x,
                         int64_t *y, float *z, float *norm, int32_t *count, mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;

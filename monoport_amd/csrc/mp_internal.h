@@ -115,6 +115,15 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, const float *feat_hwc
                  const float *calib, float z_scale, const float *bmin, const float *bmax,
                  const int *res, int n_levels, float balance, float *volume, int32_t *status,
                  hipStream_t st);
+int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
+                         const unsigned long long *ev_prev, unsigned long long *ev_cur,
+                         unsigned long long *bnd, int level, float balance, uint32_t *packed,
+                         int32_t *count, hipStream_t st);
+int launch_lattice_points(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, long long cap,
+                          int stride, int res_final, const float *bmin, const float *bmax,
+                          float *pts, hipStream_t st);
+int launch_scatter_nodes(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, long long cap,
+                         int r, const float *values, float *vol, hipStream_t st);
 // vertices.hip
 int launch_forward_vertices(mp_ctx *ctx, void *scratch, const float *vol, int r, int dir, int64_t *x, int64_t *y,
                             float *z, float *norm, int32_t *count, hipStream_t st);

@@ -190,6 +190,80 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
   }
 }
 
+// ---- level-at-a-time entry points (generic query_func) -------------------------------------------
+__global__ void lattice_points_kernel(const uint32_t *__restrict__ packed,
+                                      const int32_t *__restrict__ count, long long cap, int stride,
+                                      float res_final, float half_step, float b0, float b1, float b2,
+                                      float l0, float l1, float l2, float *__restrict__ pts) {
+  const long long n = min((long long)*count, cap);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const uint32_t c = packed[i];
+    const float cx = (float)((int)(c & 1023u) * stride), cy = (float)((int)((c >> 10) & 1023u) * stride),
+                cz = (float)((int)(c >> 20) * stride);
+    pts[3 * i + 0] = (cx / res_final + half_step) * l0 + b0;
+    pts[3 * i + 1] = (cy / res_final + half_step) * l1 + b1;
+    pts[3 * i + 2] = (cz / res_final + half_step) * l2 + b2;
+  }
+}
+
+__global__ void scatter_nodes_kernel(const uint32_t *__restrict__ packed,
+                                     const int32_t *__restrict__ count, long long cap, int r,
+                                     const float *__restrict__ values, float *__restrict__ vol) {
+  const long long n = min((long long)*count, cap);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const uint32_t c = packed[i];
+    vol[((long long)(c >> 20) * r + ((c >> 10) & 1023u)) * r + (c & 1023u)] = values[i];
+  }
+}
+
+int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
+                         const u64 *ev_prev, u64 *ev_cur, u64 *bnd, int level, float balance,
+                         uint32_t *packed, int32_t *count, hipStream_t st) {
+  const int w64 = words64(r);
+  if (!prev) {
+    const int total = r * r * r;
+    hipLaunchKernelGGL(iota_nodes_kernel, dim3((total + 255) / 256), dim3(256), 0, st, r, packed,
+                       ev_cur, w64, count);
+  } else {
+    MP_HIP(ctx, hipMemsetAsync(count, 0, sizeof(int32_t), st));
+    const long long items = (long long)r * r * w64;
+    hipLaunchKernelGGL(upsample_classify_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
+                       st, prev, rp, cur, r, balance, bnd, w64);
+    const int d = level == 1 ? 4 : (level == 2 ? 3 : 1);
+    hipLaunchKernelGGL(select_compact_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
+                       st, bnd, ev_prev, rp, words64(rp), ev_cur, r, w64, d, packed, count);
+  }
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+int launch_lattice_points(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, long long cap,
+                          int stride, int res_final, const float *bmin, const float *bmax,
+                          float *pts, hipStream_t st) {
+  if (cap == 0) return MP_OK;
+  long long blocks = (cap + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  const float rf = (float)res_final;
+  hipLaunchKernelGGL(lattice_points_kernel, dim3((unsigned)blocks), dim3(256), 0, st, packed, count,
+                     cap, stride, rf, (1.0f / rf) / 2.0f, bmin[0], bmin[1], bmin[2],
+                     bmax[0] - bmin[0], bmax[1] - bmin[1], bmax[2] - bmin[2], pts);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+int launch_scatter_nodes(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, long long cap,
+                         int r, const float *values, float *vol, hipStream_t st) {
+  if (cap == 0) return MP_OK;
+  long long blocks = (cap + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(scatter_nodes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, packed, count,
+                     cap, r, values, vol);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
 // ---- driver ------------------------------------------------------------------------------------
 int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, const float *feat_hwc, int h, int w,
                  const float *calib, float z_scale, const float *bmin, const float *bmax,

@@ -57,25 +57,42 @@ class Seg3dLossless(nn.Module):
     def forward(self, **kwargs):
         """engine(**kwargs) -> [1,1,R,R,R] f32 occupancy volume (z,y,x) or None when the coarsest
         level has nothing above ``balance_value`` (consumed at RTL/recon.py:32-35)."""
-        volume, status = self.forward_async(**kwargs)
+        binding = self._bind(kwargs)
+        if binding is None:
+            # arbitrary query function: level-at-a-time engine, occupancies from the caller
+            volume, counts = ops.recon_generic(self.query_func, kwargs, self._device_tag.device,
+                                               self.b_min[0], self.b_max[0], self.resolutions,
+                                               self.balance_value)
+            self.last_status = torch.tensor([int(volume is not None)] + counts, dtype=torch.int32)
+            return None if volume is None else volume[None, None]
+        volume, status = self._launch(binding)
         st = status.cpu()  # the one host sync of a reconstruction (upstream syncs per level)
         self.last_status = st
         if int(st[0]) == 0:
             return None
         return volume[None, None]
 
-    def forward_async(self, **kwargs):
-        """Same work, no host sync: returns (volume [R,R,R], status int32[1+levels]) on device."""
-        with capture_query() as cap:
-            probe = torch.zeros((1, 1, 3), dtype=torch.float32, device=self._device_tag.device)
-            self.query_func(points=probe, **kwargs)
-        b = cap.binding
-        if b is None:
-            raise NotImplementedError(
-                "Seg3dLossless needs a query_func that calls monoport_amd's MonoPortNet.query "
-                "(as RTL/main.py:169-183 does); arbitrary Python query functions are not supported")
+    def _bind(self, kwargs):
+        """Probe ``query_func`` once: if it ends in monoport_amd's MonoPortNet.query (as
+        RTL/main.py:169-183 does) return what that call binds, else None."""
+        try:
+            with capture_query() as cap:
+                probe = torch.zeros((1, 1, 3), dtype=torch.float32, device=self._device_tag.device)
+                self.query_func(points=probe, **kwargs)
+        except Exception:  # noqa: BLE001 -- a foreign function may not like the probe
+            return None
+        return cap.binding
+
+    def _launch(self, b):
         return ops.recon(b.mlp, b.feat_hwc, b.calib, b.z_scale, self.b_min[0], self.b_max[0],
                          self.resolutions, self.balance_value)
+
+    def forward_async(self, **kwargs):
+        """Fused path only, no host sync: (volume [R,R,R], status int32[1+levels]) on device."""
+        b = self._bind(kwargs)
+        if b is None:
+            raise NotImplementedError("forward_async needs a query_func ending in MonoPortNet.query")
+        return self._launch(b)
 
 
 class Seg3dTopk(nn.Module):

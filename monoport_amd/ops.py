@@ -234,6 +234,53 @@ def recon(mlp, feat_hwc, calib, z_scale, b_min, b_max, resolutions, balance=0.5,
     return volume, status
 
 
+def recon_generic(query_func, kwargs, device, b_min, b_max, resolutions, balance=0.5):
+    """Seg3dLossless for an ARBITRARY ``query_func(points=[1,N,3], **kwargs) -> [1,1,N]``: the
+    node selection, lattice coordinates and scatter run as HIP kernels, the occupancies come from
+    the caller's function; one host sync per level for the point count (as upstream).  Returns
+    (volume [R,R,R] or None, per-level counts)."""
+    ctx = get_context(device)
+    dev = torch.device(device)
+    res = [int(r) for r in resolutions]
+    rf = res[-1]
+    bmin = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_min, np.float32).reshape(3)])
+    bmax = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_max, np.float32).reshape(3)])
+    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    prev = ev_prev = None
+    rp = 0
+    counts = []
+    for level, r in enumerate(res):
+        words = r * r * ((r + 63) // 64)
+        cur = torch.empty((r, r, r), dtype=torch.float32, device=dev)
+        ev_cur = torch.empty((words,), dtype=torch.int64, device=dev)
+        bnd = torch.empty((words,), dtype=torch.int64, device=dev)
+        packed = torch.empty((r ** 3,), dtype=torch.int32, device=dev)
+        ctx.check(ctx.lib.mp_octree_select(
+            ctx.handle, _ptr(prev) if prev is not None else None, rp, _ptr(cur), r,
+            _ptr(ev_prev) if ev_prev is not None else None, _ptr(ev_cur), _ptr(bnd), level,
+            float(balance), _ptr(packed), _ptr(count), _stream(cur)), "mp_octree_select")
+        n = int(count.item())
+        counts.append(n)
+        if n:
+            pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            ctx.check(ctx.lib.mp_lattice_points(ctx.handle, _ptr(packed), _ptr(count), n,
+                                                (rf - 1) // (r - 1), rf, bmin, bmax, _ptr(pts),
+                                                _stream(pts)), "mp_lattice_points")
+            occ = query_func(points=pts[None], **kwargs)
+            if isinstance(occ, (list, tuple)):
+                occ = torch.stack(list(occ))
+            vals = _f32c(occ.reshape(-1))
+            if vals.shape[0] != n:
+                raise ValueError("query_func returned %d values for %d points" % (vals.shape[0], n))
+            ctx.check(ctx.lib.mp_scatter_nodes(ctx.handle, _ptr(packed), _ptr(count), n, r,
+                                               _ptr(vals), _ptr(cur), _stream(cur)),
+                      "mp_scatter_nodes")
+        if level == 0 and not bool((cur > balance).any()):
+            return None, counts
+        prev, ev_prev, rp = cur, ev_cur, r
+    return prev, counts
+
+
 def forward_vertices_raw(volume, direction="front"):
     """mp_forward_vertices: returns capacity-sized (X, Y, Z, norm, count) device tensors."""
     vol = volume

@@ -199,3 +199,34 @@ def test_full_size_properties(ops, oracle, body, res):
     xb, yb, _, _, cb = ops.forward_vertices_raw(vol, "back")
     nb = int(cb.item())
     assert nf == nb and torch.equal(xf[:nf], xb[:nb]) and torch.equal(yf[:nf], yb[:nb])
+
+
+def test_generic_query_func_engine(ops, oracle, body):
+    """Seg3dLossless with an ARBITRARY query function (not a MonoPortNet): an analytic sphere.
+    Must equal the CPU restatement driven by the same function."""
+    from monoport_amd.implicit_seg.functional import Seg3dLossless
+
+    def sphere_np(p):  # [3,N] numpy
+        d = np.sqrt((p.astype(np.float32) ** 2).sum(0, dtype=np.float32))
+        return (1.0 / (1.0 + np.exp(-(np.float32(0.6) - d) * np.float32(12)))).astype(np.float32)
+
+    def query_func(points, scale):  # torch, [1,N,3] -> [1,1,N]
+        d = torch.sqrt((points[0] ** 2).sum(1))
+        return torch.sigmoid((0.6 - d) * scale)[None, None]
+
+    res = [9, 17, 33, 65]
+    eng = Seg3dLossless(query_func=query_func, b_min=np.array([[-1., -1., -1.]]),
+                        b_max=np.array([[1., 1., 1.]]), resolutions=res, faster=True).to(DEV)
+    sdf = eng(scale=12.0)
+    assert sdf.shape == (1, 1, 65, 65, 65)
+    stats = []
+    ref = oracle.seg3d_lossless(sphere_np, BMIN, BMAX, res, stats=stats)
+    assert list(eng.last_status[1:].numpy()) == stats
+    v = sdf[0, 0].cpu().numpy()
+    assert np.abs(v - ref).max() <= 2e-6  # torch.sigmoid vs numpy exp
+    assert np.array_equal(v > 0.5, ref > 0.5)
+    # empty scene -> None
+    eng2 = Seg3dLossless(query_func=lambda points: torch.zeros(1, 1, points.shape[1], device=DEV),
+                         b_min=np.array([[-1., -1., -1.]]), b_max=np.array([[1., 1., 1.]]),
+                         resolutions=[9, 17]).to(DEV)
+    assert eng2() is None
