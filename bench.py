@@ -203,6 +203,30 @@ def main():
     launch_ms = ops.profile_end(device, capacity=8 * args.steps + 8)
     prof_pts = torch.stack(prof_status).cpu().numpy()[:, 1:]
 
+    # breakdown leg: encoder-only and encoder-excluded time per frame, one
+    # stream, features of the last frame
+    def timed(fn, n):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(prof_slot.stream):
+            fn()
+            ev0.record(prof_slot.stream)
+            for _ in range(n):
+                fn()
+            ev1.record(prof_slot.stream)
+        prof_slot.stream.synchronize()
+        return ev0.elapsed_time(ev1) / n
+
+    def recon_only():
+        mlp = prof_slot.net.surface_classifier.packed()
+        ops.recon(mlp, prof_slot.feat_hwc, prof_slot.calib, syn.Z_SCALE, B_MIN, B_MAX, resolutions,
+                  0.5, volume=prof_slot.volume, status=prof_slot.status)
+        x, y, z, nrm, count = ops.forward_vertices_raw(prof_slot.volume, "front")
+        ops.paint(x, y, nrm, 0, count, r_last, 0.5, 0.5, 0.0, 1.0)
+
+    with torch.no_grad():
+        enc_ms = timed(lambda: prof_slot.net.image_filter(prof_slot.image, last_only=True), 10)
+        rec_ms = timed(recon_only, 10)
+
     statuses = torch.stack(status_log).cpu().numpy()
     assert (statuses[:, 0] == 1).all(), "synthetic body must be non-empty"
     level_pts = statuses[:, 1:]
@@ -247,6 +271,12 @@ def main():
                 "points_per_recon": pts_all / (args.steps * world),
             },
             "mpts_per_s": pts_all / elapsed / 1e6,
+            "breakdown": {
+                "encoder_ms": enc_ms, "recon_vertices_render_ms": rec_ms,
+                "recon_per_s_encoder_excluded": 1e3 / rec_ms,
+                "points_per_level": [float(v) for v in prof_pts.mean(0)],
+                "note": "single stream, one frame at a time (no overlap)",
+            },
             "roofline": {
                 "kernel": "pifu_query_kernel<256,1> (fused gather + MLP)",
                 "bound": "mfma",

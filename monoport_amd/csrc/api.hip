@@ -384,7 +384,7 @@ int mp_forward_vertices(mp_ctx *ctx, const float *volume, int r, int direction, 
     return fail(ctx, MP_ERR_ARG, "mp_forward_vertices: bad argument");
   DeviceGuard g(ctx->device);
   void *scratch = nullptr;
-  int rc = ensure_scratch(ctx, (hipStream_t)stream, (size_t)r * r * sizeof(int32_t) + 4096, &scratch);
+  int rc = ensure_scratch(ctx, (hipStream_t)stream, (size_t)r * r * sizeof(int32_t) + ((size_t)r * r / 1024 + 2) * sizeof(int32_t) + 4096, &scratch);
   if (rc != MP_OK) return rc;
   return launch_forward_vertices(ctx, scratch, volume, r, direction, x, y, z, norm, count,
                                  (hipStream_t)stream);

@@ -34,94 +34,119 @@ __device__ __forceinline__ float view_sample(const float *__restrict__ v, int r,
   return v[(zi * r + y) * r + xi];
 }
 
-// hit[x * r + y] = first z' with s > 0.5 (recon.py:56-60), or -1.
+// hit[x * r + y] = first z' with s > 0.5 (recon.py:56-60), or kNoHit.  Each column is cut into
+// segments of kSeg voxels scanned by different threads (one thread per column leaves the chip
+// mostly idle: 66 k threads walking 257 dependent loads each); the segments meet in an atomicMin.
+constexpr int kNoHit = 0x7f7f7f7f;  // what hipMemsetAsync(0x7f) leaves behind
+constexpr int kSeg = 32;
+
 __global__ __launch_bounds__(256) void first_hit_kernel(const float *__restrict__ v, int r, int dir,
-                                                        int32_t *__restrict__ hit) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= r * r) return;
+                                                        int n_seg, int32_t *__restrict__ hit) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long cols = (long long)r * r;
+  if (t >= cols * n_seg) return;
+  const int seg = (int)(t / cols);
+  const int col = (int)(t % cols);
   // lanes run along the memory-contiguous axis for front/back, along y for left/right
   int x, y;
   if (dir == MP_DIR_FRONT || dir == MP_DIR_BACK) {
-    x = t % r;
-    y = t / r;
+    x = col % r;
+    y = col / r;
   } else {
-    y = t % r;
-    x = t / r;
+    y = col % r;
+    x = col / r;
   }
-  int found = -1;
-  for (int zp = 0; zp < r; ++zp) {
+  const int z_end = min(r, (seg + 1) * kSeg);
+  for (int zp = seg * kSeg; zp < z_end; ++zp) {
     if (view_sample(v, r, dir, x, y, zp) > 0.5f) {
-      found = zp;
+      atomicMin(&hit[x * r + y], zp);
       break;
     }
   }
-  hit[x * r + y] = found;
 }
 
-// Single workgroup: exclusive scan of the hit map in x-major order (the row order of
-// keep.nonzero(), recon.py:62) and per-vertex outputs (recon.py:63-87).
-__global__ __launch_bounds__(1024) void emit_vertices_kernel(
+// Row order = x-major order of keep.nonzero() (recon.py:62): per-block hit counts, then every
+// block sums the counts of the blocks before it and emits its rows (recon.py:63-87).
+constexpr int kEmitBlock = 1024;
+
+__global__ __launch_bounds__(kEmitBlock) void count_hits_kernel(const int32_t *__restrict__ hit,
+                                                                int total,
+                                                                int32_t *__restrict__ blk) {
+  __shared__ int wave_tot[kEmitBlock / 64];
+  const int idx = blockIdx.x * kEmitBlock + threadIdx.x;
+  const int flag = idx < total && hit[idx] != kNoHit;
+  const unsigned long long m = __ballot(flag);
+  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int k = 0; k < kEmitBlock / 64; ++k) s += wave_tot[k];
+    blk[blockIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(kEmitBlock) void emit_vertices_kernel(
     const float *__restrict__ v, int r, int dir, const int32_t *__restrict__ hit,
-    int64_t *__restrict__ xo, int64_t *__restrict__ yo, float *__restrict__ zo,
-    float *__restrict__ no, int32_t *__restrict__ count) {
-  __shared__ int wave_tot[16];
+    const int32_t *__restrict__ blk, int64_t *__restrict__ xo, int64_t *__restrict__ yo,
+    float *__restrict__ zo, float *__restrict__ no, int32_t *__restrict__ count) {
+  __shared__ int wave_tot[kEmitBlock / 64];
   __shared__ int base_s;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) base_s = 0;
-  __syncthreads();
   const int total = r * r;
-  for (int c0 = 0; c0 < total; c0 += 1024) {
-    const int idx = c0 + tid;
-    const int z1 = idx < total ? hit[idx] : -1;
-    const int flag = z1 >= 0;
-    const unsigned long long m = __ballot(flag);
-    const int before = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_tot[wv] = __popcll(m);
-    __syncthreads();
-    int off = base_s;
-    for (int k = 0; k < wv; ++k) off += wave_tot[k];
-    if (flag) {
-      const int row = off + before;
-      const int x = idx / r, y = idx % r;
-      const int z2 = min(max(z1 - 2, 0), r), y2 = min(max(y - 2, 0), r), x2 = min(max(x - 2, 0), r);
-      const float v1 = view_sample(v, r, dir, x, y, z1);
-      const float v2 = view_sample(v, r, dir, x, y, z2);
-      const float v3 = view_sample(v, r, dir, x, y2, z1);
-      const float v4 = view_sample(v, r, dir, x2, y, z1);
-      // recon.py:77: p2z * (0.5 - v1) / (v2 - v1) + p1z * (v2 - 0.5) / (v2 - v1), left to right
-      const float den = __fsub_rn(v2, v1);
-      const float ta = __fdiv_rn(__fmul_rn((float)z2, __fsub_rn(0.5f, v1)), den);
-      const float tb = __fdiv_rn(__fmul_rn((float)z1, __fsub_rn(v2, 0.5f)), den);
-      float zz = __fadd_rn(ta, tb);
-      zz = zz < 0.0f ? 0.0f : (zz > (float)r ? (float)r : zz);  // clamp keeps NaN (hit at z'=0)
-      const float nx = __fsub_rn(v4, v1), ny = __fsub_rn(v3, v1), nz = den;
-      const float len = __fsqrt_rn(
-          __fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
-      xo[row] = x;
-      yo[row] = y;
-      zo[row] = zz;
-      no[3 * row + 0] = __fdiv_rn(nx, len);
-      no[3 * row + 1] = __fdiv_rn(ny, len);
-      no[3 * row + 2] = __fdiv_rn(nz, len);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int s = base_s;
-      for (int k = 0; k < 16; ++k) s += wave_tot[k];
-      base_s = s;
-    }
-    __syncthreads();
+  const int idx = blockIdx.x * kEmitBlock + tid;
+  const int z1 = idx < total ? hit[idx] : kNoHit;
+  const int flag = z1 != kNoHit;
+  const unsigned long long m = __ballot(flag);
+  const int before = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_tot[wv] = __popcll(m);
+  if (tid == 0) {
+    int s = 0;
+    for (int k = 0; k < (int)blockIdx.x; ++k) s += blk[k];
+    base_s = s;
+    if (blockIdx.x == gridDim.x - 1) *count = s + blk[blockIdx.x];
   }
-  if (tid == 0) *count = base_s;
+  __syncthreads();
+  if (!flag) return;
+  int off = base_s;
+  for (int k = 0; k < wv; ++k) off += wave_tot[k];
+  const int row = off + before;
+  const int x = idx / r, y = idx % r;
+  const int z2 = min(max(z1 - 2, 0), r), y2 = min(max(y - 2, 0), r), x2 = min(max(x - 2, 0), r);
+  const float v1 = view_sample(v, r, dir, x, y, z1);
+  const float v2 = view_sample(v, r, dir, x, y, z2);
+  const float v3 = view_sample(v, r, dir, x, y2, z1);
+  const float v4 = view_sample(v, r, dir, x2, y, z1);
+  // recon.py:77: p2z * (0.5 - v1) / (v2 - v1) + p1z * (v2 - 0.5) / (v2 - v1), left to right
+  const float den = __fsub_rn(v2, v1);
+  const float ta = __fdiv_rn(__fmul_rn((float)z2, __fsub_rn(0.5f, v1)), den);
+  const float tb = __fdiv_rn(__fmul_rn((float)z1, __fsub_rn(v2, 0.5f)), den);
+  float zz = __fadd_rn(ta, tb);
+  zz = zz < 0.0f ? 0.0f : (zz > (float)r ? (float)r : zz);  // clamp keeps NaN (hit at z'=0)
+  const float nx = __fsub_rn(v4, v1), ny = __fsub_rn(v3, v1), nz = den;
+  const float len =
+      __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+  xo[row] = x;
+  yo[row] = y;
+  zo[row] = zz;
+  no[3 * row + 0] = __fdiv_rn(nx, len);
+  no[3 * row + 1] = __fdiv_rn(ny, len);
+  no[3 * row + 2] = __fdiv_rn(nz, len);
 }
 
-int launch_forward_vertices(mp_ctx *ctx, void *scratch, const float *vol, int r, int dir, int64_t *x, int64_t *y,
-                            float *z, float *norm, int32_t *count, hipStream_t st) {
+int launch_forward_vertices(mp_ctx *ctx, void *scratch, const float *vol, int r, int dir, int64_t *x,
+                            int64_t *y, float *z, float *norm, int32_t *count, hipStream_t st) {
   int32_t *hit = static_cast<int32_t *>(scratch);
-  hipLaunchKernelGGL(first_hit_kernel, dim3((r * r + 255) / 256), dim3(256), 0, st, vol, r, dir,
-                     hit);
-  hipLaunchKernelGGL(emit_vertices_kernel, dim3(1), dim3(1024), 0, st, vol, r, dir, hit, x, y, z,
-                     norm, count);
+  const int total = r * r;
+  const int n_blk = (total + kEmitBlock - 1) / kEmitBlock;
+  int32_t *blk = hit + total;
+  const int n_seg = (r + kSeg - 1) / kSeg;
+  MP_HIP(ctx, hipMemsetAsync(hit, 0x7f, sizeof(int32_t) * (size_t)total, st));
+  const long long threads = (long long)total * n_seg;
+  hipLaunchKernelGGL(first_hit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                     vol, r, dir, n_seg, hit);
+  hipLaunchKernelGGL(count_hits_kernel, dim3(n_blk), dim3(kEmitBlock), 0, st, hit, total, blk);
+  hipLaunchKernelGGL(emit_vertices_kernel, dim3(n_blk), dim3(kEmitBlock), 0, st, vol, r, dir, hit,
+                     blk, x, y, z, norm, count);
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
 }
