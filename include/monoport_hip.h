@@ -42,6 +42,14 @@ enum {
 /* SurfaceClassifier last_op (heads/SurfaceClassifier.py:68-69, :77, :85) */
 enum { MP_ACT_NONE = 0, MP_ACT_SIGMOID = 1, MP_ACT_TANH = 2 };
 
+/* arithmetic of the MLP GEMMs (mp_mlp_set_precision) */
+enum {
+  MP_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32: exact f32 products, the default */
+  MP_PREC_F16X3 = 1  /* f32 emulated on v_mfma_f32_32x32x16_f16: every operand split into two
+                        halves (hi + lo, 22 significant bits), three MFMAs per product term
+                        (hi*hi + hi*lo + lo*hi), f32 accumulation; netG heads (C = 256) only */
+};
+
 /* forward_vertices direction (RTL/recon.py:39-49) */
 enum { MP_DIR_FRONT = 0, MP_DIR_BACK = 1, MP_DIR_LEFT = 2, MP_DIR_RIGHT = 3 };
 
@@ -66,6 +74,10 @@ int mp_mlp_create(mp_ctx *ctx, int n_layers, const int *channels /*host, n_layer
 int mp_mlp_load(mp_ctx *ctx, int mlp, int layer, const float *W, const float *b, int out_ch,
                 int in_ch, mp_stream stream);
 int mp_mlp_destroy(mp_ctx *ctx, int mlp);
+/* Selects the arithmetic used by mp_query / mp_recon / mp_query_counted for this MLP.  Call after
+ * every layer is loaded (MP_PREC_F16X3 reads max |W| of each layer back to the host to choose the
+ * per-layer power-of-two operand scale: one small synchronous copy). */
+int mp_mlp_set_precision(mp_ctx *ctx, int mlp, int precision);
 
 /* ---- feature-map layout ------------------------------------------------------------------ */
 /* Copies src [Csrc,H,W] (the NCHW map MonoPortNet.filter emits, MonoPortNet.py:31-46) into

@@ -26,6 +26,7 @@ SIGNATURES = {
     "mp_mlp_create": (c_int, [c_vp, c_int, _pint, c_int, _pint]),
     "mp_mlp_load": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
     "mp_mlp_destroy": (c_int, [c_vp, c_int]),
+    "mp_mlp_set_precision": (c_int, [c_vp, c_int, c_int]),
     "mp_feat_pack_hwc": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     "mp_index": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     "mp_orthogonal": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),

@@ -12,9 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libmonoport_hip.so")
-SOURCES = ["api.hip", "pack.hip", "query.hip", "octree.hip", "vertices.hip", "mcubes.hip",
+SOURCES = ["api.hip", "pack.hip", "query.hip", "query16.hip", "octree.hip", "vertices.hip", "mcubes.hip",
            "encoder_ops.hip"]
-HEADERS = [os.path.join(CSRC, "mp_internal.h"),
+HEADERS = [os.path.join(CSRC, "mp_internal.h"), os.path.join(CSRC, "query_common.h"),
            os.path.join(os.path.dirname(HERE), "include", "monoport_hip.h")]
 # -ffp-contract=off: parity with the reference is op-order parity; hipcc's default (fast) lets the
 # backend fuse any a*b+c, pragmas notwithstanding.  FMAs are requested explicitly (fmaf, MFMA).

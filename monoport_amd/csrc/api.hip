@@ -1,5 +1,6 @@
 // C-ABI entry points of libmonoport_hip.so (see include/monoport_hip.h for the contract).
 #include <cstdarg>
+#include <cmath>
 #include <cstring>
 
 #include "mp_internal.h"
@@ -49,6 +50,18 @@ MlpPack Mlp::pack() const {
   }
   for (int l = 0; l < 5; ++l) p.bias[l] = (int)off_bias[l];
   p.w4 = (int)off_w4;
+  return p;
+}
+
+MlpPack16 Mlp::pack16() const {
+  MlpPack16 p;
+  p.base = buf16;
+  for (int l = 0; l < 4; ++l) {
+    p.ah[l] = (int)off16_ah[l];
+    p.ax[l] = (int)off16_ax[l];
+    p.az[l] = (int)off16_az[l];
+    p.scale[l] = scale16[l];
+  }
   return p;
 }
 
@@ -111,8 +124,11 @@ void mp_destroy(mp_ctx *ctx) {
   if (!ctx) return;
   {
     DeviceGuard g(ctx->device);
-    for (auto &m : ctx->mlps)
+    for (auto &m : ctx->mlps) {
       if (m.buf) (void)hipFree(m.buf);
+      if (m.buf16) (void)hipFree(m.buf16);
+      if (m.raw) (void)hipFree(m.raw);
+    }
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     for (auto &kv : ctx->arenas)
       if (kv.second.ptr) (void)hipFree(kv.second.ptr);
@@ -161,6 +177,14 @@ int mp_mlp_create(mp_ctx *ctx, int n_layers, const int *channels, int last_op, i
   m.total = off;
   if (hipMalloc(reinterpret_cast<void **>(&m.buf), off * sizeof(float)) != hipSuccess)
     return fail(ctx, MP_ERR_NOMEM, "mp_mlp_create: hipMalloc of %zu floats failed", off);
+  // raw copies (source for re-packing into other operand formats)
+  size_t roff = 0;
+  for (int l = 0; l < 4; ++l) {
+    m.off_raw[l] = roff;
+    roff += (size_t)kHidden[l] * ((l == 0 ? 0 : kHidden[l - 1]) + c + 1);
+  }
+  if (hipMalloc(reinterpret_cast<void **>(&m.raw), roff * sizeof(float)) != hipSuccess)
+    return fail(ctx, MP_ERR_NOMEM, "mp_mlp_create: hipMalloc of %zu floats failed", roff);
   int id = -1;
   for (size_t i = 0; i < ctx->mlps.size(); ++i)
     if (!ctx->mlps[i].used) id = (int)i;
@@ -188,7 +212,71 @@ int mp_mlp_load(mp_ctx *ctx, int mlp, int layer, const float *W, const float *b,
                 want_out, want_in, out_ch, in_ch);
   DeviceGuard g(ctx->device);
   int rc = launch_pack_layer(ctx, *m, layer, W, b, (hipStream_t)stream);
+  if (rc == MP_OK && layer < 4)
+    rc = launch_copy(ctx, W, m->raw + m->off_raw[layer], (long long)out_ch * in_ch,
+                     (hipStream_t)stream);
   if (rc == MP_OK) m->loaded[layer] = true;
+  if (rc == MP_OK && m->precision == MP_PREC_F16X3) {
+    // weights changed under an f16x3 MLP: drop back to f32 until precision is selected again
+    m->precision = MP_PREC_F32;
+  }
+  return rc;
+}
+
+int mp_mlp_set_precision(mp_ctx *ctx, int mlp, int precision) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  Mlp *m = get_mlp(ctx, mlp);
+  if (!m) return fail(ctx, MP_ERR_ARG, "mp_mlp_set_precision: unknown mlp id %d", mlp);
+  if (precision != MP_PREC_F32 && precision != MP_PREC_F16X3)
+    return fail(ctx, MP_ERR_ARG, "mp_mlp_set_precision: bad precision %d", precision);
+  if (precision == MP_PREC_F32) {
+    m->precision = MP_PREC_F32;
+    return MP_OK;
+  }
+  int rc = check_ready(ctx, m, m->c);
+  if (rc != MP_OK) return rc;
+  if (m->c != 256)
+    return fail(ctx, MP_ERR_UNSUPPORTED, "mp_mlp_set_precision: f16x3 is built for C = 256 heads only");
+  DeviceGuard g(ctx->device);
+  if (!m->buf16) {
+    size_t off = 0;  // units of 16 bytes (8 halves)
+    for (int l = 0; l < 4; ++l) {
+      const size_t n_rb = kHidden[l] / 32, k_h = l == 0 ? 0 : kHidden[l - 1];
+      m->off16_ah[l] = off;
+      off += n_rb * (k_h / 16) * 128;
+      m->off16_ax[l] = off;
+      off += n_rb * (m->c / 16) * 128;
+      m->off16_az[l] = off;
+      off += n_rb * 128;
+    }
+    if (hipMalloc(&m->buf16, off * 16) != hipSuccess)
+      return fail(ctx, MP_ERR_NOMEM, "mp_mlp_set_precision: hipMalloc(%zu) failed", off * 16);
+  }
+  unsigned int *d_bits = nullptr;
+  MP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d_bits), sizeof(unsigned int)));
+  for (int l = 0; l < 4 && rc == MP_OK; ++l) {
+    const long long n = (long long)kHidden[l] * ((l == 0 ? 0 : kHidden[l - 1]) + m->c + 1);
+    rc = launch_absmax(ctx, m->raw + m->off_raw[l], n, d_bits, nullptr);
+    unsigned int bits = 0;
+    if (rc == MP_OK && hipMemcpy(&bits, d_bits, sizeof(bits), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = fail(ctx, MP_ERR_HIP, "mp_mlp_set_precision: hipMemcpy failed");
+    float wmax;
+    memcpy(&wmax, &bits, sizeof(wmax));
+    // largest power of two S with max|w| * S <= 2^14 (f16 tops out at 65504), clamped
+    int e = 0;
+    if (wmax > 0.0f && wmax < 3.0e38f) {
+      (void)frexpf(wmax, &e);  // wmax = f * 2^e, f in [0.5, 1)
+      e = 14 - e;
+    }
+    if (e > 14) e = 14;
+    if (e < -14) e = -14;
+    m->scale16[l] = ldexpf(1.0f, e);
+    if (rc == MP_OK) rc = launch_pack_layer16(ctx, *m, l, m->raw + m->off_raw[l], nullptr);
+  }
+  (void)hipDeviceSynchronize();
+  (void)hipFree(d_bits);
+  if (rc == MP_OK) m->precision = MP_PREC_F16X3;
   return rc;
 }
 
@@ -200,6 +288,8 @@ int mp_mlp_destroy(mp_ctx *ctx, int mlp) {
   DeviceGuard g(ctx->device);
   MP_HIP(ctx, hipDeviceSynchronize());
   if (m->buf) MP_HIP(ctx, hipFree(m->buf));
+  if (m->buf16) MP_HIP(ctx, hipFree(m->buf16));
+  if (m->raw) MP_HIP(ctx, hipFree(m->raw));
   *m = Mlp();
   return MP_OK;
 }

@@ -28,6 +28,16 @@ struct MlpPack {
   int w4;       // last layer, row-major [Cout][pad4(128 + C + 1)]
 };
 
+// Split-precision copy of the same weights for the 3-term f16 MFMA kernel (query16.hip): every
+// weight w is stored as hi = f16(w * S), lo = f16(w * S - hi) with a per-layer power-of-two scale
+// S; fragments are [rb][g][hi|lo][lane] of 8 halves (16 bytes), K walked in groups of 16.
+struct MlpPack16 {
+  const void *base;   // half data, offsets below in units of 16 bytes
+  int ah[4], ax[4];   // hidden / feature segments
+  int az[4];          // z column: [rb][hi|lo][lane], only element 0 of lanes 0-31 non-zero
+  float scale[4];     // S of layers 0..3
+};
+
 // Where a query launch takes its points from and where it puts the results.
 struct PointSrc {
   // explicit mode (packed == nullptr): world coords, element (c, i) at pts[i*sn + c*sc]
@@ -55,6 +65,14 @@ struct Mlp {
   size_t off_ah[4], off_ax[4], off_az[4], off_bias[5], off_w4;
   size_t total = 0;
   MlpPack pack() const;
+  // f16x3 copy (C == 256 heads only)
+  int precision = 0;        // MP_PREC_F32 / MP_PREC_F16X3
+  void *buf16 = nullptr;
+  float *raw = nullptr;     // un-packed [out,in] copies of layers 0..3 (source for re-packing)
+  size_t off_raw[4];
+  size_t off16_ah[4], off16_ax[4], off16_az[4];
+  float scale16[4] = {1.f, 1.f, 1.f, 1.f};
+  MlpPack16 pack16() const;
 };
 
 // mcubes.hip
@@ -109,6 +127,13 @@ int launch_pack_hwc(mp_ctx *ctx, const float *src, int c_src, int h, int w, floa
                     int c_off, hipStream_t st);
 int launch_pack_layer(mp_ctx *ctx, Mlp &m, int layer, const float *w, const float *b,
                       hipStream_t st);
+int launch_pack_layer16(mp_ctx *ctx, Mlp &m, int layer, const float *w, hipStream_t st);
+int launch_copy(mp_ctx *ctx, const float *src, float *dst, long long n, hipStream_t st);
+int launch_absmax(mp_ctx *ctx, const float *src, long long n, unsigned int *out_bits, hipStream_t st);
+// query16.hip
+int launch_query16(mp_ctx *ctx, const Mlp &m, const float *feat_hwc, int h, int w,
+                   const float *calib, float z_scale, const PointSrc &src, float *out,
+                   long long max_points, hipStream_t st);
 // octree.hip
 size_t recon_scratch_bytes(const int *res, int n_levels);
 int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, const float *feat_hwc, int h, int w,

@@ -90,6 +90,87 @@ int launch_pack_layer(mp_ctx *ctx, Mlp &m, int layer, const float *w, const floa
 }
 
 // ---------------------------------------------------------------------------------------------
+// f16x3 packing (query16.hip): A16[rb][g][part][lane][e], part 0 = hi, 1 = lo,
+//   value = W[32 rb + (lane & 31)][col0 + 16 g + 8 (lane >> 5) + e] * S  split into two halves.
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_segment16_kernel(const float *__restrict__ w, int ld, int col0, int n_groups,
+                                      int n_rb, float scale, _Float16 *__restrict__ dst) {
+  const long long total = (long long)n_rb * n_groups * 512;  // (lane, e) pairs
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int e = t & 7;
+    const int lane = (t >> 3) & 63;
+    const long long q = t >> 9;
+    const int g = q % n_groups;
+    const int rb = q / n_groups;
+    const float v = w[(long long)(32 * rb + (lane & 31)) * ld + col0 + 16 * g + 8 * (lane >> 5) + e] *
+                    scale;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    _Float16 *blk = dst + q * 1024;  // 2 parts x 64 lanes x 8 halves
+    blk[lane * 8 + e] = hi;
+    blk[512 + lane * 8 + e] = lo;
+  }
+}
+
+__global__ void pack_zcol16_kernel(const float *__restrict__ w, int ld, int col, int n_rb,
+                                   float scale, _Float16 *__restrict__ dst) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_rb * 512) return;
+  const int e = t & 7, lane = (t >> 3) & 63, rb = t >> 9;
+  float v = 0.0f;
+  if (lane < 32 && e == 0) v = w[(long long)(32 * rb + lane) * ld + col] * scale;
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  dst[(long long)rb * 1024 + lane * 8 + e] = hi;
+  dst[(long long)rb * 1024 + 512 + lane * 8 + e] = lo;
+}
+
+__global__ void absmax_kernel(const float *__restrict__ src, long long n, unsigned int *out) {
+  float m = 0.0f;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n;
+       t += (long long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(src[t]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order as uints
+}
+
+int launch_absmax(mp_ctx *ctx, const float *src, long long n, unsigned int *out_bits,
+                  hipStream_t st) {
+  MP_HIP(ctx, hipMemsetAsync(out_bits, 0, sizeof(unsigned int), st));
+  hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, src, n, out_bits);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+int launch_copy(mp_ctx *ctx, const float *src, float *dst, long long n, hipStream_t st) {
+  hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)),
+                     dim3(256), 0, st, src, dst, n);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+int launch_pack_layer16(mp_ctx *ctx, Mlp &m, int layer, const float *w, hipStream_t st) {
+  const int c = m.c;
+  const int n_out = kHidden[layer];
+  const int k_h = layer == 0 ? 0 : kHidden[layer - 1];
+  const int ld = k_h + c + 1;
+  const int n_rb = n_out / 32;
+  const float s = m.scale16[layer];
+  _Float16 *base = static_cast<_Float16 *>(m.buf16);
+  if (k_h > 0)
+    hipLaunchKernelGGL(pack_segment16_kernel, dim3(2048), dim3(256), 0, st, w, ld, 0, k_h / 16,
+                       n_rb, s, base + m.off16_ah[layer] * 8);
+  hipLaunchKernelGGL(pack_segment16_kernel, dim3(2048), dim3(256), 0, st, w, ld, k_h, c / 16, n_rb,
+                     s, base + m.off16_ax[layer] * 8);
+  hipLaunchKernelGGL(pack_zcol16_kernel, dim3((n_rb * 512 + 255) / 256), dim3(256), 0, st, w, ld,
+                     k_h + c, n_rb, s, base + m.off16_az[layer] * 8);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // NCHW -> NHWC through a padded 32x32 LDS tile: coalesced 128-byte rows on both sides.
 // With channels last, one bilinear tap of the query kernel is C contiguous floats (1 KB for
 // netG), i.e. one fully coalesced 16 B/lane wave load instead of C loads 64 KB apart.

@@ -1,0 +1,506 @@
+// Fused PIFu query, split-precision variant ("f16x3"): the same computation as query.hip
+// (MonoPortNet.query in eval mode, monoport/lib/modeling/MonoPortNet.py:48-91) with every GEMM
+// operand carried as TWO halves, v = hi + lo (hi = f16(v), lo = f16(v - hi): 22 significant bits)
+// and every product expanded as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with f32
+// accumulation.  The dropped lo*lo term is 2^-22 relative, so the result is f32-class (measured
+// against the fp64 oracle in tests/test_query_gpu.py) while the matrix pipe runs 16x faster per
+// instruction: 3 MFMAs of 32 cycles replace 8 MFMAs of 64 cycles per 16-deep k-step (5.3x).
+//
+// Everything that was "free" next to f32 MFMA now matters, so the decomposition changes:
+//   * one workgroup = 8 waves = a 128-point tile (weights are re-used over twice as many points:
+//     4.7 MB of weight traffic per 128 points keeps the L2 -> CU stream ~12 TB/s chip-wide);
+//   * LDS is used to the last byte: xs[128][hi 512 B | lo 512 B] = 128 KB + one 64-row hidden chunk
+//     [128][hi 128 B | lo 128 B] = 32 KB (160 KB, one workgroup per CU, 2 waves per SIMD);
+//   * layer 0 is produced in 64-row chunks (one 32x32 tile per wave), split into halves on the way
+//     to LDS and consumed by layer 1 (each wave: 128 rows x 64 points, 128 accumulator VGPRs);
+//     layers 2 and 3 stream their inputs from the owning waves' registers the same way.
+// Weights are pre-split and pre-scaled by a per-layer power of two S (pack.hip) so that lo stays
+// out of the f16 subnormals; accumulators start at bias * S and are multiplied by 1/S (exact)
+// before the leaky ReLU.  Activations larger than 65504 would saturate -- PIFu activations are O(1-100).
+#include "mp_internal.h"
+#include "query_common.h"
+
+#pragma clang fp contract(off)
+
+namespace mp {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int kP16 = 128;        // points per workgroup tile
+constexpr int kThreads16 = 512;  // 8 waves
+constexpr int kXRow = 1024;      // bytes per point in xs: 32 hi slots | 32 lo slots (16 B each)
+constexpr int kHRow = 256;       // bytes per point in the hidden chunk: 8 hi slots | 8 lo slots
+constexpr int kLds16 = kP16 * kXRow + kP16 * kHRow;  // 163,840 B = all of a CU's LDS
+
+struct AFrag {
+  h8 hi, lo;
+};
+
+__device__ __forceinline__ void split4(const f32x4 &v, h4 &hi, h4 &lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = (_Float16)v[i];
+    lo[i] = (_Float16)(v[i] - (float)hi[i]);
+  }
+}
+
+// a: this lane's h8 of row block 0, group 0, part hi; lo is +64, group g +128 g, row block m
+// + m * rb_stride (all in h8 units)
+template <int MR, int PF>
+__device__ __forceinline__ void seg_prefetch16(AFrag (&ring)[PF + 1][MR], const h8 *__restrict__ a,
+                                               int rb_stride, int n_groups) {
+#pragma unroll
+  for (int d = 0; d < PF; ++d)
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const h8 *p = a + m * rb_stride + min(d, n_groups - 1) * 128;
+      ring[d][m].hi = p[0];
+      ring[d][m].lo = p[64];
+    }
+}
+
+// acc += A * B over n_groups k16-steps.  b: LDS address of this lane's point row for column block
+// 0 (+ n * 32 * ROWB for block n); the hi slot of group g is ((2g + hh) ^ (p & 15)) << 4 = (2g ^
+// swz) << 4 with swz = hh ^ (p & 15), the lo slot sits LO bytes further.
+template <int MR, int NR, int PF, int ROWB, int LO_SLOT>
+__device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[PF + 1][MR],
+                                           const h8 *__restrict__ a, int rb_stride, int n_groups,
+                                           const unsigned char *b, int swz) {
+  constexpr int RS = PF + 1;
+#pragma unroll 1
+  for (int g0 = 0; g0 < n_groups; g0 += RS) {
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+      const int g = g0 + r;
+      const int gp = min(g + PF, n_groups - 1);
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const h8 *p = a + m * rb_stride + gp * 128;
+        ring[(r + PF) % RS][m].hi = p[0];
+        ring[(r + PF) % RS][m].lo = p[64];
+      }
+      const int boff = ((2 * g) ^ swz) << 4;
+      const int boff_lo = ((LO_SLOT + 2 * g) ^ swz) << 4;  // lo slots start LO_SLOT slots later
+      h8 bh[NR], bl[NR];
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        bh[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + boff);
+        bl[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + boff_lo);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above the MFMAs (see query.hip)
+      // term-major order: consecutive MFMAs hit different accumulators
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[r % RS][m].hi, bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[r % RS][m].hi, bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[r % RS][m].lo, bh[n], acc[m][n], 0, 0, 0);
+    }
+  }
+}
+
+// z column: one k16-step whose only non-zero element is k = 0 of lanes 0-31.  The B operands
+// are kept as (hi, lo) scalar pairs and widened here (6 live VGPRs instead of 24).
+struct ZPair {
+  _Float16 hi, lo;
+};
+
+__device__ __forceinline__ h8 widen(_Float16 v) {
+  h8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (_Float16)0.0f;
+  r[0] = v;
+  return r;
+}
+
+template <int MR, int NR>
+__device__ __forceinline__ void gemm_z16(f32x16 (&acc)[MR][NR], const h8 *__restrict__ az,
+                                         const ZPair (&z)[NR]) {
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    const h8 ah = az[m * 128], al = az[m * 128 + 64];
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+      const h8 zh = widen(z[n].hi), zl = widen(z[n].lo);
+      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, zh, acc[m][n], 0, 0, 0);
+      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, zl, acc[m][n], 0, 0, 0);
+      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, zh, acc[m][n], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void init_from_bias16(f32x16 &v, const float *__restrict__ bias32, int hh,
+                                                 float scale) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 bq = *reinterpret_cast<const f32x4 *>(bias32 + 8 * q + 4 * hh);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[4 * q + i] = bq[i] * scale;
+  }
+}
+
+// y = lrelu(acc / S)
+__device__ __forceinline__ void finish16(f32x16 &v, float inv_scale) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const float y = v[t] * inv_scale;
+    v[t] = y > 0.0f ? y : y * 0.01f;  // SurfaceClassifier.py:58
+  }
+}
+
+// C-layout tile (rows 32 rb_local + 8q + 4hh + i of point p = 32 cb + j) -> hidden chunk halves:
+// hi slot 4 rb_local + q, lo slot 8 + that, 8 bytes at offset 8 hh inside the slot.
+__device__ __forceinline__ void store_hidden16(unsigned char *hb, const f32x16 &v, int rb_local,
+                                               int cb, int j, int hh) {
+  const int p = 32 * cb + j;
+  unsigned char *row = hb + p * kHRow + 8 * hh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 f = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    h4 hi, lo;
+    split4(f, hi, lo);
+    const int slot = 4 * rb_local + q;
+    *reinterpret_cast<h4 *>(row + ((slot ^ (p & 15)) << 4)) = hi;
+    *reinterpret_cast<h4 *>(row + (((8 + slot) ^ (p & 15)) << 4)) = lo;
+  }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(kThreads16, 2) void pifu_query16_kernel(
+    MlpPack mlp32, MlpPack16 mlp, const float *__restrict__ feat, int fh, int fw,
+    const float *__restrict__ calib, float z_scale, int act, PointSrc src,
+    float *__restrict__ out) {
+  constexpr int C = 256;
+  constexpr int NGX = C / 16;  // k16 groups of the feature segment
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *xs = smem;
+  unsigned char *hb = smem + kP16 * kXRow;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
+  const int j = lane & 31, hh = lane >> 5;
+  const int swz = hh ^ (j & 15);
+  const int rg = wv >> 1, cg = wv & 1;  // layers 1-3: row group / column half of this wave
+  const int rb0 = wv >> 2, cb0 = wv & 3;  // layer-0 chunk: tile of this wave
+
+  const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
+  const long long n_tiles = (n_pts + kP16 - 1) / kP16;
+  const float *wbase = mlp32.base;
+  const h8 *hbase = static_cast<const h8 *>(mlp.base);
+
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long n0 = tile * kP16;
+
+    // ---------------- gather: 16 points per wave, features split into halves ----------------
+    ZPair zc[2], z0[1];  // z_feat of this wave's column blocks (layers 1-3) / layer-0 tile
+    {
+      float cal[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) cal[i] = calib[i];
+      constexpr int GB = 4;
+#pragma unroll 1
+      for (int i0 = 0; i0 < 16; i0 += GB) {
+        Taps t[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const long long n = n0 + 16 * wv + i0 + u;
+          const bool live_n = n < n_pts;
+          float px = 0, py = 0, pz = 0, x, y, z;
+          uint32_t code;
+          if (live_n) load_point(src, n, px, py, pz, code);
+          project(cal, px, py, pz, x, y, z);
+          t[u] = make_taps(x, y, fh, fw, C, live_n && in_image(x, y));
+        }
+        f32x4 v[GB][4];
+#pragma unroll
+        for (int u = 0; u < GB; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            v[u][k] = *reinterpret_cast<const f32x4 *>(feat + t[u].o[k] + 4 * lane);
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int p = 16 * wv + i0 + u;
+          const f32x4 r = blend(v[u][0], v[u][1], v[u][2], v[u][3], t[u]);
+          h4 hi, lo;
+          split4(r, hi, lo);
+          unsigned char *row = xs + p * kXRow + 8 * (lane & 1);
+          const int slot = lane >> 1;
+          *reinterpret_cast<h4 *>(row + ((slot ^ (p & 15)) << 4)) = hi;
+          *reinterpret_cast<h4 *>(row + (((32 + slot) ^ (p & 15)) << 4)) = lo;
+        }
+      }
+      // z_feat B operands: element 0 of lanes 0-31, for the column blocks this wave works on
+      auto zpair = [&](int cb) {
+        const long long n = n0 + 32 * cb + j;
+        float px = 0, py = 0, pz = 0, x, y, z;
+        uint32_t code;
+        if (n < n_pts) load_point(src, n, px, py, pz, code);
+        project(cal, px, py, pz, x, y, z);
+        const float zf = (hh == 0 && n < n_pts) ? __fmul_rn(z, z_scale) : 0.0f;
+        ZPair r;
+        r.hi = (_Float16)zf;
+        r.lo = (_Float16)(zf - (float)r.hi);
+        return r;
+      };
+      z0[0] = zpair(cb0);
+      zc[0] = zpair(2 * cg);
+      zc[1] = zpair(2 * cg + 1);
+    }
+    __syncthreads();
+
+    const unsigned char *xrow = xs + j * kXRow;  // + 32 * cb * kXRow for column block cb
+    const unsigned char *hrow = hb + j * kHRow;
+
+    // ---------------- layers 0 + 1, fused over 64-row chunks of layer 0 ----------------
+    // layer-1 accumulators: rows [128 rg, +128) as two 64-row halves (two passes over each chunk
+    // keep the A ring at 32 VGPRs)
+    f32x16 acc1a[2][2], acc1b[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      init_from_bias16(acc1a[m][0], wbase + mlp32.bias[1] + 32 * (4 * rg + m), hh, mlp.scale[1]);
+      init_from_bias16(acc1b[m][0], wbase + mlp32.bias[1] + 32 * (4 * rg + 2 + m), hh, mlp.scale[1]);
+      acc1a[m][1] = acc1a[m][0];
+      acc1b[m][1] = acc1b[m][0];
+    }
+    {
+      const h8 *a0 = hbase + mlp.ax[0] + lane;  // [rb][g][part][lane]
+      const int rs1 = (kHidden[0] / 16) * 128;  // row-block stride of layer 1's hidden segment
+      const h8 *a1 = hbase + mlp.ah[1] + (long long)(4 * rg) * rs1 + lane;
+      const float inv0 = 1.0f / mlp.scale[0];
+      const unsigned char *b1 = hrow + (2 * cg) * 32 * kHRow;
+#pragma unroll 1
+      for (int ck = 0; ck < kHidden[0] / 64; ++ck) {
+        const int rb = 2 * ck + rb0;
+        {
+          AFrag ring0[4][1];
+          f32x16 acc0[1][1];
+          seg_prefetch16<1, 3>(ring0, a0 + (long long)rb * NGX * 128, 0, NGX);
+          init_from_bias16(acc0[0][0], wbase + mlp32.bias[0] + 32 * rb, hh, mlp.scale[0]);
+          seg_main16<1, 1, 3, kXRow, 32>(acc0, ring0, a0 + (long long)rb * NGX * 128, 0, NGX,
+                                         xrow + cb0 * 32 * kXRow, swz);
+          gemm_z16<1, 1>(acc0, hbase + mlp.az[0] + rb * 128 + lane, z0);
+          finish16(acc0[0][0], inv0);
+          store_hidden16(hb, acc0[0][0], rb0, cb0, j, hh);
+        }
+        AFrag ring1[2][2];
+        seg_prefetch16<2, 1>(ring1, a1 + ck * 4 * 128, rs1, 4);
+        __syncthreads();
+        seg_main16<2, 2, 1, kHRow, 8>(acc1a, ring1, a1 + ck * 4 * 128, rs1, 4, b1, swz);
+        seg_prefetch16<2, 1>(ring1, a1 + 2 * rs1 + ck * 4 * 128, rs1, 4);
+        seg_main16<2, 2, 1, kHRow, 8>(acc1b, ring1, a1 + 2 * rs1 + ck * 4 * 128, rs1, 4, b1, swz);
+        __syncthreads();
+      }
+      // skip segment + z column of layer 1
+      const h8 *a1x = hbase + mlp.ax[1] + (long long)(4 * rg) * NGX * 128 + lane;
+      const unsigned char *bx = xrow + (2 * cg) * 32 * kXRow;
+      AFrag ring1[2][2];
+      seg_prefetch16<2, 1>(ring1, a1x, NGX * 128, NGX);
+      seg_main16<2, 2, 1, kXRow, 32>(acc1a, ring1, a1x, NGX * 128, NGX, bx, swz);
+      seg_prefetch16<2, 1>(ring1, a1x + 2 * NGX * 128, NGX * 128, NGX);
+      seg_main16<2, 2, 1, kXRow, 32>(acc1b, ring1, a1x + 2 * NGX * 128, NGX * 128, NGX, bx, swz);
+      gemm_z16<2, 2>(acc1a, hbase + mlp.az[1] + (4 * rg) * 128 + lane, zc);
+      gemm_z16<2, 2>(acc1b, hbase + mlp.az[1] + (4 * rg + 2) * 128 + lane, zc);
+      const float inv1 = 1.0f / mlp.scale[1];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          finish16(acc1a[m][n], inv1);
+          finish16(acc1b[m][n], inv1);
+        }
+    }
+
+    // ---------------- layer 2: rows [64 rg, +64) x points [64 cg, +64) ----------------
+    f32x16 acc2[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      init_from_bias16(acc2[m][0], wbase + mlp32.bias[2] + 32 * (2 * rg + m), hh, mlp.scale[2]);
+      acc2[m][1] = acc2[m][0];
+    }
+    {
+      const h8 *a2 = hbase + mlp.ah[2] + (long long)(2 * rg) * (kHidden[1] / 16) * 128 + lane;
+      AFrag ring2[2][2];
+      seg_prefetch16<2, 1>(ring2, a2, (kHidden[1] / 16) * 128, 4);
+#pragma unroll
+      for (int ck = 0; ck < 8; ++ck) {
+        if (rg == (ck >> 1)) {  // owners of hidden rows [64 ck, +64): both column halves write
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+              store_hidden16(hb, (ck & 1) ? acc1b[mm][n] : acc1a[mm][n], mm, 2 * cg + n, j, hh);
+        }
+        __syncthreads();
+        seg_main16<2, 2, 1, kHRow, 8>(acc2, ring2, a2 + ck * 4 * 128, (kHidden[1] / 16) * 128, 4,
+                                        hrow + (2 * cg) * 32 * kHRow, swz);
+        if (ck < 7) seg_prefetch16<2, 1>(ring2, a2 + (ck + 1) * 4 * 128, (kHidden[1] / 16) * 128, 4);
+        __syncthreads();
+      }
+      const h8 *a2x = hbase + mlp.ax[2] + (long long)(2 * rg) * NGX * 128 + lane;
+      seg_prefetch16<2, 1>(ring2, a2x, NGX * 128, NGX);
+      seg_main16<2, 2, 1, kXRow, 32>(acc2, ring2, a2x, NGX * 128, NGX,
+                                      xrow + (2 * cg) * 32 * kXRow, swz);
+      gemm_z16<2, 2>(acc2, hbase + mlp.az[2] + (2 * rg) * 128 + lane, zc);
+      const float inv2 = 1.0f / mlp.scale[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) finish16(acc2[m][n], inv2);
+    }
+
+    // ---------------- layer 3: rows [32 rg, +32) x points [64 cg, +64) ----------------
+    f32x16 acc3[1][2];
+    init_from_bias16(acc3[0][0], wbase + mlp32.bias[3] + 32 * rg, hh, mlp.scale[3]);
+    acc3[0][1] = acc3[0][0];
+    {
+      const h8 *a3 = hbase + mlp.ah[3] + (long long)rg * (kHidden[2] / 16) * 128 + lane;
+      AFrag ring3[4][1];
+      seg_prefetch16<1, 3>(ring3, a3, 0, 4);
+#pragma unroll
+      for (int ck = 0; ck < 4; ++ck) {
+        if (rg == ck) {
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) store_hidden16(hb, acc2[mm][n], mm, 2 * cg + n, j, hh);
+        }
+        __syncthreads();
+        seg_main16<1, 2, 3, kHRow, 8>(acc3, ring3, a3 + ck * 4 * 128, 0, 4,
+                                        hrow + (2 * cg) * 32 * kHRow, swz);
+        if (ck < 3) seg_prefetch16<1, 3>(ring3, a3 + (ck + 1) * 4 * 128, 0, 4);
+        __syncthreads();
+      }
+      const h8 *a3x = hbase + mlp.ax[3] + (long long)rg * NGX * 128 + lane;
+      seg_prefetch16<1, 3>(ring3, a3x, 0, NGX);
+      seg_main16<1, 2, 3, kXRow, 32>(acc3, ring3, a3x, 0, NGX, xrow + (2 * cg) * 32 * kXRow, swz);
+      gemm_z16<1, 2>(acc3, hbase + mlp.az[3] + rg * 128 + lane, zc);
+      const float inv3 = 1.0f / mlp.scale[3];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) finish16(acc3[0][n], inv3);
+    }
+
+    // ---------------- layer 4 (Cout x (128 + C + 1)) on the VALU, f32 ----------------
+    // red[part][o][p]: parts 0-3 = hidden rows of row group `part`, parts 4-7 = feature quarter
+    float *red = reinterpret_cast<float *>(hb);
+    constexpr int K4 = (kHidden[3] + C + 1 + 3) & ~3;  // padded row stride (pack.hip)
+    {
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) {
+        const float *w4 = wbase + mlp32.w4 + o * K4 + 32 * rg + 4 * hh;
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 wq = *reinterpret_cast<const f32x4 *>(w4 + 8 * q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            s0 = fmaf(wq[i], acc3[0][0][4 * q + i], s0);
+            s1 = fmaf(wq[i], acc3[0][1][4 * q + i], s1);
+          }
+        }
+        s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 32);
+        if (hh == 0) {
+          red[(rg * COUT + o) * kP16 + 64 * cg + j] = s0;
+          red[(rg * COUT + o) * kP16 + 64 * cg + 32 + j] = s1;
+        }
+      }
+      // feature part: thread = (point, quarter of the channels); x = hi + lo
+      const int p = tid & (kP16 - 1), qd = tid >> 7;
+      float sx[COUT];
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) sx[o] = 0.0f;
+#pragma unroll 2
+      for (int s = 0; s < 8; ++s) {
+        const int slot = 8 * qd + s;  // 8 channels per slot
+        const h8 xh = *reinterpret_cast<const h8 *>(xs + p * kXRow + ((slot ^ (p & 15)) << 4));
+        const h8 xl = *reinterpret_cast<const h8 *>(xs + p * kXRow + (((32 + slot) ^ (p & 15)) << 4));
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+          const float *w4 = wbase + mlp32.w4 + o * K4 + kHidden[3] + 8 * slot;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sx[o] = fmaf(w4[e], (float)xh[e] + (float)xl[e], sx[o]);
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) red[((4 + qd) * COUT + o) * kP16 + p] = sx[o];
+    }
+    __syncthreads();
+    if (tid < COUT * kP16) {
+      const int o = tid / kP16, p = tid % kP16;
+      const long long n = n0 + p;
+      if (n < n_pts) {
+        float v = (wbase + mlp32.bias[4])[o];
+#pragma unroll
+        for (int part = 0; part < 8; ++part) v += red[(part * COUT + o) * kP16 + p];
+        float cal[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cal[i] = calib[i];
+        float px, py, pz, x, y, z;
+        uint32_t code;
+        load_point(src, n, px, py, pz, code);
+        project(cal, px, py, pz, x, y, z);
+        v = fmaf((wbase + mlp32.w4)[o * K4 + kHidden[3] + C], __fmul_rn(z, z_scale), v);
+        v = in_image(x, y) ? activate(v, act) : 0.0f;  // MonoPortNet.py:89
+        if (src.packed) {
+          const int ix = code & 1023u, iy = (code >> 10) & 1023u, iz = code >> 20;
+          out[((long long)iz * src.level_res + iy) * src.level_res + ix] = v;
+        } else {
+          out[o * src.out_stride + n] = v;
+        }
+      }
+    }
+    __syncthreads();  // red / xs are rewritten by the next tile
+  }
+}
+
+template <int COUT>
+static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w,
+                            const float *calib, float z_scale, const PointSrc &src, float *out,
+                            long long max_points, hipStream_t st) {
+  auto kern = pifu_query16_kernel<COUT>;
+  static bool attr_set[16] = {};
+  if (!attr_set[ctx->device & 15]) {
+    MP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLds16));
+    attr_set[ctx->device & 15] = true;
+  }
+  const long long tiles = (max_points + kP16 - 1) / kP16;
+  if (tiles <= 0) return MP_OK;
+  const long long resident = ctx->n_cu;  // one 160 KB workgroup per CU
+  const long long grid = src.n_dev ? (tiles < resident ? tiles : resident)
+                                   : (tiles < 8 * resident ? tiles : 8 * resident);
+  const bool prof = 2 * (ctx->prof_used + 1) <= (int)ctx->prof_events.size();
+  if (prof) MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], st));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads16), kLds16, st, m.pack(), m.pack16(),
+                     feat, h, w, calib, z_scale, m.act, src, out);
+  if (prof) {
+    MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], st));
+    ++ctx->prof_used;
+  }
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+int launch_query16(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w, const float *calib,
+                   float z_scale, const PointSrc &src, float *out, long long max_points,
+                   hipStream_t st) {
+  if (m.c != 256) return fail(ctx, MP_ERR_UNSUPPORTED, "f16x3 query kernel is built for C = 256");
+  if (m.cout == 1)
+    return launch_query16_t<1>(ctx, m, feat, h, w, calib, z_scale, src, out, max_points, st);
+  if (m.cout == 3)
+    return launch_query16_t<3>(ctx, m, feat, h, w, calib, z_scale, src, out, max_points, st);
+  return fail(ctx, MP_ERR_UNSUPPORTED, "f16x3 query kernel: Cout must be 1 or 3");
+}
+
+}  // namespace mp

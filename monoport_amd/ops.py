@@ -80,6 +80,7 @@ class PackedMLP:
         self.id = mid.value
         self.c = self.channels[0] - 1
         self.cout = self.channels[-1]
+        self.precision = "f32"
 
     def load_layer(self, layer, weight, bias):
         """weight [out,in] or [out,in,1] (Conv1d k=1), bias [out]; device tensors."""
@@ -90,6 +91,14 @@ class PackedMLP:
         # the pack kernels read w/b asynchronously: keep them alive until the stream drains
         w.record_stream(torch.cuda.current_stream(w.device))
         b.record_stream(torch.cuda.current_stream(b.device))
+
+    def set_precision(self, precision):
+        """"f32" (default: exact f32 MFMA) or "f16x3" (f32 emulated with three f16 MFMAs per
+        product, netG heads only).  Call after the layers are loaded."""
+        code = {"f32": 0, "f16x3": 1}[precision]
+        self.ctx.check(self.ctx.lib.mp_mlp_set_precision(self.ctx.handle, self.id, code),
+                       "mp_mlp_set_precision")
+        self.precision = precision
 
     @classmethod
     def from_layers(cls, device, layers, last_op):
