@@ -38,9 +38,10 @@ FLOP_PER_POINT = 2363906  # netG MLP, SURVEY.md section 8d / BASELINE.md section
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
-def build_netg(device):
+def build_netg(device, precision="f32"):
     """Random-init (seeded) encoder of the reference architecture + the analytic F-body head."""
     net = PIFuNetG().eval()
+    net.surface_classifier.set_precision(precision)
     shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
     sd = syn.seeded_state_dict(shapes, 71)
     net.image_filter.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -64,10 +65,10 @@ def build_netc(device):
     return net.to(device)
 
 
-def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False):
+def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, precision="f32"):
     """`depth` frames in flight, each the stage chain of RTL/main.py:366-428 (geometry only)
     captured in a hipGraph on its own stream (monoport_amd/pipeline.py)."""
-    net, _ = build_netg(device)
+    net, _ = build_netg(device, precision)
     planes = torch.from_numpy(syn.body_feature_planes(128, 128)).to(device)
 
     def body_planes_hook(feat):
@@ -137,6 +138,9 @@ def main():
                     help="BASELINE configs[2]: add netC (ResNet encoder + per-vertex colour MLP)")
     ap.add_argument("--levels", type=int, default=5, choices=[5, 6],
                     help="6 = octree to 513^3 (BASELINE configs[4] grid, f32 weights)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
+                    help="MLP arithmetic: exact f32 MFMA (default) or the f32-accurate 3-term f16 "
+                         "split (hi*hi + hi*lo + lo*hi on f16 MFMA, f32 accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -153,7 +157,7 @@ def main():
         import torch.distributed as dist
 
     resolutions = RESOLUTIONS + ([513] if args.levels == 6 else [])
-    pipe = make_pipeline(device, args.depth, args.graph, resolutions, args.with_color)
+    pipe = make_pipeline(device, args.depth, args.graph, resolutions, args.with_color, args.precision)
     n_frames = args.steps + args.warmup
     # distinct frames per rank: frame id = step * world + rank (frame-parallel sharding)
     images = [torch.from_numpy(syn.synthetic_image(s * world + rank))[None].to(device)
@@ -240,6 +244,8 @@ def main():
     pts_all = float(p.item())
 
     if rank == 0:
+        # f16x3 spends three f16 MFMAs (2.5 PFLOP/s dense peak) per algorithmic f32 product
+        peak_tflops = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else 2500.0 / 3.0
         n_launch = min(len(launch_ms), prof_pts.size)
         flops = prof_pts.reshape(-1)[:n_launch].astype(np.float64) * FLOP_PER_POINT
         achieved = flops.sum() / (launch_ms[:n_launch].sum() * 1e-3) / 1e12 if n_launch else 0.0
@@ -254,7 +260,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.precision == "f32" else
+                     "f32 emulated on f16 MFMA (3-term hi/lo split, f32 accumulate)",
             "data": "synthetic",
             "config": {
                 "workload": ("BASELINE configs[%d]: single 512x512 image, netG (4-stack hourglass encoder "
@@ -278,12 +285,13 @@ def main():
                 "note": "single stream, one frame at a time (no overlap)",
             },
             "roofline": {
-                "kernel": "pifu_query_kernel<256,1> (fused gather + MLP)",
+                "kernel": ("pifu_query_kernel<256,1> (fused gather + MLP)" if args.precision == "f32"
+                           else "pifu_query16_kernel<1> (fused gather + MLP, f16x3)"),
                 "bound": "mfma",
                 "achieved": achieved,
-                "peak": F32_MFMA_PEAK_TFLOPS,
+                "peak": peak_tflops,
                 "unit": "TFLOP/s",
-                "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                "frac": achieved / peak_tflops,
                 "traffic": traffic_from_profile(),
                 "launches": int(n_launch),
                 "avg_launch_ms": float(launch_ms[:n_launch].mean()) if n_launch else None,

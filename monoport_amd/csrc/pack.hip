@@ -93,8 +93,12 @@ int launch_pack_layer(mp_ctx *ctx, Mlp &m, int layer, const float *w, const floa
 // f16x3 packing (query16.hip): A16[rb][g][part][lane][e], part 0 = hi, 1 = lo,
 //   value = W[32 rb + (lane & 31)][col0 + 16 g + 8 (lane >> 5) + e] * S  split into two halves.
 // ---------------------------------------------------------------------------------------------
+// perm_t > 0 (hidden segments of layers 2 and 3): K is re-ordered so that every 64-deep chunk
+// takes 16 rows from each of the 4 waves of query16.hip (wave g owns tiles perm_t*g .. +perm_t-1
+// of the previous layer): k' = 64 c + 16 g + e  <->  source row 32 (perm_t g + (c >> 1)) + 16 (c & 1) + e.
 __global__ void pack_segment16_kernel(const float *__restrict__ w, int ld, int col0, int n_groups,
-                                      int n_rb, float scale, _Float16 *__restrict__ dst) {
+                                      int n_rb, float scale, int perm_t,
+                                      _Float16 *__restrict__ dst) {
   const long long total = (long long)n_rb * n_groups * 512;  // (lane, e) pairs
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
@@ -103,8 +107,12 @@ __global__ void pack_segment16_kernel(const float *__restrict__ w, int ld, int c
     const long long q = t >> 9;
     const int g = q % n_groups;
     const int rb = q / n_groups;
-    const float v = w[(long long)(32 * rb + (lane & 31)) * ld + col0 + 16 * g + 8 * (lane >> 5) + e] *
-                    scale;
+    int k = 16 * g + 8 * (lane >> 5) + e;
+    if (perm_t > 0) {
+      const int c = k >> 6, gw = (k >> 4) & 3, ee = k & 15;
+      k = 32 * (perm_t * gw + (c >> 1)) + 16 * (c & 1) + ee;
+    }
+    const float v = w[(long long)(32 * rb + (lane & 31)) * ld + col0 + k] * scale;
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
     _Float16 *blk = dst + q * 1024;  // 2 parts x 64 lanes x 8 halves
@@ -161,9 +169,9 @@ int launch_pack_layer16(mp_ctx *ctx, Mlp &m, int layer, const float *w, hipStrea
   _Float16 *base = static_cast<_Float16 *>(m.buf16);
   if (k_h > 0)
     hipLaunchKernelGGL(pack_segment16_kernel, dim3(2048), dim3(256), 0, st, w, ld, 0, k_h / 16,
-                       n_rb, s, base + m.off16_ah[layer] * 8);
+                       n_rb, s, layer == 2 ? 4 : (layer == 3 ? 2 : 0), base + m.off16_ah[layer] * 8);
   hipLaunchKernelGGL(pack_segment16_kernel, dim3(2048), dim3(256), 0, st, w, ld, k_h, c / 16, n_rb,
-                     s, base + m.off16_ax[layer] * 8);
+                     s, 0, base + m.off16_ax[layer] * 8);
   hipLaunchKernelGGL(pack_zcol16_kernel, dim3((n_rb * 512 + 255) / 256), dim3(256), 0, st, w, ld,
                      k_h + c, n_rb, s, base + m.off16_az[layer] * 8);
   MP_HIP(ctx, hipGetLastError());

@@ -7,16 +7,26 @@
 // instruction: 3 MFMAs of 32 cycles replace 8 MFMAs of 64 cycles per 16-deep k-step (5.3x).
 //
 // Everything that was "free" next to f32 MFMA now matters, so the decomposition changes:
-//   * one workgroup = 8 waves = a 128-point tile (weights are re-used over twice as many points:
+//   * one workgroup = 4 waves = a 128-point tile (weights are re-used over twice as many points:
 //     4.7 MB of weight traffic per 128 points keeps the L2 -> CU stream ~12 TB/s chip-wide);
+//   * one wave per SIMD with the whole 512-entry register file: layer 1's 128 rows x 128 points
+//     per wave are 256 accumulator registers, and the A ring / B fragments are deep enough to hide
+//     L2 latency without a partner wave;
 //   * LDS is used to the last byte: xs[128][hi 512 B | lo 512 B] = 128 KB + one 64-row hidden chunk
-//     [128][hi 128 B | lo 128 B] = 32 KB (160 KB, one workgroup per CU, 2 waves per SIMD);
-//   * layer 0 is produced in 64-row chunks (one 32x32 tile per wave), split into halves on the way
-//     to LDS and consumed by layer 1 (each wave: 128 rows x 64 points, 128 accumulator VGPRs);
-//     layers 2 and 3 stream their inputs from the owning waves' registers the same way.
+//     [128][hi 128 B | lo 128 B] = 32 KB (160 KB, one workgroup per CU);
+//   * layer 0 is produced in 64-row chunks (32 rows x 64 points per wave), split into halves on
+//     the way to LDS and consumed by layer 1; layers 2 and 3 stream their inputs from the owning
+//     waves' registers the same way.
 // Weights are pre-split and pre-scaled by a per-layer power of two S (pack.hip) so that lo stays
 // out of the f16 subnormals; accumulators start at bias * S and are multiplied by 1/S (exact)
 // before the leaky ReLU.  Activations larger than 65504 would saturate -- PIFu activations are O(1-100).
+//
+// Status (round 1): 143 M points/s on a 1 M-point launch (2.6x the f32 kernel), 0.2 of the
+// three-MFMA-per-product roof.  Ablation builds (-DMP16_ABLATE=1..3 stop after the gather / layers
+// 0+1 / layer 2) put 65 % of the time in the fused layer-0/1 loop at ~45 % MFMA utilisation;
+// re-reading one cached weight chunk instead of streaming all of them changes nothing, so the
+// limit is in-core: hipcc spills ~300 registers around the 256-register accumulator tile and
+// drains the prefetch queues at every reload.  Next step: hand-allocated registers for that loop.
 #include "mp_internal.h"
 #include "query_common.h"
 
@@ -28,7 +38,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 constexpr int kP16 = 128;        // points per workgroup tile
-constexpr int kThreads16 = 512;  // 8 waves
+constexpr int kThreads16 = 256;  // 4 waves = one per SIMD, each with the full 512-register file
 constexpr int kXRow = 1024;      // bytes per point in xs: 32 hi slots | 32 lo slots (16 B each)
 constexpr int kHRow = 256;       // bytes per point in the hidden chunk: 8 hi slots | 8 lo slots
 constexpr int kLds16 = kP16 * kXRow + kP16 * kHRow;  // 163,840 B = all of a CU's LDS
@@ -68,6 +78,14 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
                                            const h8 *__restrict__ a, int rb_stride, int n_groups,
                                            const unsigned char *b, int swz) {
   constexpr int RS = PF + 1;
+  // B operands are double-buffered too: the ds_reads of group g+1 are issued before the MFMAs of
+  // group g (a lone wave per SIMD has nobody to hide the ~130-cycle LDS latency behind)
+  h8 bh[NR], bl[NR];
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
+    bh[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + (swz << 4));
+    bl[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + ((LO_SLOT ^ swz) << 4));
+  }
 #pragma unroll 1
   for (int g0 = 0; g0 < n_groups; g0 += RS) {
 #pragma unroll
@@ -80,13 +98,14 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
         ring[(r + PF) % RS][m].hi = p[0];
         ring[(r + PF) % RS][m].lo = p[64];
       }
-      const int boff = ((2 * g) ^ swz) << 4;
-      const int boff_lo = ((LO_SLOT + 2 * g) ^ swz) << 4;  // lo slots start LO_SLOT slots later
-      h8 bh[NR], bl[NR];
+      const int gn = min(g + 1, n_groups - 1);
+      const int boff = ((2 * gn) ^ swz) << 4;
+      const int boff_lo = ((LO_SLOT + 2 * gn) ^ swz) << 4;  // lo slots start LO_SLOT slots later
+      h8 nh[NR], nl[NR];
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
-        bh[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + boff);
-        bl[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + boff_lo);
+        nh[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + boff);
+        nl[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + boff_lo);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above the MFMAs (see query.hip)
       // term-major order: consecutive MFMAs hit different accumulators
@@ -105,6 +124,11 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
 #pragma unroll
         for (int n = 0; n < NR; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[r % RS][m].lo, bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        bh[n] = nh[n];
+        bl[n] = nl[n];
+      }
     }
   }
 }
@@ -175,8 +199,28 @@ __device__ __forceinline__ void store_hidden16(unsigned char *hb, const f32x16 &
   }
 }
 
+// Layers 2 and 3 read their K in chunks of 64 = 16 rows from EACH wave (pack.hip permutes the
+// weights to match), so all four waves convert and write a quarter of every chunk in parallel:
+// rows 16 half .. +15 of a C-layout tile are registers 8 half .. 8 half + 7; wave `grp` fills K
+// group `grp` (hi slots 2 grp, 2 grp + 1).
+__device__ __forceinline__ void store_hidden16_part(unsigned char *hb, const f32x16 &v, int half,
+                                                    int grp, int cb, int j, int hh) {
+  const int p = 32 * cb + j;
+  unsigned char *row = hb + p * kHRow + 8 * hh;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int t0 = 8 * half + 4 * q;
+    const f32x4 f = {v[t0], v[t0 + 1], v[t0 + 2], v[t0 + 3]};
+    h4 hi, lo;
+    split4(f, hi, lo);
+    const int slot = 2 * grp + q;
+    *reinterpret_cast<h4 *>(row + ((slot ^ (p & 15)) << 4)) = hi;
+    *reinterpret_cast<h4 *>(row + (((8 + slot) ^ (p & 15)) << 4)) = lo;
+  }
+}
+
 template <int COUT>
-__global__ __launch_bounds__(kThreads16, 2) void pifu_query16_kernel(
+__global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
     MlpPack mlp32, MlpPack16 mlp, const float *__restrict__ feat, int fh, int fw,
     const float *__restrict__ calib, float z_scale, int act, PointSrc src,
     float *__restrict__ out) {
@@ -188,11 +232,10 @@ __global__ __launch_bounds__(kThreads16, 2) void pifu_query16_kernel(
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3 = row group of layers 1-3
   const int j = lane & 31, hh = lane >> 5;
   const int swz = hh ^ (j & 15);
-  const int rg = wv >> 1, cg = wv & 1;  // layers 1-3: row group / column half of this wave
-  const int rb0 = wv >> 2, cb0 = wv & 3;  // layer-0 chunk: tile of this wave
+  const int rb0 = wv >> 1, cp0 = wv & 1;  // layer-0 chunk: row block / column-block pair
 
   const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
   const long long n_tiles = (n_pts + kP16 - 1) / kP16;
@@ -202,19 +245,19 @@ __global__ __launch_bounds__(kThreads16, 2) void pifu_query16_kernel(
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long n0 = tile * kP16;
 
-    // ---------------- gather: 16 points per wave, features split into halves ----------------
-    ZPair zc[2], z0[1];  // z_feat of this wave's column blocks (layers 1-3) / layer-0 tile
+    // ---------------- gather: 32 points per wave, features split into halves ----------------
+    ZPair zc[4];  // z_feat of the four column blocks
     {
       float cal[12];
 #pragma unroll
       for (int i = 0; i < 12; ++i) cal[i] = calib[i];
-      constexpr int GB = 4;
+      constexpr int GB = 8;  // 32 independent 16-byte loads in flight per lane
 #pragma unroll 1
-      for (int i0 = 0; i0 < 16; i0 += GB) {
+      for (int i0 = 0; i0 < 32; i0 += GB) {
         Taps t[GB];
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
-          const long long n = n0 + 16 * wv + i0 + u;
+          const long long n = n0 + 32 * wv + i0 + u;
           const bool live_n = n < n_pts;
           float px = 0, py = 0, pz = 0, x, y, z;
           uint32_t code;
@@ -230,7 +273,7 @@ __global__ __launch_bounds__(kThreads16, 2) void pifu_query16_kernel(
             v[u][k] = *reinterpret_cast<const f32x4 *>(feat + t[u].o[k] + 4 * lane);
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
-          const int p = 16 * wv + i0 + u;
+          const int p = 32 * wv + i0 + u;
           const f32x4 r = blend(v[u][0], v[u][1], v[u][2], v[u][3], t[u]);
           h4 hi, lo;
           split4(r, hi, lo);
@@ -240,189 +283,198 @@ __global__ __launch_bounds__(kThreads16, 2) void pifu_query16_kernel(
           *reinterpret_cast<h4 *>(row + (((32 + slot) ^ (p & 15)) << 4)) = lo;
         }
       }
-      // z_feat B operands: element 0 of lanes 0-31, for the column blocks this wave works on
-      auto zpair = [&](int cb) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
         const long long n = n0 + 32 * cb + j;
         float px = 0, py = 0, pz = 0, x, y, z;
         uint32_t code;
         if (n < n_pts) load_point(src, n, px, py, pz, code);
         project(cal, px, py, pz, x, y, z);
         const float zf = (hh == 0 && n < n_pts) ? __fmul_rn(z, z_scale) : 0.0f;
-        ZPair r;
-        r.hi = (_Float16)zf;
-        r.lo = (_Float16)(zf - (float)r.hi);
-        return r;
-      };
-      z0[0] = zpair(cb0);
-      zc[0] = zpair(2 * cg);
-      zc[1] = zpair(2 * cg + 1);
+        zc[cb].hi = (_Float16)zf;
+        zc[cb].lo = (_Float16)(zf - (float)zc[cb].hi);
+      }
     }
     __syncthreads();
 
-    const unsigned char *xrow = xs + j * kXRow;  // + 32 * cb * kXRow for column block cb
+#ifdef MP16_ABLATE
+    if (MP16_ABLATE == 1) {  // timing experiment only: gather alone
+      if (zc[0].hi == (_Float16)123.0f) out[0] = 1.f;
+      continue;
+    }
+#endif
+    const unsigned char *xrow = xs + j * kXRow;  // column block 0; + 32 * cb * kXRow for block cb
     const unsigned char *hrow = hb + j * kHRow;
 
     // ---------------- layers 0 + 1, fused over 64-row chunks of layer 0 ----------------
-    // layer-1 accumulators: rows [128 rg, +128) as two 64-row halves (two passes over each chunk
-    // keep the A ring at 32 VGPRs)
-    f32x16 acc1a[2][2], acc1b[2][2];
+    f32x16 acc1[4][4];  // layer-1 rows [128 wv, +128) x all 128 points: 256 accumulator registers
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      init_from_bias16(acc1a[m][0], wbase + mlp32.bias[1] + 32 * (4 * rg + m), hh, mlp.scale[1]);
-      init_from_bias16(acc1b[m][0], wbase + mlp32.bias[1] + 32 * (4 * rg + 2 + m), hh, mlp.scale[1]);
-      acc1a[m][1] = acc1a[m][0];
-      acc1b[m][1] = acc1b[m][0];
+    for (int m = 0; m < 4; ++m) {
+      init_from_bias16(acc1[m][0], wbase + mlp32.bias[1] + 32 * (4 * wv + m), hh, mlp.scale[1]);
+#pragma unroll
+      for (int n = 1; n < 4; ++n) acc1[m][n] = acc1[m][0];
     }
     {
       const h8 *a0 = hbase + mlp.ax[0] + lane;  // [rb][g][part][lane]
       const int rs1 = (kHidden[0] / 16) * 128;  // row-block stride of layer 1's hidden segment
-      const h8 *a1 = hbase + mlp.ah[1] + (long long)(4 * rg) * rs1 + lane;
+      const h8 *a1 = hbase + mlp.ah[1] + (long long)(4 * wv) * rs1 + lane;
       const float inv0 = 1.0f / mlp.scale[0];
-      const unsigned char *b1 = hrow + (2 * cg) * 32 * kHRow;
+      const ZPair z0[2] = {zc[2 * cp0], zc[2 * cp0 + 1]};
+      AFrag ring0[4][1];
+      f32x16 acc0[1][2];
+      seg_prefetch16<1, 3>(ring0, a0 + (long long)rb0 * NGX * 128, 0, NGX);
+      init_from_bias16(acc0[0][0], wbase + mlp32.bias[0] + 32 * rb0, hh, mlp.scale[0]);
+      acc0[0][1] = acc0[0][0];
 #pragma unroll 1
       for (int ck = 0; ck < kHidden[0] / 64; ++ck) {
+        // layer-0 rows [64 ck + 32 rb0, +32) x points [64 cp0, +64)
         const int rb = 2 * ck + rb0;
-        {
-          AFrag ring0[4][1];
-          f32x16 acc0[1][1];
-          seg_prefetch16<1, 3>(ring0, a0 + (long long)rb * NGX * 128, 0, NGX);
-          init_from_bias16(acc0[0][0], wbase + mlp32.bias[0] + 32 * rb, hh, mlp.scale[0]);
-          seg_main16<1, 1, 3, kXRow, 32>(acc0, ring0, a0 + (long long)rb * NGX * 128, 0, NGX,
-                                         xrow + cb0 * 32 * kXRow, swz);
-          gemm_z16<1, 1>(acc0, hbase + mlp.az[0] + rb * 128 + lane, z0);
-          finish16(acc0[0][0], inv0);
-          store_hidden16(hb, acc0[0][0], rb0, cb0, j, hh);
-        }
-        AFrag ring1[2][2];
-        seg_prefetch16<2, 1>(ring1, a1 + ck * 4 * 128, rs1, 4);
+        seg_main16<1, 2, 3, kXRow, 32>(acc0, ring0, a0 + (long long)rb * NGX * 128, 0, NGX,
+                                       xrow + (2 * cp0) * 32 * kXRow, swz);
+        AFrag ring1[2][4];
+        seg_prefetch16<4, 1>(ring1, a1 + ck * 4 * 128, rs1, 4);
+        gemm_z16<1, 2>(acc0, hbase + mlp.az[0] + rb * 128 + lane, z0);
+        finish16(acc0[0][0], inv0);
+        finish16(acc0[0][1], inv0);
+        store_hidden16(hb, acc0[0][0], rb0, 2 * cp0, j, hh);
+        store_hidden16(hb, acc0[0][1], rb0, 2 * cp0 + 1, j, hh);
+        // next chunk's layer-0 operands stream in underneath the layer-1 MFMAs
+        const int rbn = min(rb + 2, kHidden[0] / 32 - 2 + rb0);
+        seg_prefetch16<1, 3>(ring0, a0 + (long long)rbn * NGX * 128, 0, NGX);
+        init_from_bias16(acc0[0][0], wbase + mlp32.bias[0] + 32 * rbn, hh, mlp.scale[0]);
+        acc0[0][1] = acc0[0][0];
         __syncthreads();
-        seg_main16<2, 2, 1, kHRow, 8>(acc1a, ring1, a1 + ck * 4 * 128, rs1, 4, b1, swz);
-        seg_prefetch16<2, 1>(ring1, a1 + 2 * rs1 + ck * 4 * 128, rs1, 4);
-        seg_main16<2, 2, 1, kHRow, 8>(acc1b, ring1, a1 + 2 * rs1 + ck * 4 * 128, rs1, 4, b1, swz);
+        seg_main16<4, 4, 1, kHRow, 8>(acc1, ring1, a1 + ck * 4 * 128, rs1, 4, hrow, swz);
         __syncthreads();
       }
       // skip segment + z column of layer 1
-      const h8 *a1x = hbase + mlp.ax[1] + (long long)(4 * rg) * NGX * 128 + lane;
-      const unsigned char *bx = xrow + (2 * cg) * 32 * kXRow;
-      AFrag ring1[2][2];
-      seg_prefetch16<2, 1>(ring1, a1x, NGX * 128, NGX);
-      seg_main16<2, 2, 1, kXRow, 32>(acc1a, ring1, a1x, NGX * 128, NGX, bx, swz);
-      seg_prefetch16<2, 1>(ring1, a1x + 2 * NGX * 128, NGX * 128, NGX);
-      seg_main16<2, 2, 1, kXRow, 32>(acc1b, ring1, a1x + 2 * NGX * 128, NGX * 128, NGX, bx, swz);
-      gemm_z16<2, 2>(acc1a, hbase + mlp.az[1] + (4 * rg) * 128 + lane, zc);
-      gemm_z16<2, 2>(acc1b, hbase + mlp.az[1] + (4 * rg + 2) * 128 + lane, zc);
+      const h8 *a1x = hbase + mlp.ax[1] + (long long)(4 * wv) * NGX * 128 + lane;
+      AFrag ring1[2][4];
+      seg_prefetch16<4, 1>(ring1, a1x, NGX * 128, NGX);
+      seg_main16<4, 4, 1, kXRow, 32>(acc1, ring1, a1x, NGX * 128, NGX, xrow, swz);
+      gemm_z16<4, 4>(acc1, hbase + mlp.az[1] + (4 * wv) * 128 + lane, zc);
       const float inv1 = 1.0f / mlp.scale[1];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          finish16(acc1a[m][n], inv1);
-          finish16(acc1b[m][n], inv1);
-        }
+        for (int n = 0; n < 4; ++n) finish16(acc1[m][n], inv1);
     }
 
-    // ---------------- layer 2: rows [64 rg, +64) x points [64 cg, +64) ----------------
-    f32x16 acc2[2][2];
+#ifdef MP16_ABLATE
+    if (MP16_ABLATE == 2) {  // timing experiment only: stop after layers 0+1
+      float sink = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) sink += acc1[m][n][0];
+      if (sink == 12345.678f) out[0] = sink;
+      __syncthreads();
+      continue;
+    }
+#endif
+    // ---------------- layer 2: rows [64 wv, +64) x 128 points ----------------
+    f32x16 acc2[2][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      init_from_bias16(acc2[m][0], wbase + mlp32.bias[2] + 32 * (2 * rg + m), hh, mlp.scale[2]);
-      acc2[m][1] = acc2[m][0];
+      init_from_bias16(acc2[m][0], wbase + mlp32.bias[2] + 32 * (2 * wv + m), hh, mlp.scale[2]);
+#pragma unroll
+      for (int n = 1; n < 4; ++n) acc2[m][n] = acc2[m][0];
     }
     {
-      const h8 *a2 = hbase + mlp.ah[2] + (long long)(2 * rg) * (kHidden[1] / 16) * 128 + lane;
+      const int rs2 = (kHidden[1] / 16) * 128;
+      const h8 *a2 = hbase + mlp.ah[2] + (long long)(2 * wv) * rs2 + lane;
       AFrag ring2[2][2];
-      seg_prefetch16<2, 1>(ring2, a2, (kHidden[1] / 16) * 128, 4);
+      seg_prefetch16<2, 1>(ring2, a2, rs2, 4);
 #pragma unroll
       for (int ck = 0; ck < 8; ++ck) {
-        if (rg == (ck >> 1)) {  // owners of hidden rows [64 ck, +64): both column halves write
 #pragma unroll
-          for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-              store_hidden16(hb, (ck & 1) ? acc1b[mm][n] : acc1a[mm][n], mm, 2 * cg + n, j, hh);
-        }
+        for (int n = 0; n < 4; ++n) store_hidden16_part(hb, acc1[ck >> 1][n], ck & 1, wv, n, j, hh);
         __syncthreads();
-        seg_main16<2, 2, 1, kHRow, 8>(acc2, ring2, a2 + ck * 4 * 128, (kHidden[1] / 16) * 128, 4,
-                                        hrow + (2 * cg) * 32 * kHRow, swz);
-        if (ck < 7) seg_prefetch16<2, 1>(ring2, a2 + (ck + 1) * 4 * 128, (kHidden[1] / 16) * 128, 4);
+        seg_main16<2, 4, 1, kHRow, 8>(acc2, ring2, a2 + ck * 4 * 128, rs2, 4, hrow, swz);
+        if (ck < 7) seg_prefetch16<2, 1>(ring2, a2 + (ck + 1) * 4 * 128, rs2, 4);
         __syncthreads();
       }
-      const h8 *a2x = hbase + mlp.ax[2] + (long long)(2 * rg) * NGX * 128 + lane;
+      const h8 *a2x = hbase + mlp.ax[2] + (long long)(2 * wv) * NGX * 128 + lane;
       seg_prefetch16<2, 1>(ring2, a2x, NGX * 128, NGX);
-      seg_main16<2, 2, 1, kXRow, 32>(acc2, ring2, a2x, NGX * 128, NGX,
-                                      xrow + (2 * cg) * 32 * kXRow, swz);
-      gemm_z16<2, 2>(acc2, hbase + mlp.az[2] + (2 * rg) * 128 + lane, zc);
+      seg_main16<2, 4, 1, kXRow, 32>(acc2, ring2, a2x, NGX * 128, NGX, xrow, swz);
+      gemm_z16<2, 4>(acc2, hbase + mlp.az[2] + (2 * wv) * 128 + lane, zc);
       const float inv2 = 1.0f / mlp.scale[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) finish16(acc2[m][n], inv2);
+        for (int n = 0; n < 4; ++n) finish16(acc2[m][n], inv2);
     }
 
-    // ---------------- layer 3: rows [32 rg, +32) x points [64 cg, +64) ----------------
-    f32x16 acc3[1][2];
-    init_from_bias16(acc3[0][0], wbase + mlp32.bias[3] + 32 * rg, hh, mlp.scale[3]);
-    acc3[0][1] = acc3[0][0];
+#ifdef MP16_ABLATE
+    if (MP16_ABLATE == 3) {  // timing experiment only: stop after layer 2
+      float sink = 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) sink += acc2[m][n][0];
+      if (sink == 12345.678f) out[0] = sink;
+      __syncthreads();
+      continue;
+    }
+#endif
+    // ---------------- layer 3: rows [32 wv, +32) x 128 points ----------------
+    f32x16 acc3[1][4];
+    init_from_bias16(acc3[0][0], wbase + mlp32.bias[3] + 32 * wv, hh, mlp.scale[3]);
+#pragma unroll
+    for (int n = 1; n < 4; ++n) acc3[0][n] = acc3[0][0];
     {
-      const h8 *a3 = hbase + mlp.ah[3] + (long long)rg * (kHidden[2] / 16) * 128 + lane;
+      const h8 *a3 = hbase + mlp.ah[3] + (long long)wv * (kHidden[2] / 16) * 128 + lane;
       AFrag ring3[4][1];
       seg_prefetch16<1, 3>(ring3, a3, 0, 4);
 #pragma unroll
       for (int ck = 0; ck < 4; ++ck) {
-        if (rg == ck) {
 #pragma unroll
-          for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) store_hidden16(hb, acc2[mm][n], mm, 2 * cg + n, j, hh);
-        }
+        for (int n = 0; n < 4; ++n) store_hidden16_part(hb, acc2[ck >> 1][n], ck & 1, wv, n, j, hh);
         __syncthreads();
-        seg_main16<1, 2, 3, kHRow, 8>(acc3, ring3, a3 + ck * 4 * 128, 0, 4,
-                                        hrow + (2 * cg) * 32 * kHRow, swz);
+        seg_main16<1, 4, 3, kHRow, 8>(acc3, ring3, a3 + ck * 4 * 128, 0, 4, hrow, swz);
         if (ck < 3) seg_prefetch16<1, 3>(ring3, a3 + (ck + 1) * 4 * 128, 0, 4);
         __syncthreads();
       }
-      const h8 *a3x = hbase + mlp.ax[3] + (long long)rg * NGX * 128 + lane;
+      const h8 *a3x = hbase + mlp.ax[3] + (long long)wv * NGX * 128 + lane;
       seg_prefetch16<1, 3>(ring3, a3x, 0, NGX);
-      seg_main16<1, 2, 3, kXRow, 32>(acc3, ring3, a3x, 0, NGX, xrow + (2 * cg) * 32 * kXRow, swz);
-      gemm_z16<1, 2>(acc3, hbase + mlp.az[3] + rg * 128 + lane, zc);
+      seg_main16<1, 4, 3, kXRow, 32>(acc3, ring3, a3x, 0, NGX, xrow, swz);
+      gemm_z16<1, 4>(acc3, hbase + mlp.az[3] + wv * 128 + lane, zc);
       const float inv3 = 1.0f / mlp.scale[3];
 #pragma unroll
-      for (int n = 0; n < 2; ++n) finish16(acc3[0][n], inv3);
+      for (int n = 0; n < 4; ++n) finish16(acc3[0][n], inv3);
     }
 
     // ---------------- layer 4 (Cout x (128 + C + 1)) on the VALU, f32 ----------------
-    // red[part][o][p]: parts 0-3 = hidden rows of row group `part`, parts 4-7 = feature quarter
+    // red[part][o][p]: parts 0-3 = hidden rows of wave `part`, parts 4-5 = feature half
     float *red = reinterpret_cast<float *>(hb);
     constexpr int K4 = (kHidden[3] + C + 1 + 3) & ~3;  // padded row stride (pack.hip)
     {
 #pragma unroll
       for (int o = 0; o < COUT; ++o) {
-        const float *w4 = wbase + mlp32.w4 + o * K4 + 32 * rg + 4 * hh;
-        float s0 = 0.0f, s1 = 0.0f;
+        const float *w4 = wbase + mlp32.w4 + o * K4 + 32 * wv + 4 * hh;
+        float sv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 wq = *reinterpret_cast<const f32x4 *>(w4 + 8 * q);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            s0 = fmaf(wq[i], acc3[0][0][4 * q + i], s0);
-            s1 = fmaf(wq[i], acc3[0][1][4 * q + i], s1);
-          }
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) sv[n] = fmaf(wq[i], acc3[0][n][4 * q + i], sv[n]);
         }
-        s0 += __shfl_xor(s0, 32);
-        s1 += __shfl_xor(s1, 32);
-        if (hh == 0) {
-          red[(rg * COUT + o) * kP16 + 64 * cg + j] = s0;
-          red[(rg * COUT + o) * kP16 + 64 * cg + 32 + j] = s1;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          sv[n] += __shfl_xor(sv[n], 32);
+          if (hh == 0) red[(wv * COUT + o) * kP16 + 32 * n + j] = sv[n];
         }
       }
-      // feature part: thread = (point, quarter of the channels); x = hi + lo
-      const int p = tid & (kP16 - 1), qd = tid >> 7;
+      // feature part: thread = (point, half of the channels); x = hi + lo
+      const int p = tid & (kP16 - 1), hf = tid >> 7;
       float sx[COUT];
 #pragma unroll
       for (int o = 0; o < COUT; ++o) sx[o] = 0.0f;
 #pragma unroll 2
-      for (int s = 0; s < 8; ++s) {
-        const int slot = 8 * qd + s;  // 8 channels per slot
+      for (int s = 0; s < 16; ++s) {
+        const int slot = 16 * hf + s;  // 8 channels per slot
         const h8 xh = *reinterpret_cast<const h8 *>(xs + p * kXRow + ((slot ^ (p & 15)) << 4));
         const h8 xl = *reinterpret_cast<const h8 *>(xs + p * kXRow + (((32 + slot) ^ (p & 15)) << 4));
 #pragma unroll
@@ -433,16 +485,16 @@ __global__ __launch_bounds__(kThreads16, 2) void pifu_query16_kernel(
         }
       }
 #pragma unroll
-      for (int o = 0; o < COUT; ++o) red[((4 + qd) * COUT + o) * kP16 + p] = sx[o];
+      for (int o = 0; o < COUT; ++o) red[((4 + hf) * COUT + o) * kP16 + p] = sx[o];
     }
     __syncthreads();
-    if (tid < COUT * kP16) {
-      const int o = tid / kP16, p = tid % kP16;
+    for (int idx = tid; idx < COUT * kP16; idx += kThreads16) {
+      const int o = idx / kP16, p = idx % kP16;
       const long long n = n0 + p;
       if (n < n_pts) {
         float v = (wbase + mlp32.bias[4])[o];
 #pragma unroll
-        for (int part = 0; part < 8; ++part) v += red[(part * COUT + o) * kP16 + p];
+        for (int part = 0; part < 6; ++part) v += red[(part * COUT + o) * kP16 + p];
         float cal[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) cal[i] = calib[i];

@@ -39,10 +39,20 @@ class SurfaceClassifier(nn.Module):
             self.filters.append(nn.Conv1d(c_in, self.filter_channels[l + 1], 1))
         self._packed = None
         self._packed_key = None
+        # arithmetic of the MLP GEMMs in the fused HIP kernel: "f32" (exact f32 MFMA, default) or
+        # "f16x3" (f32 emulated with three f16 MFMAs per product; netG head only)
+        self.precision = "f32"
 
     # ---- packed-weight cache ------------------------------------------------------------------
+    def set_precision(self, precision):
+        if precision not in ("f32", "f16x3"):
+            raise ValueError("precision must be 'f32' or 'f16x3'")
+        self.precision = precision
+        self._packed_key = None  # re-pack on next use
+        return self
+
     def _weights_key(self):
-        key = []
+        key = [self.precision]
         for f in self.filters:
             for p in (f.weight, f.bias):
                 key.append((p.data_ptr(), p._version, str(p.device)))
@@ -58,6 +68,7 @@ class SurfaceClassifier(nn.Module):
                 self._packed = ops.PackedMLP(ctx, self.filter_channels, _ACT_CODES[self.last_op])
             for i, f in enumerate(self.filters):
                 self._packed.load_layer(i, f.weight.detach(), f.bias.detach())
+            self._packed.set_precision(self.precision)
             self._packed_key = key
         return self._packed
 

@@ -161,3 +161,58 @@ def test_surface_classifier_forward_on_explicit_features(ops, oracle, kind, n):
     ref = 1 / (1 + np.exp(-y)) if kind == "G" else np.tanh(y)
     assert out.shape == ref.shape
     assert np.abs(out - ref).max() <= 2e-5
+
+
+@pytest.mark.parametrize("name", ["query_G_rand", "query_G_body"])
+def test_f16x3_query_is_f32_class(ops, oracle, name):
+    """The split-precision kernel (three f16 MFMAs per product, f32 accumulate) must meet the same
+    bars as the f32 kernel: 1e-4 against the reference's golden output, no noisier than the
+    reference's own fp32 evaluation against the fp64 oracle, and within 2e-6 of the f32 kernel."""
+    g = load_golden(name)
+    kind, layers, f, p = query_inputs(name)
+    dev = "cuda:0"
+    mlp = ops.PackedMLP.from_layers(dev, layers, syn.LAST_OP[kind])
+    fh = ops.pack_features(torch.from_numpy(f)[None].to(dev))
+    pts = torch.from_numpy(p)[None].to(dev)
+    cal = torch.from_numpy(g["calib"]).to(dev)
+    out32 = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
+    mlp.set_precision("f16x3")
+    out16 = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
+    mlp.set_precision("f32")
+    again = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
+    assert np.array_equal(again, out32)  # switching back restores the exact f32 path
+    assert np.isfinite(out16).all()
+    assert np.abs(out16 - g["out"]).max() <= TOL_REF
+    ref64 = oracle.query(f, p, g["calib"][0], layers, syn.LAST_OP[kind], syn.Z_SCALE, precision="f64")
+    err16, err_ref = np.abs(out16 - ref64).max(), np.abs(g["out"] - ref64).max()
+    print("%s f16x3: |gpu-f64| %.3g  |reference-f64| %.3g  |f16x3-f32 kernel| %.3g"
+          % (name, err16, err_ref, np.abs(out16 - out32).max()))
+    assert err16 <= max(2 * err_ref, 1e-5)
+    assert np.abs(out16 - out32).max() <= 2e-6
+    xyz = oracle.orthogonal(p, g["calib"][0])
+    outside = np.minimum(1 - np.abs(xyz[0]), 1 - np.abs(xyz[1])) < -1e-6
+    assert (out16[:, outside] == 0).all()
+
+
+@pytest.mark.parametrize("n", [1, 127, 128, 129, 1000])
+def test_f16x3_ragged_sizes_and_large_weights(ops, oracle, n):
+    """128-point tiles: ragged tails; weights spanning 1e-3..40 exercise the per-layer scaling."""
+    layers = syn.body_mlp("G", noise=0.3, seed=n)  # entries from ~1e-3 up to k = 40
+    f = syn.body_feat(256, 128, 128, 6)
+    p = syn.rand_points(n, 200 + n, 1.05)
+    calib = oracle.pifu_calib(*syn.scene_camera(40))
+    dev = "cuda:0"
+    mlp = ops.PackedMLP.from_layers(dev, layers, 1)
+    mlp.set_precision("f16x3")
+    fh = ops.pack_features(torch.from_numpy(f)[None].to(dev))
+    out = ops.query(mlp, fh, torch.from_numpy(p)[None].to(dev), torch.from_numpy(calib).to(dev),
+                    syn.Z_SCALE)[0].cpu().numpy()
+    ref = oracle.query(f, p, calib[0], layers, 1, syn.Z_SCALE, precision="f64")
+    assert out.shape == (1, n) and np.abs(out - ref).max() <= 2e-5
+
+
+def test_f16x3_rejects_netc_head(ops):
+    from monoport_amd._lib import MonoportError
+    mlp = ops.PackedMLP.from_layers("cuda:0", syn.rand_mlp("C", 3, 1.0), 2)
+    with pytest.raises(MonoportError):
+        mlp.set_precision("f16x3")

@@ -230,3 +230,28 @@ def test_generic_query_func_engine(ops, oracle, body):
                          b_min=np.array([[-1., -1., -1.]]), b_max=np.array([[1., 1., 1.]]),
                          resolutions=[9, 17]).to(DEV)
     assert eng2() is None
+
+
+def test_recon_f16x3_bit_exact_vs_oracle_driver(ops, oracle):
+    """Octree driven by the f16x3 kernel: same decisions as the CPU restatement fed by the same
+    kernel, and the same thresholded volume as the f32 path."""
+    layers = syn.body_mlp("G", noise=0.05, seed=1)
+    f = syn.body_feat(256, 128, 128, 2)
+    cal = torch.from_numpy(oracle.pifu_calib(*syn.scene_camera(30))).to(DEV)
+    fh = ops.pack_features(torch.from_numpy(f)[None].to(DEV))
+    mlp = ops.PackedMLP.from_layers(DEV, layers, 1)
+    res = [17, 33, 65, 129]
+    vol32, st32 = ops.recon(mlp, fh, cal, syn.Z_SCALE, BMIN, BMAX, res)
+    mlp.set_precision("f16x3")
+    vol16, st16 = ops.recon(mlp, fh, cal, syn.Z_SCALE, BMIN, BMAX, res)
+
+    def gpu_query(pts):
+        return ops.query(mlp, fh, torch.from_numpy(np.ascontiguousarray(pts))[None].to(DEV), cal,
+                         syn.Z_SCALE)[0, 0].cpu().numpy()
+
+    stats = []
+    ref = oracle.seg3d_lossless(gpu_query, BMIN, BMAX, res, stats=stats)
+    assert list(st16.cpu().numpy()[1:]) == stats
+    assert np.array_equal(vol16.cpu().numpy(), ref)
+    assert (vol16 - vol32).abs().max().item() <= 2e-6
+    assert torch.equal(vol16 > 0.5, vol32 > 0.5) and torch.equal(st16, st32)
