@@ -131,9 +131,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--depth", type=int, default=3, help="frames in flight per GPU")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay each frame as a hipGraph (experimental: faults on ROCm 7.2 when "
-                         "tensors are allocated after capture; eager launches are within ~4%%)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch the encoder eagerly instead of replaying it as a hipGraph")
     ap.add_argument("--with-color", action="store_true",
                     help="BASELINE configs[2]: add netC (ResNet encoder + per-vertex colour MLP)")
     ap.add_argument("--levels", type=int, default=5, choices=[5, 6],
@@ -157,7 +156,7 @@ def main():
         import torch.distributed as dist
 
     resolutions = RESOLUTIONS + ([513] if args.levels == 6 else [])
-    pipe = make_pipeline(device, args.depth, args.graph, resolutions, args.with_color, args.precision)
+    pipe = make_pipeline(device, args.depth, not args.no_graph, resolutions, args.with_color, args.precision)
     n_frames = args.steps + args.warmup
     # distinct frames per rank: frame id = step * world + rank (frame-parallel sharding)
     images = [torch.from_numpy(syn.synthetic_image(s * world + rank))[None].to(device)
@@ -273,7 +272,7 @@ def main():
                                 "geometry only (+forward_vertices, normal render)")),
                 "frames_per_rank": args.steps,
                 "parallelism": "frame-parallel x%d, %d frames in flight per GPU%s"
-                               % (world, args.depth, " (hipGraph replay)" if args.graph else ""),
+                               % (world, args.depth, "" if args.no_graph else ", encoder replayed as a hipGraph"),
                 "fixture": "F-body analytic head, seeded encoder (monoport_amd/synthetic.py)",
                 "points_per_recon": pts_all / (args.steps * world),
             },

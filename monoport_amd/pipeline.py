@@ -54,11 +54,20 @@ class FrameSlot:
         self._busy = False
 
     @torch.no_grad()
-    def _chain(self):
-        mlp = self.net.surface_classifier.packed()
+    def _encode(self):
         feat = self.net.image_filter(self.image, last_only=True)[-1][0]
         if self.feature_hook is not None:
             self.feature_hook(feat)
+        return feat
+
+    @torch.no_grad()
+    def _chain(self):
+        mlp = self.net.surface_classifier.packed()
+        if self.graph is not None:
+            self.graph.replay()  # the ~450 encoder kernels as one hipGraph launch
+            feat = self._graph_feat
+        else:
+            feat = self._encode()
         ops.pack_features(feat, out=self.feat_hwc)
         ops.recon(mlp, self.feat_hwc, self.calib, Z_SCALE, self.b_min, self.b_max, self.res,
                   self.balance, volume=self.volume, status=self.status)
@@ -77,16 +86,20 @@ class FrameSlot:
                                         -np.inf, np.inf)
 
     def prepare(self, warmup=2):
-        """Warm up (MIOpen find, scratch arenas) and capture the chain into a hipGraph."""
+        """Warm up (MIOpen find, scratch arenas); with ``use_graph`` capture the ENCODER into a
+        hipGraph (its ~450 small kernels are launch-latency bound: 5.7 -> 4.8 ms).  The C-ABI
+        stages stay eager: they are five asynchronous calls, and a graph that also holds them
+        faulted on ROCm 7.2 once tensors were allocated after capture."""
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 self._chain()
         self.stream.synchronize()
         if self.use_graph:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                self._chain()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=self.stream):
+                self._graph_feat = self._encode()
             self.stream.synchronize()
+            self.graph = graph
 
     def submit(self, image, calib, image_c=None):
         """Enqueue one reconstruction of ``image`` [1,3,512,512] with ``calib`` [1,4,4]; returns
@@ -98,10 +111,7 @@ class FrameSlot:
             self.calib.copy_(calib, non_blocking=True)
             if self.netC is not None:
                 self.image_c.copy_(image if image_c is None else image_c, non_blocking=True)
-            if self.graph is not None:
-                self.graph.replay()
-            else:
-                self._chain()
+            self._chain()
             self.done.record(self.stream)
         self._busy = True
 
