@@ -65,7 +65,8 @@ def build_netc(device):
     return net.to(device)
 
 
-def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, precision="f32"):
+def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, precision="f32",
+                  batch=1):
     """`depth` frames in flight, each the stage chain of RTL/main.py:366-428 (geometry only)
     captured in a hipGraph on its own stream (monoport_amd/pipeline.py)."""
     net, _ = build_netg(device, precision)
@@ -74,9 +75,9 @@ def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, 
     def body_planes_hook(feat):
         # synthetic-data hook: the analytic F-body head reads channels 0/1 as depth planes; the
         # other 254 channels are the encoder's output (consumed through the seeded-noise weights)
-        feat[0, 0:2].copy_(planes)
+        feat[:, 0:2].copy_(planes[None].expand(feat.shape[0], -1, -1, -1))
 
-    pipe = FramePipeline(net, device, depth=depth, resolutions=resolutions or RESOLUTIONS,
+    pipe = FramePipeline(net, device, depth=depth, batch=batch, resolutions=resolutions or RESOLUTIONS,
                          b_min=B_MIN, b_max=B_MAX, balance=0.5, feature_hook=body_planes_hook,
                          use_graph=use_graph, netC=build_netc(device) if with_color else None)
     pipe.prepare()
@@ -130,7 +131,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--depth", type=int, default=3, help="frames in flight per GPU")
+    ap.add_argument("--depth", type=int, default=3, help="pipeline slots (streams) per GPU")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="frames per slot: their encoder passes run as one batch; depth x batch "
+                         "frames are in flight (reduced to a divisor of --steps)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the encoder eagerly instead of replaying it as a hipGraph")
     ap.add_argument("--with-color", action="store_true",
@@ -156,8 +160,11 @@ def main():
         import torch.distributed as dist
 
     resolutions = RESOLUTIONS + ([513] if args.levels == 6 else [])
-    pipe = make_pipeline(device, args.depth, not args.no_graph, resolutions, args.with_color, args.precision)
-    n_frames = args.steps + args.warmup
+    batch = max(d for d in range(1, max(1, args.batch) + 1) if args.steps % d == 0)
+    pipe = make_pipeline(device, args.depth, not args.no_graph, resolutions, args.with_color,
+                         args.precision, batch)
+    n_warm = -(-args.warmup // batch) * batch  # whole batches
+    n_frames = args.steps + n_warm
     # distinct frames per rank: frame id = step * world + rank (frame-parallel sharding)
     images = [torch.from_numpy(syn.synthetic_image(s * world + rank))[None].to(device)
               for s in range(min(n_frames, 4))]
@@ -167,44 +174,46 @@ def main():
     gather = parallel.FrameGather((r_last, r_last, 3), device=device, store=False)
     status_log = []
 
-    def one_step(s, log):
-        slot = pipe.submit(images[s % len(images)], calibs[s])
+    def run_batch(s0, log):
+        """Frames s0 .. s0+batch-1 as one slot submission."""
+        slot = pipe.submit([images[s % len(images)] for s in range(s0, s0 + batch)],
+                           [calibs[s] for s in range(s0, s0 + batch)])
         with torch.cuda.stream(slot.stream):
-            # fixed-size per-frame result to rank 0 (no-op on one GPU)
-            gather.push(s, slot.render_tex if args.with_color else slot.render)
+            for b in range(batch):
+                # fixed-size per-frame result to rank 0 (no-op on one GPU)
+                gather.push(s0 + b, slot.renders_tex[b] if args.with_color else slot.renders[b])
             if log:
                 status_log.append(slot.status.clone())  # device-side copy, no sync
 
-    for s in range(args.warmup):
-        one_step(s, False)
+    for s0 in range(0, n_warm, batch):
+        run_batch(s0, False)
     pipe.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    for s in range(args.warmup, n_frames):
-        one_step(s, True)
+    for s0 in range(n_warm, n_frames, batch):
+        run_batch(s0, True)
     pipe.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
-    # roofline leg: the same frames again on ONE stream, eagerly, with every fused-query launch
-    # bracketed by HIP events on its launch stream (hipGraph replays cannot be bracketed, and
-    # concurrent frames would share CUs) -> per-launch durations of the dominant kernel
+    # roofline leg: the same frames again on ONE stream with every fused-query launch bracketed by
+    # HIP events on its launch stream (concurrent slots would share CUs) -> per-launch durations
+    # of the dominant kernel
     prof_slot = pipe.slots[0]
     prof_status = []
     ops.profile_begin(device, max_records=8 * args.steps + 8)
-    with torch.cuda.stream(prof_slot.stream):
-        for s in range(args.warmup, n_frames):
-            prof_slot.image.copy_(images[s % len(images)])
-            prof_slot.calib.copy_(calibs[s])
-            prof_slot._chain()
+    for s0 in range(n_warm, n_frames, batch):
+        prof_slot.submit([images[s % len(images)] for s in range(s0, s0 + batch)],
+                         [calibs[s] for s in range(s0, s0 + batch)])
+        with torch.cuda.stream(prof_slot.stream):
             prof_status.append(prof_slot.status.clone())
-    prof_slot.stream.synchronize()
+    prof_slot.wait()
     launch_ms = ops.profile_end(device, capacity=8 * args.steps + 8)
-    prof_pts = torch.stack(prof_status).cpu().numpy()[:, 1:]
+    prof_pts = torch.cat(prof_status).cpu().numpy()[:, 1:]
 
     # breakdown leg (SURVEY section 8d config 2): encoder-only and encoder-excluded time per frame, one
     # stream, features of the last frame
@@ -221,16 +230,16 @@ def main():
 
     def recon_only():
         mlp = prof_slot.net.surface_classifier.packed()
-        ops.recon(mlp, prof_slot.feat_hwc, prof_slot.calib, syn.Z_SCALE, B_MIN, B_MAX, resolutions,
-                  0.5, volume=prof_slot.volume, status=prof_slot.status)
+        ops.recon(mlp, prof_slot.feat_hwc, prof_slot.calib[0:1], syn.Z_SCALE, B_MIN, B_MAX,
+                  resolutions, 0.5, volume=prof_slot.volume, status=prof_slot.status[0])
         x, y, z, nrm, count = ops.forward_vertices_raw(prof_slot.volume, "front")
         ops.paint(x, y, nrm, 0, count, r_last, 0.5, 0.5, 0.0, 1.0)
 
     with torch.no_grad():
-        enc_ms = timed(lambda: prof_slot.net.image_filter(prof_slot.image, last_only=True), 10)
+        enc_ms = timed(lambda: prof_slot.net.image_filter(prof_slot.image, last_only=True), 10) / batch
         rec_ms = timed(recon_only, 10)
 
-    statuses = torch.stack(status_log).cpu().numpy()
+    statuses = torch.cat(status_log).cpu().numpy()
     assert (statuses[:, 0] == 1).all(), "synthetic body must be non-empty"
     level_pts = statuses[:, 1:]
     pts_total = int(level_pts.sum())
@@ -271,17 +280,19 @@ def main():
                                 if args.with_color else
                                 "geometry only (+forward_vertices, normal render)")),
                 "frames_per_rank": args.steps,
-                "parallelism": "frame-parallel x%d, %d frames in flight per GPU%s"
-                               % (world, args.depth, "" if args.no_graph else ", encoder replayed as a hipGraph"),
+                "parallelism": "frame-parallel x%d; per GPU %d slots x %d frames in flight, encoder "
+                               "batched per slot%s"
+                               % (world, args.depth, batch,
+                                  "" if args.no_graph else " and replayed as a hipGraph"),
                 "fixture": "F-body analytic head, seeded encoder (monoport_amd/synthetic.py)",
                 "points_per_recon": pts_all / (args.steps * world),
             },
             "mpts_per_s": pts_all / elapsed / 1e6,
             "breakdown": {
-                "encoder_ms": enc_ms, "recon_vertices_render_ms": rec_ms,
+                "encoder_ms_per_frame": enc_ms, "recon_vertices_render_ms": rec_ms,
                 "recon_per_s_encoder_excluded": 1e3 / rec_ms,
                 "points_per_level": [float(v) for v in prof_pts.mean(0)],
-                "note": "single stream, one frame at a time (no overlap)",
+                "note": "single stream, no overlap; encoder eager at the bench batch size",
             },
             "roofline": {
                 "kernel": ("pifu_query_kernel<256,1> (fused gather + MLP)" if args.precision == "f32"

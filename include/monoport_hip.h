@@ -186,13 +186,14 @@ int mp_marching_cubes(mp_ctx *ctx, const float *volume, int r, float level,
                       mp_stream stream);
 
 /* ---- encoder helpers (the convolutions stay in MIOpen) ------------------------- */
-/* y = [relu](GroupNorm(groups, C)(x)) for one image: x, y [C,HW] f32 (NCHW, batch 1), gamma/beta
- * [C]; biased variance, eps inside the sqrt -- torch.nn.GroupNorm as used by
+/* y = [relu](GroupNorm(groups, C)(x)): x, y [N,C,HW] f32 (contiguous NCHW), gamma/beta [C];
+ * biased variance, eps inside the sqrt -- torch.nn.GroupNorm as used by
  * backbones/HGFilters.py:23-27 and ResBlkFilters.py:19.  Needs HW % 4 == 0. */
-int mp_group_norm(mp_ctx *ctx, const float *x, int c, int64_t hw, int groups, const float *gamma,
-                  const float *beta, float eps, int relu, float *y, mp_stream stream);
+int mp_group_norm(mp_ctx *ctx, const float *x, int n, int c, int64_t hw, int groups,
+                  const float *gamma, const float *beta, float eps, int relu, float *y,
+                  mp_stream stream);
 /* y = [add +] bicubic_x2(x), align_corners=True, A = -0.75 (F.interpolate at HGFilters.py:108 and
- * the skip add at :111).  x [C,H,W]; add (may be NULL), y [C,2H,2W]. */
+ * the skip add at :111).  x [C,H,W] (fold a batch into C); add (may be NULL), y [C,2H,2W]. */
 int mp_upsample_bicubic2x(mp_ctx *ctx, const float *x, int c, int h, int w, const float *add,
                           float *y, mp_stream stream);
 

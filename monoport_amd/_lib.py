@@ -48,7 +48,8 @@ SIGNATURES = {
     "mp_visualize": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "mp_marching_cubes": (c_int, [c_vp, c_vp, c_int, c_f32, _pf32, _pf32, c_vp, c_i64, c_vp, c_i64,
                                   c_vp, c_vp]),
-    "mp_group_norm": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_f32, c_int, c_vp, c_vp]),
+    "mp_group_norm": (c_int, [c_vp, c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_f32, c_int, c_vp,
+                              c_vp]),
     "mp_upsample_bicubic2x": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "mp_profile_begin": (c_int, [c_vp, c_int]),
     "mp_profile_end": (c_int, [c_vp, _pf32, c_int, _pint]),

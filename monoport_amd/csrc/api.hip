@@ -529,19 +529,21 @@ int mp_marching_cubes(mp_ctx *ctx, const float *volume, int r, float level, cons
                                faces, max_faces, counts, (hipStream_t)stream);
 }
 
-int mp_group_norm(mp_ctx *ctx, const float *x, int c, int64_t hw, int groups, const float *gamma,
-                  const float *beta, float eps, int relu, float *y, mp_stream stream) {
+int mp_group_norm(mp_ctx *ctx, const float *x, int n, int c, int64_t hw, int groups,
+                  const float *gamma, const float *beta, float eps, int relu, float *y,
+                  mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  if (!x || !y || !gamma || !beta || c <= 0 || hw <= 0 || groups <= 0 || groups > 4096)
+  if (!x || !y || !gamma || !beta || n <= 0 || n > 4096 || c <= 0 || hw <= 0 || groups <= 0 ||
+      groups > 4096)
     return fail(ctx, MP_ERR_ARG, "mp_group_norm: bad argument");
   if (c % groups || hw % 4 || !aligned16(x) || !aligned16(y))
     return fail(ctx, MP_ERR_UNSUPPORTED, "mp_group_norm: needs C %% groups == 0, HW %% 4 == 0, 16-byte aligned x/y");
   DeviceGuard g(ctx->device);
   void *scratch = nullptr;
-  int rc = ensure_scratch(ctx, (hipStream_t)stream, gn_scratch_bytes(groups), &scratch);
+  int rc = ensure_scratch(ctx, (hipStream_t)stream, gn_scratch_bytes(n * groups), &scratch);
   if (rc != MP_OK) return rc;
-  return launch_group_norm(ctx, scratch, x, c, hw, groups, gamma, beta, eps, relu, y,
+  return launch_group_norm(ctx, scratch, x, n, c, hw, groups, gamma, beta, eps, relu, y,
                            (hipStream_t)stream);
 }
 

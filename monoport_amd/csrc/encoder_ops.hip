@@ -67,9 +67,9 @@ __global__ __launch_bounds__(kGnThreads) void gn_partial_kernel(const float *__r
 // y = relu?((x - mean) * rstd * gamma[c] + beta[c]); one workgroup per (group, slice)
 __global__ __launch_bounds__(kGnThreads) void gn_apply_kernel(
     const float *__restrict__ x, long long group_elems, int ch_per_group, long long hw,
-    const double *__restrict__ partial, const float *__restrict__ gamma,
+    int groups_per_image, const double *__restrict__ partial, const float *__restrict__ gamma,
     const float *__restrict__ beta, float eps, int relu, float *__restrict__ y) {
-  const int g = blockIdx.x / kGnSlices, s = blockIdx.x % kGnSlices;
+  const int g = blockIdx.x / kGnSlices, s = blockIdx.x % kGnSlices;  // g runs over images x groups
   double a = 0, b = 0;
 #pragma unroll
   for (int i = 0; i < kGnSlices; ++i) {
@@ -85,7 +85,8 @@ __global__ __launch_bounds__(kGnThreads) void gn_apply_kernel(
   const f32x4 *xp = reinterpret_cast<const f32x4 *>(x + g * group_elems);
   f32x4 *yp = reinterpret_cast<f32x4 *>(y + g * group_elems);
   for (long long i = v0 + threadIdx.x; i < v1; i += kGnThreads) {
-    const int c = g * ch_per_group + (int)((4 * i) / hw);  // hw % 4 == 0: one channel per float4
+    // hw % 4 == 0: one channel per float4; gamma / beta repeat per image
+    const int c = (g % groups_per_image) * ch_per_group + (int)((4 * i) / hw);
     const float sc = rstd * gamma[c];
     const float sh = beta[c] - mean * sc;
     f32x4 v = xp[i];
@@ -100,16 +101,16 @@ __global__ __launch_bounds__(kGnThreads) void gn_apply_kernel(
 
 size_t gn_scratch_bytes(int groups) { return (size_t)groups * kGnSlices * 2 * sizeof(double); }
 
-int launch_group_norm(mp_ctx *ctx, void *scratch, const float *x, int c, long long hw, int groups,
-                      const float *gamma, const float *beta, float eps, int relu, float *y,
-                      hipStream_t st) {
+int launch_group_norm(mp_ctx *ctx, void *scratch, const float *x, int n, int c, long long hw,
+                      int groups, const float *gamma, const float *beta, float eps, int relu,
+                      float *y, hipStream_t st) {
   const int cpg = c / groups;
   const long long ge = (long long)cpg * hw;
   double *partial = static_cast<double *>(scratch);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(groups * kGnSlices), dim3(kGnThreads), 0, st, x, ge,
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(n * groups * kGnSlices), dim3(kGnThreads), 0, st, x, ge,
                      partial);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(groups * kGnSlices), dim3(kGnThreads), 0, st, x, ge, cpg,
-                     hw, partial, gamma, beta, eps, relu, y);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(n * groups * kGnSlices), dim3(kGnThreads), 0, st, x, ge,
+                     cpg, hw, groups, partial, gamma, beta, eps, relu, y);
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
 }

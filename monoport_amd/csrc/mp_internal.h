@@ -169,9 +169,9 @@ int launch_marching_cubes(mp_ctx *ctx, void *scratch, const float *vol, int r, f
 
 // encoder_ops.hip
 size_t gn_scratch_bytes(int groups);
-int launch_group_norm(mp_ctx *ctx, void *scratch, const float *x, int c, long long hw, int groups,
-                      const float *gamma, const float *beta, float eps, int relu, float *y,
-                      hipStream_t st);
+int launch_group_norm(mp_ctx *ctx, void *scratch, const float *x, int n, int c, long long hw,
+                      int groups, const float *gamma, const float *beta, float eps, int relu,
+                      float *y, hipStream_t st);
 int launch_upsample_bicubic2x(mp_ctx *ctx, const float *x, int c, int h, int w, const float *add,
                               float *y, hipStream_t st);
 

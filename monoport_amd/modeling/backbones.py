@@ -61,7 +61,7 @@ def _run_sequential(seq, x):
 
 def _upsample2x_add(low, skip):
     """skip + bicubic x2 (align_corners=True) of ``low`` (HGFilters.py:108-111)."""
-    if low.is_cuda and low.shape[0] == 1 and low.dtype == torch.float32:
+    if low.is_cuda and low.dtype == torch.float32:
         return ops.upsample_bicubic2x(low.contiguous(), add=skip.contiguous())
     return skip + F.interpolate(low, scale_factor=2, mode="bicubic", align_corners=True)
 

@@ -376,28 +376,29 @@ def marching_cubes_raw(volume, level=0.5, b_min=(-1, -1, -1), b_max=(1, 1, 1), m
 
 
 def group_norm(x, groups, weight, bias, eps=1e-5, relu=False):
-    """[relu](GroupNorm(x)) for x [1,C,H,W] f32 contiguous on the GPU (mp_group_norm)."""
+    """[relu](GroupNorm(x)) for x [N,C,H,W] f32 contiguous on the GPU (mp_group_norm)."""
     ctx = get_context(x.device)
-    c = x.shape[1]
+    n, c = x.shape[0], x.shape[1]
     hw = x.shape[2] * x.shape[3]
     y = torch.empty_like(x)
-    ctx.check(ctx.lib.mp_group_norm(ctx.handle, _ptr(x), c, hw, int(groups), _ptr(weight),
+    ctx.check(ctx.lib.mp_group_norm(ctx.handle, _ptr(x), n, c, hw, int(groups), _ptr(weight),
                                     _ptr(bias), float(eps), int(bool(relu)), _ptr(y), _stream(x)),
               "mp_group_norm")
     return y
 
 
 def group_norm_supported(x):
-    return (x.is_cuda and x.dim() == 4 and x.shape[0] == 1 and x.dtype == torch.float32
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32
             and x.is_contiguous() and (x.shape[2] * x.shape[3]) % 4 == 0)
 
 
 def upsample_bicubic2x(x, add=None):
-    """[add +] F.interpolate(x, scale_factor=2, mode='bicubic', align_corners=True), x [1,C,H,W]."""
+    """[add +] F.interpolate(x, scale_factor=2, mode='bicubic', align_corners=True), x [N,C,H,W]
+    (the batch is folded into the channel axis: every plane is resampled independently)."""
     ctx = get_context(x.device)
-    _, c, h, w = x.shape
-    y = torch.empty((1, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
-    ctx.check(ctx.lib.mp_upsample_bicubic2x(ctx.handle, _ptr(x), c, h, w,
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    ctx.check(ctx.lib.mp_upsample_bicubic2x(ctx.handle, _ptr(x), n * c, h, w,
                                             _ptr(add) if add is not None else None, _ptr(y),
                                             _stream(x)), "mp_upsample_bicubic2x")
     return y

@@ -2,14 +2,19 @@
 
 The reference overlaps frames with one Python thread per stage (RTL/dataloader.py:734-751,
 :1026-1053).  On an MI355X the stages are so short (tens of microseconds to a few milliseconds)
-that host-side launch latency, not thread parallelism, is what matters: here each in-flight frame
-owns a HIP stream and a hipGraph holding its whole stage chain
+that host-side launch latency and GPU fill, not thread parallelism, are what matter:
 
-    netG.filter -> channels-last pack -> octree (5 levels, fused query) -> forward_vertices -> render
+* a ``FrameSlot`` owns a HIP stream and the static buffers of ``batch`` frames.  The image
+  encoder runs ONCE per slot on the whole batch (MIOpen's batch-1 convolutions under-fill 256 CUs:
+  4.9 ms/frame at batch 1, 3.1 ms/frame at batch 4) and is replayed as a hipGraph (its ~450 small
+  kernels are launch-latency bound); then each frame goes through
 
-(optional: `use_graph=True`; eager launches from one host thread are within ~4 % because every
-C-ABI call is asynchronous), and independent frames on different streams fill the CUs that the
-coarse octree levels and the small encoder kernels leave idle.
+      channels-last pack -> octree (5 levels, fused query) -> forward_vertices -> render
+
+  as asynchronous C-ABI calls on the slot's stream;
+* a ``FramePipeline`` round-robins over ``depth`` slots, so independent frames on different
+  streams fill the CUs that the coarse octree levels and the small encoder kernels leave idle
+  (``depth`` x ``batch`` frames in flight; BASELINE configs[3] asks for 8).
 """
 import numpy as np
 import torch
@@ -21,41 +26,57 @@ RESOLUTIONS = (17, 33, 65, 129, 257)  # RTL/main.py:187
 
 
 class FrameSlot:
-    """Static buffers + captured graph for one in-flight frame (geometry-only chain,
-    RTL/main.py:366-428)."""
+    """Static buffers for ``batch`` in-flight frames (geometry chain of RTL/main.py:366-428, plus
+    the netC texture stages :373-441 when ``netC`` is given)."""
 
     def __init__(self, netG, device, resolutions=RESOLUTIONS, b_min=(-1, -1, -1), b_max=(1, 1, 1),
-                 balance=0.5, feature_hook=None, use_graph=False, netC=None):
+                 balance=0.5, feature_hook=None, use_graph=False, netC=None, batch=1):
         self.net = netG
-        self.netC = netC  # optional colour network: adds the texture stages of RTL/main.py:373-441
+        self.netC = netC
         self.device = torch.device(device)
         self.res = [int(r) for r in resolutions]
         self.b_min, self.b_max, self.balance = b_min, b_max, float(balance)
-        self.feature_hook = feature_hook  # optional in-place edit of the [1,C,H,W] feature map
+        self.feature_hook = feature_hook  # optional in-place edit of the [B,C,H,W] feature map
+        self.batch = int(batch)
         r = self.res[-1]
         dev = self.device
+        b = self.batch
         self.stream = torch.cuda.Stream(device=dev)
-        self.image = torch.zeros((1, 3, 512, 512), dtype=torch.float32, device=dev)
-        self.calib = torch.eye(4, dtype=torch.float32, device=dev)[None].contiguous()
+        self.image = torch.zeros((b, 3, 512, 512), dtype=torch.float32, device=dev)
+        self.calib = torch.eye(4, dtype=torch.float32, device=dev)[None].repeat(b, 1, 1).contiguous()
         self.feat_hwc = torch.empty((128, 128, 256), dtype=torch.float32, device=dev)
-        self.volume = torch.empty((r, r, r), dtype=torch.float32, device=dev)
-        self.status = torch.zeros((1 + len(self.res),), dtype=torch.int32, device=dev)
-        self.render = None
-        self.render_tex = None
-        self.vertices = None
+        # one volume per frame of the batch: results stay readable until the next submit
+        self.volumes = [torch.empty((r, r, r), dtype=torch.float32, device=dev) for _ in range(b)]
+        self.status = torch.zeros((b, 1 + len(self.res)), dtype=torch.int32, device=dev)
+        self.renders = [None] * b
+        self.renders_tex = [None] * b
+        self.vertices = [None] * b
+        self.graph = None
+        self._graph_feat = None
+        self.use_graph = use_graph
+        self._busy = False
         if netC is not None:
             from .recon import color_matrix
             self.feat_hwc_c = torch.empty((128, 128, 512), dtype=torch.float32, device=dev)
             self.mat_color = color_matrix(b_min, b_max, r)
-            self.image_c = torch.zeros((1, 3, 512, 512), dtype=torch.float32, device=dev)
-        self.graph = None
-        self.use_graph = use_graph
-        self.done = torch.cuda.Event()  # recorded after each frame's last kernel
-        self._busy = False
+            self.image_c = torch.zeros((b, 3, 512, 512), dtype=torch.float32, device=dev)
+
+    # convenience views for batch == 1 callers
+    @property
+    def volume(self):
+        return self.volumes[0]
+
+    @property
+    def render(self):
+        return self.renders[0]
+
+    @property
+    def render_tex(self):
+        return self.renders_tex[0]
 
     @torch.no_grad()
     def _encode(self):
-        feat = self.net.image_filter(self.image, last_only=True)[-1][0]
+        feat = self.net.image_filter(self.image, last_only=True)[-1][0]  # [B,256,128,128]
         if self.feature_hook is not None:
             self.feature_hook(feat)
         return feat
@@ -64,32 +85,39 @@ class FrameSlot:
     def _chain(self):
         mlp = self.net.surface_classifier.packed()
         if self.graph is not None:
-            self.graph.replay()  # the ~450 encoder kernels as one hipGraph launch
+            self.graph.replay()  # the whole batched encoder as one hipGraph launch
             feat = self._graph_feat
         else:
             feat = self._encode()
-        ops.pack_features(feat, out=self.feat_hwc)
-        ops.recon(mlp, self.feat_hwc, self.calib, Z_SCALE, self.b_min, self.b_max, self.res,
-                  self.balance, volume=self.volume, status=self.status)
-        x, y, z, nrm, count = ops.forward_vertices_raw(self.volume, "front")
-        self.vertices = (x, y, z, nrm, count)
-        self.render = ops.paint(x, y, nrm, 0, count, self.res[-1], 0.5, 0.5, 0.0, 1.0)
+        feat_c = None
         if self.netC is not None:
-            # netC.filter(image_c, feat_prior=featG_last) -> cat([prior, featC]) (MonoPortNet.py:41-45)
-            # packed straight into one channels-last map, then netC.query on the visible vertices
             mlp_c = self.netC.surface_classifier.packed()
-            feat_c = self.netC.image_filter(self.image_c)[-1][0]
-            ops.pack_features([feat, feat_c], out=self.feat_hwc_c)
-            pts = ops.vertex_points(x, y, z, count, self.res[-1], self.mat_color)
-            preds = ops.query_counted(mlp_c, self.feat_hwc_c, pts, count, self.calib, Z_SCALE)
-            self.render_tex = ops.paint(x, y, preds, 1, count, self.res[-1], 0.5, 0.5,
-                                        -np.inf, np.inf)
+            feat_c = self.netC.image_filter(self.image_c)[-1][0]  # [B,256,128,128]
+        r = self.res[-1]
+        for b in range(self.batch):
+            fb = feat[b:b + 1]
+            ops.pack_features(fb, out=self.feat_hwc)
+            calib = self.calib[b:b + 1]
+            ops.recon(mlp, self.feat_hwc, calib, Z_SCALE, self.b_min, self.b_max, self.res,
+                      self.balance, volume=self.volumes[b], status=self.status[b])
+            x, y, z, nrm, count = ops.forward_vertices_raw(self.volumes[b], "front")
+            self.vertices[b] = (x, y, z, nrm, count)
+            self.renders[b] = ops.paint(x, y, nrm, 0, count, r, 0.5, 0.5, 0.0, 1.0)
+            if self.netC is not None:
+                # netC.filter(image_c, feat_prior=featG_last) -> cat([prior, featC])
+                # (MonoPortNet.py:41-45) packed straight into one channels-last map, then
+                # netC.query on the visible vertices (RTL/main.py:231-248)
+                ops.pack_features([fb, feat_c[b:b + 1]], out=self.feat_hwc_c)
+                pts = ops.vertex_points(x, y, z, count, r, self.mat_color)
+                preds = ops.query_counted(mlp_c, self.feat_hwc_c, pts, count, calib, Z_SCALE)
+                self.renders_tex[b] = ops.paint(x, y, preds, 1, count, r, 0.5, 0.5,
+                                                -np.inf, np.inf)
 
     def prepare(self, warmup=2):
         """Warm up (MIOpen find, scratch arenas); with ``use_graph`` capture the ENCODER into a
-        hipGraph (its ~450 small kernels are launch-latency bound: 5.7 -> 4.8 ms).  The C-ABI
-        stages stay eager: they are five asynchronous calls, and a graph that also holds them
-        faulted on ROCm 7.2 once tensors were allocated after capture."""
+        hipGraph.  The C-ABI stages stay eager: they are a handful of asynchronous calls, and a
+        graph that also holds them faulted on ROCm 7.2 once tensors were allocated after
+        capture."""
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 self._chain()
@@ -101,22 +129,30 @@ class FrameSlot:
             self.stream.synchronize()
             self.graph = graph
 
-    def submit(self, image, calib, image_c=None):
-        """Enqueue one reconstruction of ``image`` [1,3,512,512] with ``calib`` [1,4,4]; returns
-        immediately.  Results (``render``, ``volume``, ``status``, ``vertices``) are valid after
+    def submit(self, images, calibs, images_c=None):
+        """Enqueue the reconstruction of ``batch`` frames: ``images`` [B,3,512,512] (or a list of
+        [1,3,512,512]), ``calibs`` [B,4,4] (or a list of [1,4,4]); returns immediately.  Results
+        (``renders``, ``volumes``, ``status``, ``vertices``) are valid after
         ``stream.synchronize()`` and until the next submit on this slot."""
-        self.wait()  # a slot holds ONE frame: its previous results are overwritten from here on
+        self.wait()  # a slot holds ONE batch: its previous results are overwritten from here on
         with torch.cuda.stream(self.stream):
-            self.image.copy_(image, non_blocking=True)
-            self.calib.copy_(calib, non_blocking=True)
+            self._load(self.image, images)
+            self._load(self.calib, calibs)
             if self.netC is not None:
-                self.image_c.copy_(image if image_c is None else image_c, non_blocking=True)
+                self._load(self.image_c, images if images_c is None else images_c)
             self._chain()
-            self.done.record(self.stream)
         self._busy = True
 
+    @staticmethod
+    def _load(dst, src):
+        if torch.is_tensor(src):
+            dst.copy_(src.reshape(dst.shape), non_blocking=True)
+        else:
+            for b, s in enumerate(src):
+                dst[b].copy_(s.reshape(dst[b].shape), non_blocking=True)
+
     def wait(self):
-        """Block the host until this slot's frame (and anything queued after it on the slot's
+        """Block the host until this slot's batch (and anything queued after it on the slot's
         stream before the next submit) has finished."""
         if self._busy:
             self.stream.synchronize()
@@ -124,22 +160,24 @@ class FrameSlot:
 
 
 class FramePipeline:
-    """Round-robin over ``depth`` FrameSlots: frame i runs on slot i % depth."""
+    """Round-robin over ``depth`` FrameSlots of ``batch`` frames each."""
 
-    def __init__(self, netG, device, depth=2, **slot_kwargs):
-        self.slots = [FrameSlot(netG, device, **slot_kwargs) for _ in range(depth)]
+    def __init__(self, netG, device, depth=2, batch=1, **slot_kwargs):
+        self.slots = [FrameSlot(netG, device, batch=batch, **slot_kwargs) for _ in range(depth)]
+        self.batch = int(batch)
         self.n_submitted = 0
 
     def prepare(self):
         for s in self.slots:
             s.prepare()
 
-    def submit(self, image, calib, image_c=None):
+    def submit(self, images, calibs, images_c=None):
         slot = self.slots[self.n_submitted % len(self.slots)]
-        slot.submit(image, calib, image_c)
+        slot.submit(images, calibs, images_c)
         self.n_submitted += 1
         return slot
 
     def synchronize(self):
         for s in self.slots:
+            s.wait()
             s.stream.synchronize()

@@ -125,8 +125,8 @@ def test_group_norm_and_bicubic_kernels_match_torch():
     """csrc/encoder_ops.hip against the stock PyTorch ops they replace inside the encoders."""
     from monoport_amd import ops
     torch.manual_seed(3)
-    for c, h, w in ((64, 256, 256), (256, 128, 128), (128, 64, 64), (256, 32, 32)):
-        x = (torch.randn(1, c, h, w, device=DEV) * 3 + 1.5)
+    for n, c, h, w in ((1, 64, 256, 256), (1, 256, 128, 128), (3, 128, 64, 64), (2, 256, 32, 32)):
+        x = (torch.randn(n, c, h, w, device=DEV) * 3 + 1.5)
         gn = torch.nn.GroupNorm(32, c).to(DEV)
         with torch.no_grad():
             gn.weight.uniform_(0.5, 1.5)
@@ -136,9 +136,9 @@ def test_group_norm_and_bicubic_kernels_match_torch():
             out_r = ops.group_norm(x, 32, gn.weight, gn.bias, gn.eps, relu=True)
         assert (out - ref).abs().max().item() <= 2e-5
         assert torch.equal(out_r, torch.relu(out))
-    for c, h, w in ((256, 64, 64), (256, 32, 32), (8, 5, 7)):
-        x = torch.randn(1, c, h, w, device=DEV)
-        skip = torch.randn(1, c, 2 * h, 2 * w, device=DEV)
+    for n, c, h, w in ((1, 256, 64, 64), (2, 256, 32, 32), (3, 8, 5, 7)):
+        x = torch.randn(n, c, h, w, device=DEV)
+        skip = torch.randn(n, c, 2 * h, 2 * w, device=DEV)
         ref = torch.nn.functional.interpolate(x, scale_factor=2, mode="bicubic", align_corners=True)
         assert (ops.upsample_bicubic2x(x) - ref).abs().max().item() <= 2e-5
         assert (ops.upsample_bicubic2x(x, add=skip) - (skip + ref)).abs().max().item() <= 2e-5
@@ -261,3 +261,52 @@ def test_obj_export_and_vertex_colors(tmp_path):
     assert v0[0] == "v" and len(v0) == 7 and abs(float(v0[1]) - float(verts[0, 0])) < 1e-4
     f0 = lines[nv].split()
     assert f0[0] == "f" and [int(a) for a in f0[1:]] == [int(a) + 1 for a in faces[0].tolist()]
+
+
+def test_frame_pipeline_matches_direct_calls():
+    """FramePipeline (slots x batched encoder x hipGraph) must give, frame by frame, what the
+    plain call sequence gives: identical octree decisions and renders."""
+    from monoport_amd import ops
+    from monoport_amd.modeling import PIFuNetG
+    from monoport_amd.pipeline import FramePipeline
+    from monoport_amd.recon import pifu_calib
+    netG = PIFuNetG()
+    _load_mlp(netG, syn.body_mlp("G", noise=0.05, seed=81))
+    shapes = {k: tuple(v.shape) for k, v in netG.image_filter.state_dict().items()}
+    netG.image_filter.load_state_dict(
+        {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, 71).items()})
+    netG.to(DEV).eval()
+    planes = torch.from_numpy(syn.body_feature_planes(128, 128)).to(DEV)
+
+    def hook(feat):
+        feat[:, 0:2].copy_(planes[None].expand(feat.shape[0], -1, -1, -1))
+
+    res = [9, 17, 33, 65]
+    images = [torch.from_numpy(syn.synthetic_image(i))[None].to(DEV) for i in range(6)]
+    calibs = [pifu_calib(*syn.scene_camera(7 * i), device=DEV) for i in range(6)]
+
+    # direct, one frame at a time
+    direct = []
+    mlp = netG.surface_classifier.packed()
+    with torch.no_grad():
+        for img, cal in zip(images, calibs):
+            feat = netG.image_filter(img, last_only=True)[-1][0]
+            hook(feat)
+            vol, st = ops.recon(mlp, ops.pack_features(feat), cal, syn.Z_SCALE, [-1] * 3, [1] * 3, res)
+            x, y, z, n, c = ops.forward_vertices_raw(vol, "front")
+            direct.append((st.cpu(), ops.paint(x, y, n, 0, c, res[-1], 0.5, 0.5, 0.0, 1.0).cpu()))
+
+    for batch, use_graph in ((1, False), (3, True)):
+        pipe = FramePipeline(netG, DEV, depth=2, batch=batch, resolutions=res, feature_hook=hook,
+                             use_graph=use_graph)
+        pipe.prepare()
+        got = []
+        for s0 in range(0, 6, batch):
+            slot = pipe.submit(images[s0:s0 + batch], calibs[s0:s0 + batch])
+            slot.wait()
+            for b in range(batch):
+                got.append((slot.status[b].cpu(), slot.renders[b].cpu()))
+        for (st_d, r_d), (st_p, r_p) in zip(direct, got):
+            assert torch.equal(st_d, st_p)  # same points queried at every level
+            # batch > 1 lets MIOpen pick other conv algorithms: features differ in the last bits
+            assert (r_d - r_p).abs().max().item() <= (0.0 if batch == 1 else 2e-3)
