@@ -141,9 +141,10 @@ def main():
                     help="BASELINE configs[2]: add netC (ResNet encoder + per-vertex colour MLP)")
     ap.add_argument("--levels", type=int, default=5, choices=[5, 6],
                     help="6 = octree to 513^3 (BASELINE configs[4] grid, f32 weights)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
-                    help="MLP arithmetic: exact f32 MFMA (default) or the f32-accurate 3-term f16 "
-                         "split (hi*hi + hi*lo + lo*hi on f16 MFMA, f32 accumulate)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3", "f16w", "f16"],
+                    help="MLP arithmetic: exact f32 MFMA (default); f16x3 = f32-accurate 3-term f16 "
+                         "split (hi*hi + hi*lo + lo*hi on f16 MFMA, f32 accumulate); f16w = fp16 "
+                         "weights, split activations (BASELINE configs[4]); f16 = fp16 operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -252,8 +253,9 @@ def main():
     pts_all = float(p.item())
 
     if rank == 0:
-        # f16x3 spends three f16 MFMAs (2.5 PFLOP/s dense peak) per algorithmic f32 product
-        peak_tflops = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else 2500.0 / 3.0
+        # the f16 variants spend 3 / 2 / 1 f16 MFMAs (2.5 PFLOP/s dense peak) per algorithmic product
+        terms = {"f32": 0, "f16x3": 3, "f16w": 2, "f16": 1}[args.precision]
+        peak_tflops = F32_MFMA_PEAK_TFLOPS if terms == 0 else 2500.0 / terms
         n_launch = min(len(launch_ms), prof_pts.size)
         flops = prof_pts.reshape(-1)[:n_launch].astype(np.float64) * FLOP_PER_POINT
         achieved = flops.sum() / (launch_ms[:n_launch].sum() * 1e-3) / 1e12 if n_launch else 0.0
@@ -268,8 +270,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else
-                     "f32 emulated on f16 MFMA (3-term hi/lo split, f32 accumulate)",
+            "dtype": {"f32": "f32",
+                      "f16x3": "f32 emulated on f16 MFMA (3-term hi/lo split, f32 accumulate)",
+                      "f16w": "f16 weights x split-f16 activations, f32 accumulate",
+                      "f16": "f16 operands, f32 accumulate"}[args.precision],
             "data": "synthetic",
             "config": {
                 "workload": ("BASELINE configs[%d]: single 512x512 image, netG (4-stack hourglass encoder "
@@ -296,7 +300,7 @@ def main():
             },
             "roofline": {
                 "kernel": ("pifu_query_kernel<256,1> (fused gather + MLP)" if args.precision == "f32"
-                           else "pifu_query16_kernel<1> (fused gather + MLP, f16x3)"),
+                           else "pifu_query16_kernel<1,%d> (fused gather + MLP, %s)" % (terms, args.precision)),
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": peak_tflops,

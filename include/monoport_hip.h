@@ -45,9 +45,12 @@ enum { MP_ACT_NONE = 0, MP_ACT_SIGMOID = 1, MP_ACT_TANH = 2 };
 /* arithmetic of the MLP GEMMs (mp_mlp_set_precision) */
 enum {
   MP_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32: exact f32 products, the default */
-  MP_PREC_F16X3 = 1  /* f32 emulated on v_mfma_f32_32x32x16_f16: every operand split into two
+  MP_PREC_F16X3 = 1, /* f32 emulated on v_mfma_f32_32x32x16_f16: every operand split into two
                         halves (hi + lo, 22 significant bits), three MFMAs per product term
                         (hi*hi + hi*lo + lo*hi), f32 accumulation; netG heads (C = 256) only */
+  MP_PREC_F16W = 2,  /* fp16 WEIGHTS (rounded once, per-layer power-of-two scale), activations
+                        still split: hi*hi + hi*lo, two MFMAs (BASELINE configs[4]) */
+  MP_PREC_F16 = 3    /* fp16 weights and fp16 activations, f32 accumulation: one MFMA */
 };
 
 /* forward_vertices direction (RTL/recon.py:39-49) */

@@ -216,8 +216,8 @@ int mp_mlp_load(mp_ctx *ctx, int mlp, int layer, const float *W, const float *b,
     rc = launch_copy(ctx, W, m->raw + m->off_raw[layer], (long long)out_ch * in_ch,
                      (hipStream_t)stream);
   if (rc == MP_OK) m->loaded[layer] = true;
-  if (rc == MP_OK && m->precision == MP_PREC_F16X3) {
-    // weights changed under an f16x3 MLP: drop back to f32 until precision is selected again
+  if (rc == MP_OK && m->precision != MP_PREC_F32) {
+    // weights changed under an f16-packed MLP: drop back to f32 until precision is selected again
     m->precision = MP_PREC_F32;
   }
   return rc;
@@ -228,7 +228,7 @@ int mp_mlp_set_precision(mp_ctx *ctx, int mlp, int precision) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   Mlp *m = get_mlp(ctx, mlp);
   if (!m) return fail(ctx, MP_ERR_ARG, "mp_mlp_set_precision: unknown mlp id %d", mlp);
-  if (precision != MP_PREC_F32 && precision != MP_PREC_F16X3)
+  if (precision < MP_PREC_F32 || precision > MP_PREC_F16)
     return fail(ctx, MP_ERR_ARG, "mp_mlp_set_precision: bad precision %d", precision);
   if (precision == MP_PREC_F32) {
     m->precision = MP_PREC_F32;
@@ -237,7 +237,7 @@ int mp_mlp_set_precision(mp_ctx *ctx, int mlp, int precision) {
   int rc = check_ready(ctx, m, m->c);
   if (rc != MP_OK) return rc;
   if (m->c != 256)
-    return fail(ctx, MP_ERR_UNSUPPORTED, "mp_mlp_set_precision: f16x3 is built for C = 256 heads only");
+    return fail(ctx, MP_ERR_UNSUPPORTED, "mp_mlp_set_precision: the f16 kernels are built for C = 256 heads only");
   DeviceGuard g(ctx->device);
   if (!m->buf16) {
     size_t off = 0;  // units of 16 bytes (8 halves)
@@ -276,7 +276,7 @@ int mp_mlp_set_precision(mp_ctx *ctx, int mlp, int precision) {
   }
   (void)hipDeviceSynchronize();
   (void)hipFree(d_bits);
-  if (rc == MP_OK) m->precision = MP_PREC_F16X3;
+  if (rc == MP_OK) m->precision = precision;
   return rc;
 }
 

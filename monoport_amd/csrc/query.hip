@@ -543,7 +543,7 @@ static int launch_query_t(mp_ctx *ctx, const Mlp &m, const float *feat, int h, i
 int launch_query(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w, const float *calib,
                  float z_scale, const PointSrc &src, float *out, long long max_points,
                  hipStream_t st) {
-  if (m.precision == MP_PREC_F16X3 && feat != nullptr && m.c == 256)
+  if (m.precision != MP_PREC_F32 && feat != nullptr && m.c == 256)
     return launch_query16(ctx, m, feat, h, w, calib, z_scale, src, out, max_points, st);
 #define MP_QCASE(CC, CO, WP)                                                                    \
   if (m.c == CC && m.cout == CO) {                                                              \

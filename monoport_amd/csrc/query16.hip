@@ -57,7 +57,9 @@ __device__ __forceinline__ void split4(const f32x4 &v, h4 &hi, h4 &lo) {
 
 // a: this lane's h8 of row block 0, group 0, part hi; lo is +64, group g +128 g, row block m
 // + m * rb_stride (all in h8 units)
-template <int MR, int PF>
+// TERMS selects the arithmetic: 3 = hi*hi + hi*lo + lo*hi (f32-class, "f16x3"); 2 = weights
+// rounded to f16, activations still split (hi*hi + hi*lo, "f16w"); 1 = plain f16 operands ("f16").
+template <int MR, int PF, int TERMS>
 __device__ __forceinline__ void seg_prefetch16(AFrag (&ring)[PF + 1][MR], const h8 *__restrict__ a,
                                                int rb_stride, int n_groups) {
 #pragma unroll
@@ -66,14 +68,14 @@ __device__ __forceinline__ void seg_prefetch16(AFrag (&ring)[PF + 1][MR], const 
     for (int m = 0; m < MR; ++m) {
       const h8 *p = a + m * rb_stride + min(d, n_groups - 1) * 128;
       ring[d][m].hi = p[0];
-      ring[d][m].lo = p[64];
+      if (TERMS == 3) ring[d][m].lo = p[64];
     }
 }
 
 // acc += A * B over n_groups k16-steps.  b: LDS address of this lane's point row for column block
 // 0 (+ n * 32 * ROWB for block n); the hi slot of group g is ((2g + hh) ^ (p & 15)) << 4 = (2g ^
 // swz) << 4 with swz = hh ^ (p & 15), the lo slot sits LO bytes further.
-template <int MR, int NR, int PF, int ROWB, int LO_SLOT>
+template <int MR, int NR, int PF, int ROWB, int LO_SLOT, int TERMS>
 __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[PF + 1][MR],
                                            const h8 *__restrict__ a, int rb_stride, int n_groups,
                                            const unsigned char *b, int swz) {
@@ -84,7 +86,7 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
 #pragma unroll
   for (int n = 0; n < NR; ++n) {
     bh[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + (swz << 4));
-    bl[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + ((LO_SLOT ^ swz) << 4));
+    if (TERMS >= 2) bl[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + ((LO_SLOT ^ swz) << 4));
   }
 #pragma unroll 1
   for (int g0 = 0; g0 < n_groups; g0 += RS) {
@@ -96,7 +98,7 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
       for (int m = 0; m < MR; ++m) {
         const h8 *p = a + m * rb_stride + gp * 128;
         ring[(r + PF) % RS][m].hi = p[0];
-        ring[(r + PF) % RS][m].lo = p[64];
+        if (TERMS == 3) ring[(r + PF) % RS][m].lo = p[64];
       }
       const int gn = min(g + 1, n_groups - 1);
       const int boff = ((2 * gn) ^ swz) << 4;
@@ -105,7 +107,7 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
         nh[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + boff);
-        nl[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + boff_lo);
+        if (TERMS >= 2) nl[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + boff_lo);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above the MFMAs (see query.hip)
       // term-major order: consecutive MFMAs hit different accumulators
@@ -114,20 +116,24 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
 #pragma unroll
         for (int n = 0; n < NR; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[r % RS][m].hi, bh[n], acc[m][n], 0, 0, 0);
+      if (TERMS >= 2) {
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
+        for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int n = 0; n < NR; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[r % RS][m].hi, bl[n], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < NR; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[r % RS][m].hi, bl[n], acc[m][n], 0, 0, 0);
+      }
+      if (TERMS == 3) {
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
+        for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int n = 0; n < NR; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[r % RS][m].lo, bh[n], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < NR; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[r % RS][m].lo, bh[n], acc[m][n], 0, 0, 0);
+      }
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
         bh[n] = nh[n];
-        bl[n] = nl[n];
+        if (TERMS >= 2) bl[n] = nl[n];
       }
     }
   }
@@ -147,18 +153,20 @@ __device__ __forceinline__ h8 widen(_Float16 v) {
   return r;
 }
 
-template <int MR, int NR>
+template <int MR, int NR, int TERMS>
 __device__ __forceinline__ void gemm_z16(f32x16 (&acc)[MR][NR], const h8 *__restrict__ az,
                                          const ZPair (&z)[NR]) {
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
-    const h8 ah = az[m * 128], al = az[m * 128 + 64];
+    const h8 ah = az[m * 128];
 #pragma unroll
     for (int n = 0; n < NR; ++n) {
-      const h8 zh = widen(z[n].hi), zl = widen(z[n].lo);
+      const h8 zh = widen(z[n].hi);
       acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, zh, acc[m][n], 0, 0, 0);
-      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, zl, acc[m][n], 0, 0, 0);
-      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, zh, acc[m][n], 0, 0, 0);
+      if (TERMS >= 2)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, widen(z[n].lo), acc[m][n], 0, 0, 0);
+      if (TERMS == 3)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(az[m * 128 + 64], zh, acc[m][n], 0, 0, 0);
     }
   }
 }
@@ -219,7 +227,7 @@ __device__ __forceinline__ void store_hidden16_part(unsigned char *hb, const f32
   }
 }
 
-template <int COUT>
+template <int COUT, int TERMS>
 __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
     MlpPack mlp32, MlpPack16 mlp, const float *__restrict__ feat, int fh, int fw,
     const float *__restrict__ calib, float z_scale, int act, PointSrc src,
@@ -322,37 +330,37 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
       const ZPair z0[2] = {zc[2 * cp0], zc[2 * cp0 + 1]};
       AFrag ring0[4][1];
       f32x16 acc0[1][2];
-      seg_prefetch16<1, 3>(ring0, a0 + (long long)rb0 * NGX * 128, 0, NGX);
+      seg_prefetch16<1, 3, TERMS>(ring0, a0 + (long long)rb0 * NGX * 128, 0, NGX);
       init_from_bias16(acc0[0][0], wbase + mlp32.bias[0] + 32 * rb0, hh, mlp.scale[0]);
       acc0[0][1] = acc0[0][0];
 #pragma unroll 1
       for (int ck = 0; ck < kHidden[0] / 64; ++ck) {
         // layer-0 rows [64 ck + 32 rb0, +32) x points [64 cp0, +64)
         const int rb = 2 * ck + rb0;
-        seg_main16<1, 2, 3, kXRow, 32>(acc0, ring0, a0 + (long long)rb * NGX * 128, 0, NGX,
+        seg_main16<1, 2, 3, kXRow, 32, TERMS>(acc0, ring0, a0 + (long long)rb * NGX * 128, 0, NGX,
                                        xrow + (2 * cp0) * 32 * kXRow, swz);
         AFrag ring1[2][4];
-        seg_prefetch16<4, 1>(ring1, a1 + ck * 4 * 128, rs1, 4);
-        gemm_z16<1, 2>(acc0, hbase + mlp.az[0] + rb * 128 + lane, z0);
+        seg_prefetch16<4, 1, TERMS>(ring1, a1 + ck * 4 * 128, rs1, 4);
+        gemm_z16<1, 2, TERMS>(acc0, hbase + mlp.az[0] + rb * 128 + lane, z0);
         finish16(acc0[0][0], inv0);
         finish16(acc0[0][1], inv0);
         store_hidden16(hb, acc0[0][0], rb0, 2 * cp0, j, hh);
         store_hidden16(hb, acc0[0][1], rb0, 2 * cp0 + 1, j, hh);
         // next chunk's layer-0 operands stream in underneath the layer-1 MFMAs
         const int rbn = min(rb + 2, kHidden[0] / 32 - 2 + rb0);
-        seg_prefetch16<1, 3>(ring0, a0 + (long long)rbn * NGX * 128, 0, NGX);
+        seg_prefetch16<1, 3, TERMS>(ring0, a0 + (long long)rbn * NGX * 128, 0, NGX);
         init_from_bias16(acc0[0][0], wbase + mlp32.bias[0] + 32 * rbn, hh, mlp.scale[0]);
         acc0[0][1] = acc0[0][0];
         __syncthreads();
-        seg_main16<4, 4, 1, kHRow, 8>(acc1, ring1, a1 + ck * 4 * 128, rs1, 4, hrow, swz);
+        seg_main16<4, 4, 1, kHRow, 8, TERMS>(acc1, ring1, a1 + ck * 4 * 128, rs1, 4, hrow, swz);
         __syncthreads();
       }
       // skip segment + z column of layer 1
       const h8 *a1x = hbase + mlp.ax[1] + (long long)(4 * wv) * NGX * 128 + lane;
       AFrag ring1[2][4];
-      seg_prefetch16<4, 1>(ring1, a1x, NGX * 128, NGX);
-      seg_main16<4, 4, 1, kXRow, 32>(acc1, ring1, a1x, NGX * 128, NGX, xrow, swz);
-      gemm_z16<4, 4>(acc1, hbase + mlp.az[1] + (4 * wv) * 128 + lane, zc);
+      seg_prefetch16<4, 1, TERMS>(ring1, a1x, NGX * 128, NGX);
+      seg_main16<4, 4, 1, kXRow, 32, TERMS>(acc1, ring1, a1x, NGX * 128, NGX, xrow, swz);
+      gemm_z16<4, 4, TERMS>(acc1, hbase + mlp.az[1] + (4 * wv) * 128 + lane, zc);
       const float inv1 = 1.0f / mlp.scale[1];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -384,20 +392,20 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
       const int rs2 = (kHidden[1] / 16) * 128;
       const h8 *a2 = hbase + mlp.ah[2] + (long long)(2 * wv) * rs2 + lane;
       AFrag ring2[2][2];
-      seg_prefetch16<2, 1>(ring2, a2, rs2, 4);
+      seg_prefetch16<2, 1, TERMS>(ring2, a2, rs2, 4);
 #pragma unroll
       for (int ck = 0; ck < 8; ++ck) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) store_hidden16_part(hb, acc1[ck >> 1][n], ck & 1, wv, n, j, hh);
         __syncthreads();
-        seg_main16<2, 4, 1, kHRow, 8>(acc2, ring2, a2 + ck * 4 * 128, rs2, 4, hrow, swz);
-        if (ck < 7) seg_prefetch16<2, 1>(ring2, a2 + (ck + 1) * 4 * 128, rs2, 4);
+        seg_main16<2, 4, 1, kHRow, 8, TERMS>(acc2, ring2, a2 + ck * 4 * 128, rs2, 4, hrow, swz);
+        if (ck < 7) seg_prefetch16<2, 1, TERMS>(ring2, a2 + (ck + 1) * 4 * 128, rs2, 4);
         __syncthreads();
       }
       const h8 *a2x = hbase + mlp.ax[2] + (long long)(2 * wv) * NGX * 128 + lane;
-      seg_prefetch16<2, 1>(ring2, a2x, NGX * 128, NGX);
-      seg_main16<2, 4, 1, kXRow, 32>(acc2, ring2, a2x, NGX * 128, NGX, xrow, swz);
-      gemm_z16<2, 4>(acc2, hbase + mlp.az[2] + (2 * wv) * 128 + lane, zc);
+      seg_prefetch16<2, 1, TERMS>(ring2, a2x, NGX * 128, NGX);
+      seg_main16<2, 4, 1, kXRow, 32, TERMS>(acc2, ring2, a2x, NGX * 128, NGX, xrow, swz);
+      gemm_z16<2, 4, TERMS>(acc2, hbase + mlp.az[2] + (2 * wv) * 128 + lane, zc);
       const float inv2 = 1.0f / mlp.scale[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -425,20 +433,20 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
     {
       const h8 *a3 = hbase + mlp.ah[3] + (long long)wv * (kHidden[2] / 16) * 128 + lane;
       AFrag ring3[4][1];
-      seg_prefetch16<1, 3>(ring3, a3, 0, 4);
+      seg_prefetch16<1, 3, TERMS>(ring3, a3, 0, 4);
 #pragma unroll
       for (int ck = 0; ck < 4; ++ck) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) store_hidden16_part(hb, acc2[ck >> 1][n], ck & 1, wv, n, j, hh);
         __syncthreads();
-        seg_main16<1, 4, 3, kHRow, 8>(acc3, ring3, a3 + ck * 4 * 128, 0, 4, hrow, swz);
-        if (ck < 3) seg_prefetch16<1, 3>(ring3, a3 + (ck + 1) * 4 * 128, 0, 4);
+        seg_main16<1, 4, 3, kHRow, 8, TERMS>(acc3, ring3, a3 + ck * 4 * 128, 0, 4, hrow, swz);
+        if (ck < 3) seg_prefetch16<1, 3, TERMS>(ring3, a3 + (ck + 1) * 4 * 128, 0, 4);
         __syncthreads();
       }
       const h8 *a3x = hbase + mlp.ax[3] + (long long)wv * NGX * 128 + lane;
-      seg_prefetch16<1, 3>(ring3, a3x, 0, NGX);
-      seg_main16<1, 4, 3, kXRow, 32>(acc3, ring3, a3x, 0, NGX, xrow, swz);
-      gemm_z16<1, 4>(acc3, hbase + mlp.az[3] + wv * 128 + lane, zc);
+      seg_prefetch16<1, 3, TERMS>(ring3, a3x, 0, NGX);
+      seg_main16<1, 4, 3, kXRow, 32, TERMS>(acc3, ring3, a3x, 0, NGX, xrow, swz);
+      gemm_z16<1, 4, TERMS>(acc3, hbase + mlp.az[3] + wv * 128 + lane, zc);
       const float inv3 = 1.0f / mlp.scale[3];
 #pragma unroll
       for (int n = 0; n < 4; ++n) finish16(acc3[0][n], inv3);
@@ -516,11 +524,11 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
   }
 }
 
-template <int COUT>
+template <int COUT, int TERMS>
 static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w,
                             const float *calib, float z_scale, const PointSrc &src, float *out,
                             long long max_points, hipStream_t st) {
-  auto kern = pifu_query16_kernel<COUT>;
+  auto kern = pifu_query16_kernel<COUT, TERMS>;
   static bool attr_set[16] = {};
   if (!attr_set[ctx->device & 15]) {
     MP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -548,11 +556,17 @@ int launch_query16(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w, c
                    float z_scale, const PointSrc &src, float *out, long long max_points,
                    hipStream_t st) {
   if (m.c != 256) return fail(ctx, MP_ERR_UNSUPPORTED, "f16x3 query kernel is built for C = 256");
-  if (m.cout == 1)
-    return launch_query16_t<1>(ctx, m, feat, h, w, calib, z_scale, src, out, max_points, st);
-  if (m.cout == 3)
-    return launch_query16_t<3>(ctx, m, feat, h, w, calib, z_scale, src, out, max_points, st);
-  return fail(ctx, MP_ERR_UNSUPPORTED, "f16x3 query kernel: Cout must be 1 or 3");
+#define MP_Q16CASE(CO, PREC, TERMS)                                                              \
+  if (m.cout == CO && m.precision == PREC)                                                      \
+    return launch_query16_t<CO, TERMS>(ctx, m, feat, h, w, calib, z_scale, src, out, max_points, st);
+  MP_Q16CASE(1, MP_PREC_F16X3, 3)
+  MP_Q16CASE(3, MP_PREC_F16X3, 3)
+  MP_Q16CASE(1, MP_PREC_F16W, 2)
+  MP_Q16CASE(3, MP_PREC_F16W, 2)
+  MP_Q16CASE(1, MP_PREC_F16, 1)
+  MP_Q16CASE(3, MP_PREC_F16, 1)
+#undef MP_Q16CASE
+  return fail(ctx, MP_ERR_UNSUPPORTED, "f16 query kernels: Cout must be 1 or 3");
 }
 
 }  // namespace mp

@@ -45,8 +45,8 @@ class SurfaceClassifier(nn.Module):
 
     # ---- packed-weight cache ------------------------------------------------------------------
     def set_precision(self, precision):
-        if precision not in ("f32", "f16x3"):
-            raise ValueError("precision must be 'f32' or 'f16x3'")
+        if precision not in ops.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(ops.PRECISIONS))
         self.precision = precision
         self._packed_key = None  # re-pack on next use
         return self

@@ -65,6 +65,10 @@ def _f32c(t):
     return t.contiguous()
 
 
+# mp_mlp_set_precision codes (include/monoport_hip.h)
+PRECISIONS = {"f32": 0, "f16x3": 1, "f16w": 2, "f16": 3}
+
+
 class PackedMLP:
     """Device-resident SurfaceClassifier weights in MFMA fragment order."""
 
@@ -93,9 +97,10 @@ class PackedMLP:
         b.record_stream(torch.cuda.current_stream(b.device))
 
     def set_precision(self, precision):
-        """"f32" (default: exact f32 MFMA) or "f16x3" (f32 emulated with three f16 MFMAs per
-        product, netG heads only).  Call after the layers are loaded."""
-        code = {"f32": 0, "f16x3": 1}[precision]
+        """"f32" (default: exact f32 MFMA), "f16x3" (f32 emulated with three f16 MFMAs per
+        product), "f16w" (fp16 weights, split activations) or "f16" (fp16 operands); the f16
+        variants are netG heads (C = 256) only.  Call after the layers are loaded."""
+        code = PRECISIONS[precision]
         self.ctx.check(self.ctx.lib.mp_mlp_set_precision(self.ctx.handle, self.id, code),
                        "mp_mlp_set_precision")
         self.precision = precision

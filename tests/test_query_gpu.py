@@ -216,3 +216,47 @@ def test_f16x3_rejects_netc_head(ops):
     mlp = ops.PackedMLP.from_layers("cuda:0", syn.rand_mlp("C", 3, 1.0), 2)
     with pytest.raises(MonoportError):
         mlp.set_precision("f16x3")
+
+
+@pytest.mark.parametrize("calib_kind", ["scene", "identity"])
+def test_config1_dense_lattice_64(ops, oracle, calib_kind):
+    """BASELINE configs[0]: the dense 64^3 lattice p = ((i+0.5)/64)*2-1,
+    z-major, 262,144 points through one query call, against the CPU oracle."""
+    r = 64
+    layers = syn.body_mlp("G", noise=0.05, seed=1)
+    f = syn.body_feat(256, 128, 128, 2)
+    calib = (oracle.pifu_calib(*syn.scene_camera(20)) if calib_kind == "scene"
+             else np.eye(4, dtype=np.float32)[None])
+    c = (np.arange(r, dtype=np.float32) + 0.5) / r * 2 - 1
+    zz, yy, xx = np.meshgrid(c, c, c, indexing="ij")
+    p = np.stack([xx.ravel(), yy.ravel(), zz.ravel()]).astype(np.float32)  # [3, 64^3], [z,y,x] order
+    dev = "cuda:0"
+    mlp = ops.PackedMLP.from_layers(dev, layers, 1)
+    fh = ops.pack_features(torch.from_numpy(f)[None].to(dev))
+    out = ops.query(mlp, fh, torch.from_numpy(p)[None].to(dev), torch.from_numpy(calib).to(dev),
+                    syn.Z_SCALE)[0].cpu().numpy()
+    ref = oracle.query(f, p, calib[0], layers, 1, syn.Z_SCALE, precision="f32")
+    assert out.shape == (1, r ** 3)
+    assert np.abs(out - ref).max() <= 2e-5
+    inside = (out > 0.5).mean()
+    assert 0.01 < inside < 0.3  # the analytic body is a closed blob, not a degenerate field
+
+
+@pytest.mark.parametrize("precision,tol", [("f16w", 3e-4), ("f16", 5e-3)])
+@pytest.mark.parametrize("name", ["query_G_rand", "query_G_body"])
+def test_fp16_modes_report_error(ops, oracle, name, precision, tol):
+    """BASELINE configs[4] arithmetic ("fp16 weights"): NOT held to the 1e-4 bar (SURVEY.md appendix A
+    item 10 measured 7.1e-5 for weight rounding alone on the reference); the bound asserted here
+    is the looser one written above and the measured error is printed."""
+    g = load_golden(name)
+    kind, layers, f, p = query_inputs(name)
+    dev = "cuda:0"
+    mlp = ops.PackedMLP.from_layers(dev, layers, syn.LAST_OP[kind])
+    mlp.set_precision(precision)
+    fh = ops.pack_features(torch.from_numpy(f)[None].to(dev))
+    out = ops.query(mlp, fh, torch.from_numpy(p)[None].to(dev), torch.from_numpy(g["calib"]).to(dev),
+                    syn.Z_SCALE)[0].cpu().numpy()
+    ref64 = oracle.query(f, p, g["calib"][0], layers, syn.LAST_OP[kind], syn.Z_SCALE, precision="f64")
+    err = np.abs(out - ref64).max()
+    print("%s %s: |gpu - f64 oracle| max %.3g" % (name, precision, err))
+    assert np.isfinite(out).all() and err <= tol
