@@ -244,7 +244,8 @@ def main():
             prof_status.append(prof_slot.status.clone())
     prof_slot.wait()
     launch_ms = ops.profile_end(device, capacity=8 * args.steps + 8)
-    prof_pts = torch.cat(prof_status).cpu().numpy()[:, 1:]
+    # one launch per (batch, level): its points are that level's nodes summed over the batch
+    prof_pts = torch.stack(prof_status).cpu().numpy()[:, :, 1:].sum(1)
 
     # breakdown leg: encoder-only and encoder-excluded time per frame, one
     # stream, features of the last frame
@@ -261,7 +262,7 @@ def main():
 
     def recon_only():
         mlp = prof_slot.net.surface_classifier.packed()
-        ops.recon(mlp, prof_slot.feat_hwc, prof_slot.calib[0:1], syn.Z_SCALE, B_MIN, B_MAX,
+        ops.recon(mlp, prof_slot.feats_hwc[0], prof_slot.calib[0:1], syn.Z_SCALE, B_MIN, B_MAX,
                   resolutions, 0.5, volume=prof_slot.volume, status=prof_slot.status[0])
         x, y, z, nrm, count = ops.forward_vertices_raw(prof_slot.volume, "front")
         ops.paint(x, y, nrm, 0, count, r_last, 0.5, 0.5, 0.0, 1.0)
@@ -325,7 +326,7 @@ def main():
             "breakdown": {
                 "encoder_ms_per_frame": enc_ms, "recon_vertices_render_ms": rec_ms,
                 "recon_per_s_encoder_excluded": 1e3 / rec_ms,
-                "points_per_level": [float(v) for v in prof_pts.mean(0)],
+                "points_per_level": [float(v) / batch for v in prof_pts.mean(0)],
                 "note": "single stream, no overlap; encoder eager at the bench batch size",
             },
             "roofline": {
@@ -338,6 +339,7 @@ def main():
                 "frac": achieved / peak_tflops,
                 "traffic": traffic_from_profile(),
                 "launches": int(n_launch),
+                "frames_per_launch": batch,
                 "avg_launch_ms": float(launch_ms[:n_launch].mean()) if n_launch else None,
                 "flop_per_point": FLOP_PER_POINT,
             },

@@ -132,6 +132,16 @@ int mp_recon(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, c
              const int *resolutions /*host*/, int n_levels, float balance, float *volume,
              int32_t *status, mp_stream stream);
 
+/* mp_recon over n_frames (1..8) independent frames sharing the MLP, box and resolutions: every
+ * octree level evaluates the selected nodes of ALL frames in one fused-query launch, so the coarse
+ * levels (5-25 k nodes per frame) fill the 256 CUs together.  feat_hwc / calib / volume / status
+ * are HOST arrays of n_frames device pointers, each as in mp_recon; results are identical to
+ * n_frames mp_recon calls. */
+int mp_recon_batch(mp_ctx *ctx, int mlp, int n_frames, const float *const *feat_hwc, int c, int h,
+                   int w, const float *const *calib, float z_scale, const float *b_min,
+                   const float *b_max, const int *resolutions, int n_levels, float balance,
+                   float *const *volume, int32_t *const *status, mp_stream stream);
+
 /* The same engine one level at a time, for an arbitrary Python ``query_func`` (the general
  * Seg3dLossless contract, RTL/main.py:169-195): the caller evaluates the selected nodes itself.
  *   mp_octree_select: level 0 (prev == NULL) selects every node; otherwise upsamples prev [rp^3]

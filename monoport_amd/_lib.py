@@ -37,6 +37,8 @@ SIGNATURES = {
                                  c_f32, c_vp, c_vp]),
     "mp_recon": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_f32, _pf32, _pf32, _pint,
                          c_int, c_f32, c_vp, c_vp, c_vp]),
+    "mp_recon_batch": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_f32, _pf32, _pf32,
+                               _pint, c_int, c_f32, c_vp, c_vp, c_vp]),
     "mp_octree_select": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_f32, c_vp,
                                  c_vp, c_vp]),
     "mp_lattice_points": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, _pf32, _pf32, c_vp, c_vp]),

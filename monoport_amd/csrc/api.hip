@@ -397,32 +397,54 @@ int mp_query_counted(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, 
                       (hipStream_t)stream);
 }
 
-int mp_recon(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, const float *calib,
-             float z_scale, const float *b_min, const float *b_max, const int *resolutions,
-             int n_levels, float balance, float *volume, int32_t *status, mp_stream stream) {
+static int check_resolutions(mp_ctx *ctx, const char *who, const int *resolutions, int n_levels) {
+  for (int l = 0; l < n_levels; ++l) {
+    if (resolutions[l] < 2 || resolutions[l] > 1023)
+      return fail(ctx, MP_ERR_UNSUPPORTED, "%s: resolution %d outside [2,1023]", who, resolutions[l]);
+    if (l > 0 && resolutions[l] != 2 * resolutions[l - 1] - 1)
+      return fail(ctx, MP_ERR_UNSUPPORTED, "%s: resolutions must follow r -> 2r-1 (got %d after %d)",
+                  who, resolutions[l], resolutions[l - 1]);
+  }
+  return MP_OK;
+}
+
+int mp_recon_batch(mp_ctx *ctx, int mlp, int n_frames, const float *const *feat_hwc, int c, int h,
+                   int w, const float *const *calib, float z_scale, const float *b_min,
+                   const float *b_max, const int *resolutions, int n_levels, float balance,
+                   float *const *volume, int32_t *const *status, mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   const Mlp *m = get_mlp(ctx, mlp);
   int rc = check_ready(ctx, m, c);
   if (rc != MP_OK) return rc;
+  if (n_frames < 1 || n_frames > kMaxFrames)
+    return fail(ctx, MP_ERR_ARG, "mp_recon_batch: 1..%d frames per call, got %d", kMaxFrames, n_frames);
   if (!feat_hwc || !calib || !b_min || !b_max || !resolutions || !volume || !status ||
       n_levels < 1 || n_levels > 8 || h <= 0 || w <= 0)
     return fail(ctx, MP_ERR_ARG, "mp_recon: bad argument");
-  if (m->cout != 1) return fail(ctx, MP_ERR_ARG, "mp_recon: needs a 1-channel (occupancy) mlp");
-  if (!aligned16(feat_hwc)) return fail(ctx, MP_ERR_ARG, "mp_recon: feat_hwc must be 16-byte aligned");
-  for (int l = 0; l < n_levels; ++l) {
-    if (resolutions[l] < 2 || resolutions[l] > 1023)
-      return fail(ctx, MP_ERR_UNSUPPORTED, "mp_recon: resolution %d outside [2,1023]", resolutions[l]);
-    if (l > 0 && resolutions[l] != 2 * resolutions[l - 1] - 1)
-      return fail(ctx, MP_ERR_UNSUPPORTED, "mp_recon: resolutions must follow r -> 2r-1 (got %d after %d)",
-                  resolutions[l], resolutions[l - 1]);
+  for (int f = 0; f < n_frames; ++f) {
+    if (!feat_hwc[f] || !calib[f] || !volume[f] || !status[f])
+      return fail(ctx, MP_ERR_ARG, "mp_recon: null buffer for frame %d", f);
+    if (!aligned16(feat_hwc[f]))
+      return fail(ctx, MP_ERR_ARG, "mp_recon: feat_hwc must be 16-byte aligned");
   }
+  if (m->cout != 1) return fail(ctx, MP_ERR_ARG, "mp_recon: needs a 1-channel (occupancy) mlp");
+  rc = check_resolutions(ctx, "mp_recon", resolutions, n_levels);
+  if (rc != MP_OK) return rc;
   DeviceGuard g(ctx->device);
   void *scratch = nullptr;
-  rc = ensure_scratch(ctx, (hipStream_t)stream, recon_scratch_bytes(resolutions, n_levels), &scratch);
+  rc = ensure_scratch(ctx, (hipStream_t)stream, n_frames * recon_scratch_bytes(resolutions, n_levels),
+                      &scratch);
   if (rc != MP_OK) return rc;
-  return launch_recon(ctx, scratch, *m, feat_hwc, h, w, calib, z_scale, b_min, b_max, resolutions, n_levels,
-                      balance, volume, status, (hipStream_t)stream);
+  return launch_recon(ctx, scratch, *m, n_frames, feat_hwc, h, w, calib, z_scale, b_min, b_max,
+                      resolutions, n_levels, balance, volume, status, (hipStream_t)stream);
+}
+
+int mp_recon(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, const float *calib,
+             float z_scale, const float *b_min, const float *b_max, const int *resolutions,
+             int n_levels, float balance, float *volume, int32_t *status, mp_stream stream) {
+  return mp_recon_batch(ctx, mlp, 1, &feat_hwc, c, h, w, &calib, z_scale, b_min, b_max, resolutions,
+                        n_levels, balance, &volume, &status, stream);
 }
 
 int mp_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,

@@ -57,6 +57,21 @@ struct PointSrc {
   long long out_stride;  // explicit mode: out[o*out_stride + i]
 };
 
+// One launch of the fused query kernels serves up to kMaxFrames independent frames (their own
+// feature map, calibration, points and output): the tiles of all frames form one index space, so
+// the small coarse levels of several frames fill the machine together.
+constexpr int kMaxFrames = 8;
+struct QueryItem {
+  const float *feat;   // channels-last feature map [H,W,C]
+  const float *calib;  // [3,4] rows of the 4x4
+  float *out;
+  PointSrc src;
+};
+struct QuerySet {
+  int n;
+  QueryItem it[kMaxFrames];
+};
+
 struct Mlp {
   bool used = false;
   int c = 0, cout = 0, act = 0;
@@ -118,6 +133,8 @@ int ensure_scratch(mp_ctx *ctx, hipStream_t st, size_t bytes, void **out);
 int launch_query(mp_ctx *ctx, const Mlp &m, const float *feat_hwc, int h, int w,
                  const float *calib, float z_scale, const PointSrc &src, float *out,
                  long long max_points, hipStream_t st);
+int launch_query_set(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
+                     long long max_points, bool device_counts, hipStream_t st);
 int launch_index(mp_ctx *ctx, const float *feat_hwc, int c, int h, int w, const float *uv,
                  long long n, float *out, hipStream_t st);
 int launch_orthogonal(mp_ctx *ctx, const float *pts, long long n, const float *calib, float *out,
@@ -131,15 +148,14 @@ int launch_pack_layer16(mp_ctx *ctx, Mlp &m, int layer, const float *w, hipStrea
 int launch_copy(mp_ctx *ctx, const float *src, float *dst, long long n, hipStream_t st);
 int launch_absmax(mp_ctx *ctx, const float *src, long long n, unsigned int *out_bits, hipStream_t st);
 // query16.hip
-int launch_query16(mp_ctx *ctx, const Mlp &m, const float *feat_hwc, int h, int w,
-                   const float *calib, float z_scale, const PointSrc &src, float *out,
-                   long long max_points, hipStream_t st);
+int launch_query16(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
+                   long long max_points, bool device_counts, hipStream_t st);
 // octree.hip
 size_t recon_scratch_bytes(const int *res, int n_levels);
-int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, const float *feat_hwc, int h, int w,
-                 const float *calib, float z_scale, const float *bmin, const float *bmax,
-                 const int *res, int n_levels, float balance, float *volume, int32_t *status,
-                 hipStream_t st);
+int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
+                 const float *const *feat_hwc, int h, int w, const float *const *calib,
+                 float z_scale, const float *bmin, const float *bmax, const int *res, int n_levels,
+                 float balance, float *const *volume, int32_t *const *status, hipStream_t st);
 int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
                          const unsigned long long *ev_prev, unsigned long long *ev_cur,
                          unsigned long long *bnd, int level, float balance, uint32_t *packed,

@@ -265,71 +265,88 @@ int launch_scatter_nodes(mp_ctx *ctx, const uint32_t *packed, const int32_t *cou
 }
 
 // ---- driver ------------------------------------------------------------------------------------
-int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, const float *feat_hwc, int h, int w,
-                 const float *calib, float z_scale, const float *bmin, const float *bmax,
-                 const int *res, int n_levels, float balance, float *volume, int32_t *status,
-                 hipStream_t st) {
-  // carve the scratch arena
-  unsigned char *p = static_cast<unsigned char *>(scratch);
-  LevelBufs lv[8];
-  for (int l = 0; l < n_levels; ++l) {
-    const size_t r = res[l];
-    if (l < n_levels - 1) {
-      lv[l].occ = reinterpret_cast<float *>(p);
-      p += align256(r * r * r * sizeof(float));
-    } else {
-      lv[l].occ = volume;
+int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
+                 const float *const *feat_hwc, int h, int w, const float *const *calib,
+                 float z_scale, const float *bmin, const float *bmax, const int *res, int n_levels,
+                 float balance, float *const *volume, int32_t *const *status, hipStream_t st) {
+  // carve the scratch arena: one private set of level buffers per frame
+  const size_t per_frame = recon_scratch_bytes(res, n_levels);
+  LevelBufs lv[kMaxFrames][8];
+  uint32_t *packed[kMaxFrames];
+  for (int f = 0; f < n_frames; ++f) {
+    unsigned char *p = static_cast<unsigned char *>(scratch) + f * per_frame;
+    for (int l = 0; l < n_levels; ++l) {
+      const size_t r = res[l];
+      if (l < n_levels - 1) {
+        lv[f][l].occ = reinterpret_cast<float *>(p);
+        p += align256(r * r * r * sizeof(float));
+      } else {
+        lv[f][l].occ = volume[f];
+      }
+      const size_t wb = align256(r * r * words64(res[l]) * sizeof(u64));
+      lv[f][l].bnd = reinterpret_cast<u64 *>(p);
+      p += wb;
+      lv[f][l].ev = reinterpret_cast<u64 *>(p);
+      p += wb;
     }
-    const size_t wb = align256(r * r * words64(res[l]) * sizeof(u64));
-    lv[l].bnd = reinterpret_cast<u64 *>(p);
-    p += wb;
-    lv[l].ev = reinterpret_cast<u64 *>(p);
-    p += wb;
+    packed[f] = reinterpret_cast<uint32_t *>(p);
   }
-  uint32_t *packed = reinterpret_cast<uint32_t *>(p);
 
   const int rf = res[n_levels - 1];
-  PointSrc src;
-  std::memset(&src, 0, sizeof(src));
-  src.packed = packed;
-  src.res_final = (float)rf;
-  src.half_step = (1.0f / (float)rf) / 2.0f;
-  for (int i = 0; i < 3; ++i) {
-    src.bmin[i] = bmin[i];
-    src.blen[i] = bmax[i] - bmin[i];
+  QuerySet set;
+  std::memset(&set, 0, sizeof(set));
+  set.n = n_frames;
+  for (int f = 0; f < n_frames; ++f) {
+    QueryItem &q = set.it[f];
+    q.feat = feat_hwc[f];
+    q.calib = calib[f];
+    q.src.packed = packed[f];
+    q.src.res_final = (float)rf;
+    q.src.half_step = (1.0f / (float)rf) / 2.0f;
+    for (int i = 0; i < 3; ++i) {
+      q.src.bmin[i] = bmin[i];
+      q.src.blen[i] = bmax[i] - bmin[i];
+    }
+    MP_HIP(ctx, hipMemsetAsync(status[f], 0, sizeof(int32_t) * (1 + n_levels), st));
   }
 
-  MP_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * (1 + n_levels), st));
-
-  // level 0: every node
+  // level 0: every node of every frame, one query launch for the whole set
   {
     const int r = res[0], total = r * r * r;
-    hipLaunchKernelGGL(iota_nodes_kernel, dim3((total + 255) / 256), dim3(256), 0, st, r, packed,
-                       lv[0].ev, words64(r), status + 1);
-    src.stride = (rf - 1) / (r - 1);
-    src.level_res = r;
-    src.n_dev = nullptr;
-    src.n = total;
-    int rc = launch_query(ctx, m, feat_hwc, h, w, calib, z_scale, src, lv[0].occ, total, st);
+    for (int f = 0; f < n_frames; ++f) {
+      hipLaunchKernelGGL(iota_nodes_kernel, dim3((total + 255) / 256), dim3(256), 0, st, r,
+                         packed[f], lv[f][0].ev, words64(r), status[f] + 1);
+      QueryItem &q = set.it[f];
+      q.out = lv[f][0].occ;
+      q.src.stride = (rf - 1) / (r - 1);
+      q.src.level_res = r;
+      q.src.n_dev = nullptr;
+      q.src.n = total;
+    }
+    int rc = launch_query_set(ctx, m, set, h, w, z_scale, (long long)total * n_frames, false, st);
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(any_above_kernel, dim3(min((total + 255) / 256, 256)), dim3(256), 0, st,
-                       lv[0].occ, total, balance, status);
+    for (int f = 0; f < n_frames; ++f)
+      hipLaunchKernelGGL(any_above_kernel, dim3(min((total + 255) / 256, 256)), dim3(256), 0, st,
+                         lv[f][0].occ, total, balance, status[f]);
   }
   for (int l = 1; l < n_levels; ++l) {
     const int r = res[l], rp = res[l - 1], w64 = words64(r);
     const long long items = (long long)r * r * w64;
-    hipLaunchKernelGGL(upsample_classify_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
-                       st, lv[l - 1].occ, rp, lv[l].occ, r, balance, lv[l].bnd, w64);
     const int d = l == 1 ? 4 : (l == 2 ? 3 : 1);  // 9^3, 7^3, 3^3 boxes ("faster" mode)
-    hipLaunchKernelGGL(select_compact_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
-                       st, lv[l].bnd, lv[l - 1].ev, rp, words64(rp), lv[l].ev, r, w64, d, packed,
-                       status + 1 + l);
-    src.stride = (rf - 1) / (r - 1);
-    src.level_res = r;
-    src.n_dev = status + 1 + l;
-    src.n = 0;
-    int rc = launch_query(ctx, m, feat_hwc, h, w, calib, z_scale, src, lv[l].occ,
-                          (long long)r * r * r, st);
+    for (int f = 0; f < n_frames; ++f) {
+      hipLaunchKernelGGL(upsample_classify_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
+                         st, lv[f][l - 1].occ, rp, lv[f][l].occ, r, balance, lv[f][l].bnd, w64);
+      hipLaunchKernelGGL(select_compact_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
+                         st, lv[f][l].bnd, lv[f][l - 1].ev, rp, words64(rp), lv[f][l].ev, r, w64, d,
+                         packed[f], status[f] + 1 + l);
+      QueryItem &q = set.it[f];
+      q.out = lv[f][l].occ;
+      q.src.stride = (rf - 1) / (r - 1);
+      q.src.level_res = r;
+      q.src.n_dev = status[f] + 1 + l;
+      q.src.n = 0;
+    }
+    int rc = launch_query_set(ctx, m, set, h, w, z_scale, (long long)r * r * r * n_frames, true, st);
     if (rc != MP_OK) return rc;
   }
   MP_HIP(ctx, hipGetLastError());

@@ -20,6 +20,8 @@
 //     inputs the same way, chunk by chunk from the owning wave's registers.  The skip-concat
 //     (SurfaceClassifier.py:55) is just a second K segment read from the feature tile.
 //   * last layer (Cout x 385) and the activation run on the VALU.
+#include <cstring>
+
 #include "mp_internal.h"
 #include "query_common.h"
 
@@ -27,6 +29,27 @@
 // define __fmul_rn & co. as plain operators, which hipcc would otherwise contract into FMAs).
 // Fused multiply-adds are requested explicitly (fmaf / MFMA) where they are wanted.
 #pragma clang fp contract(off)
+
+// Timing experiments only (tools/ablate.py builds side libraries with these; never in the product):
+//   MP32_NOBAR   drop the chunk-loop barriers (wrong results)   -> cost of the barriers
+//   MP32_AHOT    every A fragment read hits one cached line     -> cost of weight streaming
+#ifdef MP32_NOBAR
+#define MP_CHUNK_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MP_CHUNK_SYNC() __syncthreads()
+#endif
+#ifndef MP32_PF1
+#define MP32_PF1 1  // A-fragment prefetch distance (k-groups) of the MR = 4 / MR = 2 segments
+#endif
+#ifndef MP32_PF0
+#define MP32_PF0 3  // same for layer 0's MR = 1 segment
+#endif
+#ifdef MP32_AHOT  // bit 0: layer 0's segment, bit 1: layer-1 hidden, bit 2: everything else
+constexpr int kAHot = MP32_AHOT;
+#else
+constexpr int kAHot = 0;
+#endif
+#define MP_AG(g) (HOT ? 0 : (g))
 
 namespace mp {
 
@@ -57,17 +80,17 @@ __device__ __forceinline__ void mma_group(f32x16 (&acc)[MR][NR], const f32x4 (&a
 //      + n * 32 * ROWB; group g lives in 16-byte slot (2g + h) ^ (p & 15) = (2g) ^ swz.
 // The loop is deliberately NOT unrolled beyond the ring size: hipcc clusters every load of a
 // big unrolled block at its top and spills the accumulators.
-template <int MR, int PF>
+template <int MR, int PF, bool HOT = (kAHot & 4) != 0>
 __device__ __forceinline__ void seg_prefetch(f32x4 (&ring)[PF + 1][MR],
                                              const f32x4 *__restrict__ a, int rb_stride,
                                              int n_groups) {
 #pragma unroll
   for (int d = 0; d < PF; ++d)
 #pragma unroll
-    for (int m = 0; m < MR; ++m) ring[d][m] = a[m * rb_stride + min(d, n_groups - 1) * 64];
+    for (int m = 0; m < MR; ++m) ring[d][m] = a[m * rb_stride + MP_AG(min(d, n_groups - 1)) * 64];
 }
 
-template <int MR, int NR, int PF, int ROWB>
+template <int MR, int NR, int PF, int ROWB, bool HOT = (kAHot & 4) != 0>
 __device__ __forceinline__ void seg_main(f32x16 (&acc)[MR][NR], f32x4 (&ring)[PF + 1][MR],
                                          const f32x4 *__restrict__ a, int rb_stride, int n_groups,
                                          const unsigned char *b, int swz) {
@@ -83,7 +106,7 @@ __device__ __forceinline__ void seg_main(f32x16 (&acc)[MR][NR], f32x4 (&ring)[PF
       const int g = g0 + r;
       const int gp = min(g + PF, n_groups - 1);
 #pragma unroll
-      for (int m = 0; m < MR; ++m) ring[(r + PF) % RS][m] = a[m * rb_stride + gp * 64];
+      for (int m = 0; m < MR; ++m) ring[(r + PF) % RS][m] = a[m * rb_stride + MP_AG(gp) * 64];
       const int boff = ((2 * min(g + 1, n_groups - 1)) ^ swz) << 4;
       f32x4 bnxt[NR];
 #pragma unroll
@@ -148,8 +171,7 @@ __device__ __forceinline__ void store_hidden(unsigned char *hb, const f32x16 &v,
 // sampled features and z_feat; no projection, no sampling, no mask.
 template <int C, int COUT, int WPS, bool DIRECT>
 __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
-    MlpPack mlp, const float *__restrict__ feat, int fh, int fw, const float *__restrict__ calib,
-    float z_scale, int act, PointSrc src, float *__restrict__ out) {
+    MlpPack mlp, int fh, int fw, float z_scale, int act, QuerySet set) {
   constexpr int ROWB = C * 4;
   constexpr int NGX = C / 8;  // K groups of the feature segment
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -161,13 +183,40 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
 
-  const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
-  const long long n_tiles = (n_pts + kTilePts - 1) / kTilePts;
+  // tiles of all frames of the set in one index space: frame f owns [tile_end[f-1], tile_end[f])
+  long long tile_end[kMaxFrames];
+  {
+    long long total = 0;
+#pragma unroll
+    for (int f = 0; f < kMaxFrames; ++f) {
+      if (f < set.n) {
+        const PointSrc &s = set.it[f].src;
+        const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
+        total += (nf + kTilePts - 1) / kTilePts;
+      }
+      tile_end[f] = total;
+    }
+  }
+  const long long n_tiles = tile_end[kMaxFrames - 1];
 
   const int swz = h ^ (j & 15);  // this lane's 16-byte-slot swizzle (see gemm_seg)
 
-  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const long long n0 = tile * kTilePts;
+  for (long long gtile = blockIdx.x; gtile < n_tiles; gtile += gridDim.x) {
+    int fi = 0;
+    long long tile0 = 0;
+#pragma unroll
+    for (int f = 0; f < kMaxFrames - 1; ++f)
+      if (gtile >= tile_end[f]) {
+        fi = f + 1;
+        tile0 = tile_end[f];
+      }
+    const QueryItem &item = set.it[fi];
+    const float *__restrict__ feat = item.feat;
+    const float *__restrict__ calib = item.calib;
+    float *__restrict__ out = item.out;
+    const PointSrc &src = item.src;
+    const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
+    const long long n0 = (gtile - tile0) * kTilePts;
 
     // ---------------- gather: 16 points per wave ----------------
     float zb[2];  // z_feat B operands of this wave's two column blocks
@@ -219,8 +268,13 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
         for (int part = 0; part < C / 256; ++part)
 #pragma unroll
           for (int k = 0; k < 4; ++k)
+#ifdef MP32_NTFEAT
+            v[u][part][k] = __builtin_nontemporal_load(
+                reinterpret_cast<const f32x4 *>(feat + t[u].o[k] + 4 * (lane + 64 * part)));
+#else
             v[u][part][k] =
                 *reinterpret_cast<const f32x4 *>(feat + t[u].o[k] + 4 * (lane + 64 * part));
+#endif
 #pragma unroll
       for (int u = 0; u < GB; ++u) {
         const int p = 16 * wv + i0 + u;
@@ -268,44 +322,44 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
       const f32x4 *a1 = reinterpret_cast<const f32x4 *>(wbase + mlp.ah[1]) +
                         (long long)(4 * wv) * (kHidden[0] / 8) * 64 + lane;
       const float zz[1] = {zb[cb0]};
-      f32x4 ring0[4][1];
+      f32x4 ring0[MP32_PF0 + 1][1];
       f32x16 acc0[1][1];
       float az0[1];
-      seg_prefetch<1, 3>(ring0, a0 + (long long)rb0 * NGX * 64, 0, NGX);
+      seg_prefetch<1, MP32_PF0, (kAHot & 1) != 0>(ring0, a0 + (long long)rb0 * NGX * 64, 0, NGX);
       init_from_bias(acc0[0][0], wbase + mlp.bias[0] + 32 * rb0, h);
       az0[0] = (wbase + mlp.az[0])[rb0 * 64 + lane];
 #pragma unroll 1
       for (int ck = 0; ck < kHidden[0] / 64; ++ck) {
         // layer-0 rows [64 ck + 32 rb0, +32) x points [32 cb0, +32)
         const int rb = 2 * ck + rb0;
-        seg_main<1, 1, 3, ROWB>(acc0, ring0, a0 + (long long)rb * NGX * 64, 0, NGX,
+        seg_main<1, 1, MP32_PF0, ROWB, (kAHot & 1) != 0>(acc0, ring0, a0 + (long long)rb * NGX * 64, 0, NGX,
                                 xrow + cb0 * 32 * ROWB, swz);
         // layer-1 weights of this chunk start streaming before the chunk is even stored
-        f32x4 ring1[2][4];
-        seg_prefetch<4, 1>(ring1, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8);
+        f32x4 ring1[MP32_PF1 + 1][4];
+        seg_prefetch<4, MP32_PF1, (kAHot & 2) != 0>(ring1, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8);
         gemm_z<1, 1>(acc0, az0, zz);
         lrelu(acc0[0][0]);
         store_hidden(hb, acc0[0][0], rb0, cb0, j, h);
         // next chunk's layer-0 operands
         const int rbn = min(rb + 2, kHidden[0] / 32 - 2 + rb0);
-        seg_prefetch<1, 3>(ring0, a0 + (long long)rbn * NGX * 64, 0, NGX);
+        seg_prefetch<1, MP32_PF0, (kAHot & 1) != 0>(ring0, a0 + (long long)rbn * NGX * 64, 0, NGX);
         init_from_bias(acc0[0][0], wbase + mlp.bias[0] + 32 * rbn, h);
         az0[0] = (wbase + mlp.az[0])[rbn * 64 + lane];
-        __syncthreads();
+        MP_CHUNK_SYNC();
         // layer-1 rows [128 wv, +128) += W1[:, 64 ck .. +64) * chunk
-        seg_main<4, 2, 1, kHbRowBytes>(acc1, ring1, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8,
+        seg_main<4, 2, MP32_PF1, kHbRowBytes, (kAHot & 2) != 0>(acc1, ring1, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8,
                                        hrow, swz);
-        __syncthreads();
+        MP_CHUNK_SYNC();
       }
       // skip segment of layer 1: W1[:, 1024 .. 1024 + C] * x, then the z column
       const f32x4 *a1x = reinterpret_cast<const f32x4 *>(wbase + mlp.ax[1]) +
                          (long long)(4 * wv) * NGX * 64 + lane;
-      f32x4 ring1[2][4];
+      f32x4 ring1[MP32_PF1 + 1][4];
       float az1[4];
-      seg_prefetch<4, 1>(ring1, a1x, NGX * 64, NGX);
+      seg_prefetch<4, MP32_PF1>(ring1, a1x, NGX * 64, NGX);
 #pragma unroll
       for (int m = 0; m < 4; ++m) az1[m] = (wbase + mlp.az[1])[(4 * wv + m) * 64 + lane];
-      seg_main<4, 2, 1, ROWB>(acc1, ring1, a1x, NGX * 64, NGX, xrow, swz);
+      seg_main<4, 2, MP32_PF1, ROWB>(acc1, ring1, a1x, NGX * 64, NGX, xrow, swz);
       gemm_z<4, 2>(acc1, az1, zb);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -333,11 +387,11 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
 #pragma unroll
             for (int n = 0; n < 2; ++n) store_hidden(hb, acc1[2 * (ck & 1) + mm][n], mm, n, j, h);
         }
-        __syncthreads();
+        MP_CHUNK_SYNC();
         seg_main<2, 2, 1, kHbRowBytes>(acc2, ring2, a2 + ck * 8 * 64, (kHidden[1] / 8) * 64, 8,
                                        hrow, swz);
         if (ck < 7) seg_prefetch<2, 1>(ring2, a2 + (ck + 1) * 8 * 64, (kHidden[1] / 8) * 64, 8);
-        __syncthreads();
+        MP_CHUNK_SYNC();
       }
       const f32x4 *a2x = reinterpret_cast<const f32x4 *>(wbase + mlp.ax[2]) +
                          (long long)(2 * wv) * NGX * 64 + lane;
@@ -370,10 +424,10 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
 #pragma unroll
             for (int n = 0; n < 2; ++n) store_hidden(hb, acc2[mm][n], mm, n, j, h);
         }
-        __syncthreads();
+        MP_CHUNK_SYNC();
         seg_main<1, 2, 3, kHbRowBytes>(acc3, ring3, a3 + ck * 8 * 64, 0, 8, hrow, swz);
         if (ck < 3) seg_prefetch<1, 3>(ring3, a3 + (ck + 1) * 8 * 64, 0, 8);
-        __syncthreads();
+        MP_CHUNK_SYNC();
       }
       const f32x4 *a3x = reinterpret_cast<const f32x4 *>(wbase + mlp.ax[3]) +
                          (long long)wv * NGX * 64 + lane;
@@ -510,9 +564,9 @@ __global__ void orthogonal_kernel(const float *__restrict__ pts, long long n,
 
 // ---- host side -----------------------------------------------------------------------------------
 template <int C, int COUT, int WPS, bool DIRECT>
-static int launch_query_t(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w,
-                          const float *calib, float z_scale, const PointSrc &src, float *out,
-                          long long max_points, hipStream_t st) {
+static int launch_query_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w,
+                          float z_scale, long long max_points, bool device_counts,
+                          hipStream_t st) {
   constexpr int lds = kTilePts * C * 4 + kHbBytes;
   auto kern = pifu_query_kernel<C, COUT, WPS, DIRECT>;
   static bool attr_set[16] = {};
@@ -521,17 +575,18 @@ static int launch_query_t(mp_ctx *ctx, const Mlp &m, const float *feat, int h, i
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set[ctx->device & 15] = true;
   }
-  long long tiles = (max_points + kTilePts - 1) / kTilePts;
-  if (tiles <= 0) return MP_OK;
+  if (max_points <= 0) return MP_OK;
+  // every frame of the set rounds its own tail tile up
+  const long long tiles = (max_points + kTilePts - 1) / kTilePts + (set.n - 1);
   const long long resident = (long long)ctx->n_cu * WPS;
   // device-side counts: launch the resident grid and let it stride; host-side counts: one
   // workgroup per tile up to a few waves of the machine
-  long long grid = src.n_dev ? (tiles < resident ? tiles : resident)
-                             : (tiles < 8 * resident ? tiles : 8 * resident);
+  long long grid = device_counts ? (tiles < resident ? tiles : resident)
+                                 : (tiles < 8 * resident ? tiles : 8 * resident);
   const bool prof = 2 * (ctx->prof_used + 1) <= (int)ctx->prof_events.size();
   if (prof) MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], st));
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kQueryThreads), lds, st, m.pack(), feat, h,
-                     w, calib, z_scale, m.act, src, out);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kQueryThreads), lds, st, m.pack(), h, w,
+                     z_scale, m.act, set);
   if (prof) {
     MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], st));
     ++ctx->prof_used;
@@ -540,18 +595,20 @@ static int launch_query_t(mp_ctx *ctx, const Mlp &m, const float *feat, int h, i
   return MP_OK;
 }
 
-int launch_query(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w, const float *calib,
-                 float z_scale, const PointSrc &src, float *out, long long max_points,
-                 hipStream_t st) {
-  if (m.precision != MP_PREC_F32 && feat != nullptr && m.c == 256)
-    return launch_query16(ctx, m, feat, h, w, calib, z_scale, src, out, max_points, st);
-#define MP_QCASE(CC, CO, WP)                                                                    \
-  if (m.c == CC && m.cout == CO) {                                                              \
-    if (feat == nullptr)                                                                        \
-      return launch_query_t<CC, CO, WP, true>(ctx, m, feat, h, w, calib, z_scale, src, out,     \
-                                              max_points, st);                                  \
-    return launch_query_t<CC, CO, WP, false>(ctx, m, feat, h, w, calib, z_scale, src, out,      \
-                                             max_points, st);                                   \
+int launch_query_set(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
+                     long long max_points, bool device_counts, hipStream_t st) {
+  if (set.n < 1 || set.n > kMaxFrames)
+    return fail(ctx, MP_ERR_ARG, "query: 1..%d frames per launch, got %d", kMaxFrames, set.n);
+  const bool direct = set.it[0].feat == nullptr;
+  if (m.precision != MP_PREC_F32 && !direct && m.c == 256)
+    return launch_query16(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
+#define MP_QCASE(CC, CO, WP)                                                                     \
+  if (m.c == CC && m.cout == CO) {                                                               \
+    if (direct)                                                                                  \
+      return launch_query_t<CC, CO, WP, true>(ctx, m, set, h, w, z_scale, max_points,            \
+                                              device_counts, st);                                \
+    return launch_query_t<CC, CO, WP, false>(ctx, m, set, h, w, z_scale, max_points,             \
+                                             device_counts, st);                                 \
   }
   MP_QCASE(256, 1, 2)
   MP_QCASE(256, 3, 2)
@@ -560,6 +617,19 @@ int launch_query(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w, con
 #undef MP_QCASE
   return fail(ctx, MP_ERR_UNSUPPORTED, "query kernels are built for C in {256,512}, Cout in {1,3}; got C=%d Cout=%d",
               m.c, m.cout);
+}
+
+int launch_query(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w, const float *calib,
+                 float z_scale, const PointSrc &src, float *out, long long max_points,
+                 hipStream_t st) {
+  QuerySet set;
+  std::memset(&set, 0, sizeof(set));
+  set.n = 1;
+  set.it[0].feat = feat;
+  set.it[0].calib = calib;
+  set.it[0].out = out;
+  set.it[0].src = src;
+  return launch_query_set(ctx, m, set, h, w, z_scale, max_points, src.n_dev != nullptr, st);
 }
 
 int launch_index(mp_ctx *ctx, const float *feat, int c, int h, int w, const float *uv, long long n,

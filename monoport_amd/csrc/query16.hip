@@ -229,9 +229,7 @@ __device__ __forceinline__ void store_hidden16_part(unsigned char *hb, const f32
 
 template <int COUT, int TERMS>
 __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
-    MlpPack mlp32, MlpPack16 mlp, const float *__restrict__ feat, int fh, int fw,
-    const float *__restrict__ calib, float z_scale, int act, PointSrc src,
-    float *__restrict__ out) {
+    MlpPack mlp32, MlpPack16 mlp, int fh, int fw, float z_scale, int act, QuerySet set) {
   constexpr int C = 256;
   constexpr int NGX = C / 16;  // k16 groups of the feature segment
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -245,13 +243,40 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
   const int swz = hh ^ (j & 15);
   const int rb0 = wv >> 1, cp0 = wv & 1;  // layer-0 chunk: row block / column-block pair
 
-  const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
-  const long long n_tiles = (n_pts + kP16 - 1) / kP16;
+  // tiles of all frames of the set in one index space (see query.hip)
+  long long tile_end[kMaxFrames];
+  {
+    long long total = 0;
+#pragma unroll
+    for (int f = 0; f < kMaxFrames; ++f) {
+      if (f < set.n) {
+        const PointSrc &s = set.it[f].src;
+        const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
+        total += (nf + kP16 - 1) / kP16;
+      }
+      tile_end[f] = total;
+    }
+  }
+  const long long n_tiles = tile_end[kMaxFrames - 1];
   const float *wbase = mlp32.base;
   const h8 *hbase = static_cast<const h8 *>(mlp.base);
 
-  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const long long n0 = tile * kP16;
+  for (long long gtile = blockIdx.x; gtile < n_tiles; gtile += gridDim.x) {
+    int fi = 0;
+    long long tile0 = 0;
+#pragma unroll
+    for (int f = 0; f < kMaxFrames - 1; ++f)
+      if (gtile >= tile_end[f]) {
+        fi = f + 1;
+        tile0 = tile_end[f];
+      }
+    const QueryItem &item = set.it[fi];
+    const float *__restrict__ feat = item.feat;
+    const float *__restrict__ calib = item.calib;
+    float *__restrict__ out = item.out;
+    const PointSrc &src = item.src;
+    const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
+    const long long n0 = (gtile - tile0) * kP16;
 
     // ---------------- gather: 32 points per wave, features split into halves ----------------
     ZPair zc[4];  // z_feat of the four column blocks
@@ -525,9 +550,9 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
 }
 
 template <int COUT, int TERMS>
-static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w,
-                            const float *calib, float z_scale, const PointSrc &src, float *out,
-                            long long max_points, hipStream_t st) {
+static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w,
+                            float z_scale, long long max_points, bool device_counts,
+                            hipStream_t st) {
   auto kern = pifu_query16_kernel<COUT, TERMS>;
   static bool attr_set[16] = {};
   if (!attr_set[ctx->device & 15]) {
@@ -535,15 +560,15 @@ static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const float *feat, int h,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds16));
     attr_set[ctx->device & 15] = true;
   }
-  const long long tiles = (max_points + kP16 - 1) / kP16;
-  if (tiles <= 0) return MP_OK;
+  if (max_points <= 0) return MP_OK;
+  const long long tiles = (max_points + kP16 - 1) / kP16 + (set.n - 1);
   const long long resident = ctx->n_cu;  // one 160 KB workgroup per CU
-  const long long grid = src.n_dev ? (tiles < resident ? tiles : resident)
-                                   : (tiles < 8 * resident ? tiles : 8 * resident);
+  const long long grid = device_counts ? (tiles < resident ? tiles : resident)
+                                       : (tiles < 8 * resident ? tiles : 8 * resident);
   const bool prof = 2 * (ctx->prof_used + 1) <= (int)ctx->prof_events.size();
   if (prof) MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], st));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads16), kLds16, st, m.pack(), m.pack16(),
-                     feat, h, w, calib, z_scale, m.act, src, out);
+                     h, w, z_scale, m.act, set);
   if (prof) {
     MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], st));
     ++ctx->prof_used;
@@ -552,13 +577,12 @@ static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const float *feat, int h,
   return MP_OK;
 }
 
-int launch_query16(mp_ctx *ctx, const Mlp &m, const float *feat, int h, int w, const float *calib,
-                   float z_scale, const PointSrc &src, float *out, long long max_points,
-                   hipStream_t st) {
+int launch_query16(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
+                   long long max_points, bool device_counts, hipStream_t st) {
   if (m.c != 256) return fail(ctx, MP_ERR_UNSUPPORTED, "f16x3 query kernel is built for C = 256");
-#define MP_Q16CASE(CO, PREC, TERMS)                                                              \
-  if (m.cout == CO && m.precision == PREC)                                                      \
-    return launch_query16_t<CO, TERMS>(ctx, m, feat, h, w, calib, z_scale, src, out, max_points, st);
+#define MP_Q16CASE(CO, PREC, TERMS)                                                         \
+  if (m.cout == CO && m.precision == PREC)                                                 \
+    return launch_query16_t<CO, TERMS>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
   MP_Q16CASE(1, MP_PREC_F16X3, 3)
   MP_Q16CASE(3, MP_PREC_F16X3, 3)
   MP_Q16CASE(1, MP_PREC_F16W, 2)

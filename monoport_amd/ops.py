@@ -248,6 +248,45 @@ def recon(mlp, feat_hwc, calib, z_scale, b_min, b_max, resolutions, balance=0.5,
     return volume, status
 
 
+def recon_batch(mlp, feats_hwc, calibs, z_scale, b_min, b_max, resolutions, balance=0.5,
+                volumes=None, status=None):
+    """``recon`` over up to 8 independent frames in one call: every octree level evaluates the
+    selected nodes of all frames in ONE fused-query launch (the coarse levels of a single frame
+    cannot fill 256 CUs).  feats_hwc: list of [H,W,C] maps; calibs: [B,4,4] (or list of [1,4,4]);
+    volumes: list of [R,R,R]; status: [B, 1+levels] int32.  Results equal B separate ``recon``
+    calls bit for bit."""
+    ctx = mlp.ctx
+    n = len(feats_hwc)
+    h, w, c = feats_hwc[0].shape
+    res = [int(r) for r in resolutions]
+    r_last = res[-1]
+    dev = feats_hwc[0].device
+    if torch.is_tensor(calibs):
+        calibs = [calibs[b:b + 1] for b in range(n)]
+    cals = [_calib_dev(cb, dev) for cb in calibs]
+    if volumes is None:
+        volumes = [torch.empty((r_last, r_last, r_last), dtype=torch.float32, device=dev)
+                   for _ in range(n)]
+    if status is None:
+        status = torch.empty((n, 1 + len(res)), dtype=torch.int32, device=dev)
+    assert status.is_contiguous() and status.shape == (n, 1 + len(res))
+    for f in feats_hwc:
+        assert f.shape == (h, w, c) and f.is_contiguous() and f.dtype == torch.float32
+    bmin = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_min, np.float32).reshape(3)])
+    bmax = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_max, np.float32).reshape(3)])
+    res_c = (ctypes.c_int * len(res))(*res)
+    ptrs = ctypes.c_void_p * n
+    ctx.check(ctx.lib.mp_recon_batch(
+        ctx.handle, mlp.id, n, ptrs(*[f.data_ptr() for f in feats_hwc]), c, h, w,
+        ptrs(*[cb.data_ptr() for cb in cals]), float(z_scale), bmin, bmax, res_c, len(res),
+        float(balance), ptrs(*[v.data_ptr() for v in volumes]),
+        ptrs(*[status[b].data_ptr() for b in range(n)]), _stream(volumes[0])), "mp_recon_batch")
+    stream = torch.cuda.current_stream(dev)
+    for t in cals:
+        t.record_stream(stream)
+    return volumes, status
+
+
 def recon_generic(query_func, kwargs, device, b_min, b_max, resolutions, balance=0.5):
     """Seg3dLossless for an ARBITRARY ``query_func(points=[1,N,3], **kwargs) -> [1,1,N]``: the
     node selection, lattice coordinates and scatter run as HIP kernels, the occupancies come from

@@ -11,7 +11,9 @@ that host-side launch latency and GPU fill, not thread parallelism, are what mat
 
       channels-last pack -> octree (5 levels, fused query) -> forward_vertices -> render
 
-  as asynchronous C-ABI calls on the slot's stream;
+  as asynchronous C-ABI calls on the slot's stream, the octree level by level for the whole
+  batch (``mp_recon_batch``: one fused-query launch per level covers all frames of the slot --
+  a single frame's coarse levels, 5-25 k points, leave most of the 256 CUs idle);
 * a ``FramePipeline`` round-robins over ``depth`` slots, so independent frames on different
   streams fill the CUs that the coarse octree levels and the small encoder kernels leave idle
   (``depth`` x ``batch`` frames in flight; BASELINE configs[3] asks for 8).
@@ -23,6 +25,7 @@ from . import ops
 from .synthetic import Z_SCALE
 
 RESOLUTIONS = (17, 33, 65, 129, 257)  # RTL/main.py:187
+MAX_RECON_BATCH = 8  # kMaxFrames of the C-ABI (include/monoport_hip.h, mp_recon_batch)
 
 
 class FrameSlot:
@@ -44,7 +47,8 @@ class FrameSlot:
         self.stream = torch.cuda.Stream(device=dev)
         self.image = torch.zeros((b, 3, 512, 512), dtype=torch.float32, device=dev)
         self.calib = torch.eye(4, dtype=torch.float32, device=dev)[None].repeat(b, 1, 1).contiguous()
-        self.feat_hwc = torch.empty((128, 128, 256), dtype=torch.float32, device=dev)
+        self.feats_hwc = [torch.empty((128, 128, 256), dtype=torch.float32, device=dev)
+                          for _ in range(b)]
         # one volume per frame of the batch: results stay readable until the next submit
         self.volumes = [torch.empty((r, r, r), dtype=torch.float32, device=dev) for _ in range(b)]
         self.status = torch.zeros((b, 1 + len(self.res)), dtype=torch.int32, device=dev)
@@ -95,11 +99,17 @@ class FrameSlot:
             feat_c = self.netC.image_filter(self.image_c)[-1][0]  # [B,256,128,128]
         r = self.res[-1]
         for b in range(self.batch):
+            ops.pack_features(feat[b:b + 1], out=self.feats_hwc[b])
+        # the octree of all frames of the slot level by level: one fused-query launch per level
+        # covers every frame (mp_recon_batch takes up to MAX_RECON_BATCH frames per call)
+        for b0 in range(0, self.batch, MAX_RECON_BATCH):
+            b1 = min(b0 + MAX_RECON_BATCH, self.batch)
+            ops.recon_batch(mlp, self.feats_hwc[b0:b1], self.calib[b0:b1], Z_SCALE, self.b_min,
+                            self.b_max, self.res, self.balance, volumes=self.volumes[b0:b1],
+                            status=self.status[b0:b1])
+        for b in range(self.batch):
             fb = feat[b:b + 1]
-            ops.pack_features(fb, out=self.feat_hwc)
             calib = self.calib[b:b + 1]
-            ops.recon(mlp, self.feat_hwc, calib, Z_SCALE, self.b_min, self.b_max, self.res,
-                      self.balance, volume=self.volumes[b], status=self.status[b])
             x, y, z, nrm, count = ops.forward_vertices_raw(self.volumes[b], "front")
             self.vertices[b] = (x, y, z, nrm, count)
             self.renders[b] = ops.paint(x, y, nrm, 0, count, r, 0.5, 0.5, 0.0, 1.0)

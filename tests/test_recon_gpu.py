@@ -282,3 +282,38 @@ def test_config5_513_fp16_weights(ops, oracle, precision):
     # the analytic body has a slope of k = 40 through the surface, which amplifies operand rounding:
     # plain f16 moves single near-surface values by up to ~0.2 while the surface itself stays put
     assert dmax <= (1e-3 if precision == "f16w" else 0.5)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_recon_batch_equals_single_frames(ops, oracle, precision):
+    """mp_recon_batch (one fused-query launch per level for all frames) is bit-identical to one
+    mp_recon per frame: different feature maps and cameras per frame, including an EMPTY frame."""
+    layers = syn.body_mlp("G", noise=0.05, seed=1)
+    mlp = ops.PackedMLP.from_layers(DEV, layers, 1)
+    mlp.set_precision(precision)
+    res = [17, 33, 65, 129]
+    feats, cals = [], []
+    for i in range(5):
+        f = syn.body_feat(256, 128, 128, 2 + i)
+        feats.append(ops.pack_features(torch.from_numpy(f)[None].to(DEV)))
+        calib = oracle.pifu_calib(*syn.scene_camera(25 * i))
+        if i == 3:
+            calib[0, 0, 3] = 5.0  # camera looks past the box: every node projects out of the image
+        cals.append(torch.from_numpy(calib).to(DEV))
+    vols, status = ops.recon_batch(mlp, feats, cals, syn.Z_SCALE, BMIN, BMAX, res)
+    st = status.cpu().numpy()
+    assert st[:, 1].tolist() == [17 ** 3] * 5
+    for i in range(5):
+        v1, s1 = ops.recon(mlp, feats[i], cals[i], syn.Z_SCALE, BMIN, BMAX, res)
+        assert np.array_equal(s1.cpu().numpy(), st[i]), i
+        if st[i, 0]:
+            assert torch.equal(v1, vols[i]), i
+    assert st[3, 0] == 0 and (st[[0, 1, 2, 4], 0] == 1).all()
+    assert len({tuple(r) for r in st[:, 2:].tolist()}) > 1  # the frames really differ
+
+
+def test_recon_batch_rejects_too_many_frames(ops, body):
+    from monoport_amd._lib import MonoportError
+    with pytest.raises(MonoportError):
+        ops.recon_batch(body["mlp"], [body["fh"]] * 9, [body["cal"]] * 9, syn.Z_SCALE, BMIN, BMAX,
+                        [9, 17])
