@@ -244,8 +244,11 @@ def main():
             prof_status.append(prof_slot.status.clone())
     prof_slot.wait()
     launch_ms = ops.profile_end(device, capacity=8 * args.steps + 8)
-    # one launch per (batch, level): its points are that level's nodes summed over the batch
-    prof_pts = torch.stack(prof_status).cpu().numpy()[:, :, 1:].sum(1)
+    # one launch per (batch chunk of <= 8 frames, level): its points are that level's nodes summed
+    # over the chunk's frames (monoport_amd/pipeline.py calls mp_recon_batch once per chunk)
+    from monoport_amd.pipeline import MAX_RECON_BATCH
+    prof_pts = np.stack([st.cpu().numpy()[b0:b0 + MAX_RECON_BATCH, 1:].sum(0)
+                         for st in prof_status for b0 in range(0, batch, MAX_RECON_BATCH)])
 
     # breakdown leg: encoder-only and encoder-excluded time per frame, one
     # stream, features of the last frame
@@ -326,7 +329,7 @@ def main():
             "breakdown": {
                 "encoder_ms_per_frame": enc_ms, "recon_vertices_render_ms": rec_ms,
                 "recon_per_s_encoder_excluded": 1e3 / rec_ms,
-                "points_per_level": [float(v) / batch for v in prof_pts.mean(0)],
+                "points_per_level": [float(v) / args.steps for v in prof_pts.sum(0)],
                 "note": "single stream, no overlap; encoder eager at the bench batch size",
             },
             "roofline": {
@@ -339,7 +342,7 @@ def main():
                 "frac": achieved / peak_tflops,
                 "traffic": traffic_from_profile(),
                 "launches": int(n_launch),
-                "frames_per_launch": batch,
+                "frames_per_launch": min(batch, MAX_RECON_BATCH),
                 "avg_launch_ms": float(launch_ms[:n_launch].mean()) if n_launch else None,
                 "flop_per_point": FLOP_PER_POINT,
             },

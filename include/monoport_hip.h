@@ -186,6 +186,15 @@ int mp_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *value
 int mp_visualize(mp_ctx *ctx, const float *image, int res, int size, float *out, uint8_t *mask,
                  mp_stream stream);
 
+/* Background removal + normalisation in front of the encoders (RTL/main.py:352-364): segm is the
+ * segmentation engine's [4,H,W] output (RGB in [-1,1], then the soft mask);
+ *   input_g[c] = (((segm[c] * 0.5 + 0.5) - mean[c]) / std[c]) * segm[3]     (netG input)
+ *   input_c[c] = segm[c] * segm[3]                                          (netC input, may be NULL)
+ * in exactly this operation order (bit-identical to the reference's chain of torch ops).
+ * mean / std: host float[3] (cfg.netG.mean / .std, RTL/main.py:288-289). */
+int mp_prepare_inputs(mp_ctx *ctx, const float *segm, int64_t hw, const float *mean,
+                      const float *std, float *input_g, float *input_c, mp_stream stream);
+
 /* ---- triangle mesh (north star; no counterpart in the reference) ----------------- */
 /* Marching cubes of volume [R,R,R] at `level` (inside = value > level) with the face-consistent
  * case table of tools/gen_mc_tables.py.  One welded vertex per crossing lattice edge, in edge-id

@@ -535,6 +535,17 @@ int mp_visualize(mp_ctx *ctx, const float *image, int res, int size, float *out,
   return launch_visualize(ctx, image, res, size, out, mask, (hipStream_t)stream);
 }
 
+int mp_prepare_inputs(mp_ctx *ctx, const float *segm, int64_t hw, const float *mean,
+                      const float *std, float *input_g, float *input_c, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!segm || !mean || !std || !input_g || hw < 0)
+    return fail(ctx, MP_ERR_ARG, "mp_prepare_inputs: bad argument");
+  if (hw == 0) return MP_OK;
+  DeviceGuard g(ctx->device);
+  return launch_prepare_inputs(ctx, segm, hw, mean, std, input_g, input_c, (hipStream_t)stream);
+}
+
 int mp_marching_cubes(mp_ctx *ctx, const float *volume, int r, float level, const float *b_min,
                       const float *b_max, float *verts, int64_t max_verts, int32_t *faces,
                       int64_t max_faces, int32_t *counts, mp_stream stream) {

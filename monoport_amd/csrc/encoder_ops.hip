@@ -172,4 +172,43 @@ int launch_upsample_bicubic2x(mp_ctx *ctx, const float *x, int c, int h, int w, 
   return MP_OK;
 }
 
+// ---- input pre-step (RTL/main.py:352-364) ------------------------------------------------------
+// One pass over the segmentation output instead of seven elementwise torch kernels; the operation
+// order of the reference expression is kept (file is built with -ffp-contract=off).
+struct Norm3 {
+  float mean[3], std[3];
+};
+
+__global__ __launch_bounds__(256) void prepare_inputs_kernel(const float *__restrict__ segm,
+                                                             long long hw, Norm3 nrm,
+                                                             float *__restrict__ g,
+                                                             float *__restrict__ c) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < hw;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float m = segm[3 * hw + i];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float v = segm[ch * hw + i];
+      const float a = v * 0.5f + 0.5f;                       // segm[:, 0:3] * 0.5 + 0.5
+      g[ch * hw + i] = ((a - nrm.mean[ch]) / nrm.std[ch]) * m;
+      if (c) c[ch * hw + i] = v * m;
+    }
+  }
+}
+
+int launch_prepare_inputs(mp_ctx *ctx, const float *segm, long long hw, const float *mean,
+                          const float *std, float *g, float *c, hipStream_t st) {
+  Norm3 nrm;
+  for (int i = 0; i < 3; ++i) {
+    nrm.mean[i] = mean[i];
+    nrm.std[i] = std[i];
+  }
+  long long blocks = (hw + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(prepare_inputs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, segm, hw, nrm,
+                     g, c);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
 }  // namespace mp

@@ -150,6 +150,8 @@ int launch_absmax(mp_ctx *ctx, const float *src, long long n, unsigned int *out_
 // query16.hip
 int launch_query16(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
                    long long max_points, bool device_counts, hipStream_t st);
+int launch_prepare_inputs(mp_ctx *ctx, const float *segm, long long hw, const float *mean,
+                          const float *std, float *g, float *c, hipStream_t st);
 // octree.hip
 size_t recon_scratch_bytes(const int *res, int n_levels);
 int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,

@@ -393,6 +393,24 @@ def visualize(image, size=256):
     return out, mask
 
 
+def prepare_inputs(segm, mean, std, with_color=True):
+    """RTL/main.py:352-364 in one kernel: segm [1,4,H,W] (RGB in [-1,1] + mask) ->
+    (input_netG [1,3,H,W] normalised and background-zeroed, input_netC [1,3,H,W] or None)."""
+    sg = _f32c(segm)
+    if sg.dim() != 4 or sg.shape[0] != 1 or sg.shape[1] != 4:
+        raise ValueError("segm must be [1,4,H,W], got %s" % (tuple(segm.shape),))
+    ctx = get_context(sg.device)
+    hw = sg.shape[2] * sg.shape[3]
+    g = torch.empty((1, 3) + tuple(sg.shape[2:]), dtype=torch.float32, device=sg.device)
+    c = torch.empty_like(g) if with_color else None
+    mean_c = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(mean, np.float32).reshape(3)])
+    std_c = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(std, np.float32).reshape(3)])
+    ctx.check(ctx.lib.mp_prepare_inputs(ctx.handle, _ptr(sg), hw, mean_c, std_c, _ptr(g),
+                                        _ptr(c) if c is not None else None, _stream(sg)),
+              "mp_prepare_inputs")
+    return g, c
+
+
 def marching_cubes_raw(volume, level=0.5, b_min=(-1, -1, -1), b_max=(1, 1, 1), max_verts=None,
                        max_faces=None):
     """mp_marching_cubes: capacity-sized (verts [max_v,3] f32, faces [max_f,3] int32,

@@ -86,6 +86,13 @@ def marching_cubes(sdf, level=0.5, b_min=(-1, -1, -1), b_max=(1, 1, 1)):
 
 
 @torch.no_grad()
+def prepare_inputs(segm, mean, std, with_color=True):
+    """The two "update input by removing bg" processors of RTL/main.py:352-364 as one HIP kernel:
+    returns (input_netG, input_netC)."""
+    return ops.prepare_inputs(segm, mean, std, with_color)
+
+
+@torch.no_grad()
 def visulization(render_norm, render_tex=None, render_size=256):
     """(sic) RTL/main.py:252-281: both renders scaled to 0..255, rotated by 90 degrees,
     nearest-resized to 256x256 and moved to the host as [256,256,3] numpy arrays, plus the

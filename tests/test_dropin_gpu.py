@@ -310,3 +310,22 @@ def test_frame_pipeline_matches_direct_calls():
             assert torch.equal(st_d, st_p)  # same points queried at every level
             # batch > 1 lets MIOpen pick other conv algorithms: features differ in the last bits
             assert (r_d - r_p).abs().max().item() <= (0.0 if batch == 1 else 2e-3)
+
+
+def test_prepare_inputs_bit_exact_vs_reference_expressions():
+    """RTL/main.py:352-364: the two background-removal processors, fused; same bits as the
+    reference's chain of torch ops on the same device."""
+    from monoport_amd.recon import prepare_inputs
+    g = torch.Generator().manual_seed(5)
+    segm = torch.rand((1, 4, 512, 512), generator=g) * 2 - 1
+    segm[:, 3] = (torch.rand((1, 512, 512), generator=g) > 0.4).float() * torch.rand((1, 512, 512), generator=g)
+    segm = segm.to("cuda:0")
+    mean_l, std_l = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    mean = torch.tensor(mean_l).to("cuda:0").view(1, 3, 1, 1)
+    std = torch.tensor(std_l).to("cuda:0").view(1, 3, 1, 1)
+    want_g = (((segm[:, 0:3] * 0.5 + 0.5) - mean) / std) * segm[:, 3:4]
+    want_c = segm[:, 0:3] * segm[:, 3:4]
+    got_g, got_c = prepare_inputs(segm, mean_l, std_l)
+    assert torch.equal(got_g, want_g) and torch.equal(got_c, want_c)
+    only_g, none_c = prepare_inputs(segm, mean_l, std_l, with_color=False)
+    assert none_c is None and torch.equal(only_g, want_g)
