@@ -84,14 +84,16 @@ def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, 
     return pipe
 
 
-def traffic_from_profile():
+def traffic_from_profile(frames_per_launch):
     """HBM-side bytes per fused-query launch from the committed PMC pass (separate rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, corrected as MI355X_MICROARCH.md
-    prescribes); None if the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_query_traffic.json")
+    --pmc FETCH_SIZE / WRITE_SIZE runs of tools/traffic_probe.py, corrected as
+    MI355X_MICROARCH.md prescribes); None if the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r01e_query_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)["bytes_per_launch_avg"]
+            prof = json.load(f)
+        # the profile was taken at 4 frames per launch; traffic scales with the points of a launch
+        return prof["bytes_per_launch_avg"] * frames_per_launch / prof["frames_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -244,6 +246,12 @@ def main():
             prof_status.append(prof_slot.status.clone())
     prof_slot.wait()
     launch_ms = ops.profile_end(device, capacity=8 * args.steps + 8)
+    if args.with_color:
+        # each batch also records one netC (colour MLP) launch per frame after its octree launches;
+        # the roofline is about the netG query kernel: keep the octree launches only
+        n_oct = len(resolutions) * -(-batch // 8)
+        group = n_oct + batch
+        launch_ms = np.concatenate([launch_ms[g:g + n_oct] for g in range(0, len(launch_ms), group)])
     # one launch per (batch chunk of <= 8 frames, level): its points are that level's nodes summed
     # over the chunk's frames (monoport_amd/pipeline.py calls mp_recon_batch once per chunk)
     from monoport_amd.pipeline import MAX_RECON_BATCH
@@ -340,7 +348,7 @@ def main():
                 "peak": peak_tflops,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak_tflops,
-                "traffic": traffic_from_profile(),
+                "traffic": traffic_from_profile(min(batch, MAX_RECON_BATCH)),
                 "launches": int(n_launch),
                 "frames_per_launch": min(batch, MAX_RECON_BATCH),
                 "avg_launch_ms": float(launch_ms[:n_launch].mean()) if n_launch else None,
