@@ -153,13 +153,19 @@ def main():
     args = ap.parse_args()
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (tests/test_dropin_gpu.py): exercise the N > 1 code path on a ONE-GPU box -- every
+    # rank on device 0, collectives over gloo instead of RCCL (which refuses two ranks per device)
+    one_gpu_test = os.environ.get("MONOPORT_BENCH_ONE_GPU_TEST") == "1"
+    if one_gpu_test:
+        local_rank = 0
     if int(os.environ.get("WORLD_SIZE", "1")) not in (1, args.gpus):
         raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ["WORLD_SIZE"]))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    rank, world = parallel.init_from_env(backend="nccl", device=device)  # nccl = RCCL on ROCm
+    rank, world = parallel.init_from_env(backend="gloo" if one_gpu_test else "nccl",
+                                         device=device)  # nccl = RCCL on ROCm
     dist = None
     if world > 1:
         import torch.distributed as dist

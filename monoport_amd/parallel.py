@@ -48,7 +48,13 @@ class FrameGather:
         self.dst = dst
         self.shape = tuple(shape)
         self.dtype = dtype
+        # gloo has no gather for device tensors: stage through the host (CPU tests and the
+        # one-GPU test hook of bench.py only; the GPU path is RCCL on device buffers)
+        self._stage = (self.world > 1 and dist.get_backend() == "gloo"
+                       and torch.device(device).type != "cpu")
         self.device = device
+        if self._stage:
+            device = "cpu"
         self._bufs = ([torch.empty(self.shape, dtype=dtype, device=device)
                        for _ in range(self.world)] if self.rank == dst else None)
         self._pad = torch.zeros(self.shape, dtype=dtype, device=device)
@@ -63,10 +69,12 @@ class FrameGather:
             if result is not None and self.store:
                 self.results[round_idx] = payload.clone()
             return
+        if self._stage:
+            payload = payload.cpu()
         dist.gather(payload, self._bufs, dst=self.dst)
         if self.rank == self.dst and self.store:
             for r in range(self.world):
-                self.results[round_idx * self.world + r] = self._bufs[r].clone()
+                self.results[round_idx * self.world + r] = self._bufs[r].to(self.device, copy=True)
 
     def ordered(self, n_frames):
         """[n_frames, *shape] in frame order (rank dst)."""

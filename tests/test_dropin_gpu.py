@@ -329,3 +329,25 @@ def test_prepare_inputs_bit_exact_vs_reference_expressions():
     assert torch.equal(got_g, want_g) and torch.equal(got_c, want_c)
     only_g, none_c = prepare_inputs(segm, mean_l, std_l, with_color=False)
     assert none_c is None and torch.equal(only_g, want_g)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path (rank-sharded frames, barriers, gather to rank 0, MAX-over-ranks
+    timing) with two processes on this box's single GPU: the test hook swaps RCCL for gloo, the
+    rest of the code is what the 8-GPU run executes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MONOPORT_BENCH_ONE_GPU_TEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29713", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "4", "--warmup", "2", "--depth", "1", "--batch", "2"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    assert out["value"] > 0 and "cpu_baseline" not in out and 0 < out["roofline"]["frac"] < 1
