@@ -1,0 +1,53 @@
+"""Condense a `rocprofv3 --kernel-trace --stats --output-format csv -d DIR -- python bench.py ...`
+output directory into the two small files committed under profiles/:
+
+  <prefix>_kernel_stats.csv   top kernels by total time (rocprofv3's own kernel_stats.csv, truncated)
+  <prefix>_query_launches.txt every fused-query launch in time order with its duration, plus the
+                              mean duration per octree level over the single-stream roofline leg
+                              (the launches bench.py brackets with HIP events)
+
+    python tools/profile_summary.py DIR profiles/r01f_bench "command line that was profiled"
+"""
+import csv
+import glob
+import os
+import sys
+
+
+def main(directory, prefix, command):
+    stats = glob.glob(os.path.join(directory, "**", "*kernel_stats.csv"), recursive=True)[0]
+    with open(stats) as f:
+        lines = f.readlines()
+    with open(prefix + "_kernel_stats.csv", "w") as f:
+        f.writelines(lines[:41])
+    trace = glob.glob(os.path.join(directory, "**", "*kernel_trace.csv"), recursive=True)[0]
+    rows = []
+    with open(trace) as f:
+        for r in csv.DictReader(f):
+            if "pifu_query_kernel" in r["Kernel_Name"]:  # the f32 kernel (not pifu_query16_kernel)
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:40],
+                             r["Grid_Size_X"], r["Workgroup_Size_X"]))
+    rows.sort()
+    durs = [(e - s) / 1e3 for s, e, *_ in rows]
+    with open(prefix + "_query_launches.txt", "w") as f:
+        f.write("rocprofv3 --kernel-trace --stats --output-format csv -- %s\n" % command)
+        f.write("%d fused-query launches; duration (us), grid, kernel -- in start order\n" % len(rows))
+        for (s, e, name, grid, wg), d in zip(rows, durs):
+            f.write("%10.1f  grid %-8s %s\n" % (d, grid, name))
+        # bench.py's legs in launch order: slot warm-ups, timed pass (slots overlap on 3 streams),
+        # roofline leg (ONE stream, the launches bracketed by HIP events), breakdown leg (single
+        # frames: level 0 is 77 workgroups).  The roofline leg = the last `levels * batches`
+        # multi-frame launches before the first single-frame one.
+        single = [i for i, r in enumerate(rows) if int(r[3]) == 77 * 256]
+        if single and len(sys.argv) > 4:
+            n_leg = int(sys.argv[4])
+            leg = durs[single[0] - n_leg:single[0]]
+            f.write("\nroofline leg = launches %d..%d: mean %.1f us (bench.py roofline.avg_launch_ms "
+                    "is the HIP-event mean of the same launches)\n"
+                    % (single[0] - n_leg, single[0] - 1, sum(leg) / len(leg)))
+            print("roofline leg mean us:", sum(leg) / len(leg))
+    print("launches:", len(rows), "mean us:", sum(durs) / max(1, len(durs)))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
