@@ -171,10 +171,10 @@ def main():
         import torch.distributed as dist
 
     resolutions = RESOLUTIONS + ([513] if args.levels == 6 else [])
-    batch = max(d for d in range(1, max(1, args.batch) + 1) if args.steps % d == 0)
+    batch = max(1, min(args.batch, args.steps))  # a pass's last batch may be shorter
     pipe = make_pipeline(device, args.depth, not args.no_graph, resolutions, args.with_color,
                          args.precision, batch)
-    n_warm = -(-args.warmup // batch) * batch  # whole batches
+    n_warm = args.warmup
     n_frames = args.steps + n_warm
     # distinct frames per rank: frame id = step * world + rank (frame-parallel sharding)
     images = [torch.from_numpy(syn.synthetic_image(s * world + rank))[None].to(device)
@@ -185,28 +185,28 @@ def main():
     gather = parallel.FrameGather((r_last, r_last, 3), device=device, store=False)
     status_log = []
 
-    def run_batch(s0, log):
-        """Frames s0 .. s0+batch-1 as one slot submission."""
-        slot = pipe.submit([images[s % len(images)] for s in range(s0, s0 + batch)],
-                           [calibs[s] for s in range(s0, s0 + batch)])
+    def run_batch(s0, s1, log):
+        """Frames s0 .. s1-1 (at most `batch`) as one slot submission."""
+        slot = pipe.submit([images[s % len(images)] for s in range(s0, s1)],
+                           [calibs[s] for s in range(s0, s1)])
         with torch.cuda.stream(slot.stream):
-            for b in range(batch):
+            for b in range(s1 - s0):
                 # fixed-size per-frame result to rank 0 (no-op on one GPU)
                 gather.push(s0 + b, slot.renders_tex[b] if args.with_color else slot.renders[b])
             if log:
-                status_log.append(slot.status.clone())  # device-side copy, no sync
+                status_log.append(slot.status[:s1 - s0].clone())  # device-side copy, no sync
 
     def timed_pass(log):
         """Warm-up batches, then EXACTLY --steps frames between barrier + synchronize pairs."""
         for s0 in range(0, n_warm, batch):
-            run_batch(s0, False)
+            run_batch(s0, min(s0 + batch, n_warm), False)
         pipe.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
         for s0 in range(n_warm, n_frames, batch):
-            run_batch(s0, log)
+            run_batch(s0, min(s0 + batch, n_frames), log)
         pipe.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
@@ -220,15 +220,16 @@ def main():
     alt = None
     if world == 1 and args.precision == "f32" and not args.no_alt and not args.with_color:
         last_slot = pipe.slots[(pipe.n_submitted - 1) % len(pipe.slots)]
-        vol_f32 = last_slot.volumes[-1].clone()
+        vol_f32 = last_slot.volumes[last_slot.n_active - 1].clone()
         head = pipe.slots[0].net.surface_classifier
         head.set_precision("f16x3")
         head.packed()  # re-pack now, on this stream, and drain before the slots' streams use it
         torch.cuda.synchronize()
         alt_elapsed = timed_pass(False)
         last_slot = pipe.slots[(pipe.n_submitted - 1) % len(pipe.slots)]
-        diff = (last_slot.volumes[-1] - vol_f32).abs().max().item()
-        flips = int(((last_slot.volumes[-1] > 0.5) != (vol_f32 > 0.5)).sum().item())
+        vol_alt = last_slot.volumes[last_slot.n_active - 1]
+        diff = (vol_alt - vol_f32).abs().max().item()
+        flips = int(((vol_alt > 0.5) != (vol_f32 > 0.5)).sum().item())
         head.set_precision("f32")
         head.packed()
         torch.cuda.synchronize()
@@ -242,27 +243,32 @@ def main():
     # roofline leg: the same frames again on ONE stream with every fused-query launch bracketed by
     # HIP events on its launch stream (concurrent slots would share CUs) -> per-launch durations
     # of the dominant kernel
+    from monoport_amd.pipeline import MAX_RECON_BATCH
     prof_slot = pipe.slots[0]
     prof_status = []
     ops.profile_begin(device, max_records=8 * args.steps + 8)
     for s0 in range(n_warm, n_frames, batch):
-        prof_slot.submit([images[s % len(images)] for s in range(s0, s0 + batch)],
-                         [calibs[s] for s in range(s0, s0 + batch)])
+        s1 = min(s0 + batch, n_frames)
+        prof_slot.submit([images[s % len(images)] for s in range(s0, s1)],
+                         [calibs[s] for s in range(s0, s1)])
         with torch.cuda.stream(prof_slot.stream):
-            prof_status.append(prof_slot.status.clone())
+            prof_status.append(prof_slot.status[:s1 - s0].clone())
     prof_slot.wait()
-    launch_ms = ops.profile_end(device, capacity=8 * args.steps + 8)
-    if args.with_color:
-        # each batch also records one netC (colour MLP) launch per frame after its octree launches;
-        # the roofline is about the netG query kernel: keep the octree launches only
-        n_oct = len(resolutions) * -(-batch // 8)
-        group = n_oct + batch
-        launch_ms = np.concatenate([launch_ms[g:g + n_oct] for g in range(0, len(launch_ms), group)])
-    # one launch per (batch chunk of <= 8 frames, level): its points are that level's nodes summed
-    # over the chunk's frames (monoport_amd/pipeline.py calls mp_recon_batch once per chunk)
-    from monoport_amd.pipeline import MAX_RECON_BATCH
-    prof_pts = np.stack([st.cpu().numpy()[b0:b0 + MAX_RECON_BATCH, 1:].sum(0)
-                         for st in prof_status for b0 in range(0, batch, MAX_RECON_BATCH)])
+    all_ms = ops.profile_end(device, capacity=8 * args.steps + 8)
+    # launch order per submission of n frames: for every chunk of <= 8 frames one launch per level
+    # (its points = that level's nodes summed over the chunk, pipeline.py / mp_recon_batch); with
+    # --with-color one netC launch per frame follows, which the netG roofline skips
+    launch_ms, prof_pts, cursor = [], [], 0
+    for st in prof_status:
+        counts = st.cpu().numpy()[:, 1:]
+        for b0 in range(0, counts.shape[0], MAX_RECON_BATCH):
+            prof_pts.append(counts[b0:b0 + MAX_RECON_BATCH].sum(0))
+            launch_ms.append(all_ms[cursor:cursor + len(resolutions)])
+            cursor += len(resolutions)
+        if args.with_color:
+            cursor += counts.shape[0]
+    launch_ms = np.concatenate(launch_ms)
+    prof_pts = np.stack(prof_pts)
 
     # breakdown leg: encoder-only and encoder-excluded time per frame, one
     # stream, features of the last frame

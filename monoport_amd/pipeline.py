@@ -59,6 +59,7 @@ class FrameSlot:
         self._graph_feat = None
         self.use_graph = use_graph
         self._busy = False
+        self.n_active = b  # frames of the current submission (a stream's last batch may be short)
         if netC is not None:
             from .recon import color_matrix
             self.feat_hwc_c = torch.empty((128, 128, 512), dtype=torch.float32, device=dev)
@@ -98,16 +99,17 @@ class FrameSlot:
             mlp_c = self.netC.surface_classifier.packed()
             feat_c = self.netC.image_filter(self.image_c)[-1][0]  # [B,256,128,128]
         r = self.res[-1]
-        for b in range(self.batch):
+        n = self.n_active
+        for b in range(n):
             ops.pack_features(feat[b:b + 1], out=self.feats_hwc[b])
         # the octree of all frames of the slot level by level: one fused-query launch per level
         # covers every frame (mp_recon_batch takes up to MAX_RECON_BATCH frames per call)
-        for b0 in range(0, self.batch, MAX_RECON_BATCH):
-            b1 = min(b0 + MAX_RECON_BATCH, self.batch)
+        for b0 in range(0, n, MAX_RECON_BATCH):
+            b1 = min(b0 + MAX_RECON_BATCH, n)
             ops.recon_batch(mlp, self.feats_hwc[b0:b1], self.calib[b0:b1], Z_SCALE, self.b_min,
                             self.b_max, self.res, self.balance, volumes=self.volumes[b0:b1],
                             status=self.status[b0:b1])
-        for b in range(self.batch):
+        for b in range(n):
             fb = feat[b:b + 1]
             calib = self.calib[b:b + 1]
             x, y, z, nrm, count = ops.forward_vertices_raw(self.volumes[b], "front")
@@ -140,11 +142,17 @@ class FrameSlot:
             self.graph = graph
 
     def submit(self, images, calibs, images_c=None):
-        """Enqueue the reconstruction of ``batch`` frames: ``images`` [B,3,512,512] (or a list of
-        [1,3,512,512]), ``calibs`` [B,4,4] (or a list of [1,4,4]); returns immediately.  Results
-        (``renders``, ``volumes``, ``status``, ``vertices``) are valid after
-        ``stream.synchronize()`` and until the next submit on this slot."""
+        """Enqueue the reconstruction of n <= ``batch`` frames: ``images`` [n,3,512,512] (or a list
+        of [1,3,512,512]), ``calibs`` [n,4,4] (or a list of [1,4,4]); returns immediately.  Results
+        (``renders``, ``volumes``, ``status``, ``vertices``; entries 0..n-1) are valid after
+        ``stream.synchronize()`` and until the next submit on this slot.  A short batch (the tail of
+        a stream) still runs the encoder at the slot's batch size -- the graph is captured for it --
+        on stale images in the unused entries; the octree and everything after it see n frames."""
+        n = images.shape[0] if torch.is_tensor(images) else len(images)
+        if not 1 <= n <= self.batch:
+            raise ValueError("slot of %d frames got %d" % (self.batch, n))
         self.wait()  # a slot holds ONE batch: its previous results are overwritten from here on
+        self.n_active = n
         with torch.cuda.stream(self.stream):
             self._load(self.image, images)
             self._load(self.calib, calibs)
@@ -156,7 +164,8 @@ class FrameSlot:
     @staticmethod
     def _load(dst, src):
         if torch.is_tensor(src):
-            dst.copy_(src.reshape(dst.shape), non_blocking=True)
+            n = src.shape[0]
+            dst[:n].copy_(src.reshape(dst[:n].shape), non_blocking=True)
         else:
             for b, s in enumerate(src):
                 dst[b].copy_(s.reshape(dst[b].shape), non_blocking=True)

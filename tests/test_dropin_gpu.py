@@ -296,7 +296,7 @@ def test_frame_pipeline_matches_direct_calls():
             x, y, z, n, c = ops.forward_vertices_raw(vol, "front")
             direct.append((st.cpu(), ops.paint(x, y, n, 0, c, res[-1], 0.5, 0.5, 0.0, 1.0).cpu()))
 
-    for batch, use_graph in ((1, False), (3, True)):
+    for batch, use_graph in ((1, False), (3, True), (4, True)):  # 4: the last batch is short (6 = 4 + 2)
         pipe = FramePipeline(netG, DEV, depth=2, batch=batch, resolutions=res, feature_hook=hook,
                              use_graph=use_graph)
         pipe.prepare()
@@ -304,8 +304,10 @@ def test_frame_pipeline_matches_direct_calls():
         for s0 in range(0, 6, batch):
             slot = pipe.submit(images[s0:s0 + batch], calibs[s0:s0 + batch])
             slot.wait()
-            for b in range(batch):
+            assert slot.n_active == min(batch, 6 - s0)
+            for b in range(slot.n_active):
                 got.append((slot.status[b].cpu(), slot.renders[b].cpu()))
+        assert len(got) == 6
         for (st_d, r_d), (st_p, r_p) in zip(direct, got):
             assert torch.equal(st_d, st_p)  # same points queried at every level
             # batch > 1 lets MIOpen pick other conv algorithms: features differ in the last bits
