@@ -182,7 +182,10 @@ def main():
     calibs = [pifu_calib(*syn.scene_camera(3 * (s * world + rank)), device=device)
               for s in range(n_frames)]
     r_last = resolutions[-1]
-    gather = parallel.FrameGather((r_last, r_last, 3), device=device, store=False)
+    # one gather per slot submission: [batch, R, R, 3] renders to rank 0 (a no-op on one GPU)
+    gather = parallel.FrameGather((batch, r_last, r_last, 3), device=device, store=False)
+    render_pack = [torch.zeros((batch, r_last, r_last, 3), dtype=torch.float32, device=device)
+                   for _ in range(args.depth)]
     status_log = []
 
     def run_batch(s0, s1, log):
@@ -190,9 +193,11 @@ def main():
         slot = pipe.submit([images[s % len(images)] for s in range(s0, s1)],
                            [calibs[s] for s in range(s0, s1)])
         with torch.cuda.stream(slot.stream):
-            for b in range(s1 - s0):
-                # fixed-size per-frame result to rank 0 (no-op on one GPU)
-                gather.push(s0 + b, slot.renders_tex[b] if args.with_color else slot.renders[b])
+            if world > 1:
+                pack = render_pack[(pipe.n_submitted - 1) % args.depth]  # this slot's staging buffer
+                for b in range(s1 - s0):
+                    pack[b].copy_(slot.renders_tex[b] if args.with_color else slot.renders[b])
+                gather.push(s0 // batch, pack)
             if log:
                 status_log.append(slot.status[:s1 - s0].clone())  # device-side copy, no sync
 
