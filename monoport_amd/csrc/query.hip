@@ -183,33 +183,32 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
 
-  // tiles of all frames of the set in one index space: frame f owns [tile_end[f-1], tile_end[f])
-  long long tile_end[kMaxFrames];
-  {
-    long long total = 0;
-#pragma unroll
-    for (int f = 0; f < kMaxFrames; ++f) {
-      if (f < set.n) {
-        const PointSrc &s = set.it[f].src;
-        const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
-        total += (nf + kTilePts - 1) / kTilePts;
-      }
-      tile_end[f] = total;
-    }
-  }
-  const long long n_tiles = tile_end[kMaxFrames - 1];
-
+  // The tiles of all frames of the set form one index space: frame f owns the next
+  // ceil(n_f / tile) global tiles.  The owner of a global tile is looked up from the (device-side)
+  // counts at the top of every iteration -- eight scalar loads -- instead of keeping a prefix
+  // table alive in SGPRs across the whole MLP.
   const int swz = h ^ (j & 15);  // this lane's 16-byte-slot swizzle (see gemm_seg)
 
-  for (long long gtile = blockIdx.x; gtile < n_tiles; gtile += gridDim.x) {
-    int fi = 0;
+  for (long long gtile = blockIdx.x;; gtile += gridDim.x) {
+    int fi = -1;
     long long tile0 = 0;
+    {
+      long long acc = 0;
 #pragma unroll
-    for (int f = 0; f < kMaxFrames - 1; ++f)
-      if (gtile >= tile_end[f]) {
-        fi = f + 1;
-        tile0 = tile_end[f];
+      for (int f = 0; f < kMaxFrames; ++f) {
+        if (f < set.n) {
+          const PointSrc &s = set.it[f].src;
+          const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
+          const long long t = (nf + kTilePts - 1) / kTilePts;
+          if (fi < 0 && gtile < acc + t) {
+            fi = f;
+            tile0 = acc;
+          }
+          acc += t;
+        }
       }
+    }
+    if (fi < 0) break;  // past the last tile of the last frame
     const QueryItem &item = set.it[fi];
     const float *__restrict__ feat = item.feat;
     const float *__restrict__ calib = item.calib;

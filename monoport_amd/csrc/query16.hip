@@ -243,33 +243,33 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
   const int swz = hh ^ (j & 15);
   const int rb0 = wv >> 1, cp0 = wv & 1;  // layer-0 chunk: row block / column-block pair
 
-  // tiles of all frames of the set in one index space (see query.hip)
-  long long tile_end[kMaxFrames];
-  {
-    long long total = 0;
-#pragma unroll
-    for (int f = 0; f < kMaxFrames; ++f) {
-      if (f < set.n) {
-        const PointSrc &s = set.it[f].src;
-        const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
-        total += (nf + kP16 - 1) / kP16;
-      }
-      tile_end[f] = total;
-    }
-  }
-  const long long n_tiles = tile_end[kMaxFrames - 1];
+  // The tiles of all frames of the set form one index space: frame f owns the next
+  // ceil(n_f / tile) global tiles.  The owner of a global tile is looked up from the (device-side)
+  // counts at the top of every iteration -- eight scalar loads -- instead of keeping a prefix
+  // table alive in SGPRs across the whole MLP.
   const float *wbase = mlp32.base;
   const h8 *hbase = static_cast<const h8 *>(mlp.base);
 
-  for (long long gtile = blockIdx.x; gtile < n_tiles; gtile += gridDim.x) {
-    int fi = 0;
+  for (long long gtile = blockIdx.x;; gtile += gridDim.x) {
+    int fi = -1;
     long long tile0 = 0;
+    {
+      long long acc = 0;
 #pragma unroll
-    for (int f = 0; f < kMaxFrames - 1; ++f)
-      if (gtile >= tile_end[f]) {
-        fi = f + 1;
-        tile0 = tile_end[f];
+      for (int f = 0; f < kMaxFrames; ++f) {
+        if (f < set.n) {
+          const PointSrc &s = set.it[f].src;
+          const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
+          const long long t = (nf + kP16 - 1) / kP16;
+          if (fi < 0 && gtile < acc + t) {
+            fi = f;
+            tile0 = acc;
+          }
+          acc += t;
+        }
       }
+    }
+    if (fi < 0) break;  // past the last tile of the last frame
     const QueryItem &item = set.it[fi];
     const float *__restrict__ feat = item.feat;
     const float *__restrict__ calib = item.calib;
