@@ -33,6 +33,7 @@
 // Timing experiments only (tools/ablate.py builds side libraries with these; never in the product):
 //   MP32_NOBAR   drop the chunk-loop barriers (wrong results)   -> cost of the barriers
 //   MP32_AHOT    every A fragment read hits one cached line     -> cost of weight streaming
+//   MP32_GATHER_ONLY  stop after the gather                     -> the sampling stage on its own
 #ifdef MP32_NOBAR
 #define MP_CHUNK_SYNC() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -299,6 +300,10 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
     }
     }
     __syncthreads();
+#ifdef MP32_GATHER_ONLY  // timing experiment: the sampling stage alone (projection + 4-tap gather + blend)
+    if (zb[0] == 123.456f) out[0] = xs[tid];
+    continue;
+#endif
 
     const unsigned char *xrow = xs + j * ROWB;       // this lane's point row, column block 0
     const unsigned char *hrow = hb + j * kHbRowBytes;
