@@ -74,51 +74,12 @@ __global__ void any_above_kernel(const float *__restrict__ occ, int n, float bal
 }
 
 // ---- upsample + boundary flags ---------------------------------------------------------------
-// One wave per (z, y, 64-wide x span).  Interpolation order z, then y, then x with weights 0.5/0.5
-// -- the exact sequence of oracle upsample2x (axis 0 first), so values agree bit for bit.
-__global__ __launch_bounds__(256) void upsample_classify_kernel(const float *__restrict__ prev,
-                                                                int rp, float *__restrict__ cur,
-                                                                int r, float balance,
-                                                                u64 *__restrict__ bnd, int w64) {
-  const int lane = threadIdx.x & 63;
-  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long long n_items = (long long)r * r * w64;
-  if (item >= n_items) return;
-  const int w = item % w64;
-  const int y = (item / w64) % r;
-  const int z = item / ((long long)w64 * r);
-  const int x = 64 * w + lane;
-  bool flag = false;
-  if (x < r) {
-    const int z0 = z >> 1, y0 = y >> 1, x0 = x >> 1;
-    const int oz = z & 1, oy = y & 1, ox = x & 1;
-    float vx[2];
-    int n_in = 0, n_all = 0;
-#pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      float vy[2];
-#pragma unroll
-      for (int dy = 0; dy < 2; ++dy) {
-        const int xx = min(x0 + dx, rp - 1), yy = min(y0 + dy, rp - 1);
-        const float a = prev[((long long)z0 * rp + yy) * rp + xx];
-        const float b = prev[((long long)min(z0 + 1, rp - 1) * rp + yy) * rp + xx];
-        vy[dy] = oz ? 0.5f * a + 0.5f * b : a;
-        if (dx <= ox && dy <= oy) {  // corners with non-zero trilinear weight
-          n_all += 1 + oz;
-          n_in += (a > balance) + (oz ? (b > balance) : 0);
-        }
-      }
-      vx[dx] = oy ? 0.5f * vy[0] + 0.5f * vy[1] : vy[0];
-    }
-    const float v = ox ? 0.5f * vx[0] + 0.5f * vx[1] : vx[0];
-    cur[((long long)z * r + y) * r + x] = v;
-    flag = n_in > 0 && n_in < n_all;  // 0 < upsampled mask < 1
-  }
-  const u64 bits = __ballot(flag);
-  if (lane == 0) bnd[item] = bits;
-}
-
-// ---- dilate, drop evaluated nodes, compact ----------------------------------------------------
+// One lane per PARENT node (z0, y0, x0): it loads the 2x2x2 parent cell once and emits the up to
+// eight fine nodes (2 z0 + oz, 2 y0 + oy, 2 x0 + ox) that interpolate inside it -- 8 loads per 8
+// outputs instead of 8 per output (the kernel was VALU-bound on address arithmetic).  Interpolation
+// order z, then y, then x with weights 0.5/0.5 -- the exact sequence of oracle upsample2x (axis 0
+// first), so values agree bit for bit.  A wave covers 64 parents = 128 fine x positions = two
+// boundary words per fine row.  grid = (ceil(rp * ceil(rp/64) / 4), rp): blockIdx.y is z0.
 __device__ __forceinline__ u64 spread32(u64 x) {  // bit i -> bit 2i
   x &= 0xffffffffull;
   x = (x | (x << 16)) & 0x0000ffff0000ffffull;
@@ -129,18 +90,92 @@ __device__ __forceinline__ u64 spread32(u64 x) {  // bit i -> bit 2i
   return x;
 }
 
+__global__ __launch_bounds__(256) void upsample_classify_kernel(const float *__restrict__ prev,
+                                                                int rp, float *__restrict__ cur,
+                                                                int r, float balance,
+                                                                u64 *__restrict__ bnd, int w64) {
+  const int lane = threadIdx.x & 63;
+  const int wpx = (rp + 63) >> 6;  // waves per parent row
+  const unsigned plane_item = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (plane_item >= (unsigned)(rp * wpx)) return;
+  const int wx = plane_item % (unsigned)wpx;
+  const int y0 = plane_item / (unsigned)wpx;
+  const int z0 = blockIdx.y;
+  const int x0 = 64 * wx + lane;
+  const bool valid = x0 < rp;
+
+  float pv[2][2][2];  // [dz][dy][dx]
+  bool pin[2][2][2];
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int zz = min(z0 + dz, rp - 1), yy = min(y0 + dy, rp - 1), xx = min(x0 + dx, rp - 1);
+        const float v = valid ? prev[((long long)zz * rp + yy) * rp + xx] : 0.0f;
+        pv[dz][dy][dx] = v;
+        pin[dz][dy][dx] = v > balance;
+      }
+
+#pragma unroll
+  for (int oz = 0; oz < 2; ++oz) {
+    const int z = 2 * z0 + oz;
+    if (z >= r) continue;  // uniform: only the last parent plane has no odd child
+#pragma unroll
+    for (int oy = 0; oy < 2; ++oy) {
+      const int y = 2 * y0 + oy;
+      if (y >= r) continue;
+      float vx[2];
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float vy[2];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+          vy[dy] = oz ? 0.5f * pv[0][dy][dx] + 0.5f * pv[1][dy][dx] : pv[0][dy][dx];
+        vx[dx] = oy ? 0.5f * vy[0] + 0.5f * vy[1] : vy[0];
+      }
+      // corners with non-zero trilinear weight: dz <= oz, dy <= oy, dx <= ox
+      int in0 = 0, in1 = 0;  // inside-corner counts for ox = 0 / the extra ones of ox = 1
+#pragma unroll
+      for (int dz = 0; dz <= oz; ++dz)
+#pragma unroll
+        for (int dy = 0; dy <= oy; ++dy) {
+          in0 += pin[dz][dy][0];
+          in1 += pin[dz][dy][1];
+        }
+      const int all0 = (1 + oz) * (1 + oy);
+      const float v_even = vx[0];
+      const float v_odd = 0.5f * vx[0] + 0.5f * vx[1];
+      const bool has_odd = valid && 2 * x0 + 1 < r;
+      float *row = cur + ((long long)z * r + y) * r;
+      if (valid) row[2 * x0] = v_even;
+      if (has_odd) row[2 * x0 + 1] = v_odd;
+      const bool f_even = valid && in0 > 0 && in0 < all0;  // 0 < upsampled mask < 1
+      const bool f_odd = has_odd && (in0 + in1) > 0 && (in0 + in1) < 2 * all0;
+      const u64 be = __ballot(f_even), bo = __ballot(f_odd);
+      if (lane == 0) {
+        u64 *words = bnd + ((long long)z * r + y) * w64 + 2 * wx;
+        words[0] = spread32(be) | (spread32(bo) << 1);
+        if (2 * wx + 1 < w64) words[1] = spread32(be >> 32) | (spread32(bo >> 32) << 1);
+      }
+    }
+  }
+}
+
+// ---- dilate, drop evaluated nodes, compact ----------------------------------------------------
 __global__ __launch_bounds__(256) void select_compact_kernel(
     const u64 *__restrict__ bnd, const u64 *__restrict__ ev_prev, int rp, int w64p,
     u64 *__restrict__ ev, int r, int w64, int d, uint32_t *__restrict__ packed,
     int32_t *__restrict__ count) {
-  const long long n_items = (long long)r * r * w64;
-  const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned n_items = (unsigned)(r * r * w64);  // <= 1023 * 1023 * 16
+  const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
   u64 sel = 0;
   int w = 0, y = 0, z = 0;
   if (item < n_items) {
-    w = item % w64;
-    y = (item / w64) % r;
-    z = item / ((long long)w64 * r);
+    w = item % (unsigned)w64;
+    y = (item / (unsigned)w64) % (unsigned)r;
+    z = item / (unsigned)(w64 * r);
     u64 acc = 0;
     for (int dz = -d; dz <= d; ++dz) {
       const int zz = z + dz;
@@ -229,7 +264,8 @@ int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int
   } else {
     MP_HIP(ctx, hipMemsetAsync(count, 0, sizeof(int32_t), st));
     const long long items = (long long)r * r * w64;
-    hipLaunchKernelGGL(upsample_classify_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
+    hipLaunchKernelGGL(upsample_classify_kernel,
+                       dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp), dim3(256), 0,
                        st, prev, rp, cur, r, balance, bnd, w64);
     const int d = level == 1 ? 4 : (level == 2 ? 3 : 1);
     hipLaunchKernelGGL(select_compact_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
@@ -334,8 +370,9 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
     const long long items = (long long)r * r * w64;
     const int d = l == 1 ? 4 : (l == 2 ? 3 : 1);  // 9^3, 7^3, 3^3 boxes ("faster" mode)
     for (int f = 0; f < n_frames; ++f) {
-      hipLaunchKernelGGL(upsample_classify_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
-                         st, lv[f][l - 1].occ, rp, lv[f][l].occ, r, balance, lv[f][l].bnd, w64);
+      hipLaunchKernelGGL(upsample_classify_kernel,
+                         dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp), dim3(256),
+                         0, st, lv[f][l - 1].occ, rp, lv[f][l].occ, r, balance, lv[f][l].bnd, w64);
       hipLaunchKernelGGL(select_compact_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
                          st, lv[f][l].bnd, lv[f][l - 1].ev, rp, words64(rp), lv[f][l].ev, r, w64, d,
                          packed[f], status[f] + 1 + l);
