@@ -81,23 +81,25 @@ class FrameSlot:
 
     @torch.no_grad()
     def _encode(self):
-        feat = self.net.image_filter(self.image, last_only=True)[-1][0]  # [B,256,128,128]
+        """Both encoders on the slot's image buffers: (featG [B,256,128,128], featC or None)."""
+        feat = self.net.image_filter(self.image, last_only=True)[-1][0]
         if self.feature_hook is not None:
             self.feature_hook(feat)
-        return feat
+        feat_c = None
+        if self.netC is not None:
+            feat_c = self.netC.image_filter(self.image_c)[-1][0]  # [B,256,128,128]
+        return feat, feat_c
 
     @torch.no_grad()
     def _chain(self):
         mlp = self.net.surface_classifier.packed()
         if self.graph is not None:
-            self.graph.replay()  # the whole batched encoder as one hipGraph launch
-            feat = self._graph_feat
+            self.graph.replay()  # the batched encoder(s) as one hipGraph launch
+            feat, feat_c = self._graph_feat
         else:
-            feat = self._encode()
-        feat_c = None
+            feat, feat_c = self._encode()
         if self.netC is not None:
             mlp_c = self.netC.surface_classifier.packed()
-            feat_c = self.netC.image_filter(self.image_c)[-1][0]  # [B,256,128,128]
         r = self.res[-1]
         n = self.n_active
         for b in range(n):
