@@ -138,7 +138,9 @@ class FrameSlot:
         self.stream.synchronize()
         if self.use_graph:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=self.stream):
+            # thread_local: RCCL's watchdog thread (multi-GPU runs) and the other slots' host
+            # threads may touch the HIP runtime while this thread captures
+            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
                 self._graph_feat = self._encode()
             self.stream.synchronize()
             self.graph = graph
