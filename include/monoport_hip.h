@@ -219,6 +219,12 @@ int mp_group_norm(mp_ctx *ctx, const float *x, int n, int c, int64_t hw, int gro
 int mp_upsample_bicubic2x(mp_ctx *ctx, const float *x, int c, int h, int w, const float *add,
                           float *y, mp_stream stream);
 
+/* y = cat((a, b, c), channel axis) + shortcut: the tail of the encoders' pyramid block
+ * (backbones/HGFilters.py:57-60: torch.cat((out1, out2, out3), 1) followed by `out3 += residual`)
+ * in one pass.  a [N,Ca,HW], b [N,Cb,HW], c [N,Cc,HW], shortcut and y [N,Ca+Cb+Cc,HW]; HW % 4 == 0. */
+int mp_concat3_add(mp_ctx *ctx, const float *a, int ca, const float *b, int cb, const float *c,
+                   int cc, const float *shortcut, int n, int64_t hw, float *y, mp_stream stream);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Brackets every fused-query kernel launch made through this context with a pair of HIP events
  * recorded on the launch stream (bench.py's roofline leg).  mp_profile_end waits for the last

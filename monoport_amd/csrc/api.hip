@@ -590,6 +590,18 @@ int mp_upsample_bicubic2x(mp_ctx *ctx, const float *x, int c, int h, int w, cons
   return launch_upsample_bicubic2x(ctx, x, c, h, w, add, y, (hipStream_t)stream);
 }
 
+int mp_concat3_add(mp_ctx *ctx, const float *a, int ca, const float *b, int cb, const float *c,
+                   int cc, const float *shortcut, int n, int64_t hw, float *y, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!a || !b || !c || !shortcut || !y || ca <= 0 || cb <= 0 || cc <= 0 || n <= 0 || hw <= 0)
+    return fail(ctx, MP_ERR_ARG, "mp_concat3_add: bad argument");
+  if (hw % 4 || !aligned16(a) || !aligned16(b) || !aligned16(c) || !aligned16(shortcut) || !aligned16(y))
+    return fail(ctx, MP_ERR_UNSUPPORTED, "mp_concat3_add: needs HW %% 4 == 0 and 16-byte aligned buffers");
+  DeviceGuard g(ctx->device);
+  return launch_concat3_add(ctx, a, ca, b, cb, c, cc, shortcut, n, hw, y, (hipStream_t)stream);
+}
+
 int mp_profile_begin(mp_ctx *ctx, int max_records) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);

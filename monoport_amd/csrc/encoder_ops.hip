@@ -172,6 +172,46 @@ int launch_upsample_bicubic2x(mp_ctx *ctx, const float *x, int c, int h, int w, 
   return MP_OK;
 }
 
+// ---- concat + residual add (HGFilters.py:57-60) --------------------------------------------------
+// torch runs cat (read 1x, write 1x) and add (read 2x, write 1x); here 2x read + 1x write.
+__global__ __launch_bounds__(256) void concat3_add_kernel(const float *__restrict__ a, int ca,
+                                                          const float *__restrict__ b, int cb,
+                                                          const float *__restrict__ c, int cc,
+                                                          const float *__restrict__ sc, long long hw4,
+                                                          long long total4, float *__restrict__ y) {
+  const int ct = ca + cb + cc;
+  const f32x4 *a4 = reinterpret_cast<const f32x4 *>(a), *b4 = reinterpret_cast<const f32x4 *>(b),
+              *c4 = reinterpret_cast<const f32x4 *>(c), *s4 = reinterpret_cast<const f32x4 *>(sc);
+  f32x4 *y4 = reinterpret_cast<f32x4 *>(y);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long plane = i / hw4, off = i - plane * hw4;  // plane = image * ct + channel
+    const long long img = plane / ct;
+    const int ch = (int)(plane - img * ct);
+    f32x4 v;
+    if (ch < ca) v = a4[(img * ca + ch) * hw4 + off];
+    else if (ch < ca + cb) v = b4[(img * cb + (ch - ca)) * hw4 + off];
+    else v = c4[(img * cc + (ch - ca - cb)) * hw4 + off];
+    const f32x4 r = s4[i];
+    v[0] += r[0];
+    v[1] += r[1];
+    v[2] += r[2];
+    v[3] += r[3];
+    y4[i] = v;
+  }
+}
+
+int launch_concat3_add(mp_ctx *ctx, const float *a, int ca, const float *b, int cb, const float *c,
+                       int cc, const float *sc, int n, long long hw, float *y, hipStream_t st) {
+  const long long total4 = (long long)n * (ca + cb + cc) * (hw / 4);
+  long long blocks = (total4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(concat3_add_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, ca, b, cb, c,
+                     cc, sc, hw / 4, total4, y);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
 // ---- input pre-step (RTL/main.py:352-364) ------------------------------------------------------
 // One pass over the segmentation output instead of seven elementwise torch kernels; the operation
 // order of the reference expression is kept (file is built with -ffp-contract=off).

@@ -150,6 +150,8 @@ int launch_absmax(mp_ctx *ctx, const float *src, long long n, unsigned int *out_
 // query16.hip
 int launch_query16(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
                    long long max_points, bool device_counts, hipStream_t st);
+int launch_concat3_add(mp_ctx *ctx, const float *a, int ca, const float *b, int cb, const float *c,
+                       int cc, const float *sc, int n, long long hw, float *y, hipStream_t st);
 int launch_prepare_inputs(mp_ctx *ctx, const float *segm, long long hw, const float *mean,
                           const float *std, float *g, float *c, hipStream_t st);
 // octree.hip

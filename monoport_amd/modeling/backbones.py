@@ -91,6 +91,8 @@ class ConvBlock(nn.Module):
         b = self.conv2(self.bn2(a, relu=True))
         c = self.conv3(self.bn3(b, relu=True))
         shortcut = x if self.downsample is None else _run_sequential(self.downsample, x)
+        if not self.training and ops.concat3_add_supported(a, b, c, shortcut):
+            return ops.concat3_add(a, b, c, shortcut)  # one pass instead of cat + add
         return torch.cat((a, b, c), 1) + shortcut
 
 

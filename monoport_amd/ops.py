@@ -466,6 +466,25 @@ def upsample_bicubic2x(x, add=None):
     return y
 
 
+def concat3_add_supported(a, b, c, shortcut):
+    ts = (a, b, c, shortcut)
+    return (all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 for t in ts)
+            and (a.shape[2] * a.shape[3]) % 4 == 0
+            and a.shape[1] + b.shape[1] + c.shape[1] == shortcut.shape[1])
+
+
+def concat3_add(a, b, c, shortcut):
+    """torch.cat((a, b, c), 1) + shortcut in one pass (the tail of the encoders' ConvBlock)."""
+    a, b, c, shortcut = _f32c(a), _f32c(b), _f32c(c), _f32c(shortcut)
+    ctx = get_context(a.device)
+    n, ca, h, w = a.shape
+    y = torch.empty_like(shortcut)
+    ctx.check(ctx.lib.mp_concat3_add(ctx.handle, _ptr(a), ca, _ptr(b), b.shape[1], _ptr(c),
+                                     c.shape[1], _ptr(shortcut), n, h * w, _ptr(y), _stream(a)),
+              "mp_concat3_add")
+    return y
+
+
 def profile_begin(device, max_records=4096):
     """Start bracketing fused-query launches on ``device`` with HIP events (bench.py roofline)."""
     ctx = get_context(device)

@@ -144,6 +144,20 @@ def test_group_norm_and_bicubic_kernels_match_torch():
         assert (ops.upsample_bicubic2x(x, add=skip) - (skip + ref)).abs().max().item() <= 2e-5
 
 
+def test_concat3_add_bit_exact_vs_torch():
+    """The pyramid block's tail (HGFilters.py:57-60) fused: same bits as torch.cat + add."""
+    from monoport_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for n, (ca, cb, cc), hw in ((1, (128, 64, 64), (128, 128)), (3, (64, 32, 32), (8, 8)),
+                               (4, (128, 64, 64), (32, 32))):
+        a, b, c = (torch.randn((n, k) + hw, generator=g).to(DEV) for k in (ca, cb, cc))
+        sc = torch.randn((n, ca + cb + cc) + hw, generator=g).to(DEV)
+        assert ops.concat3_add_supported(a, b, c, sc)
+        assert torch.equal(ops.concat3_add(a, b, c, sc), torch.cat((a, b, c), 1) + sc)
+    odd = torch.randn((1, 4, 3, 3)).to(DEV)  # HW % 4 != 0 -> the modules fall back to torch ops
+    assert not ops.concat3_add_supported(odd, odd, odd, torch.cat((odd, odd, odd), 1))
+
+
 def test_processors_list_through_stage_pipeline():
     """The hot-path stages of RTL/main.py:326-452 as a processors=[...] list on the torch-2.x
     stage pipeline (thread + HIP stream per stage): results must equal sequential execution."""
