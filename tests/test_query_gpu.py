@@ -260,3 +260,26 @@ def test_fp16_modes_report_error(ops, oracle, name, precision, tol):
     err = np.abs(out - ref64).max()
     print("%s %s: |gpu - f64 oracle| max %.3g" % (name, precision, err))
     assert np.isfinite(out).all() and err <= tol
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15])
+def test_f16x3_no_noisier_than_f32_kernel_on_random_heads(ops, oracle, seed):
+    """Random-weight heads (gain 1-3), random features and cameras: against the fp64 oracle the
+    split-precision kernel's error stays within 1.5x of the exact-f32 kernel's own error."""
+    rs = np.random.RandomState(seed)
+    layers = syn.rand_mlp("G", seed, float(rs.uniform(1.0, 3.0)))
+    f = syn.rand_feat(256, 128, 128, seed)
+    p = syn.rand_points(3000, seed, 1.1)
+    calib = oracle.pifu_calib(*syn.scene_camera(int(rs.randint(0, 120))))
+    dev = "cuda:0"
+    mlp = ops.PackedMLP.from_layers(dev, layers, 1)
+    fh = ops.pack_features(torch.from_numpy(f)[None].to(dev))
+    pts = torch.from_numpy(p)[None].to(dev)
+    cal = torch.from_numpy(calib).to(dev)
+    out32 = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
+    mlp.set_precision("f16x3")
+    out16 = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
+    ref = oracle.query(f, p, calib[0], layers, 1, syn.Z_SCALE, precision="f64")
+    e32, e16 = np.abs(out32 - ref).max(), np.abs(out16 - ref).max()
+    print("seed %d: |f32 kernel - f64| %.3g, |f16x3 - f64| %.3g" % (seed, e32, e16))
+    assert e32 <= 1e-4 and e16 <= 1e-4 and e16 <= 1.5 * e32 + 1e-7
