@@ -164,9 +164,14 @@ __global__ __launch_bounds__(256) void upsample_classify_kernel(const float *__r
 }
 
 // ---- dilate, drop evaluated nodes, compact ----------------------------------------------------
+// D = half width of the dilation box (4 / 3 / 1 for the 9^3 / 7^3 / 3^3 boxes).  The (2D+1) rows of
+// one dz are loaded branch-free (out-of-range rows read row 0 and are masked) so the 3 (2D+1)
+// word loads are in flight together: on the small grids of levels 1-2 the kernel is a handful of
+// waves and purely latency-bound.
+template <int D>
 __global__ __launch_bounds__(256) void select_compact_kernel(
     const u64 *__restrict__ bnd, const u64 *__restrict__ ev_prev, int rp, int w64p,
-    u64 *__restrict__ ev, int r, int w64, int d, uint32_t *__restrict__ packed,
+    u64 *__restrict__ ev, int r, int w64, uint32_t *__restrict__ packed,
     int32_t *__restrict__ count) {
   const unsigned n_items = (unsigned)(r * r * w64);  // <= 1023 * 1023 * 16
   const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,20 +182,31 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
     y = (item / (unsigned)w64) % (unsigned)r;
     z = item / (unsigned)(w64 * r);
     u64 acc = 0;
-    for (int dz = -d; dz <= d; ++dz) {
+    for (int dz = -D; dz <= D; ++dz) {
       const int zz = z + dz;
       if (zz < 0 || zz >= r) continue;
-      for (int dy = -d; dy <= d; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= r) continue;
-        const u64 *row = bnd + ((long long)zz * r + yy) * w64;
-        const u64 c = row[w];
-        const u64 lo = w > 0 ? row[w - 1] : 0ull;
-        const u64 hi = w < w64 - 1 ? row[w + 1] : 0ull;
-        u64 hd = c;
-        for (int s = 1; s <= d; ++s) hd |= (c << s) | (lo >> (64 - s)) | (c >> s) | (hi << (64 - s));
-        acc |= hd;
+      u64 c[2 * D + 1], lo[2 * D + 1], hi[2 * D + 1];
+#pragma unroll
+      for (int k = 0; k < 2 * D + 1; ++k) {
+        const int yy = y + k - D;
+        const bool ok = yy >= 0 && yy < r;
+        const u64 *row = bnd + ((long long)zz * r + (ok ? yy : 0)) * w64;
+        const u64 m = ok ? ~0ull : 0ull;
+        c[k] = row[w] & m;
+        lo[k] = w > 0 ? row[w - 1] & m : 0ull;
+        hi[k] = w < w64 - 1 ? row[w + 1] & m : 0ull;
       }
+      u64 cc = 0, ll = 0, hh = 0;  // OR over the rows first: the x dilation is linear in OR
+#pragma unroll
+      for (int k = 0; k < 2 * D + 1; ++k) {
+        cc |= c[k];
+        ll |= lo[k];
+        hh |= hi[k];
+      }
+      u64 hd = cc;
+#pragma unroll
+      for (int s = 1; s <= D; ++s) hd |= (cc << s) | (ll >> (64 - s)) | (cc >> s) | (hh << (64 - s));
+      acc |= hd;
     }
     // nodes already evaluated: even (z, y, x) that were evaluated one level up
     u64 done = 0;
@@ -223,6 +239,21 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
     sel &= sel - 1;
     packed[pos++] = (uint32_t)(64 * w + b) | yz;
   }
+}
+
+// 9^3, 7^3, 3^3 boxes at levels 1, 2, 3+ (the upstream engine's "faster" schedule)
+static void launch_select(int level, unsigned blocks, hipStream_t st, const u64 *bnd,
+                          const u64 *ev_prev, int rp, int w64p, u64 *ev, int r, int w64,
+                          uint32_t *packed, int32_t *count) {
+  if (level == 1)
+    hipLaunchKernelGGL(select_compact_kernel<4>, dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp,
+                       w64p, ev, r, w64, packed, count);
+  else if (level == 2)
+    hipLaunchKernelGGL(select_compact_kernel<3>, dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp,
+                       w64p, ev, r, w64, packed, count);
+  else
+    hipLaunchKernelGGL(select_compact_kernel<1>, dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp,
+                       w64p, ev, r, w64, packed, count);
 }
 
 // ---- level-at-a-time entry points (generic query_func) -------------------------------------------
@@ -267,9 +298,8 @@ int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int
     hipLaunchKernelGGL(upsample_classify_kernel,
                        dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp), dim3(256), 0,
                        st, prev, rp, cur, r, balance, bnd, w64);
-    const int d = level == 1 ? 4 : (level == 2 ? 3 : 1);
-    hipLaunchKernelGGL(select_compact_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
-                       st, bnd, ev_prev, rp, words64(rp), ev_cur, r, w64, d, packed, count);
+    launch_select(level, (unsigned)((items + 255) / 256), st, bnd, ev_prev, rp, words64(rp), ev_cur, r,
+                  w64, packed, count);
   }
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
@@ -368,14 +398,12 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
   for (int l = 1; l < n_levels; ++l) {
     const int r = res[l], rp = res[l - 1], w64 = words64(r);
     const long long items = (long long)r * r * w64;
-    const int d = l == 1 ? 4 : (l == 2 ? 3 : 1);  // 9^3, 7^3, 3^3 boxes ("faster" mode)
     for (int f = 0; f < n_frames; ++f) {
       hipLaunchKernelGGL(upsample_classify_kernel,
                          dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp), dim3(256),
                          0, st, lv[f][l - 1].occ, rp, lv[f][l].occ, r, balance, lv[f][l].bnd, w64);
-      hipLaunchKernelGGL(select_compact_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
-                         st, lv[f][l].bnd, lv[f][l - 1].ev, rp, words64(rp), lv[f][l].ev, r, w64, d,
-                         packed[f], status[f] + 1 + l);
+      launch_select(l, (unsigned)((items + 255) / 256), st, lv[f][l].bnd, lv[f][l - 1].ev, rp,
+                    words64(rp), lv[f][l].ev, r, w64, packed[f], status[f] + 1 + l);
       QueryItem &q = set.it[f];
       q.out = lv[f][l].occ;
       q.src.stride = (rf - 1) / (r - 1);
