@@ -63,3 +63,33 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
                 assert "pifu_oracle" not in text or f.endswith((".hip", ".h")) or \
                     not re.search(r"import.*pifu_oracle", text), f
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path, lib):
+    """The boundary is a C ABI: include/monoport_hip.h compiles as C11 (no C++-isms, no torch
+    types) and a C program links against the shared library and reads the version / an error
+    string through it -- the binding any other host language would make."""
+    import shutil
+    import subprocess
+    from monoport_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "c_client.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "monoport_hip.h"\n'
+        "int main(void) {\n"
+        "  mp_ctx *ctx = NULL;\n"
+        "  int v = mp_version();\n"
+        "  int rc = mp_query(NULL, 0, NULL, 0, 0, 0, NULL, 0, 0, 0, NULL, 0.0f, NULL, NULL);\n"
+        '  printf("%d %d %s\\n", v, rc, rc == MP_ERR_ARG ? "arg" : "other");\n'
+        "  mp_destroy(ctx);\n"
+        "  return 0;\n}\n")
+    exe = tmp_path / "c_client"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run([gcc, "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe), "-L", libdir, "-lmonoport_hip",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+                    "-Wl,--allow-shlib-undefined"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == lib.mp_version() and out[2] == "arg"
