@@ -317,3 +317,31 @@ def test_recon_batch_rejects_too_many_frames(ops, body):
     with pytest.raises(MonoportError):
         ops.recon_batch(body["mlp"], [body["fh"]] * 9, [body["cal"]] * 9, syn.Z_SCALE, BMIN, BMAX,
                         [9, 17])
+
+
+@pytest.mark.parametrize("res", [[17, 33, 65, 129, 257], [17, 33, 65, 129, 257, 513]])
+def test_octree_lossless_against_full_dense_evaluation(ops, body, res):
+    """The defining property of the engine at BASELINE sizes, checked on EVERY node: the thresholded
+    coarse-to-fine volume equals the thresholded dense evaluation of all R^3 lattice points
+    (17 M / 135 M fused queries -- 0.3 s / 2.5 s on the GPU).  Measured: 1-4 differing nodes of
+    17 M at 257^3, 12-17 of 135 M at 513^3 (isolated nodes whose trilinear estimate sits on the
+    other side of 0.5); the bar is IoU >= 0.99999."""
+    r = res[-1]
+    vol, status = ops.recon(body["mlp"], body["fh"], body["cal"], syn.Z_SCALE, BMIN, BMAX, res)
+    c = (torch.arange(r, device=DEV, dtype=torch.float32) + 0.5) / r * 2 - 1
+    inter = union = exact = evaluated = 0
+    for z0 in range(0, r, 16):
+        z1 = min(z0 + 16, r)
+        zz, yy, xx = torch.meshgrid(c[z0:z1], c, c, indexing="ij")
+        pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)])[None].contiguous()
+        dense = ops.query(body["mlp"], body["fh"], pts, body["cal"], syn.Z_SCALE)[0, 0]
+        dense = dense.reshape(z1 - z0, r, r)
+        a, b = dense > 0.5, vol[z0:z1] > 0.5
+        inter += int((a & b).sum().item())
+        union += int((a | b).sum().item())
+        exact += int((dense == vol[z0:z1]).sum().item())
+    n_queried = int(status[1:].sum().item())
+    print("R=%d: IoU %.7f (%d differing nodes), %d nodes carry the exact network value, %d queried"
+          % (r, inter / union, union - inter, exact, n_queried))
+    assert inter / union >= 0.99999
+    assert exact >= n_queried  # every queried node holds its exact value (plus coincidences)
