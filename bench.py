@@ -67,8 +67,9 @@ def build_netc(device):
 
 def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, precision="f32",
                   batch=1):
-    """`depth` frames in flight, each the stage chain of RTL/main.py:366-428 (geometry only)
-    captured in a hipGraph on its own stream (monoport_amd/pipeline.py)."""
+    """`depth` slots of `batch` frames each (monoport_amd/pipeline.py): per slot the batched
+    encoder (a hipGraph unless --no-graph), then the stage chain of RTL/main.py:389-428 as
+    asynchronous C-ABI calls on the slot's stream."""
     net, _ = build_netg(device, precision)
     planes = torch.from_numpy(syn.body_feature_planes(128, 128)).to(device)
 
