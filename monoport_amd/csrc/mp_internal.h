@@ -7,6 +7,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/monoport_hip.h"
@@ -111,6 +112,8 @@ struct mp_ctx {
     size_t bytes = 0;
   };
   std::unordered_map<void *, Arena> arenas;
+  // kernels whose dynamic-LDS limit has been raised on this context's device (guarded by mu)
+  std::unordered_set<const void *> lds_attr_done;
   // optional event bracketing of query launches (mp_profile_begin / mp_profile_end)
   std::vector<hipEvent_t> prof_events;  // start/stop pairs
   int prof_used = 0;                    // pairs recorded

@@ -573,11 +573,10 @@ static int launch_query_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h,
                           hipStream_t st) {
   constexpr int lds = kTilePts * C * 4 + kHbBytes;
   auto kern = pifu_query_kernel<C, COUT, WPS, DIRECT>;
-  static bool attr_set[16] = {};
-  if (!attr_set[ctx->device & 15]) {
-    MP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set[ctx->device & 15] = true;
+  const void *kern_id = reinterpret_cast<const void *>(kern);
+  if (!ctx->lds_attr_done.count(kern_id)) {  // once per kernel and context (= device)
+    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    ctx->lds_attr_done.insert(kern_id);
   }
   if (max_points <= 0) return MP_OK;
   // every frame of the set rounds its own tail tile up

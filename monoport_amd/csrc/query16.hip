@@ -554,11 +554,10 @@ static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int 
                             float z_scale, long long max_points, bool device_counts,
                             hipStream_t st) {
   auto kern = pifu_query16_kernel<COUT, TERMS>;
-  static bool attr_set[16] = {};
-  if (!attr_set[ctx->device & 15]) {
-    MP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLds16));
-    attr_set[ctx->device & 15] = true;
+  const void *kern_id = reinterpret_cast<const void *>(kern);
+  if (!ctx->lds_attr_done.count(kern_id)) {  // once per kernel and context (= device)
+    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, kLds16));
+    ctx->lds_attr_done.insert(kern_id);
   }
   if (max_points <= 0) return MP_OK;
   const long long tiles = (max_points + kP16 - 1) / kP16 + (set.n - 1);
