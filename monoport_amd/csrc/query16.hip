@@ -37,11 +37,12 @@ namespace mp {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
-constexpr int kP16 = 128;        // points per workgroup tile
 constexpr int kThreads16 = 256;  // 4 waves = one per SIMD, each with the full 512-register file
 constexpr int kXRow = 1024;      // bytes per point in xs: 32 hi slots | 32 lo slots (16 B each)
 constexpr int kHRow = 256;       // bytes per point in the hidden chunk: 8 hi slots | 8 lo slots
-constexpr int kLds16 = kP16 * kXRow + kP16 * kHRow;  // 163,840 B = all of a CU's LDS
+#ifndef MP16_NB
+#define MP16_NB 4  // tile shape the launcher instantiates (see pifu_query16_kernel)
+#endif
 
 struct AFrag {
   h8 hi, lo;
@@ -227,14 +228,22 @@ __device__ __forceinline__ void store_hidden16_part(unsigned char *hb, const f32
   }
 }
 
-template <int COUT, int TERMS>
-__global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
+// NB = 32-point column blocks per tile: 4 = the 128-point tile described above (one workgroup per
+// CU); 2 = a 64-point tile with half the LDS and half the accumulators per wave, two workgroups per
+// CU (the partner hides barriers and epilogues, at twice the weight bytes per point).  Measured
+// (1 M points, -DMP16_NB=2): f16x3 11.3 ms vs 7.4 ms, plain f16 4.4 vs 4.0 -- weight streaming wins,
+// the launcher instantiates NB = 4.
+template <int COUT, int TERMS, int NB>
+__global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kernel(
     MlpPack mlp32, MlpPack16 mlp, int fh, int fw, float z_scale, int act, QuerySet set) {
   constexpr int C = 256;
   constexpr int NGX = C / 16;  // k16 groups of the feature segment
+  constexpr int P = 32 * NB;   // points per tile
+  constexpr int NR0 = NB / 2;  // column blocks per wave in a layer-0 chunk
+  constexpr int PW = P / 4;    // points gathered per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *xs = smem;
-  unsigned char *hb = smem + kP16 * kXRow;
+  unsigned char *hb = smem + P * kXRow;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
         if (f < set.n) {
           const PointSrc &s = set.it[f].src;
           const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
-          const long long t = (nf + kP16 - 1) / kP16;
+          const long long t = (nf + P - 1) / P;
           if (fi < 0 && gtile < acc + t) {
             fi = f;
             tile0 = acc;
@@ -276,21 +285,21 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
     float *__restrict__ out = item.out;
     const PointSrc &src = item.src;
     const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
-    const long long n0 = (gtile - tile0) * kP16;
+    const long long n0 = (gtile - tile0) * P;
 
     // ---------------- gather: 32 points per wave, features split into halves ----------------
-    ZPair zc[4];  // z_feat of the four column blocks
+    ZPair zc[NB];  // z_feat of the column blocks
     {
       float cal[12];
 #pragma unroll
       for (int i = 0; i < 12; ++i) cal[i] = calib[i];
       constexpr int GB = 8;  // 32 independent 16-byte loads in flight per lane
 #pragma unroll 1
-      for (int i0 = 0; i0 < 32; i0 += GB) {
+      for (int i0 = 0; i0 < PW; i0 += GB) {
         Taps t[GB];
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
-          const long long n = n0 + 32 * wv + i0 + u;
+          const long long n = n0 + PW * wv + i0 + u;
           const bool live_n = n < n_pts;
           float px = 0, py = 0, pz = 0, x, y, z;
           uint32_t code;
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
             v[u][k] = *reinterpret_cast<const f32x4 *>(feat + t[u].o[k] + 4 * lane);
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
-          const int p = 32 * wv + i0 + u;
+          const int p = PW * wv + i0 + u;
           const f32x4 r = blend(v[u][0], v[u][1], v[u][2], v[u][3], t[u]);
           h4 hi, lo;
           split4(r, hi, lo);
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
         }
       }
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
+      for (int cb = 0; cb < NB; ++cb) {
         const long long n = n0 + 32 * cb + j;
         float px = 0, py = 0, pz = 0, x, y, z;
         uint32_t code;
@@ -340,57 +349,62 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
     const unsigned char *hrow = hb + j * kHRow;
 
     // ---------------- layers 0 + 1, fused over 64-row chunks of layer 0 ----------------
-    f32x16 acc1[4][4];  // layer-1 rows [128 wv, +128) x all 128 points: 256 accumulator registers
+    f32x16 acc1[4][NB];  // layer-1 rows [128 wv, +128) x all points: 256 accumulator registers at NB = 4
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       init_from_bias16(acc1[m][0], wbase + mlp32.bias[1] + 32 * (4 * wv + m), hh, mlp.scale[1]);
 #pragma unroll
-      for (int n = 1; n < 4; ++n) acc1[m][n] = acc1[m][0];
+      for (int n = 1; n < NB; ++n) acc1[m][n] = acc1[m][0];
     }
     {
       const h8 *a0 = hbase + mlp.ax[0] + lane;  // [rb][g][part][lane]
       const int rs1 = (kHidden[0] / 16) * 128;  // row-block stride of layer 1's hidden segment
       const h8 *a1 = hbase + mlp.ah[1] + (long long)(4 * wv) * rs1 + lane;
       const float inv0 = 1.0f / mlp.scale[0];
-      const ZPair z0[2] = {zc[2 * cp0], zc[2 * cp0 + 1]};
+      ZPair z0[NR0];
+#pragma unroll
+      for (int n = 0; n < NR0; ++n) z0[n] = zc[NR0 * cp0 + n];
       AFrag ring0[4][1];
-      f32x16 acc0[1][2];
+      f32x16 acc0[1][NR0];
       seg_prefetch16<1, 3, TERMS>(ring0, a0 + (long long)rb0 * NGX * 128, 0, NGX);
       init_from_bias16(acc0[0][0], wbase + mlp32.bias[0] + 32 * rb0, hh, mlp.scale[0]);
-      acc0[0][1] = acc0[0][0];
+#pragma unroll
+      for (int n = 1; n < NR0; ++n) acc0[0][n] = acc0[0][0];
 #pragma unroll 1
       for (int ck = 0; ck < kHidden[0] / 64; ++ck) {
-        // layer-0 rows [64 ck + 32 rb0, +32) x points [64 cp0, +64)
+        // layer-0 rows [64 ck + 32 rb0, +32) x column blocks [NR0 cp0, +NR0)
         const int rb = 2 * ck + rb0;
-        seg_main16<1, 2, 3, kXRow, 32, TERMS>(acc0, ring0, a0 + (long long)rb * NGX * 128, 0, NGX,
-                                       xrow + (2 * cp0) * 32 * kXRow, swz);
+        seg_main16<1, NR0, 3, kXRow, 32, TERMS>(acc0, ring0, a0 + (long long)rb * NGX * 128, 0, NGX,
+                                         xrow + (NR0 * cp0) * 32 * kXRow, swz);
         AFrag ring1[2][4];
         seg_prefetch16<4, 1, TERMS>(ring1, a1 + ck * 4 * 128, rs1, 4);
-        gemm_z16<1, 2, TERMS>(acc0, hbase + mlp.az[0] + rb * 128 + lane, z0);
-        finish16(acc0[0][0], inv0);
-        finish16(acc0[0][1], inv0);
-        store_hidden16(hb, acc0[0][0], rb0, 2 * cp0, j, hh);
-        store_hidden16(hb, acc0[0][1], rb0, 2 * cp0 + 1, j, hh);
+        gemm_z16<1, NR0, TERMS>(acc0, hbase + mlp.az[0] + rb * 128 + lane, z0);
+#pragma unroll
+        for (int n = 0; n < NR0; ++n) {
+          finish16(acc0[0][n], inv0);
+          store_hidden16(hb, acc0[0][n], rb0, NR0 * cp0 + n, j, hh);
+        }
         // next chunk's layer-0 operands stream in underneath the layer-1 MFMAs
         const int rbn = min(rb + 2, kHidden[0] / 32 - 2 + rb0);
         seg_prefetch16<1, 3, TERMS>(ring0, a0 + (long long)rbn * NGX * 128, 0, NGX);
         init_from_bias16(acc0[0][0], wbase + mlp32.bias[0] + 32 * rbn, hh, mlp.scale[0]);
-        acc0[0][1] = acc0[0][0];
+#pragma unroll
+        for (int n = 1; n < NR0; ++n) acc0[0][n] = acc0[0][0];
         __syncthreads();
-        seg_main16<4, 4, 1, kHRow, 8, TERMS>(acc1, ring1, a1 + ck * 4 * 128, rs1, 4, hrow, swz);
+        seg_main16<4, NB, 1, kHRow, 8, TERMS>(acc1, ring1, a1 + ck * 4 * 128, rs1, 4, hrow, swz);
         __syncthreads();
       }
       // skip segment + z column of layer 1
       const h8 *a1x = hbase + mlp.ax[1] + (long long)(4 * wv) * NGX * 128 + lane;
       AFrag ring1[2][4];
       seg_prefetch16<4, 1, TERMS>(ring1, a1x, NGX * 128, NGX);
-      seg_main16<4, 4, 1, kXRow, 32, TERMS>(acc1, ring1, a1x, NGX * 128, NGX, xrow, swz);
-      gemm_z16<4, 4, TERMS>(acc1, hbase + mlp.az[1] + (4 * wv) * 128 + lane, zc);
+      seg_main16<4, NB, 1, kXRow, 32, TERMS>(acc1, ring1, a1x, NGX * 128, NGX, xrow, swz);
+      gemm_z16<4, NB, TERMS>(acc1, hbase + mlp.az[1] + (4 * wv) * 128 + lane, zc);
       const float inv1 = 1.0f / mlp.scale[1];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) finish16(acc1[m][n], inv1);
+        for (int n = 0; n < NB; ++n) finish16(acc1[m][n], inv1);
     }
 
 #ifdef MP16_ABLATE
@@ -399,19 +413,19 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) sink += acc1[m][n][0];
+        for (int n = 0; n < NB; ++n) sink += acc1[m][n][0];
       if (sink == 12345.678f) out[0] = sink;
       __syncthreads();
       continue;
     }
 #endif
     // ---------------- layer 2: rows [64 wv, +64) x 128 points ----------------
-    f32x16 acc2[2][4];
+    f32x16 acc2[2][NB];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       init_from_bias16(acc2[m][0], wbase + mlp32.bias[2] + 32 * (2 * wv + m), hh, mlp.scale[2]);
 #pragma unroll
-      for (int n = 1; n < 4; ++n) acc2[m][n] = acc2[m][0];
+      for (int n = 1; n < NB; ++n) acc2[m][n] = acc2[m][0];
     }
     {
       const int rs2 = (kHidden[1] / 16) * 128;
@@ -421,21 +435,21 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
 #pragma unroll
       for (int ck = 0; ck < 8; ++ck) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) store_hidden16_part(hb, acc1[ck >> 1][n], ck & 1, wv, n, j, hh);
+        for (int n = 0; n < NB; ++n) store_hidden16_part(hb, acc1[ck >> 1][n], ck & 1, wv, n, j, hh);
         __syncthreads();
-        seg_main16<2, 4, 1, kHRow, 8, TERMS>(acc2, ring2, a2 + ck * 4 * 128, rs2, 4, hrow, swz);
+        seg_main16<2, NB, 1, kHRow, 8, TERMS>(acc2, ring2, a2 + ck * 4 * 128, rs2, 4, hrow, swz);
         if (ck < 7) seg_prefetch16<2, 1, TERMS>(ring2, a2 + (ck + 1) * 4 * 128, rs2, 4);
         __syncthreads();
       }
       const h8 *a2x = hbase + mlp.ax[2] + (long long)(2 * wv) * NGX * 128 + lane;
       seg_prefetch16<2, 1, TERMS>(ring2, a2x, NGX * 128, NGX);
-      seg_main16<2, 4, 1, kXRow, 32, TERMS>(acc2, ring2, a2x, NGX * 128, NGX, xrow, swz);
-      gemm_z16<2, 4, TERMS>(acc2, hbase + mlp.az[2] + (2 * wv) * 128 + lane, zc);
+      seg_main16<2, NB, 1, kXRow, 32, TERMS>(acc2, ring2, a2x, NGX * 128, NGX, xrow, swz);
+      gemm_z16<2, NB, TERMS>(acc2, hbase + mlp.az[2] + (2 * wv) * 128 + lane, zc);
       const float inv2 = 1.0f / mlp.scale[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) finish16(acc2[m][n], inv2);
+        for (int n = 0; n < NB; ++n) finish16(acc2[m][n], inv2);
     }
 
 #ifdef MP16_ABLATE
@@ -444,17 +458,17 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) sink += acc2[m][n][0];
+        for (int n = 0; n < NB; ++n) sink += acc2[m][n][0];
       if (sink == 12345.678f) out[0] = sink;
       __syncthreads();
       continue;
     }
 #endif
     // ---------------- layer 3: rows [32 wv, +32) x 128 points ----------------
-    f32x16 acc3[1][4];
+    f32x16 acc3[1][NB];
     init_from_bias16(acc3[0][0], wbase + mlp32.bias[3] + 32 * wv, hh, mlp.scale[3]);
 #pragma unroll
-    for (int n = 1; n < 4; ++n) acc3[0][n] = acc3[0][0];
+    for (int n = 1; n < NB; ++n) acc3[0][n] = acc3[0][0];
     {
       const h8 *a3 = hbase + mlp.ah[3] + (long long)wv * (kHidden[2] / 16) * 128 + lane;
       AFrag ring3[4][1];
@@ -462,52 +476,56 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
 #pragma unroll
       for (int ck = 0; ck < 4; ++ck) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) store_hidden16_part(hb, acc2[ck >> 1][n], ck & 1, wv, n, j, hh);
+        for (int n = 0; n < NB; ++n) store_hidden16_part(hb, acc2[ck >> 1][n], ck & 1, wv, n, j, hh);
         __syncthreads();
-        seg_main16<1, 4, 3, kHRow, 8, TERMS>(acc3, ring3, a3 + ck * 4 * 128, 0, 4, hrow, swz);
+        seg_main16<1, NB, 3, kHRow, 8, TERMS>(acc3, ring3, a3 + ck * 4 * 128, 0, 4, hrow, swz);
         if (ck < 3) seg_prefetch16<1, 3, TERMS>(ring3, a3 + (ck + 1) * 4 * 128, 0, 4);
         __syncthreads();
       }
       const h8 *a3x = hbase + mlp.ax[3] + (long long)wv * NGX * 128 + lane;
       seg_prefetch16<1, 3, TERMS>(ring3, a3x, 0, NGX);
-      seg_main16<1, 4, 3, kXRow, 32, TERMS>(acc3, ring3, a3x, 0, NGX, xrow, swz);
-      gemm_z16<1, 4, TERMS>(acc3, hbase + mlp.az[3] + wv * 128 + lane, zc);
+      seg_main16<1, NB, 3, kXRow, 32, TERMS>(acc3, ring3, a3x, 0, NGX, xrow, swz);
+      gemm_z16<1, NB, TERMS>(acc3, hbase + mlp.az[3] + wv * 128 + lane, zc);
       const float inv3 = 1.0f / mlp.scale[3];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) finish16(acc3[0][n], inv3);
+      for (int n = 0; n < NB; ++n) finish16(acc3[0][n], inv3);
     }
 
     // ---------------- layer 4 (Cout x (128 + C + 1)) on the VALU, f32 ----------------
-    // red[part][o][p]: parts 0-3 = hidden rows of wave `part`, parts 4-5 = feature half
+    // red[part][o][p]: parts 0-3 = hidden rows of wave `part`, parts 4.. = slices of the features
+    constexpr int FP = kThreads16 / P;  // feature slices (threads per point)
+    constexpr int SL = 32 / FP;         // 8-channel slots per slice
     float *red = reinterpret_cast<float *>(hb);
     constexpr int K4 = (kHidden[3] + C + 1 + 3) & ~3;  // padded row stride (pack.hip)
     {
 #pragma unroll
       for (int o = 0; o < COUT; ++o) {
         const float *w4 = wbase + mlp32.w4 + o * K4 + 32 * wv + 4 * hh;
-        float sv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float sv[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) sv[n] = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 wq = *reinterpret_cast<const f32x4 *>(w4 + 8 * q);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) sv[n] = fmaf(wq[i], acc3[0][n][4 * q + i], sv[n]);
+            for (int n = 0; n < NB; ++n) sv[n] = fmaf(wq[i], acc3[0][n][4 * q + i], sv[n]);
         }
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < NB; ++n) {
           sv[n] += __shfl_xor(sv[n], 32);
-          if (hh == 0) red[(wv * COUT + o) * kP16 + 32 * n + j] = sv[n];
+          if (hh == 0) red[(wv * COUT + o) * P + 32 * n + j] = sv[n];
         }
       }
-      // feature part: thread = (point, half of the channels); x = hi + lo
-      const int p = tid & (kP16 - 1), hf = tid >> 7;
+      // feature part: thread = (point, slice of the channels); x = hi + lo
+      const int p = tid & (P - 1), hf = tid / P;
       float sx[COUT];
 #pragma unroll
       for (int o = 0; o < COUT; ++o) sx[o] = 0.0f;
 #pragma unroll 2
-      for (int s = 0; s < 16; ++s) {
-        const int slot = 16 * hf + s;  // 8 channels per slot
+      for (int s = 0; s < SL; ++s) {
+        const int slot = SL * hf + s;  // 8 channels per slot
         const h8 xh = *reinterpret_cast<const h8 *>(xs + p * kXRow + ((slot ^ (p & 15)) << 4));
         const h8 xl = *reinterpret_cast<const h8 *>(xs + p * kXRow + (((32 + slot) ^ (p & 15)) << 4));
 #pragma unroll
@@ -518,16 +536,16 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
         }
       }
 #pragma unroll
-      for (int o = 0; o < COUT; ++o) red[((4 + hf) * COUT + o) * kP16 + p] = sx[o];
+      for (int o = 0; o < COUT; ++o) red[((4 + hf) * COUT + o) * P + p] = sx[o];
     }
     __syncthreads();
-    for (int idx = tid; idx < COUT * kP16; idx += kThreads16) {
-      const int o = idx / kP16, p = idx % kP16;
+    for (int idx = tid; idx < COUT * P; idx += kThreads16) {
+      const int o = idx / P, p = idx % P;
       const long long n = n0 + p;
       if (n < n_pts) {
         float v = (wbase + mlp32.bias[4])[o];
 #pragma unroll
-        for (int part = 0; part < 6; ++part) v += red[(part * COUT + o) * kP16 + p];
+        for (int part = 0; part < 4 + FP; ++part) v += red[(part * COUT + o) * P + p];
         float cal[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) cal[i] = calib[i];
@@ -549,24 +567,26 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_kernel(
   }
 }
 
-template <int COUT, int TERMS>
+template <int COUT, int TERMS, int NB>
 static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w,
                             float z_scale, long long max_points, bool device_counts,
                             hipStream_t st) {
-  auto kern = pifu_query16_kernel<COUT, TERMS>;
+  constexpr int P = 32 * NB;
+  constexpr int lds = P * (kXRow + kHRow);
+  auto kern = pifu_query16_kernel<COUT, TERMS, NB>;
   const void *kern_id = reinterpret_cast<const void *>(kern);
   if (!ctx->lds_attr_done.count(kern_id)) {  // once per kernel and context (= device)
-    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, kLds16));
+    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     ctx->lds_attr_done.insert(kern_id);
   }
   if (max_points <= 0) return MP_OK;
-  const long long tiles = (max_points + kP16 - 1) / kP16 + (set.n - 1);
-  const long long resident = ctx->n_cu;  // one 160 KB workgroup per CU
+  const long long tiles = (max_points + P - 1) / P + (set.n - 1);
+  const long long resident = (long long)ctx->n_cu * (NB == 4 ? 1 : 2);  // 160 KB / 80 KB of LDS each
   const long long grid = device_counts ? (tiles < resident ? tiles : resident)
                                        : (tiles < 8 * resident ? tiles : 8 * resident);
   const bool prof = 2 * (ctx->prof_used + 1) <= (int)ctx->prof_events.size();
   if (prof) MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], st));
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads16), kLds16, st, m.pack(), m.pack16(),
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads16), lds, st, m.pack(), m.pack16(),
                      h, w, z_scale, m.act, set);
   if (prof) {
     MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], st));
@@ -581,7 +601,7 @@ int launch_query16(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w,
   if (m.c != 256) return fail(ctx, MP_ERR_UNSUPPORTED, "f16x3 query kernel is built for C = 256");
 #define MP_Q16CASE(CO, PREC, TERMS)                                                         \
   if (m.cout == CO && m.precision == PREC)                                                 \
-    return launch_query16_t<CO, TERMS>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
+    return launch_query16_t<CO, TERMS, MP16_NB>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
   MP_Q16CASE(1, MP_PREC_F16X3, 3)
   MP_Q16CASE(3, MP_PREC_F16X3, 3)
   MP_Q16CASE(1, MP_PREC_F16W, 2)
