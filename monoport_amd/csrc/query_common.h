@@ -31,15 +31,21 @@ __device__ __forceinline__ void load_point(const PointSrc &s, long long n, float
   }
 }
 
-// geometry.py:27-29: trans + rot @ p, unfused like the CPU oracle.
+// geometry.py:27-29: trans + rot @ p through torch.baddbmm.  On the reference's CPU path that is an
+// MKL sgemm (any N >= 64): the K = 3 dot product is an FMA chain started by a plain product, the
+// translation is added last -- t + fma(r2, pz, fma(r1, py, r0 * px)).  Restated exactly (checked
+// bit for bit against torch.baddbmm in tests/test_oracle_golden.py::test_orthogonal_*), because the
+// in-image mask and the bilinear coordinates hang on the last bit of x and y.
+__device__ __forceinline__ float project_row(const float *__restrict__ r, float px, float py,
+                                             float pz) {
+  return __fadd_rn(r[3], fmaf(r[2], pz, fmaf(r[1], py, __fmul_rn(r[0], px))));
+}
+
 __device__ __forceinline__ void project(const float *__restrict__ cal, float px, float py,
                                         float pz, float &x, float &y, float &z) {
-  x = __fadd_rn(cal[3], __fadd_rn(__fadd_rn(__fmul_rn(cal[0], px), __fmul_rn(cal[1], py)),
-                                  __fmul_rn(cal[2], pz)));
-  y = __fadd_rn(cal[7], __fadd_rn(__fadd_rn(__fmul_rn(cal[4], px), __fmul_rn(cal[5], py)),
-                                  __fmul_rn(cal[6], pz)));
-  z = __fadd_rn(cal[11], __fadd_rn(__fadd_rn(__fmul_rn(cal[8], px), __fmul_rn(cal[9], py)),
-                                   __fmul_rn(cal[10], pz)));
+  x = project_row(cal, px, py, pz);
+  y = project_row(cal + 4, px, py, pz);
+  z = project_row(cal + 8, px, py, pz);
 }
 
 __device__ __forceinline__ bool in_image(float x, float y) {  // MonoPortNet.py:74
@@ -77,12 +83,15 @@ __device__ __forceinline__ Taps make_taps(float x, float y, int h, int w, int c,
   return t;
 }
 
+// torch's CPU grid_sample (vectorised bilinear kernel, built with FMA contraction) evaluates
+// fma(se, w_se, fma(sw, w_sw, fma(ne, w_ne, nw * w_nw))): restated exactly -- the sampled features
+// are bit-identical to the reference's (tests: index golden, array_equal).
 __device__ __forceinline__ f32x4 blend(const f32x4 &a, const f32x4 &b, const f32x4 &c,
                                        const f32x4 &d, const Taps &t) {
-  f32x4 r = a * t.w[0];
-  r += b * t.w[1];
-  r += c * t.w[2];
-  r += d * t.w[3];
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    r[i] = fmaf(d[i], t.w[3], fmaf(c[i], t.w[2], fmaf(b[i], t.w[1], __fmul_rn(a[i], t.w[0]))));
   return r;
 }
 

@@ -165,10 +165,10 @@ __global__ void vertex_points_kernel(const int64_t *__restrict__ x, const int64_
     const float vx = (float)x[i], vy = (float)y[i], vz = __fsub_rn((float)res, z[i]);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
+      // orthogonal() = torch.baddbmm: t + fma(r2, z, fma(r1, y, r0 * x)) (query_common.h: project)
       pts[k * cap + i] = __fadd_rn(
           mat.m[4 * k + 3],
-          __fadd_rn(__fadd_rn(__fmul_rn(mat.m[4 * k], vx), __fmul_rn(mat.m[4 * k + 1], vy)),
-                    __fmul_rn(mat.m[4 * k + 2], vz)));
+          fmaf(mat.m[4 * k + 2], vz, fmaf(mat.m[4 * k + 1], vy, __fmul_rn(mat.m[4 * k], vx))));
   }
 }
 

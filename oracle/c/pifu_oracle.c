@@ -15,17 +15,23 @@
 #include <omp.h>
 #endif
 
+/* Built with -ffp-contract=off: every fused multiply-add of the reference's CPU path is written
+ * as RFMA, everything else rounds after each operation (op-order parity with torch). */
 #define REAL float
 #define SUFFIX _f32
+#define RFMA(a, b, c) fmaf((a), (b), (c))
 #include "pifu_oracle_body.inc"
 #undef REAL
 #undef SUFFIX
+#undef RFMA
 
 #define REAL double
 #define SUFFIX _f64
+#define RFMA(a, b, c) fma((a), (b), (c))
 #include "pifu_oracle_body.inc"
 #undef REAL
 #undef SUFFIX
+#undef RFMA
 
 int orc_num_threads(void) {
 #ifdef _OPENMP

@@ -43,11 +43,12 @@ def load_mlp(net, layers):
 @torch.no_grad()
 def gen_query():
     import recon as ref_recon
+    from monoport.lib.modeling.geometry import orthogonal
     cases = {
         # name: (kind, mlp, feat, points, camera step)
-        "query_G_rand": ("G", ("rand", 11, 2.0), ("rand", 256, 21), (4096, 31, 1.2), 33),
-        "query_C_rand": ("C", ("rand", 12, 2.0), ("rand", 512, 22), (2048, 32, 1.2), 75),
-        "query_G_body": ("G", ("body", 13, 0.05), ("body", 256, 23), (4096, 33, 1.0), 12),
+        "query_G_rand": ("G", ("rand", 11, 2.0), ("rand", 256, 21), (49152, 31, 0.8), 33),
+        "query_C_rand": ("C", ("rand", 12, 2.0), ("rand", 512, 22), (40960, 32, 0.8), 75),
+        "query_G_body": ("G", ("body", 13, 0.05), ("body", 256, 23), (40960, 33, 0.7), 12),
     }
     for name, (kind, mlp, feat, pts, step) in cases.items():
         net = ref_net(kind)
@@ -65,7 +66,9 @@ def gen_query():
         np.savez_compressed(
             os.path.join(OUT, name + ".npz"), out=out, calib=calib.numpy(),
             meta=np.array([repr(dict(kind=kind, mlp=mlp, feat=feat, pts=pts, step=step))]))
-        print(name, out.shape, float(out.min()), float(out.max()),
+        xyz = orthogonal(torch.from_numpy(p)[None], calib)[0].numpy()
+        inside = (np.abs(xyz[0]) <= 1) & (np.abs(xyz[1]) <= 1)
+        print(name, out.shape, float(out.min()), float(out.max()), "in-image:", int(inside.sum()),
               "zeros:", int((out == 0).all(0).sum()))
 
 
@@ -212,9 +215,115 @@ def gen_pipeline():
     print("pipeline", stats, int(X.shape[0]), "verts; margin", float(np.abs(sdf - 0.5).min()))
 
 
+def dense_lattice(res):
+    """p = ((i + 0.5) / res) * 2 - 1 for i in [0, res)^3, ordered
+    [z, y, x] (x fastest) -> [3, res^3] f32."""
+    g = ((np.arange(res, dtype=np.float32) + np.float32(0.5)) / np.float32(res)) * np.float32(2) - np.float32(1)
+    zz, yy, xx = np.meshgrid(g, g, g, indexing="ij")
+    return np.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], 0).astype(np.float32)
+
+
+@torch.no_grad()
+def gen_dense64():
+    """BASELINE configs[0]: the dense 64^3 grid (262,144 points) through the REFERENCE netG.query
+    on the CPU, no octree.  Three cases: F-rand head on a seeded feature map, F-body head on the
+    body feature map (the HIP kernel sees bit-identical features: 1e-4 bar), and the F-rand head
+    on the output of the REFERENCE encoder netG.filter(image) (the GPU test runs OUR encoder on
+    the GPU: encoder-in-the-loop error, reported)."""
+    import time
+    import recon as ref_recon
+    res = 64
+    p = torch.from_numpy(dense_lattice(res))[None]
+    ext, intr = syn.scene_camera(30)
+    calib = ref_recon.pifu_calib(ext, intr, device="cpu")
+    store = {"calib": calib.numpy()}
+    times = {}
+    net = ref_net("G")
+    load_mlp(net, syn.rand_mlp("G", 91, 2.0))
+    f = syn.rand_feat(256, 128, 128, 92)
+    feats = [[torch.zeros(1, 256, 2, 2)]] * 3 + [[torch.from_numpy(f)[None]]]
+    t0 = time.perf_counter()
+    store["out_rand"] = net.query(feats, p, calibs=calib)[0][0, 0].numpy()
+    times["query_dense64_s"] = time.perf_counter() - t0
+    # encoder in the loop: seeded encoder weights (71), synthetic image 74, F-rand head
+    shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
+    sd = syn.seeded_state_dict(shapes, 71)
+    net.image_filter.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    img = torch.from_numpy(syn.synthetic_image(74))[None]
+    t0 = time.perf_counter()
+    feats_enc = net.filter(img)
+    times["filter_s"] = time.perf_counter() - t0
+    store["out_enc"] = net.query(feats_enc, p, calibs=calib)[0][0, 0].numpy()
+    store["enc_feat_slice"] = feats_enc[-1][0][0, ::8, ::8, ::8].numpy()
+    load_mlp(net, syn.body_mlp("G", noise=0.05, seed=93))
+    fb = syn.body_feat(256, 128, 128, 94)
+    feats = [[torch.zeros(1, 256, 2, 2)]] * 3 + [[torch.from_numpy(fb)[None]]]
+    store["out_body"] = net.query(feats, p, calibs=calib)[0][0, 0].numpy()
+    store["meta"] = np.array([
+        "lattice=dense_lattice(64) scene_camera(30); out_rand: rand_mlp(G,91,2.0) rand_feat(256,128,128,92); "
+        "out_body: body_mlp(G,.05,93) body_feat(256,128,128,94); out_enc: rand_mlp(G,91,2.0) on "
+        "reference netG.filter(synthetic_image(74)), encoder seeded_state_dict(.,71); "
+        "reference CPU times here (%d threads): %r" % (torch.get_num_threads(), times)])
+    np.savez_compressed(os.path.join(OUT, "dense64.npz"), **store)
+    for k in ("out_rand", "out_enc", "out_body"):
+        o = store[k]
+        print("dense64", k, o.shape, float(o.min()), float(o.max()), "zeros:", int((o == 0).sum()))
+    print("dense64 times", times)
+
+
+@torch.no_grad()
+def gen_pipeline257():
+    """BASELINE configs[1] size: one frame at 17..257 with the REFERENCE netG.query as query_func
+    (RTL/main.py:169-183) and the reference forward_vertices; the octree schedule is OUR
+    restatement (implicit_seg is not vendored).  Stored: the set of nodes the octree queried
+    (bit mask over the 257^3 lattice) with the reference's value at each of them in raster
+    order, per-level counts, and X / Y / Z / norm of the front view."""
+    import time
+    import recon as ref_recon
+    from oracle import pifu_oracle as orc
+    net = ref_net("G")
+    load_mlp(net, syn.body_mlp("G", noise=0.05, seed=95))
+    f = syn.body_feat(256, 128, 128, 96)
+    feats = [[torch.zeros(1, 256, 2, 2)]] * 3 + [[torch.from_numpy(f)[None]]]
+    # camera step 170: of 14 orbit positions tried it leaves the widest gap between a queried
+    # value and the 0.5 threshold (6e-6; fp32 evaluation noise is ~1e-6), so fp32 / fp64 / MFMA
+    # evaluations of the same field take identical octree decisions
+    ext, intr = syn.scene_camera(170)
+    calib = ref_recon.pifu_calib(ext, intr, device="cpu")
+    res = [17, 33, 65, 129, 257]
+    rf = res[-1]
+    queried = np.zeros((rf, rf, rf), bool)
+
+    def query_func(points):  # RTL/main.py:169-183 on [3,N] numpy
+        pt = torch.from_numpy(points.T.copy())[None]          # [1,N,3]
+        samples = pt.repeat(1, 1, 1).permute(0, 2, 1)        # [1,3,N]
+        return net.query(feats, points=samples, calibs=calib)[0][0, 0].numpy()
+
+    stats = []
+    t0 = time.perf_counter()
+    sdf = orc.seg3d_lossless(query_func, [-1, -1, -1], [1, 1, 1], res, stats=stats,
+                             evaluated_out=queried)
+    t1 = time.perf_counter()
+    X, Y, Z, norm = ref_recon.forward_vertices(torch.from_numpy(sdf)[None, None], "front")
+    t2 = time.perf_counter()
+    assert int(queried.sum()) == sum(stats)
+    vals = sdf[queried]
+    margin = float(np.abs(vals - 0.5).min())
+    np.savez_compressed(
+        os.path.join(OUT, "pipeline257.npz"), queried=np.packbits(queried.reshape(-1)),
+        values=vals.astype(np.float32), stats=np.array(stats), X=X.numpy().astype(np.int16),
+        Y=Y.numpy().astype(np.int16), Z=Z.numpy(), norm=norm.numpy(), calib=calib.numpy(),
+        meta=np.array(["mlp=body_mlp(G,.05,95) feat=body_feat(256,128,128,96) scene_camera(170) "
+                       "res=17..257; reference CPU times (%d threads): octree+query %.2fs, "
+                       "forward_vertices %.2fs" % (torch.get_num_threads(), t1 - t0, t2 - t1)]))
+    print("pipeline257", stats, sum(stats), int(X.shape[0]), "verts; margin", margin,
+          "octree+query %.2fs forward_vertices %.2fs" % (t1 - t0, t2 - t1))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["query", "misc", "vertices", "color", "encoders", "pipeline"]
+    which = sys.argv[1:] or ["query", "misc", "vertices", "color", "encoders", "pipeline",
+                             "dense64", "pipeline257"]
     if "query" in which:
         gen_query()
     if "misc" in which:
@@ -227,3 +336,7 @@ if __name__ == "__main__":
         gen_encoders()
     if "pipeline" in which:
         gen_pipeline()
+    if "dense64" in which:
+        gen_dense64()
+    if "pipeline257" in which:
+        gen_pipeline257()

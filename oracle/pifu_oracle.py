@@ -30,9 +30,9 @@ _lib = None
 
 def build(force=False):
     """Compile oracle/c/ with gcc (recipe: oracle/Makefile)."""
-    if force or not os.path.exists(_LIB_PATH):
-        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []),
-                              stdout=subprocess.DEVNULL)
+    # make decides about staleness (sources and the Makefile itself are prerequisites)
+    subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []),
+                          stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
@@ -44,6 +44,7 @@ def _load():
         for suf in ("_f32", "_f64"):
             getattr(_lib, "orc_query" + suf).restype = ctypes.c_int
             getattr(_lib, "orc_sample" + suf).restype = ctypes.c_int
+            getattr(_lib, "orc_orthogonal" + suf).restype = ctypes.c_int
         _lib.orc_num_threads.restype = ctypes.c_int
     return _lib
 
@@ -111,10 +112,22 @@ def query(feat, points, calib, layers, last_op, z_scale, precision="f64", thread
 # ------------------------------------------------------------------------------------------
 # small numpy restatements
 # ------------------------------------------------------------------------------------------
-def orthogonal(points, calib):
-    """trans + rot @ points  (monoport/lib/modeling/geometry.py:27-29); points [3,N]."""
-    calib = np.asarray(calib, np.float32)
-    return (calib[:3, 3:4] + calib[:3, :3] @ np.asarray(points, np.float32)).astype(np.float32)
+def orthogonal(points, calib, precision="f32"):
+    """trans + rot @ points  (monoport/lib/modeling/geometry.py:27-29); points [3,N].
+
+    fp32: the exact op sequence of torch.baddbmm on the reference's CPU path (MKL sgemm):
+    t + fma(r2, z, fma(r1, y, r0 * x)) -- bit-identical to the reference (golden test)."""
+    lib = _load()
+    points = np.ascontiguousarray(points, np.float32)
+    assert points.shape[0] == 3
+    n = points.shape[1]
+    calib12 = np.ascontiguousarray(np.asarray(calib, np.float32)[:3, :4]).reshape(12)
+    out = np.empty((3, n), np.float32)
+    rc = getattr(lib, "orc_orthogonal_" + precision)(_fptr(points), ctypes.c_int64(n),
+                                                     _fptr(calib12), _fptr(out))
+    if rc != 0:
+        raise RuntimeError("orc_orthogonal failed: %d" % rc)
+    return out
 
 
 def pifu_calib(extrinsic, intrinsic):
@@ -266,10 +279,12 @@ def dilation_for_level(level):
     return {1: 9, 2: 7}.get(level, 3)
 
 
-def seg3d_lossless(query_func, b_min, b_max, resolutions, balance_value=0.5, stats=None):
+def seg3d_lossless(query_func, b_min, b_max, resolutions, balance_value=0.5, stats=None,
+                   evaluated_out=None):
     """Coarse-to-fine occupancy volume [R,R,R] (z,y,x) f32, or None if level 0 is empty.
 
     ``query_func(points[3,N] f32) -> [N] f32``.  Requires resolutions[i+1] == 2*resolutions[i]-1.
+    ``evaluated_out`` (bool [R,R,R] of the final resolution) receives the set of queried nodes.
     """
     res = [int(r) for r in resolutions]
     for a, b in zip(res[:-1], res[1:]):
@@ -305,6 +320,8 @@ def seg3d_lossless(query_func, b_min, b_max, resolutions, balance_value=0.5, sta
                               np.float32)
             occ[idx[:, 0], idx[:, 1], idx[:, 2]] = vals
         evaluated = ev | sel
+    if evaluated_out is not None:
+        evaluated_out[...] = evaluated
     return occ
 
 
