@@ -16,7 +16,15 @@
  *   - a context may be used from any host thread; calls on ONE context are serialised by an
  *     internal mutex (RTL/dataloader.py:1026-1053 runs every pipeline stage on its own thread:
  *     give each stage its own context);
- *   - return value: MP_OK or a negative MP_ERR_*; mp_last_error(ctx) gives the message.
+ *   - return value: MP_OK or a negative MP_ERR_*; mp_last_error(ctx) gives the message of the
+ *     last failing call MADE BY THE CALLING HOST THREAD (per-thread storage, like errno), valid
+ *     until that thread's next failing call;
+ *   - calls that SYNCHRONISE: mp_mlp_set_precision (drains the stream of the last mp_mlp_load),
+ *     mp_mlp_destroy, mp_stream_release and mp_destroy (hipDeviceSynchronize), mp_profile_end
+ *     (waits for the recorded events).  Everything else only enqueues.
+ *   - scratch: one arena per (context, stream), grown by adding blocks -- a pointer handed to a
+ *     kernel stays valid until mp_stream_release / mp_destroy, so work captured in a hipGraph
+ *     keeps working after later, larger calls on the same stream.
  */
 #ifndef MONOPORT_HIP_H
 #define MONOPORT_HIP_H
@@ -62,12 +70,16 @@ int mp_version(void);
  * there is no CPU fallback. */
 int mp_create(int device, mp_ctx **out);
 void mp_destroy(mp_ctx *ctx);
-const char *mp_last_error(mp_ctx *ctx); /* ctx may be NULL: last error of mp_create */
+const char *mp_last_error(mp_ctx *ctx); /* calling thread's last error; ctx may be NULL */
+/* Frees the scratch arena the context keeps for `stream` (call when the stream is destroyed, e.g.
+ * by the owner of a pipeline slot; arenas are keyed by the stream handle).  Synchronises the
+ * device.  Unknown streams are fine (MP_OK). */
+int mp_stream_release(mp_ctx *ctx, mp_stream stream);
 
 /* ---- SurfaceClassifier weights ------------------------------------------------------------ */
 /* Replaces SurfaceClassifier.__init__ (heads/SurfaceClassifier.py:7-37) for the skip-concat
  * MLPs the reference instantiates: channels = {C+1,1024,512,256,128,Cout} with C in {256,512},
- * Cout in 1..4 (PIFuNetGMLP :74-79, PIFuNetCMLP :82-87).  Other shapes: MP_ERR_UNSUPPORTED. */
+ * Cout in {1,3} (PIFuNetGMLP :74-79, PIFuNetCMLP :82-87).  Other shapes: MP_ERR_UNSUPPORTED. */
 int mp_mlp_create(mp_ctx *ctx, int n_layers, const int *channels /*host, n_layers+1*/,
                   int last_op, int *mlp_out);
 /* Loads filters.{layer}.{weight,bias} (state-dict layout, weight [out,in(,1)] row-major with the
@@ -76,10 +88,12 @@ int mp_mlp_create(mp_ctx *ctx, int n_layers, const int *channels /*host, n_layer
  * (MonoPortNet.py:153-160). */
 int mp_mlp_load(mp_ctx *ctx, int mlp, int layer, const float *W, const float *b, int out_ch,
                 int in_ch, mp_stream stream);
-int mp_mlp_destroy(mp_ctx *ctx, int mlp);
+int mp_mlp_destroy(mp_ctx *ctx, int mlp); /* synchronises the device before freeing */
 /* Selects the arithmetic used by mp_query / mp_recon / mp_query_counted for this MLP.  Call after
- * every layer is loaded (MP_PREC_F16X3 reads max |W| of each layer back to the host to choose the
- * per-layer power-of-two operand scale: one small synchronous copy). */
+ * every layer is loaded.  The f16 variants re-pack the weights ON THE STREAM OF THE LAST
+ * mp_mlp_load (so the re-pack is ordered behind the loads), read max |W| of each layer back to
+ * the host to choose the per-layer power-of-two operand scale, and drain that stream before
+ * returning: SYNCHRONOUS, call it at set-up time. */
 int mp_mlp_set_precision(mp_ctx *ctx, int mlp, int precision);
 
 /* ---- feature-map layout ------------------------------------------------------------------ */
@@ -153,6 +167,21 @@ int mp_recon_batch(mp_ctx *ctx, int mlp, int n_frames, const float *const *feat_
 int mp_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
                      const uint64_t *ev_prev, uint64_t *ev_cur, uint64_t *bnd, int level,
                      float balance, uint32_t *packed, int32_t *count, mp_stream stream);
+/* mp_octree_select with an explicit dilation box (3, 7 or 9) instead of the faster-mode schedule
+ * 9 / 7 / 3 by level: the upstream engine's faster=False mode dilates by 3^3 at every level. */
+int mp_octree_select_box(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
+                         const uint64_t *ev_prev, uint64_t *ev_cur, uint64_t *bnd, int box,
+                         float balance, uint32_t *packed, int32_t *count, mp_stream stream);
+/* Conflict re-examination of the upstream engine's faster=False mode.  For each of the first
+ * *count nodes of `packed` (just evaluated: values[i]; volume [r^3] still holds the value
+ * INTERPOLATED from the coarser level at that node): if (interp - balance) * (value - balance) < 0
+ * every node of its 3x3x3 neighbourhood that is not yet in the evaluated bitset `ev` is claimed
+ * (bit set atomically) and appended to out_packed (capacity r^3; order unspecified); *out_count
+ * = their number.  Call mp_scatter_nodes for `packed` afterwards, then evaluate out_packed and
+ * repeat until *out_count is 0. */
+int mp_octree_conflicts(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, int64_t capacity,
+                        int r, const float *values, const float *volume, float balance,
+                        uint64_t *ev, uint32_t *out_packed, int32_t *out_count, mp_stream stream);
 int mp_lattice_points(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, int64_t capacity,
                       int stride, int res_final, const float *b_min /*host[3]*/,
                       const float *b_max /*host[3]*/, float *points, mp_stream stream);

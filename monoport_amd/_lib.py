@@ -23,6 +23,7 @@ SIGNATURES = {
     "mp_create": (c_int, [c_int, ctypes.POINTER(c_vp)]),
     "mp_destroy": (None, [c_vp]),
     "mp_last_error": (ctypes.c_char_p, [c_vp]),
+    "mp_stream_release": (c_int, [c_vp, c_vp]),
     "mp_mlp_create": (c_int, [c_vp, c_int, _pint, c_int, _pint]),
     "mp_mlp_load": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
     "mp_mlp_destroy": (c_int, [c_vp, c_int]),
@@ -43,6 +44,10 @@ SIGNATURES = {
     "mp_prepare_inputs": (c_int, [c_vp, c_vp, c_i64, _pf32, _pf32, c_vp, c_vp, c_vp]),
     "mp_octree_select": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_f32, c_vp,
                                  c_vp, c_vp]),
+    "mp_octree_select_box": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_f32, c_vp,
+                                     c_vp, c_vp]),
+    "mp_octree_conflicts": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp,
+                                    c_vp]),
     "mp_lattice_points": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, _pf32, _pf32, c_vp, c_vp]),
     "mp_scatter_nodes": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "mp_forward_vertices": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

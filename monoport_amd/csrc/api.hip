@@ -7,34 +7,38 @@
 
 namespace mp {
 
-static thread_local std::string g_create_error;
+// The last error message is kept PER HOST THREAD (like errno): the stage threads of a pipeline
+// share one context, and a message must not be overwritten -- or its storage reallocated --
+// between a failing call and the caller's mp_last_error on the same thread.
+static thread_local std::string g_last_error;
 
 int fail(mp_ctx *ctx, int code, const char *fmt, ...) {
+  (void)ctx;
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  if (ctx)
-    ctx->err = buf;
-  else
-    g_create_error = buf;
+  g_last_error = buf;
   return code;
 }
 
+// Scratch grows by ADDING a block: the previous block stays allocated until mp_stream_release /
+// mp_destroy, because a hipGraph captured on this stream (the encoder graph of a pipeline slot
+// bakes mp_group_norm's scratch pointer) or work still queued on it may reference it.  Sizes are
+// rounded up geometrically so a stream retires at most a handful of blocks.
 int ensure_scratch(mp_ctx *ctx, hipStream_t st, size_t bytes, void **out) {
   mp_ctx::Arena &a = ctx->arenas[(void *)st];
   if (bytes > a.bytes) {
-    if (a.ptr) {
-      // the old arena may still be read by work queued on this stream
-      MP_HIP(ctx, hipStreamSynchronize(st));
-      MP_HIP(ctx, hipFree(a.ptr));
-    }
-    a.ptr = nullptr;
-    a.bytes = 0;
-    if (hipMalloc(&a.ptr, bytes) != hipSuccess)
-      return fail(ctx, MP_ERR_NOMEM, "scratch arena: hipMalloc(%zu) failed", bytes);
-    a.bytes = bytes;
+    size_t want = a.bytes + a.bytes / 2;
+    if (want < bytes) want = bytes;
+    want = (want + 0xFFFF) & ~size_t(0xFFFF);
+    void *p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess && (want == bytes || hipMalloc(&p, want = bytes) != hipSuccess))
+      return fail(ctx, MP_ERR_NOMEM, "scratch arena: hipMalloc(%zu) failed", want);
+    if (a.ptr) a.retired.push_back(a.ptr);
+    a.ptr = p;
+    a.bytes = want;
   }
   *out = a.ptr;
   return MP_OK;
@@ -130,13 +134,32 @@ void mp_destroy(mp_ctx *ctx) {
       if (m.raw) (void)hipFree(m.raw);
     }
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
-    for (auto &kv : ctx->arenas)
+    for (auto &kv : ctx->arenas) {
       if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+      for (void *p : kv.second.retired) (void)hipFree(p);
+    }
   }
   delete ctx;
 }
 
-const char *mp_last_error(mp_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *mp_last_error(mp_ctx *ctx) {
+  (void)ctx;
+  return g_last_error.c_str();
+}
+
+int mp_stream_release(mp_ctx *ctx, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  auto it = ctx->arenas.find((void *)stream);
+  if (it == ctx->arenas.end()) return MP_OK;
+  DeviceGuard g(ctx->device);
+  // the stream may already be destroyed (that is when this is called): drain the device instead
+  MP_HIP(ctx, hipDeviceSynchronize());
+  if (it->second.ptr) MP_HIP(ctx, hipFree(it->second.ptr));
+  for (void *p : it->second.retired) MP_HIP(ctx, hipFree(p));
+  ctx->arenas.erase(it);
+  return MP_OK;
+}
 
 int mp_mlp_create(mp_ctx *ctx, int n_layers, const int *channels, int last_op, int *mlp_out) {
   if (!ctx) return MP_ERR_ARG;
@@ -183,8 +206,10 @@ int mp_mlp_create(mp_ctx *ctx, int n_layers, const int *channels, int last_op, i
     m.off_raw[l] = roff;
     roff += (size_t)kHidden[l] * ((l == 0 ? 0 : kHidden[l - 1]) + c + 1);
   }
-  if (hipMalloc(reinterpret_cast<void **>(&m.raw), roff * sizeof(float)) != hipSuccess)
+  if (hipMalloc(reinterpret_cast<void **>(&m.raw), roff * sizeof(float)) != hipSuccess) {
+    (void)hipFree(m.buf);
     return fail(ctx, MP_ERR_NOMEM, "mp_mlp_create: hipMalloc of %zu floats failed", roff);
+  }
   int id = -1;
   for (size_t i = 0; i < ctx->mlps.size(); ++i)
     if (!ctx->mlps[i].used) id = (int)i;
@@ -215,7 +240,10 @@ int mp_mlp_load(mp_ctx *ctx, int mlp, int layer, const float *W, const float *b,
   if (rc == MP_OK && layer < 4)
     rc = launch_copy(ctx, W, m->raw + m->off_raw[layer], (long long)out_ch * in_ch,
                      (hipStream_t)stream);
-  if (rc == MP_OK) m->loaded[layer] = true;
+  if (rc == MP_OK) {
+    m->loaded[layer] = true;
+    m->load_stream = (hipStream_t)stream;  // mp_mlp_set_precision orders itself behind it
+  }
   if (rc == MP_OK && m->precision != MP_PREC_F32) {
     // weights changed under an f16-packed MLP: drop back to f32 until precision is selected again
     m->precision = MP_PREC_F32;
@@ -253,14 +281,20 @@ int mp_mlp_set_precision(mp_ctx *ctx, int mlp, int precision) {
     if (hipMalloc(&m->buf16, off * 16) != hipSuccess)
       return fail(ctx, MP_ERR_NOMEM, "mp_mlp_set_precision: hipMalloc(%zu) failed", off * 16);
   }
+  // The raw weight copies were written by mp_mlp_load on the caller's stream; torch's side
+  // streams do not synchronise with the NULL stream, so the re-pack runs on that same stream
+  // (ordered behind the loads) and is drained before returning.
+  const hipStream_t st = m->load_stream;
   unsigned int *d_bits = nullptr;
   MP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d_bits), sizeof(unsigned int)));
   for (int l = 0; l < 4 && rc == MP_OK; ++l) {
     const long long n = (long long)kHidden[l] * ((l == 0 ? 0 : kHidden[l - 1]) + m->c + 1);
-    rc = launch_absmax(ctx, m->raw + m->off_raw[l], n, d_bits, nullptr);
+    rc = launch_absmax(ctx, m->raw + m->off_raw[l], n, d_bits, st);
     unsigned int bits = 0;
-    if (rc == MP_OK && hipMemcpy(&bits, d_bits, sizeof(bits), hipMemcpyDeviceToHost) != hipSuccess)
-      rc = fail(ctx, MP_ERR_HIP, "mp_mlp_set_precision: hipMemcpy failed");
+    if (rc == MP_OK &&
+        (hipMemcpyAsync(&bits, d_bits, sizeof(bits), hipMemcpyDeviceToHost, st) != hipSuccess ||
+         hipStreamSynchronize(st) != hipSuccess))
+      rc = fail(ctx, MP_ERR_HIP, "mp_mlp_set_precision: reading max|W| back failed");
     float wmax;
     memcpy(&wmax, &bits, sizeof(wmax));
     // largest power of two S with max|w| * S <= 2^14 (f16 tops out at 65504), clamped
@@ -272,9 +306,11 @@ int mp_mlp_set_precision(mp_ctx *ctx, int mlp, int precision) {
     if (e > 14) e = 14;
     if (e < -14) e = -14;
     m->scale16[l] = ldexpf(1.0f, e);
-    if (rc == MP_OK) rc = launch_pack_layer16(ctx, *m, l, m->raw + m->off_raw[l], nullptr);
+    if (rc == MP_OK) rc = launch_pack_layer16(ctx, *m, l, m->raw + m->off_raw[l], st);
   }
-  (void)hipDeviceSynchronize();
+  // drained: the packed f16 weights are complete before any stream can launch a query on them
+  if (hipStreamSynchronize(st) != hipSuccess && rc == MP_OK)
+    rc = fail(ctx, MP_ERR_HIP, "mp_mlp_set_precision: hipStreamSynchronize failed");
   (void)hipFree(d_bits);
   if (rc == MP_OK) m->precision = precision;
   return rc;
@@ -447,21 +483,52 @@ int mp_recon(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, c
                         n_levels, balance, &volume, &status, stream);
 }
 
-int mp_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
-                     const uint64_t *ev_prev, uint64_t *ev_cur, uint64_t *bnd, int level,
-                     float balance, uint32_t *packed, int32_t *count, mp_stream stream) {
+static int octree_select_impl(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
+                              const uint64_t *ev_prev, uint64_t *ev_cur, uint64_t *bnd, int level,
+                              int box, float balance, uint32_t *packed, int32_t *count,
+                              mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!ev_cur || !packed || !count || r < 2 || r > 1023 || level < 0)
     return fail(ctx, MP_ERR_ARG, "mp_octree_select: bad argument");
   if (prev && (!cur || !ev_prev || !bnd || r != 2 * rp - 1 || level < 1))
     return fail(ctx, MP_ERR_ARG, "mp_octree_select: refinement needs cur, ev_prev, bnd and r == 2 rp - 1");
+  if (box != 3 && box != 7 && box != 9)
+    return fail(ctx, MP_ERR_UNSUPPORTED, "mp_octree_select_box: dilation box must be 3, 7 or 9, got %d", box);
   DeviceGuard g(ctx->device);
   return launch_octree_select(ctx, prev, rp, cur, r,
                               reinterpret_cast<const unsigned long long *>(ev_prev),
                               reinterpret_cast<unsigned long long *>(ev_cur),
-                              reinterpret_cast<unsigned long long *>(bnd), level, balance, packed,
+                              reinterpret_cast<unsigned long long *>(bnd), box, balance, packed,
                               count, (hipStream_t)stream);
+}
+
+int mp_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
+                     const uint64_t *ev_prev, uint64_t *ev_cur, uint64_t *bnd, int level,
+                     float balance, uint32_t *packed, int32_t *count, mp_stream stream) {
+  return octree_select_impl(ctx, prev, rp, cur, r, ev_prev, ev_cur, bnd, level,
+                            octree_box_of_level(level), balance, packed, count, stream);
+}
+
+int mp_octree_select_box(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
+                         const uint64_t *ev_prev, uint64_t *ev_cur, uint64_t *bnd, int box,
+                         float balance, uint32_t *packed, int32_t *count, mp_stream stream) {
+  return octree_select_impl(ctx, prev, rp, cur, r, ev_prev, ev_cur, bnd, prev ? 1 : 0, box, balance,
+                            packed, count, stream);
+}
+
+int mp_octree_conflicts(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, int64_t capacity,
+                        int r, const float *values, const float *volume, float balance,
+                        uint64_t *ev, uint32_t *out_packed, int32_t *out_count, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!packed || !count || capacity < 0 || r < 2 || r > 1023 || !volume || !ev || !out_packed ||
+      !out_count || (capacity > 0 && !values))
+    return fail(ctx, MP_ERR_ARG, "mp_octree_conflicts: bad argument");
+  DeviceGuard g(ctx->device);
+  return launch_octree_conflicts(ctx, packed, count, capacity, r, values, volume, balance,
+                                 reinterpret_cast<unsigned long long *>(ev), out_packed, out_count,
+                                 (hipStream_t)stream);
 }
 
 int mp_lattice_points(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, int64_t capacity,

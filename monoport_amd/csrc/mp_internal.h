@@ -77,6 +77,7 @@ struct Mlp {
   bool used = false;
   int c = 0, cout = 0, act = 0;
   bool loaded[5] = {false, false, false, false, false};
+  hipStream_t load_stream = nullptr;  // stream of the most recent mp_mlp_load
   float *buf = nullptr;  // one allocation holding every packed segment
   size_t off_ah[4], off_ax[4], off_az[4], off_bias[5], off_w4;
   size_t total = 0;
@@ -103,13 +104,13 @@ struct mp_ctx {
   int device = 0;
   int n_cu = 0;
   std::mutex mu;
-  std::string err;
   std::vector<mp::Mlp> mlps;
   // scratch arenas, one per stream the context has been used on (grown on demand): calls that
   // are in flight on different streams never share scratch; calls on one stream are ordered.
   struct Arena {
-    void *ptr = nullptr;
+    void *ptr = nullptr;  // current block
     size_t bytes = 0;
+    std::vector<void *> retired;  // outgrown blocks, kept until mp_stream_release / mp_destroy
   };
   std::unordered_map<void *, Arena> arenas;
   // kernels whose dynamic-LDS limit has been raised on this context's device (guarded by mu)
@@ -165,8 +166,13 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
                  float balance, float *const *volume, int32_t *const *status, hipStream_t st);
 int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
                          const unsigned long long *ev_prev, unsigned long long *ev_cur,
-                         unsigned long long *bnd, int level, float balance, uint32_t *packed,
+                         unsigned long long *bnd, int box, float balance, uint32_t *packed,
                          int32_t *count, hipStream_t st);
+int octree_box_of_level(int level);
+int launch_octree_conflicts(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, long long cap,
+                            int r, const float *values, const float *vol, float balance,
+                            unsigned long long *ev, uint32_t *out, int32_t *out_count,
+                            hipStream_t st);
 int launch_lattice_points(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, long long cap,
                           int stride, int res_final, const float *bmin, const float *bmax,
                           float *pts, hipStream_t st);

@@ -36,6 +36,8 @@ struct LevelBufs {
 static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 static inline int words64(int r) { return (r + 63) / 64; }
 
+int octree_box_of_level(int level) { return level == 1 ? 9 : level == 2 ? 7 : 3; }
+
 size_t recon_scratch_bytes(const int *res, int n_levels) {
   size_t total = 0;
   for (int l = 0; l < n_levels; ++l) {
@@ -242,18 +244,65 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
 }
 
 // 9^3, 7^3, 3^3 boxes at levels 1, 2, 3+ (the upstream engine's "faster" schedule)
-static void launch_select(int level, unsigned blocks, hipStream_t st, const u64 *bnd,
+static int box_of_level(int level) { return level == 1 ? 9 : level == 2 ? 7 : 3; }
+
+static void launch_select(int box, unsigned blocks, hipStream_t st, const u64 *bnd,
                           const u64 *ev_prev, int rp, int w64p, u64 *ev, int r, int w64,
                           uint32_t *packed, int32_t *count) {
-  if (level == 1)
+  if (box == 9)
     hipLaunchKernelGGL(select_compact_kernel<4>, dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp,
                        w64p, ev, r, w64, packed, count);
-  else if (level == 2)
+  else if (box == 7)
     hipLaunchKernelGGL(select_compact_kernel<3>, dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp,
                        w64p, ev, r, w64, packed, count);
   else
     hipLaunchKernelGGL(select_compact_kernel<1>, dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp,
                        w64p, ev, r, w64, packed, count);
+}
+
+// ---- conflict re-examination (the upstream engine's faster=False mode) ------------------------
+// A node just evaluated is in CONFLICT when its exact value and the value interpolated from the
+// coarser level lie on different sides of the threshold: the surface passes where the coarse
+// level did not expect it.  Every not-yet-evaluated node of its 3x3x3 neighbourhood is then queued
+// (claimed with an atomic test-and-set on the evaluated bitset) for the next round.
+// vol still holds the INTERPOLATED values of the nodes in `packed` (scatter comes afterwards).
+__global__ void conflict_expand_kernel(const uint32_t *__restrict__ packed,
+                                       const int32_t *__restrict__ count, long long cap, int r,
+                                       int w64, const float *__restrict__ values,
+                                       const float *__restrict__ vol, float balance,
+                                       u64 *__restrict__ ev, uint32_t *__restrict__ out,
+                                       int32_t *__restrict__ out_count) {
+  const long long n = min((long long)*count, cap);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const uint32_t c = packed[i];
+    const int x = c & 1023u, y = (c >> 10) & 1023u, z = c >> 20;
+    const float interp = vol[((long long)z * r + y) * r + x];
+    if (!((interp - balance) * (values[i] - balance) < 0.0f)) continue;
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int xx = x + dx, yy = y + dy, zz = z + dz;
+          if (xx < 0 || yy < 0 || zz < 0 || xx >= r || yy >= r || zz >= r) continue;
+          u64 *word = ev + ((long long)zz * r + yy) * w64 + (xx >> 6);
+          const u64 bit = 1ull << (xx & 63);
+          if (atomicOr(word, bit) & bit) continue;  // already evaluated / claimed
+          out[atomicAdd(out_count, 1)] = (uint32_t)xx | ((uint32_t)yy << 10) | ((uint32_t)zz << 20);
+        }
+  }
+}
+
+int launch_octree_conflicts(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, long long cap,
+                            int r, const float *values, const float *vol, float balance, u64 *ev,
+                            uint32_t *out, int32_t *out_count, hipStream_t st) {
+  MP_HIP(ctx, hipMemsetAsync(out_count, 0, sizeof(int32_t), st));
+  if (cap == 0) return MP_OK;
+  long long blocks = (cap + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(conflict_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, st, packed, count,
+                     cap, r, words64(r), values, vol, balance, ev, out, out_count);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
 }
 
 // ---- level-at-a-time entry points (generic query_func) -------------------------------------------
@@ -285,7 +334,7 @@ __global__ void scatter_nodes_kernel(const uint32_t *__restrict__ packed,
 }
 
 int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
-                         const u64 *ev_prev, u64 *ev_cur, u64 *bnd, int level, float balance,
+                         const u64 *ev_prev, u64 *ev_cur, u64 *bnd, int box, float balance,
                          uint32_t *packed, int32_t *count, hipStream_t st) {
   const int w64 = words64(r);
   if (!prev) {
@@ -298,7 +347,7 @@ int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int
     hipLaunchKernelGGL(upsample_classify_kernel,
                        dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp), dim3(256), 0,
                        st, prev, rp, cur, r, balance, bnd, w64);
-    launch_select(level, (unsigned)((items + 255) / 256), st, bnd, ev_prev, rp, words64(rp), ev_cur, r,
+    launch_select(box, (unsigned)((items + 255) / 256), st, bnd, ev_prev, rp, words64(rp), ev_cur, r,
                   w64, packed, count);
   }
   MP_HIP(ctx, hipGetLastError());
@@ -402,7 +451,7 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
       hipLaunchKernelGGL(upsample_classify_kernel,
                          dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp), dim3(256),
                          0, st, lv[f][l - 1].occ, rp, lv[f][l].occ, r, balance, lv[f][l].bnd, w64);
-      launch_select(l, (unsigned)((items + 255) / 256), st, lv[f][l].bnd, lv[f][l - 1].ev, rp,
+      launch_select(box_of_level(l), (unsigned)((items + 255) / 256), st, lv[f][l].bnd, lv[f][l - 1].ev, rp,
                     words64(rp), lv[f][l].ev, r, w64, packed[f], status[f] + 1 + l);
       QueryItem &q = set.it[f];
       q.out = lv[f][l].occ;

@@ -1,20 +1,35 @@
 """``implicit_seg.functional``: the coarse-to-fine ("lossless octree") reconstruction engine.
 
 ``Seg3dLossless`` keeps the constructor and call surface the reference uses
-(RTL/main.py:185-195, :392-394) but runs every level on the GPU without touching the host:
-upsample + boundary ballot, dilation + compaction, fused PIFu query with scatter
-(csrc/octree.hip, csrc/query.hip).
+(RTL/main.py:185-195, :392-394) but runs every level on the GPU: upsample + boundary ballot,
+dilation + compaction, fused PIFu query with scatter (csrc/octree.hip, csrc/query.hip).
 
 PARITY NOTE: the upstream package is not vendored and not version-pinned by the reference, so the
 algorithm here is our restatement of its published scheme; it is checked bit for
 bit against the CPU restatement in oracle/pifu_oracle.py and against dense evaluation.
+
+Constructor flags (upstream names):
+  ``faster=True``   dilation boxes 9^3 / 7^3 / 3^3 by level, no conflict re-examination.  With a
+                    ``query_func`` that is a plain MonoPortNet.query call (RTL/main.py:169-183) the
+                    whole reconstruction is ONE asynchronous C-ABI call (fused path).
+  ``faster=False``  3^3 boxes at every level plus the conflict re-examination loop (nodes whose
+                    exact value contradicts the interpolated one get their 3x3x3 neighbourhood
+                    evaluated, repeated until none is left); level-at-a-time engine, one host sync
+                    per round as upstream.
+  ``use_cuda_impl`` upstream switches the implementation of its interpolation, not its results:
+                    accepted, both values run the same HIP kernels.
+  ``debug``         accepted (upstream only prints timings).
+  ``align_corners=True``, ``visualize=True``, ``use_shadow=True``, ``channels != 1``: not built,
+                    NotImplementedError at construction.
 """
+import warnings
+
 import numpy as np
 import torch
 import torch.nn as nn
 
 from ... import ops
-from ...modeling.MonoPortNet import capture_query
+from ...modeling.MonoPortNet import record_query
 from . import utils  # noqa: F401
 
 
@@ -23,6 +38,8 @@ class Seg3dLossless(nn.Module):
                  align_corners=False, visualize=False, debug=False, use_cuda_impl=False,
                  faster=False, use_shadow=False, **kwargs):
         super().__init__()
+        if kwargs:
+            raise TypeError("Seg3dLossless: unknown arguments %s" % sorted(kwargs))
         self.query_func = query_func
         self.b_min = np.asarray(b_min, np.float32).reshape(-1, 3)
         self.b_max = np.asarray(b_max, np.float32).reshape(-1, 3)
@@ -44,55 +61,79 @@ class Seg3dLossless(nn.Module):
             raise NotImplementedError("one occupancy channel")
         if align_corners:
             raise NotImplementedError("align_corners=False lattice only (the reference's setting)")
+        if visualize:
+            raise NotImplementedError("visualize=True (upstream's interactive plots) is not built")
+        if use_shadow:
+            raise NotImplementedError("use_shadow=True is not built (the reference leaves it off)")
         self.resolutions = res
         self.channels = channels
         self.balance_value = float(balance_value)
-        self.faster = bool(faster)  # dilation boxes 9/7/3 either way; kept for API parity
-        self.use_cuda_impl = use_cuda_impl
+        self.faster = bool(faster)
+        self.use_cuda_impl = bool(use_cuda_impl)  # same kernels either way (see module docstring)
+        self.debug = bool(debug)
         self.last_status = None
+        self.last_path = None  # "fused" | "generic": which engine served the last call
         # nn.Module.to(device) is called on the engine (RTL/main.py:195): carry a buffer so it
         # has a device like the upstream module does
         self.register_buffer("_device_tag", torch.zeros(1), persistent=False)
 
     def forward(self, **kwargs):
         """engine(**kwargs) -> [1,1,R,R,R] f32 occupancy volume (z,y,x) or None when the coarsest
-        level has nothing above ``balance_value`` (consumed at RTL/recon.py:32-35)."""
-        binding = self._bind(kwargs)
-        if binding is None:
-            # arbitrary query function: level-at-a-time engine, occupancies from the caller
-            volume, counts = ops.recon_generic(self.query_func, kwargs, self._device_tag.device,
-                                               self.b_min[0], self.b_max[0], self.resolutions,
-                                               self.balance_value)
-            self.last_status = torch.tensor([int(volume is not None)] + counts, dtype=torch.int32)
-            return None if volume is None else volume[None, None]
-        volume, status = self._launch(binding)
-        st = status.cpu()  # the one host sync of a reconstruction (upstream syncs per level)
-        self.last_status = st
-        if int(st[0]) == 0:
-            return None
-        return volume[None, None]
+        level has nothing above ``balance_value`` (consumed at RTL/recon.py:32-35).
 
-    def _bind(self, kwargs):
-        """Probe ``query_func`` once: if it ends in monoport_amd's MonoPortNet.query (as
-        RTL/main.py:169-183 does) return what that call binds, else None."""
-        try:
-            with capture_query() as cap:
-                probe = torch.zeros((1, 1, 3), dtype=torch.float32, device=self._device_tag.device)
-                self.query_func(points=probe, **kwargs)
-        except Exception:  # noqa: BLE001 -- a foreign function may not like the probe
-            return None
-        return cap.binding
-
-    def _launch(self, b):
-        return ops.recon(b.mlp, b.feat_hwc, b.calib, b.z_scale, self.b_min[0], self.b_max[0],
-                         self.resolutions, self.balance_value)
+        The coarsest level (17^3 = 4913 points for the reference's settings) is ALWAYS evaluated
+        through the caller's ``query_func``, for real.  If that call was exactly one
+        MonoPortNet.query and ``faster`` is on, the fused engine runs the whole reconstruction and
+        its coarsest level is compared with what ``query_func`` returned; only if they are
+        identical is the fused volume returned.  Anything else -- another network, extra
+        arithmetic around the call (1 - pred, scaled points, ...), several calls -- goes through
+        the level-at-a-time engine, which evaluates every level with ``query_func`` itself."""
+        dev = self._device_tag.device
+        eng = ops.LevelEngine(dev, self.b_min[0], self.b_max[0], self.resolutions,
+                              self.balance_value, self.faster)
+        pts0 = eng.select()
+        with record_query() as rec:
+            occ0 = self.query_func(points=pts0[None], **kwargs)
+        binding = rec.binding if rec.calls == 1 else None
+        if binding is not None and self.faster:
+            volume, status = ops.recon(binding.mlp, binding.feat_hwc, binding.calib, binding.z_scale,
+                                       self.b_min[0], self.b_max[0], self.resolutions,
+                                       self.balance_value)
+            eng.scatter(occ0)  # the caller's values on the coarsest lattice, [r0,r0,r0]
+            s = (self.resolutions[-1] - 1) // (self.resolutions[0] - 1)
+            differs = (volume[::s, ::s, ::s] != eng.cur).any().to(torch.int32).reshape(1)
+            # the one host sync of a reconstruction (upstream syncs at every level)
+            st = torch.cat([status, differs]).cpu()
+            if int(st[-1]) == 0:
+                self.last_status, self.last_path = st[:-1], "fused"
+                return None if int(st[0]) == 0 else volume[None, None]
+            warnings.warn("Seg3dLossless: query_func is not a plain MonoPortNet.query call (its "
+                          "values differ from the fused kernel's); using the level-at-a-time engine")
+            volume, counts = ops.recon_generic(self.query_func, kwargs, dev, self.b_min[0],
+                                               self.b_max[0], self.resolutions, self.balance_value,
+                                               self.faster)
+        else:
+            volume, counts = ops.recon_generic(self.query_func, kwargs, dev, self.b_min[0],
+                                               self.b_max[0], self.resolutions, self.balance_value,
+                                               self.faster, level0=(eng, occ0))
+        self.last_path = "generic"
+        self.last_status = torch.tensor([int(volume is not None)] + counts, dtype=torch.int32)
+        return None if volume is None else volume[None, None]
 
     def forward_async(self, **kwargs):
-        """Fused path only, no host sync: (volume [R,R,R], status int32[1+levels]) on device."""
-        b = self._bind(kwargs)
+        """Fused path only, no host sync and no validation of ``query_func`` (the caller vouches
+        that it is a plain MonoPortNet.query call): (volume [R,R,R], status int32[1+levels]) on
+        the device."""
+        if not self.faster:
+            raise NotImplementedError("forward_async is the faster=True schedule")
+        probe = torch.zeros((1, 1, 3), dtype=torch.float32, device=self._device_tag.device)
+        with record_query(capture_only=True) as rec:
+            self.query_func(points=probe, **kwargs)
+        b = rec.binding
         if b is None:
             raise NotImplementedError("forward_async needs a query_func ending in MonoPortNet.query")
-        return self._launch(b)
+        return ops.recon(b.mlp, b.feat_hwc, b.calib, b.z_scale, self.b_min[0], self.b_max[0],
+                         self.resolutions, self.balance_value)
 
 
 class Seg3dTopk(nn.Module):

@@ -41,13 +41,18 @@ class QueryBinding:
         self.net, self.mlp, self.feat_hwc, self.calib, self.z_scale = net, mlp, feat_hwc, calib, z_scale
 
 
-class capture_query:
-    """Context manager: inside it, the first ``MonoPortNet.query`` records its QueryBinding in
-    ``.binding`` and returns zeros instead of launching (used by Seg3dLossless to see through an
-    opaque ``query_func`` closure such as RTL/main.py:169-183)."""
+class record_query:
+    """Context manager (per host thread): counts the ``MonoPortNet.query`` calls made inside it
+    and keeps the QueryBinding of the first one in ``.binding``.  The calls run normally.  With
+    ``capture_only=True`` the first call returns zeros instead of launching (a probe).  Used by
+    Seg3dLossless to see through an opaque ``query_func`` closure such as RTL/main.py:169-183."""
+
+    def __init__(self, capture_only=False):
+        self.capture_only = capture_only
 
     def __enter__(self):
         self.binding = None
+        self.calls = 0
         self._prev = getattr(_tls, "capture", None)
         _tls.capture = self
         return self
@@ -55,6 +60,11 @@ class capture_query:
     def __exit__(self, *exc):
         _tls.capture = self._prev
         return False
+
+
+def capture_query():
+    """Probe form of ``record_query`` (the first query call is recorded, not executed)."""
+    return record_query(capture_only=True)
 
 
 class _AttrDict(dict):
@@ -121,10 +131,13 @@ class MonoPortNet(nn.Module):
             raise NotImplementedError("query(transforms=...) is a training-time option")
         binding = self.bind(feats_stages, calibs)
         cap = getattr(_tls, "capture", None)
-        if cap is not None and cap.binding is None:
-            cap.binding = binding
-            return [torch.zeros((points.shape[0], binding.mlp.cout, points.shape[2]),
-                                dtype=torch.float32, device=points.device)]
+        if cap is not None:
+            cap.calls += 1
+            if cap.binding is None:
+                cap.binding = binding
+                if cap.capture_only:
+                    return [torch.zeros((points.shape[0], binding.mlp.cout, points.shape[2]),
+                                        dtype=torch.float32, device=points.device)]
         if points.shape[0] != 1:
             raise NotImplementedError("batch size 1 (RTL/main.py:175 asserts the same)")
         return [ops.query(binding.mlp, binding.feat_hwc, points, binding.calib, binding.z_scale)]

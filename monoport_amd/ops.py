@@ -287,51 +287,132 @@ def recon_batch(mlp, feats_hwc, calibs, z_scale, b_min, b_max, resolutions, bala
     return volumes, status
 
 
-def recon_generic(query_func, kwargs, device, b_min, b_max, resolutions, balance=0.5):
-    """Seg3dLossless for an ARBITRARY ``query_func(points=[1,N,3], **kwargs) -> [1,1,N]``: the
-    node selection, lattice coordinates and scatter run as HIP kernels, the occupancies come from
-    the caller's function; one host sync per level for the point count (as upstream).  Returns
-    (volume [R,R,R] or None, per-level counts)."""
-    ctx = get_context(device)
-    dev = torch.device(device)
-    res = [int(r) for r in resolutions]
-    rf = res[-1]
-    bmin = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_min, np.float32).reshape(3)])
-    bmax = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_max, np.float32).reshape(3)])
-    count = torch.zeros((1,), dtype=torch.int32, device=dev)
-    prev = ev_prev = None
-    rp = 0
-    counts = []
-    for level, r in enumerate(res):
+class LevelEngine:
+    """The coarse-to-fine engine one step at a time, for an ARBITRARY ``query_func``: node
+    selection, lattice coordinates, conflict detection and scatter run as HIP kernels
+    (csrc/octree.hip), the occupancies come from the caller; one host sync per step for the point
+    count (as the upstream engine).  ``faster=True``: dilation boxes 9/7/3 by level, no conflict
+    re-examination; ``faster=False``: 3^3 boxes at every level and, after each evaluation, the
+    3x3x3 neighbourhoods of nodes whose exact value contradicts the interpolated one are evaluated
+    too, until no contradiction is left."""
+
+    def __init__(self, device, b_min, b_max, resolutions, balance=0.5, faster=True):
+        self.ctx = get_context(device)
+        self.dev = torch.device(device)
+        self.res = [int(r) for r in resolutions]
+        self.rf = self.res[-1]
+        self.balance = float(balance)
+        self.faster = bool(faster)
+        self.bmin = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_min, np.float32).reshape(3)])
+        self.bmax = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_max, np.float32).reshape(3)])
+        self.count = torch.zeros((1,), dtype=torch.int32, device=self.dev)
+        self.level = -1
+        self.prev = self.ev_prev = None
+        self.cur = self.ev_cur = self.packed = None
+        self.counts = []       # points queried per level (conflict rounds included)
+        self.rounds = []       # conflict rounds per level
+
+    def _points(self, packed, n, r):
+        pts = torch.empty((n, 3), dtype=torch.float32, device=self.dev)
+        ctx = self.ctx
+        ctx.check(ctx.lib.mp_lattice_points(ctx.handle, _ptr(packed), _ptr(self.count), n,
+                                            (self.rf - 1) // (r - 1), self.rf, self.bmin, self.bmax,
+                                            _ptr(pts), _stream(pts)), "mp_lattice_points")
+        return pts
+
+    def select(self):
+        """Advance to the next level: returns the [n,3] world points to evaluate (n may be 0)."""
+        self.level += 1
+        level, r = self.level, self.res[self.level]
+        ctx, dev = self.ctx, self.dev
         words = r * r * ((r + 63) // 64)
-        cur = torch.empty((r, r, r), dtype=torch.float32, device=dev)
-        ev_cur = torch.empty((words,), dtype=torch.int64, device=dev)
+        if level > 0:
+            self.prev, self.ev_prev = self.cur, self.ev_cur
+        self.cur = torch.empty((r, r, r), dtype=torch.float32, device=dev)
+        self.ev_cur = torch.empty((words,), dtype=torch.int64, device=dev)
         bnd = torch.empty((words,), dtype=torch.int64, device=dev)
-        packed = torch.empty((r ** 3,), dtype=torch.int32, device=dev)
-        ctx.check(ctx.lib.mp_octree_select(
-            ctx.handle, _ptr(prev) if prev is not None else None, rp, _ptr(cur), r,
-            _ptr(ev_prev) if ev_prev is not None else None, _ptr(ev_cur), _ptr(bnd), level,
-            float(balance), _ptr(packed), _ptr(count), _stream(cur)), "mp_octree_select")
-        n = int(count.item())
-        counts.append(n)
-        if n:
-            pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
-            ctx.check(ctx.lib.mp_lattice_points(ctx.handle, _ptr(packed), _ptr(count), n,
-                                                (rf - 1) // (r - 1), rf, bmin, bmax, _ptr(pts),
-                                                _stream(pts)), "mp_lattice_points")
-            occ = query_func(points=pts[None], **kwargs)
-            if isinstance(occ, (list, tuple)):
-                occ = torch.stack(list(occ))
-            vals = _f32c(occ.reshape(-1))
-            if vals.shape[0] != n:
-                raise ValueError("query_func returned %d values for %d points" % (vals.shape[0], n))
-            ctx.check(ctx.lib.mp_scatter_nodes(ctx.handle, _ptr(packed), _ptr(count), n, r,
-                                               _ptr(vals), _ptr(cur), _stream(cur)),
-                      "mp_scatter_nodes")
-        if level == 0 and not bool((cur > balance).any()):
-            return None, counts
-        prev, ev_prev, rp = cur, ev_cur, r
-    return prev, counts
+        self.packed = torch.empty((r ** 3,), dtype=torch.int32, device=dev)
+        box = 3 if not self.faster else {1: 9, 2: 7}.get(level, 3)
+        ctx.check(ctx.lib.mp_octree_select_box(
+            ctx.handle, _ptr(self.prev) if level > 0 else None, self.res[level - 1] if level > 0 else 0,
+            _ptr(self.cur), r, _ptr(self.ev_prev) if level > 0 else None, _ptr(self.ev_cur),
+            _ptr(bnd), box, self.balance, _ptr(self.packed), _ptr(self.count), _stream(self.cur)),
+            "mp_octree_select_box")
+        self.n = int(self.count.item())
+        self.counts.append(self.n)
+        self.rounds.append(0)
+        return self._points(self.packed, self.n, r) if self.n else None
+
+    def _values(self, occ, n):
+        if isinstance(occ, (list, tuple)):
+            occ = torch.stack(list(occ))
+        vals = _f32c(occ.reshape(-1))
+        if vals.shape[0] != n:
+            raise ValueError("query_func returned %d values for %d points" % (vals.shape[0], n))
+        return vals
+
+    def scatter(self, occ):
+        """Hand over the occupancies of the points ``select`` (or the previous ``scatter``)
+        returned.  Returns the next batch of points of THIS level to evaluate (faster=False:
+        neighbourhoods of conflicting nodes) or None when the level is complete."""
+        ctx, r, n = self.ctx, self.res[self.level], self.n
+        vals = self._values(occ, n)
+        nxt = None
+        if not self.faster and self.level > 0:
+            nxt = torch.empty((r ** 3,), dtype=torch.int32, device=self.dev)
+            nxt_count = torch.zeros((1,), dtype=torch.int32, device=self.dev)
+            ctx.check(ctx.lib.mp_octree_conflicts(
+                ctx.handle, _ptr(self.packed), _ptr(self.count), n, r, _ptr(vals), _ptr(self.cur),
+                self.balance, _ptr(self.ev_cur), _ptr(nxt), _ptr(nxt_count), _stream(vals)),
+                "mp_octree_conflicts")
+        ctx.check(ctx.lib.mp_scatter_nodes(ctx.handle, _ptr(self.packed), _ptr(self.count), n, r,
+                                           _ptr(vals), _ptr(self.cur), _stream(self.cur)),
+                  "mp_scatter_nodes")
+        if nxt is None:
+            return None
+        m = int(nxt_count.item())
+        if m == 0:
+            return None
+        # claimed through atomics: sort for a reproducible evaluation order
+        self.packed = torch.sort(nxt[:m])[0].contiguous()
+        self.count = nxt_count
+        self.n = m
+        self.counts[-1] += m
+        self.rounds[-1] += 1
+        return self._points(self.packed, m, r)
+
+    def empty(self):
+        """Level 0 only: nothing above the threshold (the engine then returns None)."""
+        return not bool((self.cur > self.balance).any())
+
+
+def recon_generic(query_func, kwargs, device, b_min, b_max, resolutions, balance=0.5, faster=True,
+                  level0=None):
+    """Seg3dLossless for an ARBITRARY ``query_func(points=[1,N,3], **kwargs) -> [1,1,N]`` on top
+    of ``LevelEngine``.  ``level0`` = (engine, occupancies) when the caller has already evaluated
+    the coarsest level through the engine.  Returns (volume [R,R,R] or None, per-level counts)."""
+    if level0 is None:
+        eng = LevelEngine(device, b_min, b_max, resolutions, balance, faster)
+        pts = eng.select()
+        occ = query_func(points=pts[None], **kwargs)
+    else:
+        eng, occ = level0
+    eng.scatter(occ)
+    if eng.empty():
+        return None, eng.counts
+    for _ in range(1, len(eng.res)):
+        pts = eng.select()
+        while pts is not None:
+            pts = eng.scatter(query_func(points=pts[None], **kwargs))
+    return eng.cur, eng.counts
+
+
+def stream_release(stream):
+    """Free the scratch arena the context keeps for ``stream`` (a torch.cuda.Stream); call it when
+    a stream that made C-ABI calls is retired.  Synchronises the device."""
+    ctx = get_context(stream.device)
+    ctx.check(ctx.lib.mp_stream_release(ctx.handle, ctypes.c_void_p(stream.cuda_stream)),
+              "mp_stream_release")
 
 
 def forward_vertices_raw(volume, direction="front"):

@@ -157,6 +157,9 @@ class FrameSlot:
             raise ValueError("slot of %d frames got %d" % (self.batch, n))
         self.wait()  # a slot holds ONE batch: its previous results are overwritten from here on
         self.n_active = n
+        # the caller may have produced the frames asynchronously on ITS stream (segmentation,
+        # prepare_inputs, an H2D copy from pinned memory): order the slot's copies behind that work
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
             self._load(self.image, images)
             self._load(self.calib, calibs)
@@ -165,21 +168,32 @@ class FrameSlot:
             self._chain()
         self._busy = True
 
-    @staticmethod
-    def _load(dst, src):
+    def _load(self, dst, src):
         if torch.is_tensor(src):
             n = src.shape[0]
             dst[:n].copy_(src.reshape(dst[:n].shape), non_blocking=True)
+            srcs = [src]
         else:
             for b, s in enumerate(src):
                 dst[b].copy_(s.reshape(dst[b].shape), non_blocking=True)
+            srcs = list(src)
+        for s in srcs:
+            if s.is_cuda:  # the caching allocator must not recycle a source the copy still reads
+                s.record_stream(self.stream)
 
     def wait(self):
         """Block the host until this slot's batch (and anything queued after it on the slot's
-        stream before the next submit) has finished."""
+        stream before the next submit) has finished.  Results are to be consumed after ``wait()``
+        or on a stream that has done ``wait_stream(slot.stream)``."""
         if self._busy:
             self.stream.synchronize()
             self._busy = False
+
+    def close(self):
+        """Release the C-ABI scratch arena keyed by this slot's stream (mp_stream_release)."""
+        self.wait()
+        self.graph = None
+        ops.stream_release(self.stream)
 
 
 class FramePipeline:
@@ -204,3 +218,7 @@ class FramePipeline:
         for s in self.slots:
             s.wait()
             s.stream.synchronize()
+
+    def close(self):
+        for s in self.slots:
+            s.close()

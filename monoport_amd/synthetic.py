@@ -70,12 +70,28 @@ _PARTS = [
     (-0.13, 0.50, 0.00, 0.11, 0.40, 0.12),  # left leg
     (0.13, 0.50, 0.00, 0.11, 0.40, 0.12),  # right leg
 ]
+# further figures for the octree tests: thin limbs (radius ~2 voxels at 257^3), two separate bodies
+_PARTS_THIN = [
+    (0.00, -0.55, 0.00, 0.10, 0.12, 0.10),   # head
+    (0.00, -0.10, 0.00, 0.05, 0.40, 0.05),   # spine
+    (-0.30, -0.20, 0.03, 0.018, 0.36, 0.018),  # very thin arms / legs
+    (0.30, -0.20, 0.03, 0.018, 0.36, 0.018),
+    (-0.10, 0.55, 0.00, 0.02, 0.35, 0.02),
+    (0.10, 0.55, 0.00, 0.02, 0.35, 0.02),
+    (0.00, -0.30, 0.00, 0.34, 0.015, 0.015),  # thin horizontal bar (shoulders)
+]
+_PARTS_TWO = [
+    (-0.45, -0.10, -0.30, 0.22, 0.55, 0.20),  # two disconnected bodies at different depths
+    (0.48, 0.15, 0.35, 0.18, 0.42, 0.16),
+    (0.48, -0.45, 0.35, 0.10, 0.12, 0.10),
+]
+FIGURES = {"figure": _PARTS, "thin": _PARTS_THIN, "two": _PARTS_TWO}
 _EMPTY_FRONT = -4.0  # depth planes where no part covers the pixel: z_f < z_b -> always outside
 _EMPTY_BACK = 4.0
 
 
-def body_depth_maps(h=128, w=128):
-    """Front (max z) and back (min z) depth maps [H,W] f32 of the capsule figure.
+def body_depth_maps(h=128, w=128, figure="figure"):
+    """Front (max z) and back (min z) depth maps [H,W] f32 of a capsule figure (``FIGURES``).
 
     Pixel (i, j) sits at x = -1 + 2j/(W-1), y = -1 + 2i/(H-1): the align_corners=True grid
     of monoport/lib/modeling/geometry.py:15.
@@ -84,7 +100,7 @@ def body_depth_maps(h=128, w=128):
     xs = np.linspace(-1.0, 1.0, w)[None, :]
     zf = np.full((h, w), _EMPTY_FRONT, dtype=np.float64)
     zb = np.full((h, w), _EMPTY_BACK, dtype=np.float64)
-    for cx, cy, cz, rx, ry, rz in _PARTS:
+    for cx, cy, cz, rx, ry, rz in FIGURES[figure]:
         q = 1.0 - ((xs - cx) / rx) ** 2 - ((ys - cy) / ry) ** 2
         inside = q > 0
         dz = rz * np.sqrt(np.where(inside, q, 0.0))
@@ -93,9 +109,9 @@ def body_depth_maps(h=128, w=128):
     return zf.astype(np.float32), zb.astype(np.float32)
 
 
-def body_feature_planes(h=128, w=128):
+def body_feature_planes(h=128, w=128, figure="figure"):
     """The two feature channels F-body reads: channel 0 = z_front, channel 1 = z_back."""
-    zf, zb = body_depth_maps(h, w)
+    zf, zb = body_depth_maps(h, w, figure)
     return np.stack([zf, zb], 0)
 
 
@@ -142,10 +158,10 @@ def body_mlp(kind="G", k=40.0, c=2.0, noise=0.0, seed=0):
     return layers
 
 
-def body_feat(c=256, h=128, w=128, seed=0, scale=1.0):
+def body_feat(c=256, h=128, w=128, seed=0, scale=1.0, figure="figure"):
     """Seeded feature map whose channels 0/1 carry the body depth planes."""
     f = rand_feat(c, h, w, seed, scale)
-    f[0:2] = body_feature_planes(h, w)
+    f[0:2] = body_feature_planes(h, w, figure)
     return f
 
 

@@ -280,11 +280,16 @@ def dilation_for_level(level):
 
 
 def seg3d_lossless(query_func, b_min, b_max, resolutions, balance_value=0.5, stats=None,
-                   evaluated_out=None):
+                   evaluated_out=None, faster=True, rounds=None):
     """Coarse-to-fine occupancy volume [R,R,R] (z,y,x) f32, or None if level 0 is empty.
 
     ``query_func(points[3,N] f32) -> [N] f32``.  Requires resolutions[i+1] == 2*resolutions[i]-1.
     ``evaluated_out`` (bool [R,R,R] of the final resolution) receives the set of queried nodes.
+    ``faster=True``: dilation boxes 9/7/3 by level, no re-examination (the mode RTL/main.py:194
+    selects).  ``faster=False``: 3^3 boxes at every level and the conflict loop -- a node whose
+    exact value and interpolated value lie on different sides of the threshold gets its 3x3x3
+    neighbourhood (at this level's spacing) evaluated as well, repeated until no new conflict;
+    ``stats`` counts those points with their level, ``rounds`` receives the rounds per level.
     """
     res = [int(r) for r in resolutions]
     for a, b in zip(res[:-1], res[1:]):
@@ -292,6 +297,7 @@ def seg3d_lossless(query_func, b_min, b_max, resolutions, balance_value=0.5, sta
             raise ValueError("resolutions must follow r -> 2r-1")
     rf = res[-1]
     r0 = res[0]
+    bv = np.float32(balance_value)
     stride = (rf - 1) // (r0 - 1)
     idx = np.stack(np.meshgrid(np.arange(r0), np.arange(r0), np.arange(r0), indexing="ij"),
                    -1).reshape(-1, 3)
@@ -299,27 +305,46 @@ def seg3d_lossless(query_func, b_min, b_max, resolutions, balance_value=0.5, sta
                      np.float32).reshape(r0, r0, r0)
     if stats is not None:
         stats.append(idx.shape[0])
-    if not (occ > np.float32(balance_value)).any():
+    if rounds is not None:
+        rounds.append(0)
+    if not (occ > bv).any():
         return None
     evaluated = np.ones((r0, r0, r0), bool)
     for level in range(1, len(res)):
         r = res[level]
         stride = (rf - 1) // (r - 1)
-        valid = upsample2x((occ > np.float32(balance_value)).astype(np.float32))
+        valid = upsample2x((occ > bv).astype(np.float32))
         occ = upsample2x(occ)
         boundary = (valid > 0) & (valid < 1)
-        sel = dilate_box(boundary, dilation_for_level(level))
+        sel = dilate_box(boundary, dilation_for_level(level) if faster else 3)
         ev = np.zeros((r, r, r), bool)
         ev[::2, ::2, ::2] = evaluated
         sel &= ~ev
         idx = np.argwhere(sel)
-        if stats is not None:
-            stats.append(idx.shape[0])
-        if idx.shape[0]:
+        n_level, n_rounds = idx.shape[0], 0
+        evaluated = ev | sel
+        while idx.shape[0]:
             vals = np.asarray(query_func(lattice_points(idx, stride, rf, b_min, b_max)),
                               np.float32)
+            interp = occ[idx[:, 0], idx[:, 1], idx[:, 2]]
             occ[idx[:, 0], idx[:, 1], idx[:, 2]] = vals
-        evaluated = ev | sel
+            if faster:
+                break
+            conflict = ((interp - bv) * (vals - bv)) < 0
+            if not conflict.any():
+                break
+            grow = np.zeros((r, r, r), bool)
+            c = idx[conflict]
+            grow[c[:, 0], c[:, 1], c[:, 2]] = True
+            grow = dilate_box(grow, 3) & ~evaluated
+            idx = np.argwhere(grow)
+            evaluated |= grow
+            n_level += idx.shape[0]
+            n_rounds += 1 if idx.shape[0] else 0
+        if stats is not None:
+            stats.append(n_level)
+        if rounds is not None:
+            rounds.append(n_rounds)
     if evaluated_out is not None:
         evaluated_out[...] = evaluated
     return occ

@@ -44,14 +44,15 @@ def test_dense64_vs_reference(case):
     print("dense64 %s: max|HIP - reference| = %.3g" % (case, err))
     assert np.array_equal((out == 0), (ref == 0)) or case == "out_body"  # identical in-image mask
     assert err <= TOL_REF
-    assert err <= 2e-5  # measured ~1e-6: only the GEMM summation order differs
+    assert err <= 5e-6  # measured 3.0e-7 on both heads: only the GEMM summation order differs
 
 
 def test_dense64_with_gpu_encoder_in_the_loop():
     """Same grid, but the features come from OUR encoder on the GPU (MIOpen convolutions) while
     the fixture used the reference's netG.filter on the CPU: the SDF error with the GPU encoder in
-    the loop.  Convolution algorithms differ (Winograd), so this is not held to 1e-4 on the
-    random-weight head (gain 2: every feature channel matters); the measured value is printed."""
+    the loop, on the random-weight head (gain 2: every feature channel matters).  Measured on the
+    MI355X: features within 5.7e-6 of the reference's, SDF within 1.6e-6 (MIOpen's fp32
+    convolution algorithms differ from the CPU's in the last bits only)."""
     from monoport_amd.modeling import PIFuNetG
     g = load_golden("dense64")
     net = PIFuNetG().eval()
@@ -70,7 +71,7 @@ def test_dense64_with_gpu_encoder_in_the_loop():
     print("encoder in the loop: max|feat - reference feat| = %.3g; SDF max %.3g, mean %.3g, "
           "99.9th pct %.3g" % (fe, err.max(), err.mean(), np.quantile(err, 0.999)))
     assert np.array_equal(out == 0, g["out_enc"] == 0)
-    assert fe <= 5e-3 and err.max() <= 5e-3
+    assert fe <= 1e-4 and err.max() <= TOL_REF
 
 
 def test_pipeline257_vs_reference():
@@ -105,10 +106,11 @@ def test_pipeline257_vs_reference():
     err = float(np.abs(vol[queried] - g["values"]).max())
     print("pipeline257: %d queried nodes, max|HIP - reference| = %.3g" % (queried.sum(), err))
     assert err <= TOL_REF
+    assert err <= 5e-6  # measured 4.5e-7
     X, Y, Z, norm = forward_vertices(sdf, direction="front")
     assert np.array_equal(X.cpu().numpy(), g["X"].astype(np.int64))
     assert np.array_equal(Y.cpu().numpy(), g["Y"].astype(np.int64))
     zerr = float(np.abs(Z.cpu().numpy() - g["Z"]).max())
     nerr = float(np.abs(norm.cpu().numpy() - g["norm"]).max())
     print("pipeline257: %d vertices, max|dZ| = %.3g voxels, max|dnorm| = %.3g" % (X.shape[0], zerr, nerr))
-    assert zerr <= 1e-3 and nerr <= 1e-3
+    assert zerr <= 1e-3 and nerr <= 1e-4  # measured 3.1e-5 voxels / 2.4e-6

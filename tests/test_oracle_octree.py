@@ -66,6 +66,21 @@ def test_lossless_vs_dense(oracle, body_query, res):
     assert sum(stats) < 0.5 * res[-1] ** 3
 
 
+@pytest.mark.parametrize("res", [[9, 17, 33], [5, 9, 17, 33, 65]])
+def test_non_faster_mode_is_lossless_and_re_examines(oracle, body_query, res):
+    """faster=False: 3^3 dilation + conflict loop.  Still lossless against dense evaluation; it
+    queries fewer points at the coarse levels than the 9^3 / 7^3 schedule and recovers by
+    re-examining conflicts (at least one round on this body)."""
+    stats, rounds, stats_fast = [], [], []
+    vol = oracle.seg3d_lossless(body_query, BMIN, BMAX, res, stats=stats, faster=False,
+                                rounds=rounds)
+    oracle.seg3d_lossless(body_query, BMIN, BMAX, res, stats=stats_fast)
+    dense = oracle.dense_volume(body_query, BMIN, BMAX, res[-1])
+    assert np.array_equal(vol > 0.5, dense > 0.5)
+    assert len(stats) == len(rounds) == len(res) and rounds[0] == 0
+    assert sum(rounds) >= 1 and stats[1] < stats_fast[1]
+
+
 def test_empty_returns_none(oracle):
     assert oracle.seg3d_lossless(lambda p: np.zeros(p.shape[1], np.float32), BMIN, BMAX,
                                  [5, 9]) is None
