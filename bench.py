@@ -85,18 +85,135 @@ def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, 
     return pipe
 
 
-def traffic_from_profile(frames_per_launch):
+TRAFFIC_PROFILE = "r02_query_traffic.json"
+
+
+def traffic_from_profile(args, frames_per_launch):
     """HBM-side bytes per fused-query launch from the committed PMC pass (separate rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE runs of tools/traffic_probe.py, corrected as
-    MI355X_MICROARCH.md prescribes); None if the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r01e_query_traffic.json")
+    MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process, so the
+    figure is reported ONLY for the configuration the pass covered (f32 kernel, 5 levels, geometry
+    only, same frames per launch) and is None for every other run or when the profile is absent."""
+    if args.precision != "f32" or args.levels != 5 or args.with_color:
+        return None
+    path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
     try:
         with open(path) as f:
             prof = json.load(f)
-        # the profile was taken at 4 frames per launch; traffic scales with the points of a launch
-        return prof["bytes_per_launch_avg"] * frames_per_launch / prof["frames_per_launch"]
+        if int(prof["frames_per_launch"]) != int(frames_per_launch):
+            return None
+        return prof["bytes_per_launch_avg"]
     except (OSError, KeyError, ValueError):
         return None
+
+
+def dropin_surface(device, n_frames, n_warm, resolutions):
+    """The reference's own call surface, as RTL/main.py:326-452 drives it: the processors=[...]
+    list (H2D, camera, pifu_calib, input normalisation, netG.filter, reconEngine =
+    Seg3dLossless(query_func) with its per-frame host sync, forward_vertices with its .item(),
+    colorization) on the thread-per-stage pipeline -- one frame per call, batch 1, eager encoder.
+    Returns recon/s through that surface and the latency of a single frame run stage by stage."""
+    from monoport_amd.implicit_seg.functional import Seg3dLossless
+    from monoport_amd.recon import colorization, forward_vertices
+    from monoport_amd.stage_pipeline import StagePipeline
+    netG, _ = build_netg(device)
+    planes = torch.from_numpy(syn.body_feature_planes(128, 128)).to(device)
+
+    def query_func(points, im_feat_list, calib_tensor):  # RTL/main.py:169-183
+        assert len(points) == 1
+        samples = points.repeat(1, 1, 1)
+        samples = samples.permute(0, 2, 1)
+        return netG.query(im_feat_list, points=samples, calibs=calib_tensor)[0]
+
+    engine = Seg3dLossless(query_func=query_func, b_min=np.array([B_MIN], np.float32),
+                           b_max=np.array([B_MAX], np.float32), resolutions=resolutions,
+                           balance_value=0.5, use_cuda_impl=False, faster=True).to(device)
+    mean, std = 0.5, 0.5
+    r_last = resolutions[-1]
+
+    def filt(d):
+        feats = netG.filter(d["input_netG"])
+        feats[-1][0][0, 0:2].copy_(planes)  # synthetic body planes, as in the headline run
+        return {**d, "feat_tensor_G": feats}
+
+    def processors(step):
+        def camera(d):
+            ext, intr = syn.scene_camera(3 * step[0])
+            step[0] += 1
+            return {**d, "extrinsic": ext, "intrinsic": intr}
+        return [
+            lambda data: {"input": data.to(device, non_blocking=True)},                    # main.py:327
+            camera,                                                                       # :330-336
+            lambda d: {**d, "calib_tensor": pifu_calib(d["extrinsic"], d["intrinsic"], device=device)},
+            lambda d: {**d, "input_netG": (((d["input"][:, 0:3] * 0.5 + 0.5) - mean) / std)
+                       * d["input"][:, 3:4]},                                             # :353-357
+            filt,                                                                         # :367-370
+            lambda d: {**d, "sdf": engine(im_feat_list=d["feat_tensor_G"],
+                                          calib_tensor=d["calib_tensor"])},               # :390-395
+            lambda d: {**d, **dict(zip(["X", "Y", "Z", "norm"],
+                                       forward_vertices(d["sdf"], direction="front")))},  # :401-406
+            lambda d: {**d, "render_norm": colorization(None, None, d["X"], d["Y"], d["Z"],
+                                                        d["calib_tensor"], d["norm"],
+                                                        resolution=r_last)},              # :418-428
+        ]
+
+    frames = []
+    for i in range(4):
+        img = torch.from_numpy(syn.synthetic_image(i))
+        mask = (img.abs().sum(0, keepdim=True) > 0).float()
+        frames.append(torch.cat([img, mask], 0)[None].pin_memory())
+
+    # single-frame latency: one frame through the stages, one after the other, nothing else on
+    # the GPU; median of 5 after a warm-up
+    procs = processors([0])
+    lat = []
+    with torch.no_grad():
+        for i in range(2 + 5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d = frames[i % 4]
+            for p in procs:
+                d = p(d)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+    assert d["render_norm"] is not None
+    latency_ms = float(np.median(lat[2:])) * 1e3
+
+    # throughput: the same list on the stage pipeline (thread + stream per stage, FIFO order)
+    def source():
+        for i in range(n_warm + n_frames):
+            yield frames[i % 4]
+
+    out_count, t0 = 0, None
+    with torch.no_grad():
+        for d in StagePipeline(source(), processors([0]), device=device, max_in_flight=8):
+            out_count += 1
+            if out_count == n_warm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert out_count == n_warm + n_frames and engine.last_path == "fused"
+    return {
+        "surface": "RTL/main.py processors list on StagePipeline: Seg3dLossless(query_func) + "
+                   "forward_vertices + colorization, batch 1, eager encoder, 8 frames in flight",
+        "value": n_frames / elapsed, "unit": "recon/s", "ms_per_step": elapsed / n_frames * 1e3,
+        "latency_ms_single_frame": latency_ms,
+        "frames": n_frames,
+    }
+
+
+def rank_devices(dist, device, world):
+    """(device index, PCI bus id, uuid-ish name) of every rank, gathered on all ranks."""
+    props = torch.cuda.get_device_properties(device)
+    bus = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1),
+                              getattr(props, "pci_device_id", -1))
+    mine = "%d|%s|%s" % (torch.cuda.current_device(), bus, props.name)
+    if dist is None:
+        return [mine]
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    return got
 
 
 def cpu_baseline(threads):
@@ -135,9 +252,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--depth", type=int, default=3, help="pipeline slots (streams) per GPU")
-    ap.add_argument("--batch", type=int, default=4,
-                    help="frames per slot: their encoder passes run as one batch; depth x batch "
-                         "frames are in flight (reduced to a divisor of --steps)")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="frames per slot (upper bound): their encoder passes run as one batch and "
+                         "their octree levels as one fused-query launch; depth x batch frames are in "
+                         "flight.  The largest divisor of --steps not above this is used, so no slot "
+                         "submission is short (a short batch would still pay the full-batch encoder)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the encoder eagerly instead of replaying it as a hipGraph")
     ap.add_argument("--with-color", action="store_true",
@@ -148,6 +267,13 @@ def main():
                     help="MLP arithmetic: exact f32 MFMA (default); f16x3 = f32-accurate 3-term f16 "
                          "split (hi*hi + hi*lo + lo*hi on f16 MFMA, f32 accumulate); f16w = fp16 "
                          "weights, split activations (BASELINE configs[4]); f16 = fp16 operands")
+    ap.add_argument("--mode", default="pipeline", choices=["pipeline", "dropin"],
+                    help="pipeline (default): the headline -- FramePipeline, frames batched per slot, no "
+                         "host sync; dropin: `value` is measured through the reference's call surface "
+                         "(StagePipeline + Seg3dLossless + forward_vertices), as the default run's "
+                         "`dropin` object")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the drop-in-surface pass a default N=1 run appends")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the informational f16x3 pass that a default N=1 run appends")
@@ -170,11 +296,47 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    # every rank on its own GPU: (device index, PCI bus id) must be N distinct values (the one-GPU
+    # test hook deliberately shares device 0)
+    devices = rank_devices(dist, device, world)
+    if world > 1 and not one_gpu_test:
+        assert len(set(devices)) == world, "ranks share a GPU: %s" % devices
 
     resolutions = RESOLUTIONS + ([513] if args.levels == 6 else [])
-    batch = max(1, min(args.batch, args.steps))  # a pass's last batch may be shorter
-    pipe = make_pipeline(device, args.depth, not args.no_graph, resolutions, args.with_color,
-                         args.precision, batch)
+    if args.mode == "dropin":
+        assert world == 1, "--mode dropin is a single-GPU measurement"
+        res = dropin_surface(device, args.steps, args.warmup, resolutions)
+        print(json.dumps({
+            "metric": "reconstructions/sec (512^2 in, %d^3 grid) through the drop-in surface" % (resolutions[-1] - 1),
+            "value": res["value"], "unit": "recon/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": res["surface"]},
+            "latency_ms_single_frame": res["latency_ms_single_frame"]}), flush=True)
+        return
+    batch = max(b for b in range(1, max(1, min(args.batch, args.steps)) + 1) if args.steps % b == 0)
+    use_graph = not args.no_graph
+    try:
+        pipe = make_pipeline(device, args.depth, use_graph, resolutions, args.with_color,
+                             args.precision, batch)
+    except RuntimeError as e:
+        # hipGraph capture can fail next to an initialised RCCL communicator (its watchdog thread
+        # touches the runtime): fall back to eager encoder launches rather than lose the run
+        if not use_graph:
+            raise
+        sys.stderr.write("bench: hipGraph capture failed (%s); falling back to --no-graph\n" % e)
+        torch.cuda.synchronize()
+        use_graph = False
+        pipe = make_pipeline(device, args.depth, False, resolutions, args.with_color,
+                             args.precision, batch)
+    if dist is not None:  # all ranks run the same variant
+        flag = torch.tensor([int(use_graph)], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if use_graph and int(flag.item()) == 0:
+            use_graph = False
+            pipe = make_pipeline(device, args.depth, False, resolutions, args.with_color,
+                                 args.precision, batch)
     n_warm = args.warmup
     n_frames = args.steps + n_warm
     # distinct frames per rank: frame id = step * world + rank (frame-parallel sharding)
@@ -185,6 +347,7 @@ def main():
     r_last = resolutions[-1]
     # one gather per slot submission: [batch, R, R, 3] renders to rank 0 (a no-op on one GPU)
     gather = parallel.FrameGather((batch, r_last, r_last, 3), device=device, store=False)
+    gather_checked = [False]
     render_pack = [torch.zeros((batch, r_last, r_last, 3), dtype=torch.float32, device=device)
                    for _ in range(args.depth)]
     status_log = []
@@ -199,6 +362,12 @@ def main():
                 for b in range(s1 - s0):
                     pack[b].copy_(slot.renders_tex[b] if args.with_color else slot.renders[b])
                 gather.push(s0 // batch, pack)
+                if not log and rank == 0 and not gather_checked[0]:
+                    # (warm-up only: this syncs) the gathered copy of rank 0's own frames must
+                    # equal what rank 0 rendered
+                    got = gather.received(0)[:s1 - s0].to(pack.device)
+                    assert torch.equal(got, pack[:s1 - s0]), "gather mismatch"
+                    gather_checked[0] = True
             if log:
                 status_log.append(slot.status[:s1 - s0].clone())  # device-side copy, no sync
 
@@ -335,7 +504,7 @@ def main():
         flops = prof_pts.reshape(-1)[:n_launch].astype(np.float64) * FLOP_PER_POINT
         achieved = flops.sum() / (launch_ms[:n_launch].sum() * 1e-3) / 1e12 if n_launch else 0.0
         out = {
-            "metric": "reconstructions/sec (512^2 in, 256^3 grid)",
+            "metric": "reconstructions/sec (512^2 in, %d^3 grid)" % (r_last - 1),
             "value": args.steps * world / elapsed,
             "unit": "recon/s",
             "n_gpus": world,
@@ -359,10 +528,14 @@ def main():
                                 if args.with_color else
                                 "geometry only (+forward_vertices, normal render)")),
                 "frames_per_rank": args.steps,
-                "parallelism": "frame-parallel x%d; per GPU %d slots x %d frames in flight, encoder "
+                "devices": devices,
+                "gather_checked": bool(gather_checked[0]) if world > 1 else None,
+                "parallelism": "frame-parallel x%d (one process per GPU, renders gathered to rank 0 "
+                               "over %s); per GPU %d slots x %d frames in flight, encoder "
                                "batched per slot%s"
-                               % (world, args.depth, batch,
-                                  "" if args.no_graph else " and replayed as a hipGraph"),
+                               % (world, "gloo (one-GPU test hook)" if one_gpu_test else "RCCL",
+                                  args.depth, batch,
+                                  " and replayed as a hipGraph" if use_graph else ""),
                 "fixture": "F-body analytic head, seeded encoder (monoport_amd/synthetic.py)",
                 "points_per_recon": pts_all / (args.steps * world),
             },
@@ -384,7 +557,9 @@ def main():
                 "peak": peak_tflops,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak_tflops,
-                "traffic": traffic_from_profile(min(batch, MAX_RECON_BATCH)),
+                "traffic": traffic_from_profile(args, min(batch, MAX_RECON_BATCH)),
+                "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                   "this configuration)" % TRAFFIC_PROFILE),
                 "launches": int(n_launch),
                 "frames_per_launch": min(batch, MAX_RECON_BATCH),
                 "avg_launch_ms": float(launch_ms[:n_launch].mean()) if n_launch else None,
@@ -393,6 +568,9 @@ def main():
         }
         if alt is not None:
             out["alt_precision"] = alt
+        if world == 1 and not args.no_dropin and not args.with_color and args.precision == "f32":
+            out["dropin"] = dropin_surface(device, args.steps, args.warmup, resolutions)
+            out["latency_ms_single_frame"] = out["dropin"]["latency_ms_single_frame"]
         if world == 1 and not args.no_cpu_baseline and not args.with_color and args.levels == 5:
             # bounded thread count: torch-CPU convs at batch 1 collapse when oversubscribed
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))

@@ -54,6 +54,7 @@ MlpPack Mlp::pack() const {
   }
   for (int l = 0; l < 5; ++l) p.bias[l] = (int)off_bias[l];
   p.w4 = (int)off_w4;
+  p.n_floats = (int)total;
   return p;
 }
 

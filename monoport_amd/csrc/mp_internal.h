@@ -27,6 +27,7 @@ struct MlpPack {
   int az[4];    // z-column A fragments [n_out/32][64]
   int bias[5];  // biases of layers 0..4
   int w4;       // last layer, row-major [Cout][pad4(128 + C + 1)]
+  int n_floats; // size of the whole packed buffer (buffer-resource bound of the weight loads)
 };
 
 // Split-precision copy of the same weights for the 3-term f16 MFMA kernel (query16.hip): every

@@ -54,6 +54,45 @@ constexpr int kAHot = 0;
 
 namespace mp {
 
+// ---- weight stream -----------------------------------------------------------------------------
+// Every weight / bias read of the MLP is  base + (wave-uniform offset) + (lane part): issued as
+// buffer loads through ONE 128-bit resource descriptor in SGPRs, the lane part in one shared
+// VGPR and the uniform part in the instruction's scalar offset (SALU adds).  With 64-bit flat
+// addresses hipcc hoisted ~70 lane-dependent pointers out of the tile loop and spilled them
+// (132 VGPRs, 161 scratch reloads and 6 scratch stores per tile -- the WRITE_SIZE of round 1).
+struct WStream {
+  __amdgpu_buffer_rsrc_t rs;
+  int lane16;  // lane * 16: this lane's 16-byte slot of a 64-lane fragment
+  int lane4;   // lane * 4
+  int h16;     // (lane >> 5) * 16
+};
+
+__device__ __forceinline__ WStream make_wstream(const float *base, int n_floats, int lane) {
+  WStream w;
+  // 0x00020000: raw buffer, 32-bit data format (cdna_hip_programming.md T8); base and size come
+  // from kernel arguments, so the descriptor is provably wave-uniform (no waterfall loops, T20)
+  w.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, n_floats * 4, 0x00020000);
+  w.lane16 = lane * 16;
+  w.lane4 = lane * 4;
+  w.h16 = (lane >> 5) * 16;
+  return w;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// fragment `idx` (units of 64 x 16 bytes would be idx * 64; here idx is in 16-byte units)
+__device__ __forceinline__ f32x4 wload128(const WStream &w, int idx16) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.lane16, idx16 * 16, 0));
+}
+// one float per lane at float index f0 + lane
+__device__ __forceinline__ float wload32(const WStream &w, int f0) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w.rs, w.lane4, f0 * 4, 0));
+}
+// 4 floats at float index f0 + 4 h (bias pieces of a C-layout tile)
+__device__ __forceinline__ f32x4 wload_bias4(const WStream &w, int f0) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.h16, f0 * 4, 0));
+}
+
 constexpr int kHbRowBytes = 64 * 4;                    // one point's 64-row hidden chunk
 constexpr int kHbBytes = kTilePts * kHbRowBytes;       // 16 KB
 
@@ -75,25 +114,26 @@ __device__ __forceinline__ void mma_group(f32x16 (&acc)[MR][NR], const f32x4 (&a
 //                  (before the previous segment's epilogue / barrier) so L2 latency is hidden;
 //   seg_main     : the K loop.  Every iteration issues the A fragment PF groups ahead and the B
 //                  operand one group ahead, then the 4*MR*NR MFMAs of the current group.
-//   a: fragment stream of row block 0 at group 0 for this lane (float4 units); row block m is
+//   a: fragment stream of row block 0 at group 0 as a wave-uniform index into the weight buffer
+//      (16-byte units; the lane's slot is added by the buffer load); row block m is
 //      a + m * rb_stride; group g is + g * 64.
 //   b: LDS byte address of this lane's point row for column block 0; column block n is
 //      + n * 32 * ROWB; group g lives in 16-byte slot (2g + h) ^ (p & 15) = (2g) ^ swz.
 // The loop is deliberately NOT unrolled beyond the ring size: hipcc clusters every load of a
 // big unrolled block at its top and spills the accumulators.
 template <int MR, int PF, bool HOT = (kAHot & 4) != 0>
-__device__ __forceinline__ void seg_prefetch(f32x4 (&ring)[PF + 1][MR],
-                                             const f32x4 *__restrict__ a, int rb_stride,
-                                             int n_groups) {
+__device__ __forceinline__ void seg_prefetch(f32x4 (&ring)[PF + 1][MR], const WStream &ws, int a,
+                                             int rb_stride, int n_groups) {
 #pragma unroll
   for (int d = 0; d < PF; ++d)
 #pragma unroll
-    for (int m = 0; m < MR; ++m) ring[d][m] = a[m * rb_stride + MP_AG(min(d, n_groups - 1)) * 64];
+    for (int m = 0; m < MR; ++m)
+      ring[d][m] = wload128(ws, a + m * rb_stride + MP_AG(min(d, n_groups - 1)) * 64);
 }
 
 template <int MR, int NR, int PF, int ROWB, bool HOT = (kAHot & 4) != 0>
 __device__ __forceinline__ void seg_main(f32x16 (&acc)[MR][NR], f32x4 (&ring)[PF + 1][MR],
-                                         const f32x4 *__restrict__ a, int rb_stride, int n_groups,
+                                         const WStream &ws, int a, int rb_stride, int n_groups,
                                          const unsigned char *b, int swz) {
   constexpr int RS = PF + 1;
   f32x4 bcur[NR];
@@ -107,7 +147,8 @@ __device__ __forceinline__ void seg_main(f32x16 (&acc)[MR][NR], f32x4 (&ring)[PF
       const int g = g0 + r;
       const int gp = min(g + PF, n_groups - 1);
 #pragma unroll
-      for (int m = 0; m < MR; ++m) ring[(r + PF) % RS][m] = a[m * rb_stride + MP_AG(gp) * 64];
+      for (int m = 0; m < MR; ++m)
+        ring[(r + PF) % RS][m] = wload128(ws, a + m * rb_stride + MP_AG(gp) * 64);
       const int boff = ((2 * min(g + 1, n_groups - 1)) ^ swz) << 4;
       f32x4 bnxt[NR];
 #pragma unroll
@@ -137,10 +178,10 @@ __device__ __forceinline__ void gemm_z(f32x16 (&acc)[MR][NR], const float (&az)[
 // Accumulators start from the bias: register t of lane (j, h) of a C-layout tile holds row
 // (t & 3) + 8 (t >> 2) + 4 h of the 32-row block (cdna_hip_programming.md section 3), so the 16
 // registers are four 16-byte pieces of the bias vector.
-__device__ __forceinline__ void init_from_bias(f32x16 &v, const float *__restrict__ bias32, int h) {
+__device__ __forceinline__ void init_from_bias(f32x16 &v, const WStream &ws, int bias32) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const f32x4 bq = *reinterpret_cast<const f32x4 *>(bias32 + 8 * q + 4 * h);
+    const f32x4 bq = wload_bias4(ws, bias32 + 8 * q);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[4 * q + i] = bq[i];
   }
@@ -189,6 +230,7 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
   // counts at the top of every iteration -- eight scalar loads -- instead of keeping a prefix
   // table alive in SGPRs across the whole MLP.
   const int swz = h ^ (j & 15);  // this lane's 16-byte-slot swizzle (see gemm_seg)
+  const WStream ws = make_wstream(mlp.base, mlp.n_floats, lane);
 
   for (long long gtile = blockIdx.x;; gtile += gridDim.x) {
     int fi = -1;
@@ -309,61 +351,54 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
     const unsigned char *hrow = hb + j * kHbRowBytes;
 
     // ---------------- layers 0 + 1, fused over 64-row chunks of layer 0 ----------------
-    // NB: hipcc hoists ~70 lane-dependent weight addresses out of the tile loop and spills them in
-    // the workgroup prologue (139 KB of scratch per workgroup, visible as WRITE_SIZE).  Making the
-    // base opaque per tile removes the spills but measured 2 % SLOWER (address recomputation sits
-    // on the MFMA issue path), so the hoist stays.
-    const float *wbase = mlp.base;
     f32x16 acc1[4][2];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      init_from_bias(acc1[m][0], wbase + mlp.bias[1] + 32 * (4 * wv + m), h);
+      init_from_bias(acc1[m][0], ws, mlp.bias[1] + 32 * (4 * wv + m));
       acc1[m][1] = acc1[m][0];
     }
     {
       const int rb0 = wv >> 1, cb0 = wv & 1;  // this wave's tile inside a layer-0 chunk
-      const f32x4 *a0 = reinterpret_cast<const f32x4 *>(wbase + mlp.ax[0]) + lane;
-      const f32x4 *a1 = reinterpret_cast<const f32x4 *>(wbase + mlp.ah[1]) +
-                        (long long)(4 * wv) * (kHidden[0] / 8) * 64 + lane;
+      const int a0 = mlp.ax[0] / 4;           // 16-byte units (segments are 256-byte aligned)
+      const int a1 = mlp.ah[1] / 4 + (4 * wv) * (kHidden[0] / 8) * 64;
       const float zz[1] = {zb[cb0]};
       f32x4 ring0[MP32_PF0 + 1][1];
       f32x16 acc0[1][1];
       float az0[1];
-      seg_prefetch<1, MP32_PF0, (kAHot & 1) != 0>(ring0, a0 + (long long)rb0 * NGX * 64, 0, NGX);
-      init_from_bias(acc0[0][0], wbase + mlp.bias[0] + 32 * rb0, h);
-      az0[0] = (wbase + mlp.az[0])[rb0 * 64 + lane];
+      seg_prefetch<1, MP32_PF0, (kAHot & 1) != 0>(ring0, ws, a0 + rb0 * NGX * 64, 0, NGX);
+      init_from_bias(acc0[0][0], ws, mlp.bias[0] + 32 * rb0);
+      az0[0] = wload32(ws, mlp.az[0] + rb0 * 64);
 #pragma unroll 1
       for (int ck = 0; ck < kHidden[0] / 64; ++ck) {
         // layer-0 rows [64 ck + 32 rb0, +32) x points [32 cb0, +32)
         const int rb = 2 * ck + rb0;
-        seg_main<1, 1, MP32_PF0, ROWB, (kAHot & 1) != 0>(acc0, ring0, a0 + (long long)rb * NGX * 64, 0, NGX,
+        seg_main<1, 1, MP32_PF0, ROWB, (kAHot & 1) != 0>(acc0, ring0, ws, a0 + rb * NGX * 64, 0, NGX,
                                 xrow + cb0 * 32 * ROWB, swz);
         // layer-1 weights of this chunk start streaming before the chunk is even stored
         f32x4 ring1[MP32_PF1 + 1][4];
-        seg_prefetch<4, MP32_PF1, (kAHot & 2) != 0>(ring1, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8);
+        seg_prefetch<4, MP32_PF1, (kAHot & 2) != 0>(ring1, ws, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8);
         gemm_z<1, 1>(acc0, az0, zz);
         lrelu(acc0[0][0]);
         store_hidden(hb, acc0[0][0], rb0, cb0, j, h);
         // next chunk's layer-0 operands
         const int rbn = min(rb + 2, kHidden[0] / 32 - 2 + rb0);
-        seg_prefetch<1, MP32_PF0, (kAHot & 1) != 0>(ring0, a0 + (long long)rbn * NGX * 64, 0, NGX);
-        init_from_bias(acc0[0][0], wbase + mlp.bias[0] + 32 * rbn, h);
-        az0[0] = (wbase + mlp.az[0])[rbn * 64 + lane];
+        seg_prefetch<1, MP32_PF0, (kAHot & 1) != 0>(ring0, ws, a0 + rbn * NGX * 64, 0, NGX);
+        init_from_bias(acc0[0][0], ws, mlp.bias[0] + 32 * rbn);
+        az0[0] = wload32(ws, mlp.az[0] + rbn * 64);
         MP_CHUNK_SYNC();
         // layer-1 rows [128 wv, +128) += W1[:, 64 ck .. +64) * chunk
-        seg_main<4, 2, MP32_PF1, kHbRowBytes, (kAHot & 2) != 0>(acc1, ring1, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8,
+        seg_main<4, 2, MP32_PF1, kHbRowBytes, (kAHot & 2) != 0>(acc1, ring1, ws, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8,
                                        hrow, swz);
         MP_CHUNK_SYNC();
       }
       // skip segment of layer 1: W1[:, 1024 .. 1024 + C] * x, then the z column
-      const f32x4 *a1x = reinterpret_cast<const f32x4 *>(wbase + mlp.ax[1]) +
-                         (long long)(4 * wv) * NGX * 64 + lane;
+      const int a1x = mlp.ax[1] / 4 + (4 * wv) * NGX * 64;
       f32x4 ring1[MP32_PF1 + 1][4];
       float az1[4];
-      seg_prefetch<4, MP32_PF1>(ring1, a1x, NGX * 64, NGX);
+      seg_prefetch<4, MP32_PF1>(ring1, ws, a1x, NGX * 64, NGX);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) az1[m] = (wbase + mlp.az[1])[(4 * wv + m) * 64 + lane];
-      seg_main<4, 2, MP32_PF1, ROWB>(acc1, ring1, a1x, NGX * 64, NGX, xrow, swz);
+      for (int m = 0; m < 4; ++m) az1[m] = wload32(ws, mlp.az[1] + (4 * wv + m) * 64);
+      seg_main<4, 2, MP32_PF1, ROWB>(acc1, ring1, ws, a1x, NGX * 64, NGX, xrow, swz);
       gemm_z<4, 2>(acc1, az1, zb);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -375,14 +410,13 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
     f32x16 acc2[2][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      init_from_bias(acc2[m][0], wbase + mlp.bias[2] + 32 * (2 * wv + m), h);
+      init_from_bias(acc2[m][0], ws, mlp.bias[2] + 32 * (2 * wv + m));
       acc2[m][1] = acc2[m][0];
     }
     {
-      const f32x4 *a2 = reinterpret_cast<const f32x4 *>(wbase + mlp.ah[2]) +
-                        (long long)(2 * wv) * (kHidden[1] / 8) * 64 + lane;
+      const int a2 = mlp.ah[2] / 4 + (2 * wv) * (kHidden[1] / 8) * 64;
       f32x4 ring2[2][2];
-      seg_prefetch<2, 1>(ring2, a2, (kHidden[1] / 8) * 64, 8);
+      seg_prefetch<2, 1>(ring2, ws, a2, (kHidden[1] / 8) * 64, 8);
 #pragma unroll
       for (int ck = 0; ck < 8; ++ck) {
         if (wv == (ck >> 1)) {  // owner of hidden rows [64 ck, +64): row blocks 2(ck&1), +1
@@ -392,18 +426,17 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
             for (int n = 0; n < 2; ++n) store_hidden(hb, acc1[2 * (ck & 1) + mm][n], mm, n, j, h);
         }
         MP_CHUNK_SYNC();
-        seg_main<2, 2, 1, kHbRowBytes>(acc2, ring2, a2 + ck * 8 * 64, (kHidden[1] / 8) * 64, 8,
+        seg_main<2, 2, 1, kHbRowBytes>(acc2, ring2, ws, a2 + ck * 8 * 64, (kHidden[1] / 8) * 64, 8,
                                        hrow, swz);
-        if (ck < 7) seg_prefetch<2, 1>(ring2, a2 + (ck + 1) * 8 * 64, (kHidden[1] / 8) * 64, 8);
+        if (ck < 7) seg_prefetch<2, 1>(ring2, ws, a2 + (ck + 1) * 8 * 64, (kHidden[1] / 8) * 64, 8);
         MP_CHUNK_SYNC();
       }
-      const f32x4 *a2x = reinterpret_cast<const f32x4 *>(wbase + mlp.ax[2]) +
-                         (long long)(2 * wv) * NGX * 64 + lane;
+      const int a2x = mlp.ax[2] / 4 + (2 * wv) * NGX * 64;
       float az2[2];
-      seg_prefetch<2, 1>(ring2, a2x, NGX * 64, NGX);
+      seg_prefetch<2, 1>(ring2, ws, a2x, NGX * 64, NGX);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) az2[m] = (wbase + mlp.az[2])[(2 * wv + m) * 64 + lane];
-      seg_main<2, 2, 1, ROWB>(acc2, ring2, a2x, NGX * 64, NGX, xrow, swz);
+      for (int m = 0; m < 2; ++m) az2[m] = wload32(ws, mlp.az[2] + (2 * wv + m) * 64);
+      seg_main<2, 2, 1, ROWB>(acc2, ring2, ws, a2x, NGX * 64, NGX, xrow, swz);
       gemm_z<2, 2>(acc2, az2, zb);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -413,13 +446,12 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
 
     // ---------------- layer 3: rows [32 wv, +32), K = 256 hidden (4 chunks) + skip ----------------
     f32x16 acc3[1][2];
-    init_from_bias(acc3[0][0], wbase + mlp.bias[3] + 32 * wv, h);
+    init_from_bias(acc3[0][0], ws, mlp.bias[3] + 32 * wv);
     acc3[0][1] = acc3[0][0];
     {
-      const f32x4 *a3 = reinterpret_cast<const f32x4 *>(wbase + mlp.ah[3]) +
-                        (long long)wv * (kHidden[2] / 8) * 64 + lane;
+      const int a3 = mlp.ah[3] / 4 + wv * (kHidden[2] / 8) * 64;
       f32x4 ring3[4][1];
-      seg_prefetch<1, 3>(ring3, a3, 0, 8);
+      seg_prefetch<1, 3>(ring3, ws, a3, 0, 8);
 #pragma unroll
       for (int ck = 0; ck < 4; ++ck) {
         if (wv == ck) {
@@ -429,16 +461,15 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
             for (int n = 0; n < 2; ++n) store_hidden(hb, acc2[mm][n], mm, n, j, h);
         }
         MP_CHUNK_SYNC();
-        seg_main<1, 2, 3, kHbRowBytes>(acc3, ring3, a3 + ck * 8 * 64, 0, 8, hrow, swz);
-        if (ck < 3) seg_prefetch<1, 3>(ring3, a3 + (ck + 1) * 8 * 64, 0, 8);
+        seg_main<1, 2, 3, kHbRowBytes>(acc3, ring3, ws, a3 + ck * 8 * 64, 0, 8, hrow, swz);
+        if (ck < 3) seg_prefetch<1, 3>(ring3, ws, a3 + (ck + 1) * 8 * 64, 0, 8);
         MP_CHUNK_SYNC();
       }
-      const f32x4 *a3x = reinterpret_cast<const f32x4 *>(wbase + mlp.ax[3]) +
-                         (long long)wv * NGX * 64 + lane;
+      const int a3x = mlp.ax[3] / 4 + wv * NGX * 64;
       float az3[1];
-      seg_prefetch<1, 3>(ring3, a3x, 0, NGX);
-      az3[0] = (wbase + mlp.az[3])[wv * 64 + lane];
-      seg_main<1, 2, 3, ROWB>(acc3, ring3, a3x, 0, NGX, xrow, swz);
+      seg_prefetch<1, 3>(ring3, ws, a3x, 0, NGX);
+      az3[0] = wload32(ws, mlp.az[3] + wv * 64);
+      seg_main<1, 2, 3, ROWB>(acc3, ring3, ws, a3x, 0, NGX, xrow, swz);
       gemm_z<1, 2>(acc3, az3, zb);
 #pragma unroll
       for (int n = 0; n < 2; ++n) lrelu(acc3[0][n]);

@@ -76,6 +76,10 @@ class FrameGather:
             for r in range(self.world):
                 self.results[round_idx * self.world + r] = self._bufs[r].to(self.device, copy=True)
 
+    def received(self, rank):
+        """Rank ``rank``'s payload of the newest round (rank dst only; on the collective's stream)."""
+        return self._bufs[rank]
+
     def ordered(self, n_frames):
         """[n_frames, *shape] in frame order (rank dst)."""
         return torch.stack([self.results[i] for i in range(n_frames)])

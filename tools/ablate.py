@@ -1,6 +1,6 @@
 """Timing experiments on side builds of the library (never the product).
 
-  python tools/ablate.py build NAME FILE.hip -DFLAG [-DFLAG ...]   # here: lib/libmp_ablateNAME.so
+  python tools/ablate.py build NAME FILE.hip[:STEM] -DFLAG [-DFLAG ...]   # here: lib/libmp_ablateNAME.so
   python tools/ablate.py run NAME [precision] [n ...]              # on the GPU box
 """
 import os
@@ -12,10 +12,14 @@ sys.path.insert(0, ROOT)
 
 
 def build(name, src, flags):
+    """``src`` may be FILE.hip:STEM -- a side source (e.g. an older revision saved next to the
+    product's) that REPLACES the product's STEM.hip in the side library."""
     from monoport_amd import build as b
     lib_dir = os.path.join(ROOT, "monoport_amd", "lib")
     obj = os.path.join(lib_dir, "obj", "ablate_%s.o" % name)
     stem = os.path.splitext(os.path.basename(src))[0]
+    if ":" in src:
+        src, stem = src.split(":")
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + b.FLAGS + flags +
                           ["-c", os.path.join(ROOT, "monoport_amd", "csrc", src), "-o", obj])
     others = [os.path.join(lib_dir, "obj", s.replace(".hip", ".o")) for s in b.SOURCES
