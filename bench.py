@@ -432,7 +432,7 @@ def main():
     all_ms = ops.profile_end(device, capacity=8 * args.steps + 8)
     # launch order per submission of n frames: for every chunk of <= 8 frames one launch per level
     # (its points = that level's nodes summed over the chunk, pipeline.py / mp_recon_batch); with
-    # --with-color one netC launch per frame follows, which the netG roofline skips
+    # --with-color one netC launch per chunk follows, which the netG roofline skips
     launch_ms, prof_pts, cursor = [], [], 0
     for st in prof_status:
         counts = st.cpu().numpy()[:, 1:]
@@ -440,8 +440,8 @@ def main():
             prof_pts.append(counts[b0:b0 + MAX_RECON_BATCH].sum(0))
             launch_ms.append(all_ms[cursor:cursor + len(resolutions)])
             cursor += len(resolutions)
-        if args.with_color:
-            cursor += counts.shape[0]
+        if args.with_color:  # one netC launch per chunk of <= 8 frames follows (skipped here)
+            cursor += (counts.shape[0] + MAX_RECON_BATCH - 1) // MAX_RECON_BATCH
     launch_ms = np.concatenate(launch_ms)
     prof_pts = np.stack(prof_pts)
 

@@ -134,6 +134,15 @@ int mp_query_counted(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, 
                      const float *points, int64_t capacity, const int32_t *count,
                      const float *calib, float z_scale, float *out, mp_stream stream);
 
+/* mp_query_counted over n_frames (1..8) independent frames in ONE launch (the per-vertex colour
+ * queries of all frames of a pipeline slot: ~14 k points each cannot fill 256 CUs alone).
+ * feat_hwc / points / count / calib / out are HOST arrays of n_frames device pointers, each as in
+ * mp_query_counted (one `capacity` for all); results are identical to n_frames separate calls. */
+int mp_query_counted_batch(mp_ctx *ctx, int mlp, int n_frames, const float *const *feat_hwc, int c,
+                           int h, int w, const float *const *points, int64_t capacity,
+                           const int32_t *const *count, const float *const *calib, float z_scale,
+                           float *const *out, mp_stream stream);
+
 /* ---- coarse-to-fine reconstruction --------------------------------------------------------- */
 /* Replaces implicit_seg.functional.Seg3dLossless.forward(faster=True) driving query_func
  * (RTL/main.py:185-195, :392-394; un-vendored dependency, requirements.txt:15).

@@ -36,6 +36,8 @@ SIGNATURES = {
     "mp_mlp_forward": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp]),
     "mp_query_counted": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp,
                                  c_f32, c_vp, c_vp]),
+    "mp_query_counted_batch": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp,
+                                       c_vp, c_f32, c_vp, c_vp]),
     "mp_recon": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_f32, _pf32, _pf32, _pint,
                          c_int, c_f32, c_vp, c_vp, c_vp]),
     "mp_recon_batch": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_f32, _pf32, _pf32,

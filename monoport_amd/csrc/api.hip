@@ -67,6 +67,7 @@ MlpPack16 Mlp::pack16() const {
     p.az[l] = (int)off16_az[l];
     p.scale[l] = scale16[l];
   }
+  p.n16 = (int)total16;
   return p;
 }
 
@@ -281,6 +282,7 @@ int mp_mlp_set_precision(mp_ctx *ctx, int mlp, int precision) {
     }
     if (hipMalloc(&m->buf16, off * 16) != hipSuccess)
       return fail(ctx, MP_ERR_NOMEM, "mp_mlp_set_precision: hipMalloc(%zu) failed", off * 16);
+    m->total16 = off;
   }
   // The raw weight copies were written by mp_mlp_load on the caller's stream; torch's side
   // streams do not synchronise with the NULL stream, so the re-pack runs on that same stream
@@ -432,6 +434,43 @@ int mp_query_counted(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, 
   DeviceGuard g(ctx->device);
   return launch_query(ctx, *m, feat_hwc, h, w, calib, z_scale, src, out, capacity,
                       (hipStream_t)stream);
+}
+
+int mp_query_counted_batch(mp_ctx *ctx, int mlp, int n_frames, const float *const *feat_hwc, int c,
+                           int h, int w, const float *const *points, int64_t capacity,
+                           const int32_t *const *count, const float *const *calib, float z_scale,
+                           float *const *out, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const Mlp *m = get_mlp(ctx, mlp);
+  int rc = check_ready(ctx, m, c);
+  if (rc != MP_OK) return rc;
+  if (n_frames < 1 || n_frames > kMaxFrames)
+    return fail(ctx, MP_ERR_ARG, "mp_query_counted_batch: 1..%d frames per call, got %d", kMaxFrames,
+                n_frames);
+  if (!feat_hwc || !points || !count || !calib || !out || capacity < 0 || h <= 0 || w <= 0)
+    return fail(ctx, MP_ERR_ARG, "mp_query_counted_batch: bad argument");
+  if (capacity == 0) return MP_OK;
+  QuerySet set;
+  std::memset(&set, 0, sizeof(set));
+  set.n = n_frames;
+  for (int f = 0; f < n_frames; ++f) {
+    if (!feat_hwc[f] || !points[f] || !count[f] || !calib[f] || !out[f])
+      return fail(ctx, MP_ERR_ARG, "mp_query_counted_batch: null buffer for frame %d", f);
+    if (!aligned16(feat_hwc[f]))
+      return fail(ctx, MP_ERR_ARG, "mp_query_counted_batch: feat_hwc must be 16-byte aligned");
+    QueryItem &q = set.it[f];
+    q.feat = feat_hwc[f];
+    q.calib = calib[f];
+    q.out = out[f];
+    q.src.pts = points[f];
+    q.src.sn = 1;
+    q.src.sc = capacity;
+    q.src.n_dev = count[f];
+    q.src.out_stride = capacity;
+  }
+  DeviceGuard g(ctx->device);
+  return launch_query_set(ctx, *m, set, h, w, z_scale, capacity * n_frames, true, (hipStream_t)stream);
 }
 
 static int check_resolutions(mp_ctx *ctx, const char *who, const int *resolutions, int n_levels) {

@@ -38,6 +38,7 @@ struct MlpPack16 {
   int ah[4], ax[4];   // hidden / feature segments
   int az[4];          // z column: [rb][hi|lo][lane], only element 0 of lanes 0-31 non-zero
   float scale[4];     // S of layers 0..3
+  int n16;            // size of the buffer in 16-byte units (buffer-resource bound)
 };
 
 // Where a query launch takes its points from and where it puts the results.
@@ -88,7 +89,7 @@ struct Mlp {
   void *buf16 = nullptr;
   float *raw = nullptr;     // un-packed [out,in] copies of layers 0..3 (source for re-packing)
   size_t off_raw[4];
-  size_t off16_ah[4], off16_ax[4], off16_az[4];
+  size_t off16_ah[4], off16_ax[4], off16_az[4], total16 = 0;
   float scale16[4] = {1.f, 1.f, 1.f, 1.f};
   MlpPack16 pack16() const;
 };

@@ -54,48 +54,6 @@ constexpr int kAHot = 0;
 
 namespace mp {
 
-// ---- weight stream -----------------------------------------------------------------------------
-// Every weight / bias read of the MLP is  base + (wave-uniform offset) + (lane part): issued as
-// buffer loads through ONE 128-bit resource descriptor in SGPRs, the lane part in one shared
-// VGPR and the uniform part in the instruction's scalar offset (SALU adds).  With 64-bit flat
-// addresses hipcc hoisted ~70 lane-dependent pointers out of the tile loop and spilled them
-// (132 VGPRs, 161 scratch reloads and 6 scratch stores per tile -- the WRITE_SIZE of round 1).
-struct WStream {
-  __amdgpu_buffer_rsrc_t rs;
-  int lane16;  // lane * 16: this lane's 16-byte slot of a 64-lane fragment
-  int lane4;   // lane * 4
-  int h16;     // (lane >> 5) * 16
-};
-
-__device__ __forceinline__ WStream make_wstream(const float *base, int n_floats, int lane) {
-  WStream w;
-  // 0x00020000: raw buffer, 32-bit data format (cdna_hip_programming.md T8); base and size come
-  // from kernel arguments, so the descriptor is provably wave-uniform (no waterfall loops, T20)
-  w.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, n_floats * 4, 0x00020000);
-  w.lane16 = lane * 16;
-  w.lane4 = lane * 4;
-  w.h16 = (lane >> 5) * 16;
-  return w;
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// fragment `idx` (units of 64 x 16 bytes would be idx * 64; here idx is in 16-byte units)
-__device__ __forceinline__ f32x4 wload128(const WStream &w, int idx16) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.lane16, idx16 * 16, 0));
-}
-// one float per lane at float index f0 + lane
-__device__ __forceinline__ float wload32(const WStream &w, int f0) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w.rs, w.lane4, f0 * 4, 0));
-}
-// 4 floats at float index f0 + 4 h (bias pieces of a C-layout tile)
-__device__ __forceinline__ f32x4 wload_bias4(const WStream &w, int f0) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.h16, f0 * 4, 0));
-}
-
-constexpr int kHbRowBytes = 64 * 4;                    // one point's 64-row hidden chunk
-constexpr int kHbBytes = kTilePts * kHbRowBytes;       // 16 KB
-
 // ---- MFMA building blocks ----------------------------------------------------------------------
 template <int MR, int NR>
 __device__ __forceinline__ void mma_group(f32x16 (&acc)[MR][NR], const f32x4 (&a)[MR],

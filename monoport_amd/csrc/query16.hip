@@ -56,20 +56,25 @@ __device__ __forceinline__ void split4(const f32x4 &v, h4 &hi, h4 &lo) {
   }
 }
 
-// a: this lane's h8 of row block 0, group 0, part hi; lo is +64, group g +128 g, row block m
-// + m * rb_stride (all in h8 units)
+// a: wave-uniform index (16-byte units) of row block 0, group 0, part hi in the f16 weight buffer
+// (the lane's slot is added by the buffer load, see WStream in query_common.h); lo is +64,
+// group g +128 g, row block m + m * rb_stride
 // TERMS selects the arithmetic: 3 = hi*hi + hi*lo + lo*hi (f32-class, "f16x3"); 2 = weights
 // rounded to f16, activations still split (hi*hi + hi*lo, "f16w"); 1 = plain f16 operands ("f16").
+__device__ __forceinline__ h8 hload(const WStream &w, int idx16) {
+  return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.lane16, idx16 * 16, 0));
+}
+
 template <int MR, int PF, int TERMS>
-__device__ __forceinline__ void seg_prefetch16(AFrag (&ring)[PF + 1][MR], const h8 *__restrict__ a,
+__device__ __forceinline__ void seg_prefetch16(AFrag (&ring)[PF + 1][MR], const WStream &ws, int a,
                                                int rb_stride, int n_groups) {
 #pragma unroll
   for (int d = 0; d < PF; ++d)
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
-      const h8 *p = a + m * rb_stride + min(d, n_groups - 1) * 128;
-      ring[d][m].hi = p[0];
-      if (TERMS == 3) ring[d][m].lo = p[64];
+      const int p = a + m * rb_stride + min(d, n_groups - 1) * 128;
+      ring[d][m].hi = hload(ws, p);
+      if (TERMS == 3) ring[d][m].lo = hload(ws, p + 64);
     }
 }
 
@@ -78,7 +83,7 @@ __device__ __forceinline__ void seg_prefetch16(AFrag (&ring)[PF + 1][MR], const 
 // swz) << 4 with swz = hh ^ (p & 15), the lo slot sits LO bytes further.
 template <int MR, int NR, int PF, int ROWB, int LO_SLOT, int TERMS>
 __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[PF + 1][MR],
-                                           const h8 *__restrict__ a, int rb_stride, int n_groups,
+                                           const WStream &ws, int a, int rb_stride, int n_groups,
                                            const unsigned char *b, int swz) {
   constexpr int RS = PF + 1;
   // B operands are double-buffered too: the ds_reads of group g+1 are issued before the MFMAs of
@@ -97,9 +102,9 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
       const int gp = min(g + PF, n_groups - 1);
 #pragma unroll
       for (int m = 0; m < MR; ++m) {
-        const h8 *p = a + m * rb_stride + gp * 128;
-        ring[(r + PF) % RS][m].hi = p[0];
-        if (TERMS == 3) ring[(r + PF) % RS][m].lo = p[64];
+        const int p = a + m * rb_stride + gp * 128;
+        ring[(r + PF) % RS][m].hi = hload(ws, p);
+        if (TERMS == 3) ring[(r + PF) % RS][m].lo = hload(ws, p + 64);
       }
       const int gn = min(g + 1, n_groups - 1);
       const int boff = ((2 * gn) ^ swz) << 4;
@@ -155,11 +160,11 @@ __device__ __forceinline__ h8 widen(_Float16 v) {
 }
 
 template <int MR, int NR, int TERMS>
-__device__ __forceinline__ void gemm_z16(f32x16 (&acc)[MR][NR], const h8 *__restrict__ az,
+__device__ __forceinline__ void gemm_z16(f32x16 (&acc)[MR][NR], const WStream &ws, int az,
                                          const ZPair (&z)[NR]) {
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
-    const h8 ah = az[m * 128];
+    const h8 ah = hload(ws, az + m * 128);
 #pragma unroll
     for (int n = 0; n < NR; ++n) {
       const h8 zh = widen(z[n].hi);
@@ -167,16 +172,16 @@ __device__ __forceinline__ void gemm_z16(f32x16 (&acc)[MR][NR], const h8 *__rest
       if (TERMS >= 2)
         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, widen(z[n].lo), acc[m][n], 0, 0, 0);
       if (TERMS == 3)
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(az[m * 128 + 64], zh, acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hload(ws, az + m * 128 + 64), zh, acc[m][n], 0, 0, 0);
     }
   }
 }
 
-__device__ __forceinline__ void init_from_bias16(f32x16 &v, const float *__restrict__ bias32, int hh,
+__device__ __forceinline__ void init_from_bias16(f32x16 &v, const WStream &w32, int bias32,
                                                  float scale) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const f32x4 bq = *reinterpret_cast<const f32x4 *>(bias32 + 8 * q + 4 * hh);
+    const f32x4 bq = wload_bias4(w32, bias32 + 8 * q);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[4 * q + i] = bq[i] * scale;
   }
@@ -256,8 +261,9 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
   // ceil(n_f / tile) global tiles.  The owner of a global tile is looked up from the (device-side)
   // counts at the top of every iteration -- eight scalar loads -- instead of keeping a prefix
   // table alive in SGPRs across the whole MLP.
-  const float *wbase = mlp32.base;
-  const h8 *hbase = static_cast<const h8 *>(mlp.base);
+  const float *wbase = mlp32.base;  // last layer (VALU) only
+  const WStream w32 = make_wstream(mlp32.base, mlp32.n_floats, lane);        // biases
+  const WStream ws = make_wstream(static_cast<const float *>(mlp.base), mlp.n16 * 4, lane);  // f16 fragments
 
   for (long long gtile = blockIdx.x;; gtile += gridDim.x) {
     int fi = -1;
@@ -352,33 +358,33 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
     f32x16 acc1[4][NB];  // layer-1 rows [128 wv, +128) x all points: 256 accumulator registers at NB = 4
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      init_from_bias16(acc1[m][0], wbase + mlp32.bias[1] + 32 * (4 * wv + m), hh, mlp.scale[1]);
+      init_from_bias16(acc1[m][0], w32, mlp32.bias[1] + 32 * (4 * wv + m), mlp.scale[1]);
 #pragma unroll
       for (int n = 1; n < NB; ++n) acc1[m][n] = acc1[m][0];
     }
     {
-      const h8 *a0 = hbase + mlp.ax[0] + lane;  // [rb][g][part][lane]
+      const int a0 = mlp.ax[0];                 // [rb][g][part][lane]
       const int rs1 = (kHidden[0] / 16) * 128;  // row-block stride of layer 1's hidden segment
-      const h8 *a1 = hbase + mlp.ah[1] + (long long)(4 * wv) * rs1 + lane;
+      const int a1 = mlp.ah[1] + (4 * wv) * rs1;
       const float inv0 = 1.0f / mlp.scale[0];
       ZPair z0[NR0];
 #pragma unroll
       for (int n = 0; n < NR0; ++n) z0[n] = zc[NR0 * cp0 + n];
       AFrag ring0[4][1];
       f32x16 acc0[1][NR0];
-      seg_prefetch16<1, 3, TERMS>(ring0, a0 + (long long)rb0 * NGX * 128, 0, NGX);
-      init_from_bias16(acc0[0][0], wbase + mlp32.bias[0] + 32 * rb0, hh, mlp.scale[0]);
+      seg_prefetch16<1, 3, TERMS>(ring0, ws, a0 + rb0 * NGX * 128, 0, NGX);
+      init_from_bias16(acc0[0][0], w32, mlp32.bias[0] + 32 * rb0, mlp.scale[0]);
 #pragma unroll
       for (int n = 1; n < NR0; ++n) acc0[0][n] = acc0[0][0];
 #pragma unroll 1
       for (int ck = 0; ck < kHidden[0] / 64; ++ck) {
         // layer-0 rows [64 ck + 32 rb0, +32) x column blocks [NR0 cp0, +NR0)
         const int rb = 2 * ck + rb0;
-        seg_main16<1, NR0, 3, kXRow, 32, TERMS>(acc0, ring0, a0 + (long long)rb * NGX * 128, 0, NGX,
+        seg_main16<1, NR0, 3, kXRow, 32, TERMS>(acc0, ring0, ws, a0 + rb * NGX * 128, 0, NGX,
                                          xrow + (NR0 * cp0) * 32 * kXRow, swz);
         AFrag ring1[2][4];
-        seg_prefetch16<4, 1, TERMS>(ring1, a1 + ck * 4 * 128, rs1, 4);
-        gemm_z16<1, NR0, TERMS>(acc0, hbase + mlp.az[0] + rb * 128 + lane, z0);
+        seg_prefetch16<4, 1, TERMS>(ring1, ws, a1 + ck * 4 * 128, rs1, 4);
+        gemm_z16<1, NR0, TERMS>(acc0, ws, mlp.az[0] + rb * 128, z0);
 #pragma unroll
         for (int n = 0; n < NR0; ++n) {
           finish16(acc0[0][n], inv0);
@@ -386,20 +392,20 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
         }
         // next chunk's layer-0 operands stream in underneath the layer-1 MFMAs
         const int rbn = min(rb + 2, kHidden[0] / 32 - 2 + rb0);
-        seg_prefetch16<1, 3, TERMS>(ring0, a0 + (long long)rbn * NGX * 128, 0, NGX);
-        init_from_bias16(acc0[0][0], wbase + mlp32.bias[0] + 32 * rbn, hh, mlp.scale[0]);
+        seg_prefetch16<1, 3, TERMS>(ring0, ws, a0 + rbn * NGX * 128, 0, NGX);
+        init_from_bias16(acc0[0][0], w32, mlp32.bias[0] + 32 * rbn, mlp.scale[0]);
 #pragma unroll
         for (int n = 1; n < NR0; ++n) acc0[0][n] = acc0[0][0];
         __syncthreads();
-        seg_main16<4, NB, 1, kHRow, 8, TERMS>(acc1, ring1, a1 + ck * 4 * 128, rs1, 4, hrow, swz);
+        seg_main16<4, NB, 1, kHRow, 8, TERMS>(acc1, ring1, ws, a1 + ck * 4 * 128, rs1, 4, hrow, swz);
         __syncthreads();
       }
       // skip segment + z column of layer 1
-      const h8 *a1x = hbase + mlp.ax[1] + (long long)(4 * wv) * NGX * 128 + lane;
+      const int a1x = mlp.ax[1] + (4 * wv) * NGX * 128;
       AFrag ring1[2][4];
-      seg_prefetch16<4, 1, TERMS>(ring1, a1x, NGX * 128, NGX);
-      seg_main16<4, NB, 1, kXRow, 32, TERMS>(acc1, ring1, a1x, NGX * 128, NGX, xrow, swz);
-      gemm_z16<4, NB, TERMS>(acc1, hbase + mlp.az[1] + (4 * wv) * 128 + lane, zc);
+      seg_prefetch16<4, 1, TERMS>(ring1, ws, a1x, NGX * 128, NGX);
+      seg_main16<4, NB, 1, kXRow, 32, TERMS>(acc1, ring1, ws, a1x, NGX * 128, NGX, xrow, swz);
+      gemm_z16<4, NB, TERMS>(acc1, ws, mlp.az[1] + (4 * wv) * 128, zc);
       const float inv1 = 1.0f / mlp.scale[1];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -423,28 +429,28 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
     f32x16 acc2[2][NB];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      init_from_bias16(acc2[m][0], wbase + mlp32.bias[2] + 32 * (2 * wv + m), hh, mlp.scale[2]);
+      init_from_bias16(acc2[m][0], w32, mlp32.bias[2] + 32 * (2 * wv + m), mlp.scale[2]);
 #pragma unroll
       for (int n = 1; n < NB; ++n) acc2[m][n] = acc2[m][0];
     }
     {
       const int rs2 = (kHidden[1] / 16) * 128;
-      const h8 *a2 = hbase + mlp.ah[2] + (long long)(2 * wv) * rs2 + lane;
+      const int a2 = mlp.ah[2] + (2 * wv) * rs2;
       AFrag ring2[2][2];
-      seg_prefetch16<2, 1, TERMS>(ring2, a2, rs2, 4);
+      seg_prefetch16<2, 1, TERMS>(ring2, ws, a2, rs2, 4);
 #pragma unroll
       for (int ck = 0; ck < 8; ++ck) {
 #pragma unroll
         for (int n = 0; n < NB; ++n) store_hidden16_part(hb, acc1[ck >> 1][n], ck & 1, wv, n, j, hh);
         __syncthreads();
-        seg_main16<2, NB, 1, kHRow, 8, TERMS>(acc2, ring2, a2 + ck * 4 * 128, rs2, 4, hrow, swz);
-        if (ck < 7) seg_prefetch16<2, 1, TERMS>(ring2, a2 + (ck + 1) * 4 * 128, rs2, 4);
+        seg_main16<2, NB, 1, kHRow, 8, TERMS>(acc2, ring2, ws, a2 + ck * 4 * 128, rs2, 4, hrow, swz);
+        if (ck < 7) seg_prefetch16<2, 1, TERMS>(ring2, ws, a2 + (ck + 1) * 4 * 128, rs2, 4);
         __syncthreads();
       }
-      const h8 *a2x = hbase + mlp.ax[2] + (long long)(2 * wv) * NGX * 128 + lane;
-      seg_prefetch16<2, 1, TERMS>(ring2, a2x, NGX * 128, NGX);
-      seg_main16<2, NB, 1, kXRow, 32, TERMS>(acc2, ring2, a2x, NGX * 128, NGX, xrow, swz);
-      gemm_z16<2, NB, TERMS>(acc2, hbase + mlp.az[2] + (2 * wv) * 128 + lane, zc);
+      const int a2x = mlp.ax[2] + (2 * wv) * NGX * 128;
+      seg_prefetch16<2, 1, TERMS>(ring2, ws, a2x, NGX * 128, NGX);
+      seg_main16<2, NB, 1, kXRow, 32, TERMS>(acc2, ring2, ws, a2x, NGX * 128, NGX, xrow, swz);
+      gemm_z16<2, NB, TERMS>(acc2, ws, mlp.az[2] + (2 * wv) * 128, zc);
       const float inv2 = 1.0f / mlp.scale[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -466,26 +472,26 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
 #endif
     // ---------------- layer 3: rows [32 wv, +32) x 128 points ----------------
     f32x16 acc3[1][NB];
-    init_from_bias16(acc3[0][0], wbase + mlp32.bias[3] + 32 * wv, hh, mlp.scale[3]);
+    init_from_bias16(acc3[0][0], w32, mlp32.bias[3] + 32 * wv, mlp.scale[3]);
 #pragma unroll
     for (int n = 1; n < NB; ++n) acc3[0][n] = acc3[0][0];
     {
-      const h8 *a3 = hbase + mlp.ah[3] + (long long)wv * (kHidden[2] / 16) * 128 + lane;
+      const int a3 = mlp.ah[3] + wv * (kHidden[2] / 16) * 128;
       AFrag ring3[4][1];
-      seg_prefetch16<1, 3, TERMS>(ring3, a3, 0, 4);
+      seg_prefetch16<1, 3, TERMS>(ring3, ws, a3, 0, 4);
 #pragma unroll
       for (int ck = 0; ck < 4; ++ck) {
 #pragma unroll
         for (int n = 0; n < NB; ++n) store_hidden16_part(hb, acc2[ck >> 1][n], ck & 1, wv, n, j, hh);
         __syncthreads();
-        seg_main16<1, NB, 3, kHRow, 8, TERMS>(acc3, ring3, a3 + ck * 4 * 128, 0, 4, hrow, swz);
-        if (ck < 3) seg_prefetch16<1, 3, TERMS>(ring3, a3 + (ck + 1) * 4 * 128, 0, 4);
+        seg_main16<1, NB, 3, kHRow, 8, TERMS>(acc3, ring3, ws, a3 + ck * 4 * 128, 0, 4, hrow, swz);
+        if (ck < 3) seg_prefetch16<1, 3, TERMS>(ring3, ws, a3 + (ck + 1) * 4 * 128, 0, 4);
         __syncthreads();
       }
-      const h8 *a3x = hbase + mlp.ax[3] + (long long)wv * NGX * 128 + lane;
-      seg_prefetch16<1, 3, TERMS>(ring3, a3x, 0, NGX);
-      seg_main16<1, NB, 3, kXRow, 32, TERMS>(acc3, ring3, a3x, 0, NGX, xrow, swz);
-      gemm_z16<1, NB, TERMS>(acc3, hbase + mlp.az[3] + wv * 128 + lane, zc);
+      const int a3x = mlp.ax[3] + wv * NGX * 128;
+      seg_prefetch16<1, 3, TERMS>(ring3, ws, a3x, 0, NGX);
+      seg_main16<1, NB, 3, kXRow, 32, TERMS>(acc3, ring3, ws, a3x, 0, NGX, xrow, swz);
+      gemm_z16<1, NB, TERMS>(acc3, ws, mlp.az[3] + wv * 128, zc);
       const float inv3 = 1.0f / mlp.scale[3];
 #pragma unroll
       for (int n = 0; n < NB; ++n) finish16(acc3[0][n], inv3);

@@ -225,6 +225,32 @@ def query_counted(mlp, feat_hwc, points, count, calib, z_scale, out=None):
     return out
 
 
+def query_counted_batch(mlp, feats_hwc, points, counts, calibs, z_scale, outs=None):
+    """mp_query_counted_batch: one fused-query launch for up to 8 frames.  feats_hwc / points
+    ([3,cap] each, one cap) / counts (int32[1] each) / calibs: lists of per-frame device tensors
+    -> list of [Cout,cap]."""
+    ctx = mlp.ctx
+    n = len(feats_hwc)
+    h, w, c = feats_hwc[0].shape
+    cap = points[0].shape[1]
+    dev = feats_hwc[0].device
+    cals = [_calib_dev(cb, dev) for cb in calibs]
+    if outs is None:
+        outs = [torch.zeros((mlp.cout, cap), dtype=torch.float32, device=dev) for _ in range(n)]
+    for f, p in zip(feats_hwc, points):
+        assert f.shape == (h, w, c) and f.is_contiguous() and p.shape == (3, cap) and p.is_contiguous()
+    ptrs = ctypes.c_void_p * n
+    ctx.check(ctx.lib.mp_query_counted_batch(
+        ctx.handle, mlp.id, n, ptrs(*[f.data_ptr() for f in feats_hwc]), c, h, w,
+        ptrs(*[p.data_ptr() for p in points]), cap, ptrs(*[k.data_ptr() for k in counts]),
+        ptrs(*[cb.data_ptr() for cb in cals]), float(z_scale), ptrs(*[o.data_ptr() for o in outs]),
+        _stream(outs[0])), "mp_query_counted_batch")
+    stream = torch.cuda.current_stream(dev)
+    for t in cals:
+        t.record_stream(stream)
+    return outs
+
+
 def recon(mlp, feat_hwc, calib, z_scale, b_min, b_max, resolutions, balance=0.5, volume=None,
           status=None):
     """Coarse-to-fine occupancy volume (Seg3dLossless replacement).  Returns (volume [R,R,R]

@@ -62,7 +62,9 @@ class FrameSlot:
         self.n_active = b  # frames of the current submission (a stream's last batch may be short)
         if netC is not None:
             from .recon import color_matrix
-            self.feat_hwc_c = torch.empty((128, 128, 512), dtype=torch.float32, device=dev)
+            # one channels-last netC map per frame: the colour queries of the whole slot are one launch
+            self.feats_hwc_c = [torch.empty((128, 128, 512), dtype=torch.float32, device=dev)
+                                for _ in range(b)]
             self.mat_color = color_matrix(b_min, b_max, r)
             self.image_c = torch.zeros((b, 3, 512, 512), dtype=torch.float32, device=dev)
 
@@ -111,21 +113,29 @@ class FrameSlot:
             ops.recon_batch(mlp, self.feats_hwc[b0:b1], self.calib[b0:b1], Z_SCALE, self.b_min,
                             self.b_max, self.res, self.balance, volumes=self.volumes[b0:b1],
                             status=self.status[b0:b1])
+        pts_all = []
         for b in range(n):
-            fb = feat[b:b + 1]
-            calib = self.calib[b:b + 1]
             x, y, z, nrm, count = ops.forward_vertices_raw(self.volumes[b], "front")
             self.vertices[b] = (x, y, z, nrm, count)
             self.renders[b] = ops.paint(x, y, nrm, 0, count, r, 0.5, 0.5, 0.0, 1.0)
             if self.netC is not None:
                 # netC.filter(image_c, feat_prior=featG_last) -> cat([prior, featC])
-                # (MonoPortNet.py:41-45) packed straight into one channels-last map, then
-                # netC.query on the visible vertices (RTL/main.py:231-248)
-                ops.pack_features([fb, feat_c[b:b + 1]], out=self.feat_hwc_c)
-                pts = ops.vertex_points(x, y, z, count, r, self.mat_color)
-                preds = ops.query_counted(mlp_c, self.feat_hwc_c, pts, count, calib, Z_SCALE)
-                self.renders_tex[b] = ops.paint(x, y, preds, 1, count, r, 0.5, 0.5,
-                                                -np.inf, np.inf)
+                # (MonoPortNet.py:41-45) packed straight into one channels-last map per frame
+                ops.pack_features([feat[b:b + 1], feat_c[b:b + 1]], out=self.feats_hwc_c[b])
+                pts_all.append(ops.vertex_points(x, y, z, count, r, self.mat_color))
+        if self.netC is not None:
+            # netC.query on the visible vertices (RTL/main.py:231-248) of ALL frames of the slot:
+            # one fused-query launch per chunk of 8 frames (14 k points per frame alone would
+            # leave most CUs idle)
+            for b0 in range(0, n, MAX_RECON_BATCH):
+                b1 = min(b0 + MAX_RECON_BATCH, n)
+                preds = ops.query_counted_batch(
+                    mlp_c, self.feats_hwc_c[b0:b1], pts_all[b0:b1],
+                    [self.vertices[b][4] for b in range(b0, b1)], self.calib[b0:b1], Z_SCALE)
+                for b in range(b0, b1):
+                    x, y, _, _, count = self.vertices[b]
+                    self.renders_tex[b] = ops.paint(x, y, preds[b - b0], 1, count, r, 0.5, 0.5,
+                                                    -np.inf, np.inf)
 
     def prepare(self, warmup=2):
         """Warm up (MIOpen find, scratch arenas); with ``use_graph`` capture the ENCODER into a

@@ -126,6 +126,29 @@ def test_colorization_vs_reference(ops):
     assert np.abs(img_t.cpu().numpy() - g["tex_image"]).max() <= 1e-4
 
 
+def test_query_counted_batch_equals_per_frame_calls(ops):
+    """The colour queries of all frames of a slot in ONE launch (mp_query_counted_batch) give the
+    bits of one mp_query_counted per frame: different maps, calibrations and device-side counts
+    (including an empty frame)."""
+    mlp = ops.PackedMLP.from_layers(DEV, syn.rand_mlp("C", 61, 2.0), 2)
+    cap, counts_host = 5000, [4097, 0, 64, 5000, 1]
+    feats, pts, cnts, cals = [], [], [], []
+    for i, c in enumerate(counts_host):
+        feats.append(ops.pack_features(torch.from_numpy(syn.rand_feat(512, 128, 128, 70 + i))[None].to(DEV)))
+        pts.append(torch.from_numpy(syn.rand_points(cap, 80 + i, 1.0)).to(DEV).contiguous())
+        cnts.append(torch.tensor([c], dtype=torch.int32, device=DEV))
+        cal = np.eye(4, dtype=np.float32)[None]
+        cal[0, 0, 0] = 1.0 - 0.05 * i
+        cals.append(torch.from_numpy(cal).to(DEV))
+    outs = ops.query_counted_batch(mlp, feats, pts, cnts, cals, syn.Z_SCALE)
+    for i, c in enumerate(counts_host):
+        one = ops.query_counted(mlp, feats[i], pts[i], cnts[i], cals[i], syn.Z_SCALE)
+        assert torch.equal(outs[i], one), i
+        assert float(outs[i][:, c:].abs().max()) == 0.0 if c < cap else True
+        if c:
+            assert float(outs[i][:, :c].abs().max()) > 0.0
+
+
 def _sphere(r, radius=0.6, sharp=8.0):
     g = ((np.arange(r) + 0.5) / r) * 2 - 1
     z, y, x = np.meshgrid(g, g, g, indexing="ij")
