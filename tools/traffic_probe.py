@@ -6,7 +6,7 @@
 
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python tools/traffic_probe.py run
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python tools/traffic_probe.py run
-  python tools/traffic_probe.py parse gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01e_query_traffic.json
+  python tools/traffic_probe.py parse gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_query_traffic.json
 """
 import csv
 import glob
@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-BATCH, LEVELS = 4, 5
+BATCH, LEVELS = 5, 5  # bench.py default: --steps 20 -> 5 frames per slot submission / launch
 
 
 def run():
