@@ -263,6 +263,34 @@ int mp_upsample_bicubic2x(mp_ctx *ctx, const float *x, int c, int h, int w, cons
 int mp_concat3_add(mp_ctx *ctx, const float *a, int ca, const float *b, int cb, const float *c,
                    int cc, const float *shortcut, int n, int64_t hw, float *y, mp_stream stream);
 
+/* ---- encoder convolutions with fused GroupNorm (hand-written, f32 MFMA) ------------------------ */
+/* The pyramid block of the encoders is conv3x3(relu(GroupNorm(x))) three times
+ * (backbones/HGFilters.py:40-62).  mp_conv3x3_gn computes
+ *     y = conv3x3(v, W),  v = relu?(x * scale[n,c] + shift[n,c])  (v = x when ss == NULL),
+ * stride 1, zero padding 1 (applied to v), no bias -- nn.Conv2d(Cin, Cout, 3, 1, 1, bias=False) on
+ * the normalised tensor -- as an implicit GEMM on v_mfma_f32_32x32x2_f32, and optionally emits the
+ * partial sums the NEXT GroupNorm(32, Cout) needs.  x [N,Cin,H,W], y [N,Cout,H,W] contiguous NCHW;
+ * ss [N,Cin,2] = (scale, shift) from mp_gn_finalize; packed = W re-ordered by mp_conv3x3_pack
+ * (Cout*Cin*9 floats).  stats: NULL or double [N,32,S,2] with S = mp_conv3x3_stat_slices(Cout,H,W).
+ * Needs Cin % 16 == 0, Cout % 32 == 0, W a power of two >= 32; else MP_ERR_UNSUPPORTED. */
+int mp_conv3x3_pack(mp_ctx *ctx, const float *w /*[Cout,Cin,3,3]*/, int cout, int cin, float *packed,
+                    mp_stream stream);
+int mp_conv3x3_supported(int cin, int cout, int h, int w); /* 1 if the shape is built, else 0 */
+int mp_conv3x3_stat_slices(int cout, int h, int w);
+int mp_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss, int relu,
+                  const float *packed, int cout, float *y, double *stats, mp_stream stream);
+/* GroupNorm statistics as two steps.  mp_gn_stats: partial (sum, sum of squares) of x [N,C,HW] per
+ * (image, group, slice) -> double [N*groups, mp_gn_stat_slices(), 2] (one read pass; for tensors
+ * that do not come out of mp_conv3x3_gn).  mp_gn_finalize: partial sums (either source) -> ss [N,C,2] =
+ * (gamma rstd, beta - mean gamma rstd), biased variance over `count` elements per group, eps inside
+ * the square root (torch.nn.GroupNorm). */
+int mp_gn_stat_slices(void);
+int mp_gn_stats(mp_ctx *ctx, const float *x, int n, int c, int64_t hw, int groups, double *partial,
+                mp_stream stream);
+int mp_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int groups, int slices,
+                   int64_t count, const float *gamma, const float *beta, float eps, float *ss,
+                   mp_stream stream);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Brackets every fused-query kernel launch made through this context with a pair of HIP events
  * recorded on the launch stream (bench.py's roofline leg).  mp_profile_end waits for the last

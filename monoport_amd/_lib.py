@@ -62,6 +62,15 @@ SIGNATURES = {
     "mp_group_norm": (c_int, [c_vp, c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_f32, c_int, c_vp,
                               c_vp]),
     "mp_upsample_bicubic2x": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "mp_conv3x3_pack": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "mp_conv3x3_stat_slices": (c_int, [c_int, c_int, c_int]),
+    "mp_conv3x3_gn": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp,
+                              c_vp, c_vp]),
+    "mp_conv3x3_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "mp_gn_stat_slices": (c_int, []),
+    "mp_gn_stats": (c_int, [c_vp, c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp]),
+    "mp_gn_finalize": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp, c_f32, c_vp,
+                               c_vp]),
     "mp_profile_begin": (c_int, [c_vp, c_int]),
     "mp_profile_end": (c_int, [c_vp, _pf32, c_int, _pint]),
 }

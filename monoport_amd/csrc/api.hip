@@ -709,6 +709,61 @@ int mp_concat3_add(mp_ctx *ctx, const float *a, int ca, const float *b, int cb, 
   return launch_concat3_add(ctx, a, ca, b, cb, c, cc, shortcut, n, hw, y, (hipStream_t)stream);
 }
 
+int mp_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *packed, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!w || !packed || cout <= 0 || cin <= 0) return fail(ctx, MP_ERR_ARG, "mp_conv3x3_pack: bad argument");
+  if (cin % 16 || cout % 32)
+    return fail(ctx, MP_ERR_UNSUPPORTED, "mp_conv3x3_pack: needs Cin %% 16 == 0 and Cout %% 32 == 0");
+  DeviceGuard g(ctx->device);
+  return launch_conv3x3_pack(ctx, w, cout, cin, packed, (hipStream_t)stream);
+}
+
+int mp_conv3x3_supported(int cin, int cout, int h, int w) { return conv3x3_supported(cin, cout, h, w) ? 1 : 0; }
+
+int mp_gn_stat_slices(void) { return gn_stat_slices(); }
+
+int mp_conv3x3_stat_slices(int cout, int h, int w) {
+  if (cout < 32 || cout % 32 || h < 1 || w < 32) return 0;
+  return conv3x3_stat_slices(cout, h, w);
+}
+
+int mp_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss, int relu,
+                  const float *packed, int cout, float *y, double *stats, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!x || !packed || !y || n <= 0 || n > 65535 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0)
+    return fail(ctx, MP_ERR_ARG, "mp_conv3x3_gn: bad argument");
+  if (!aligned16(packed)) return fail(ctx, MP_ERR_ARG, "mp_conv3x3_gn: packed weights must be 16-byte aligned");
+  DeviceGuard g(ctx->device);
+  return launch_conv3x3_gn(ctx, x, n, cin, h, w, ss, relu, packed, cout, y, stats, (hipStream_t)stream);
+}
+
+int mp_gn_stats(mp_ctx *ctx, const float *x, int n, int c, int64_t hw, int groups, double *partial,
+                mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!x || !partial || n <= 0 || c <= 0 || hw <= 0 || groups <= 0)
+    return fail(ctx, MP_ERR_ARG, "mp_gn_stats: bad argument");
+  if (c % groups || hw % 4 || !aligned16(x))
+    return fail(ctx, MP_ERR_UNSUPPORTED, "mp_gn_stats: needs C %% groups == 0, HW %% 4 == 0, 16-byte aligned x");
+  DeviceGuard g(ctx->device);
+  return launch_gn_stats(ctx, x, n, c, hw, groups, partial, (hipStream_t)stream);
+}
+
+int mp_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int groups, int slices,
+                   int64_t count, const float *gamma, const float *beta, float eps, float *ss,
+                   mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!partial || !gamma || !beta || !ss || n <= 0 || c <= 0 || groups <= 0 || slices <= 0 ||
+      count <= 0 || c % groups || c / groups > 64)
+    return fail(ctx, MP_ERR_ARG, "mp_gn_finalize: bad argument");
+  DeviceGuard g(ctx->device);
+  return launch_gn_finalize(ctx, partial, n, c, groups, slices, (double)count, gamma, beta, eps, ss,
+                            (hipStream_t)stream);
+}
+
 int mp_profile_begin(mp_ctx *ctx, int max_records) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);

@@ -1,0 +1,369 @@
+// 3x3 convolutions of the image encoders on f32 MFMA, with the GroupNorm around them fused in
+// (backbones/HGFilters.py:40-62 ConvBlock, :87-111 HourGlass).
+//
+// The reference's pyramid block runs  conv(relu(GroupNorm(x)))  three times.  Under MIOpen that is,
+// per convolution, a statistics pass, a normalise+ReLU pass (read + write of the whole tensor) and
+// an fp32 Winograd kernel that reaches ~75 TFLOP/s direct-equivalent at these shapes.  Here:
+//   * ONE kernel per convolution: implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32, FMA chain
+//     per output like the fused MLP kernel), M = output channels, N = pixels, K = (tap, cin);
+//   * GroupNorm + ReLU are applied to the INPUT while it is staged into LDS:
+//     v = max(x * scale[n,c] + shift[n,c], 0), zero outside the image (the convolution pads the
+//     normalised tensor, HGFilters.py:15-19 padding=1);
+//   * the epilogue writes NCHW and, on request, the per-channel sum / sum of squares of the tile
+//     (f32 over <= 128 values, then double): the NEXT GroupNorm's statistics without another pass;
+//   * weights stream from L2 in MFMA fragment order through a buffer resource (conv3x3_pack_kernel),
+//     the activation tile is staged pixel-major, XOR-swizzled, double-buffered over 16-channel chunks.
+//
+// Decomposition: workgroup = 4 waves = (32 RBW) output channels x (32 NR 4/RBW) pixels; wave =
+// one 32-row block x NR column blocks of 32 consecutive pixels of one image row.
+//   Cout = 128: RBW = 4, NR = 4 (128-pixel tile);  Cout = 64: RBW = 2, NR = 4 (256 pixels);
+//   Cout = 32:  RBW = 1, NR = 2 (256 pixels).
+// Algorithmic work: 2 * 9 * Cin * Cout FLOP per output pixel; roofline = f32 MFMA (157.3 TFLOP/s).
+#include "mp_internal.h"
+#include "query_common.h"
+
+namespace mp {
+
+constexpr int kCK = 16;           // input channels per LDS chunk
+constexpr int kPixBytes = kCK * 4;  // 64 bytes per staged pixel
+constexpr int kMaxHalo = 520;     // (TH + 2) * (TW + 2) <= 4 * 130
+constexpr int kStageIters = (kMaxHalo + 63) / 64;  // 9
+
+struct ConvArgs {
+  const float *x;    // [N, Cin, H, W]
+  const float *ss;   // [N, Cin, 2] (scale, shift) of the fused GroupNorm, or nullptr: plain input
+  const float *wp;   // packed weights [Cout/32][Cin/16 * 18][64][4]
+  float *y;          // [N, Cout, H, W]
+  double *stats;     // nullptr or [N, 32, S, 2] partial (sum, sumsq), S = slots * (Cout/32)
+  int n_img, cin, cout, h, w;
+  int tw, th;        // tile width / height in pixels (th * tw = 32 * NR * CW)
+  int relu;          // apply ReLU to the (normalised) input
+  int wp_floats;     // size of wp
+};
+
+// W [Cout][Cin][3][3] -> fragment order: group kg = (chunk * 9 + tap) * 2 + g holds, for lane
+// (r = lane & 31, hh = lane >> 5), the 4 weights W[32 rb + r][16 chunk + 8 g + 4 hh + i][tap].
+__global__ void conv3x3_pack_kernel(const float *__restrict__ w, int cout, int cin,
+                                    float *__restrict__ wp) {
+  const long long total = (long long)cout * cin * 9;
+  const int kgt = (cin / kCK) * 18;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t & 3), lane = (int)((t >> 2) & 63);
+    const long long q = t >> 8;
+    const int kg = (int)(q % kgt), rb = (int)(q / kgt);
+    const int g = kg & 1, tap = (kg >> 1) % 9, chunk = (kg >> 1) / 9;
+    const int co = 32 * rb + (lane & 31);
+    const int ci = kCK * chunk + 8 * g + 4 * (lane >> 5) + i;
+    wp[t] = w[((long long)co * cin + ci) * 9 + tap];
+  }
+}
+
+template <int RBW, int NR>
+__global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(ConvArgs p) {
+  constexpr int CW = 4 / RBW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int rbi = wv % RBW, cwi = wv / RBW;
+
+  const int TW = p.tw, TH = p.th, PW = TW + 2;
+  const int NPH = (TH + 2) * PW;          // staged pixels (tile + halo)
+  const int buf_bytes = NPH * kPixBytes;
+  const int tiles_x = p.w / TW, tiles = tiles_x * (p.h / TH);
+  const int tile = blockIdx.x % tiles, img = blockIdx.x / tiles;
+  const int y0 = (tile / tiles_x) * TH, x0 = (tile % tiles_x) * TW;
+  const int rb = blockIdx.y * RBW + rbi;  // 32-row block of output channels
+  const int hw = p.h * p.w;
+  const int n_chunks = p.cin / kCK;
+  const int kgt = n_chunks * 18;          // K groups (8 deep) in total
+
+  const WStream ws = make_wstream(p.wp, p.wp_floats, lane);
+
+  // ---- staging plan: wave wv stages channels 4 wv .. 4 wv + 3 of every chunk, lane = pixel ----
+  int goff[kStageIters];  // offset inside a channel plane, -1 = outside the image / the halo
+#pragma unroll
+  for (int it = 0; it < kStageIters; ++it) {
+    const int lp = lane + 64 * it;
+    const int r = lp / PW, c = lp - r * PW;
+    const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+    const bool ok = lp < NPH && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+    goff[it] = ok ? gy * p.w + gx : -1;
+  }
+  const float *xin = p.x + (long long)img * p.cin * hw;
+  const float *ssn = p.ss ? p.ss + (long long)img * p.cin * 2 : nullptr;
+
+  f32x4 stg[kStageIters];
+  auto stage_load = [&](int chunk) {
+    const float *pl = xin + (long long)(chunk * kCK + 4 * wv) * hw;
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+      const int o = goff[it] < 0 ? 0 : goff[it];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) stg[it][k] = pl[(long long)k * hw + o];
+    }
+  };
+  auto stage_store = [&](int chunk, unsigned char *buf) {
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ssn) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sc[k] = ssn[2 * (chunk * kCK + 4 * wv + k)];
+        sh[k] = ssn[2 * (chunk * kCK + 4 * wv + k) + 1];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+      const int lp = lane + 64 * it;
+      if (lp < NPH) {
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float t = fmaf(stg[it][k], sc[k], sh[k]);
+          if (p.relu) t = fmaxf(t, 0.0f);
+          v[k] = goff[it] < 0 ? 0.0f : t;
+        }
+        *reinterpret_cast<f32x4 *>(buf + lp * kPixBytes + ((wv ^ ((lp >> 2) & 3)) << 4)) = v;
+      }
+    }
+  };
+
+  // ---- this wave's output pixels: column block n = 32 consecutive pixels of one tile row ----
+  int lpc[NR];  // linear halo-pixel index of this lane's pixel, per column block
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
+    const int cb = cwi * NR + n;
+    const int ty = (32 * cb) / TW, tx = (32 * cb) - ty * TW;
+    lpc[n] = (ty + 1) * PW + tx + j + 1;
+  }
+
+  f32x16 acc[NR];
+#pragma unroll
+  for (int n = 0; n < NR; ++n)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[n][t] = 0.0f;
+
+  // A ring: 6 fragments = the 3 taps x 2 groups of one kernel row; slot k is refilled with the
+  // same slot of the NEXT row-step right after its MFMAs were issued (prefetch distance 6 groups)
+  const int a_base = rb * kgt * 64;
+  f32x4 ring[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ring[k] = wload128(ws, a_base + min(k, kgt - 1) * 64);
+
+  stage_load(0);
+  stage_store(0, smem);
+  __syncthreads();
+
+  int kg0 = 0;  // first K group of the current row-step
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    const unsigned char *buf = smem + (chunk & 1) * buf_bytes;
+    const bool more = chunk + 1 < n_chunks;
+    if (more) stage_load(chunk + 1);  // lands under this chunk's 72 NR MFMAs
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+      const int row_off = (ky - 1) * PW;
+      // B operand of the first group of this row-step
+      f32x4 bcur[NR];
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        const int lp = lpc[n] + row_off - 1;
+        bcur[n] = *reinterpret_cast<const f32x4 *>(buf + lp * kPixBytes + ((h ^ ((lp >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {  // s = 2 * kx + g
+        // next group's B operand (the first group of the next row-step is read at its top)
+        f32x4 bnxt[NR];
+        if (s < 5) {
+          const int sn = s + 1;
+#pragma unroll
+          for (int n = 0; n < NR; ++n) {
+            const int lp = lpc[n] + row_off + (sn >> 1) - 1;
+            bnxt[n] = *reinterpret_cast<const f32x4 *>(
+                buf + lp * kPixBytes + (((2 * (sn & 1) + h) ^ ((lp >> 2) & 3)) << 4));
+          }
+        }
+        const f32x4 a = ring[s];
+        ring[s] = wload128(ws, a_base + min(kg0 + 6 + s, kgt - 1) * 64);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above the MFMAs (see query.hip)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int n = 0; n < NR; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[n][i], acc[n], 0, 0, 0);
+        if (s < 5) {
+#pragma unroll
+          for (int n = 0; n < NR; ++n) bcur[n] = bnxt[n];
+        }
+      }
+      kg0 += 6;
+    }
+    if (more) stage_store(chunk + 1, smem + ((chunk + 1) & 1) * buf_bytes);
+    __syncthreads();
+  }
+
+  // ---- epilogue: NCHW store + per-channel statistics of this wave's 32 x (32 NR) tile ----
+  float *yb = p.y + ((long long)img * p.cout + 32 * rb) * hw;
+  float s1[16], s2[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) s1[t] = s2[t] = 0.0f;
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
+    const int cb = cwi * NR + n;
+    const int ty = (32 * cb) / TW, tx = (32 * cb) - ty * TW;
+    float *row = yb + (long long)(y0 + ty) * p.w + x0 + tx + j;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int r = (t & 3) + 8 * (t >> 2) + 4 * h;
+      const float v = acc[n][t];
+      row[(long long)r * hw] = v;
+      s1[t] += v;
+      s2[t] = fmaf(v, v, s2[t]);
+    }
+  }
+  if (p.stats) {
+    // sum over the 32 lanes that share h (the pixels); lanes j == 0 then hold the row sums
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        s1[t] += __shfl_xor(s1[t], o);
+        s2[t] += __shfl_xor(s2[t], o);
+      }
+    }
+    if (j == 0) {
+      const int cpg = p.cout / 32;                 // channels per GroupNorm(32, Cout) group
+      const int slots = tiles * CW;
+      const int S = slots * cpg;
+      const int slot = tile * CW + cwi;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int co = 32 * rb + (t & 3) + 8 * (t >> 2) + 4 * h;
+        const int grp = co / cpg, s = slot * cpg + (co - grp * cpg);
+        double *dst = p.stats + (((long long)img * 32 + grp) * S + s) * 2;
+        dst[0] = (double)s1[t];
+        dst[1] = (double)s2[t];
+      }
+    }
+  }
+}
+
+// (scale, shift) of GroupNorm(groups, C) from partial sums: ss[n][c] = (gamma[c] rstd,
+// beta[c] - mean gamma[c] rstd).  One wave per (image, group); partial [(n*groups + g)*S + s][2].
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const double *__restrict__ partial, int groups,
+                                                         int slices, double count, int cpg,
+                                                         const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, float eps,
+                                                         float *__restrict__ ss) {
+  const int g = blockIdx.x % groups, n = blockIdx.x / groups;
+  const double *pp = partial + (long long)blockIdx.x * slices * 2;
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < slices; i += 64) {
+    a += pp[2 * i];
+    b += pp[2 * i + 1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+  }
+  const double mean_d = a / count;
+  const double var_d = fmax(b / count - mean_d * mean_d, 0.0);
+  const float mean = (float)mean_d;
+  const float rstd = (float)(1.0 / sqrt(var_d + (double)eps));
+  if ((int)threadIdx.x < cpg) {
+    const int c = g * cpg + threadIdx.x;
+    const float sc = rstd * gamma[c];
+    float *o = ss + ((long long)n * groups * cpg + c) * 2;
+    o[0] = sc;
+    o[1] = beta[c] - mean * sc;
+  }
+}
+
+int launch_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *wp, hipStream_t st) {
+  const long long total = (long long)cout * cin * 9;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, cout, cin, wp);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+// Tile shape of the kernel instantiation that serves `cout`: pixels per workgroup and the number
+// of statistics slots per image.
+static void conv_shape(int cout, int h, int w, int &rbw, int &px, int &tw, int &th, int &slots) {
+  rbw = cout % 128 == 0 ? 4 : cout % 64 == 0 ? 2 : 1;
+  px = rbw == 4 ? 128 : 256;
+  tw = w < 128 ? w : 128;
+  th = px / tw;
+  slots = (h / th) * (w / tw) * (4 / rbw);
+}
+
+int conv3x3_stat_slices(int cout, int h, int w) {
+  int rbw, px, tw, th, slots;
+  conv_shape(cout, h, w, rbw, px, tw, th, slots);
+  return slots * (cout / 32);
+}
+
+bool conv3x3_supported(int cin, int cout, int h, int w) {
+  if (cin % kCK || cout % 32 || cin < kCK || cout < 32 || w < 32 || (w & (w - 1)) || h < 1) return false;
+  int rbw, px, tw, th, slots;
+  conv_shape(cout, h, w, rbw, px, tw, th, slots);
+  return th >= 1 && h % th == 0 && w % tw == 0 && (th + 2) * (tw + 2) <= kMaxHalo;
+}
+
+template <int RBW, int NR>
+static int launch_conv_t(mp_ctx *ctx, const ConvArgs &a, int tiles, hipStream_t st) {
+  const int lds = 2 * (a.th + 2) * (a.tw + 2) * kPixBytes;
+  auto kern = conv3x3_gn_kernel<RBW, NR>;
+  const void *kern_id = reinterpret_cast<const void *>(kern);
+  if (!ctx->lds_attr_done.count(kern_id)) {
+    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * kMaxHalo * kPixBytes));
+    ctx->lds_attr_done.insert(kern_id);
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * a.n_img), (unsigned)(a.cout / (32 * RBW))), dim3(256),
+                     lds, st, a);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss,
+                      int relu, const float *wp, int cout, float *y, double *stats, hipStream_t st) {
+  if (!conv3x3_supported(cin, cout, h, w))
+    return fail(ctx, MP_ERR_UNSUPPORTED,
+                "conv3x3: needs Cin %% 16 == 0, Cout %% 32 == 0, W a power of two >= 32 (got %d -> %d at %dx%d)",
+                cin, cout, h, w);
+  ConvArgs a;
+  a.x = x;
+  a.ss = ss;
+  a.wp = wp;
+  a.y = y;
+  a.stats = stats;
+  a.n_img = n;
+  a.cin = cin;
+  a.cout = cout;
+  a.h = h;
+  a.w = w;
+  a.relu = relu;
+  a.wp_floats = cout * cin * 9;
+  int rbw, px, slots;
+  conv_shape(cout, h, w, rbw, px, a.tw, a.th, slots);
+  const int tiles = (h / a.th) * (w / a.tw);
+  if (rbw == 4) return launch_conv_t<4, 4>(ctx, a, tiles, st);
+  if (rbw == 2) return launch_conv_t<2, 4>(ctx, a, tiles, st);
+  return launch_conv_t<1, 2>(ctx, a, tiles, st);
+}
+
+int launch_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int groups, int slices,
+                       double count, const float *gamma, const float *beta, float eps, float *ss,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(n * groups)), dim3(64), 0, st, partial, groups,
+                     slices, count, c / groups, gamma, beta, eps, ss);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+}  // namespace mp

@@ -99,6 +99,17 @@ __global__ __launch_bounds__(kGnThreads) void gn_apply_kernel(
   }
 }
 
+int gn_stat_slices() { return kGnSlices; }
+
+int launch_gn_stats(mp_ctx *ctx, const float *x, int n, int c, long long hw, int groups,
+                    double *partial, hipStream_t st) {
+  const long long ge = (long long)(c / groups) * hw;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(n * groups * kGnSlices), dim3(kGnThreads), 0, st, x, ge,
+                     partial);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
 size_t gn_scratch_bytes(int groups) { return (size_t)groups * kGnSlices * 2 * sizeof(double); }
 
 int launch_group_norm(mp_ctx *ctx, void *scratch, const float *x, int n, int c, long long hw,

@@ -198,7 +198,19 @@ int launch_marching_cubes(mp_ctx *ctx, void *scratch, const float *vol, int r, f
                           const float *bmin, const float *bmax, float *verts, long long max_v,
                           int32_t *faces, long long max_f, int32_t *counts, hipStream_t st);
 
+// conv3x3.hip
+int launch_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *wp, hipStream_t st);
+int conv3x3_stat_slices(int cout, int h, int w);
+bool conv3x3_supported(int cin, int cout, int h, int w);
+int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss,
+                      int relu, const float *wp, int cout, float *y, double *stats, hipStream_t st);
+int launch_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int groups, int slices,
+                       double count, const float *gamma, const float *beta, float eps, float *ss,
+                       hipStream_t st);
 // encoder_ops.hip
+int gn_stat_slices();
+int launch_gn_stats(mp_ctx *ctx, const float *x, int n, int c, long long hw, int groups,
+                    double *partial, hipStream_t st);
 size_t gn_scratch_bytes(int groups);
 int launch_group_norm(mp_ctx *ctx, void *scratch, const float *x, int n, int c, long long hw,
                       int groups, const float *gamma, const float *beta, float eps, int relu,

@@ -16,7 +16,12 @@ import torch.nn.functional as F
 
 from .. import ops
 
+import os
+
 _GROUPS = 32  # GroupNorm(32, C) everywhere (HGFilters.py:23-27, ResBlkFilters.py:19)
+# "hip" (default): the pyramid blocks' GroupNorm -> ReLU -> conv3x3 chains run as the fused f32-MFMA
+# kernels of csrc/conv3x3.hip; "miopen": stock convolutions + the stand-alone GroupNorm kernel
+ENCODER_CONV = os.environ.get("MONOPORT_ENCODER_CONV", "hip")
 
 
 class _GroupNorm(nn.GroupNorm):
@@ -86,7 +91,49 @@ class ConvBlock(nn.Module):
         else:
             self.downsample = None
 
+    def _packed(self, conv):
+        """conv's weight in MFMA fragment order, re-packed when the parameter changes."""
+        cache = self.__dict__.setdefault("_packed_cache", {})
+        w = conv.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.PackedConv3x3(w))
+            cache[id(conv)] = hit
+        return hit[1]
+
+    def _fused_ok(self, x):
+        if self.training or ENCODER_CONV != "hip" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+            return False
+        h, w = x.shape[2], x.shape[3]
+        return ((h * w) % 4 == 0 and all(ops.conv3x3_supported(c.in_channels, c.out_channels, h, w)
+                                         for c in (self.conv1, self.conv2, self.conv3)))
+
+    def _forward_fused(self, x):
+        """GroupNorm -> ReLU -> conv3x3, three times, as three kernels: the normalisation is
+        applied while the input tile is staged, each convolution's epilogue leaves the partial
+        sums the next GroupNorm needs (csrc/conv3x3.hip); only bn1 needs a statistics pass of
+        its own (its input comes from another block)."""
+        x = x.contiguous()
+        n, c_in, h, w = x.shape
+        hw = h * w
+        ss = ops.gn_finalize(ops.gn_stats(x, _GROUPS), n, c_in, _GROUPS, (c_in // _GROUPS) * hw,
+                             self.bn1.weight, self.bn1.bias, self.bn1.eps)
+        a, st = ops.conv3x3_gn(x, ss, self._packed(self.conv1), relu=True, want_stats=True)
+        ca = a.shape[1]
+        ss = ops.gn_finalize(st, n, ca, _GROUPS, (ca // _GROUPS) * hw, self.bn2.weight, self.bn2.bias,
+                             self.bn2.eps)
+        b, st = ops.conv3x3_gn(a, ss, self._packed(self.conv2), relu=True, want_stats=True)
+        cb = b.shape[1]
+        ss = ops.gn_finalize(st, n, cb, _GROUPS, (cb // _GROUPS) * hw, self.bn3.weight, self.bn3.bias,
+                             self.bn3.eps)
+        c, _ = ops.conv3x3_gn(b, ss, self._packed(self.conv3), relu=True, want_stats=False)
+        shortcut = x if self.downsample is None else _run_sequential(self.downsample, x)
+        return ops.concat3_add(a, b, c, shortcut)
+
     def forward(self, x):
+        if self._fused_ok(x):
+            return self._forward_fused(x)
         a = self.conv1(self.bn1(x, relu=True))
         b = self.conv2(self.bn2(a, relu=True))
         c = self.conv3(self.bn3(b, relu=True))

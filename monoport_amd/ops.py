@@ -592,6 +592,70 @@ def concat3_add(a, b, c, shortcut):
     return y
 
 
+class PackedConv3x3:
+    """nn.Conv2d(Cin, Cout, 3, 1, 1, bias=False) weights in the MFMA fragment order of
+    csrc/conv3x3.hip (mp_conv3x3_pack)."""
+
+    def __init__(self, weight):
+        w = _f32c(weight.detach())
+        self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
+        if tuple(w.shape[2:]) != (3, 3):
+            raise ValueError("PackedConv3x3 wants a [Cout,Cin,3,3] weight, got %s" % (tuple(w.shape),))
+        ctx = get_context(w.device)
+        self.data = torch.empty((w.numel(),), dtype=torch.float32, device=w.device)
+        ctx.check(ctx.lib.mp_conv3x3_pack(ctx.handle, _ptr(w), self.cout, self.cin, _ptr(self.data),
+                                          _stream(w)), "mp_conv3x3_pack")
+        w.record_stream(torch.cuda.current_stream(w.device))
+
+
+def conv3x3_supported(cin, cout, h, w):
+    """True if csrc/conv3x3.hip is built for this shape (mp_conv3x3_supported)."""
+    return bool(_lib.load().mp_conv3x3_supported(int(cin), int(cout), int(h), int(w)))
+
+
+def conv3x3_gn(x, ss, packed, relu=True, want_stats=False):
+    """y = conv3x3(relu?(x * scale + shift)) (stride 1, zero padding 1, no bias) as one f32-MFMA
+    kernel; ``ss`` [N,Cin,2] from ``gn_finalize`` or None (plain x).  Returns (y, stats) where
+    stats = (partial sums double [N,32,S,2], S) of GroupNorm(32, Cout) over y, or None."""
+    ctx = get_context(x.device)
+    n, cin, h, w = x.shape
+    if cin != packed.cin:
+        raise ValueError("conv3x3_gn: input has %d channels, weights expect %d" % (cin, packed.cin))
+    y = torch.empty((n, packed.cout, h, w), dtype=torch.float32, device=x.device)
+    stats = None
+    if want_stats:
+        s = ctx.lib.mp_conv3x3_stat_slices(packed.cout, h, w)
+        stats = (torch.empty((n, 32, s, 2), dtype=torch.float64, device=x.device), s)
+    ctx.check(ctx.lib.mp_conv3x3_gn(ctx.handle, _ptr(x), n, cin, h, w,
+                                    _ptr(ss) if ss is not None else None, int(bool(relu)),
+                                    _ptr(packed.data), packed.cout, _ptr(y),
+                                    _ptr(stats[0]) if stats else None, _stream(x)), "mp_conv3x3_gn")
+    return y, stats
+
+
+def gn_stats(x, groups):
+    """One read pass over x [N,C,H,W]: (partial sums double [N*groups, S, 2], S)."""
+    ctx = get_context(x.device)
+    n, c = x.shape[0], x.shape[1]
+    hw = x.shape[2] * x.shape[3]
+    s = ctx.lib.mp_gn_stat_slices()
+    partial = torch.empty((n * groups, s, 2), dtype=torch.float64, device=x.device)
+    ctx.check(ctx.lib.mp_gn_stats(ctx.handle, _ptr(x), n, c, hw, int(groups), _ptr(partial),
+                                  _stream(x)), "mp_gn_stats")
+    return partial, s
+
+
+def gn_finalize(stats, n, c, groups, count, weight, bias, eps):
+    """Partial sums -> ss [N,C,2] = (gamma rstd, beta - mean gamma rstd) of GroupNorm(groups, C)."""
+    partial, slices = stats
+    ctx = get_context(partial.device)
+    ss = torch.empty((n, c, 2), dtype=torch.float32, device=partial.device)
+    ctx.check(ctx.lib.mp_gn_finalize(ctx.handle, _ptr(partial), n, c, int(groups), int(slices),
+                                     int(count), _ptr(weight), _ptr(bias), float(eps), _ptr(ss),
+                                     _stream(partial)), "mp_gn_finalize")
+    return ss
+
+
 def profile_begin(device, max_records=4096):
     """Start bracketing fused-query launches on ``device`` with HIP events (bench.py roofline)."""
     ctx = get_context(device)

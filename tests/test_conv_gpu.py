@@ -1,0 +1,124 @@
+"""csrc/conv3x3.hip (fused GroupNorm -> ReLU -> conv3x3 on f32 MFMA) against the stock PyTorch ops
+it replaces inside the encoders' pyramid blocks (backbones/HGFilters.py:40-62).  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from monoport_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+DEV = "cuda:0"
+
+# (N, Cin, Cout, H, W): the shapes the hourglass encoder uses, each kernel instantiation
+# (Cout 128 / 64 / 32) and tile shape (W = 128 / 64 / 32 / 256)
+SHAPES = [(2, 256, 128, 128, 128), (1, 128, 64, 128, 128), (1, 64, 64, 128, 128), (3, 128, 64, 64, 64),
+          (2, 256, 128, 32, 32), (1, 64, 32, 256, 256), (2, 32, 32, 64, 64), (1, 128, 128, 64, 64),
+          (1, 64, 64, 32, 32), (1, 16, 32, 32, 32)]
+
+
+def _ref_conv(x, gn, w):
+    with torch.no_grad():
+        v = torch.relu(gn(x)) if gn is not None else x
+        # fp64 on the GPU: an order-independent reference for the 9 * Cin-term sums
+        return torch.nn.functional.conv2d(v.double(), w.double(), padding=1)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", SHAPES)
+def test_conv3x3_gn_matches_torch(n, cin, cout, h, w):
+    from monoport_amd import ops
+    g = torch.Generator().manual_seed(n * 1000 + cin + cout + h)
+    x = (torch.randn((n, cin, h, w), generator=g) * 2 + 0.3).to(DEV)
+    wt = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).to(DEV)
+    assert ops.conv3x3_supported(cin, cout, h, w)
+    packed = ops.PackedConv3x3(wt)
+    gn = None
+    if cin % 32 == 0:
+        gn = torch.nn.GroupNorm(32, cin).to(DEV)
+        with torch.no_grad():
+            gn.weight.uniform_(0.5, 1.5)
+            gn.bias.uniform_(-0.5, 0.5)
+        ss = ops.gn_finalize(ops.gn_stats(x, 32), n, cin, 32, (cin // 32) * h * w, gn.weight, gn.bias, gn.eps)
+        # (scale, shift) against GroupNorm's definition
+        xg = x.double().reshape(n, 32, -1)
+        mean, var = xg.mean(2), xg.var(2, unbiased=False)
+        rstd = 1.0 / torch.sqrt(var + gn.eps)
+        sc = (rstd[:, :, None] * gn.weight.double().reshape(1, 32, -1)).reshape(n, cin)
+        sh = gn.bias.double()[None] - (mean[:, :, None].expand(-1, -1, cin // 32).reshape(n, cin)) * sc
+        assert (ss[..., 0].double() - sc).abs().max().item() <= 1e-5
+        assert (ss[..., 1].double() - sh).abs().max().item() <= 1e-5
+    else:
+        ss = None
+    y, stats = ops.conv3x3_gn(x, ss, packed, relu=gn is not None, want_stats=True)
+    ref = _ref_conv(x, gn, wt)
+    err = (y.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    print("conv %s: max|d| %.3g (max|ref| %.3g)" % ((n, cin, cout, h, w), err, scale))
+    assert y.shape == ref.shape and err <= 2e-5 * max(1.0, scale)
+    # epilogue statistics -> the NEXT GroupNorm's scale / shift
+    gn2 = torch.nn.GroupNorm(32, cout).to(DEV)
+    with torch.no_grad():
+        gn2.weight.uniform_(0.5, 1.5)
+        gn2.bias.uniform_(-0.5, 0.5)
+    ss2 = ops.gn_finalize(stats, n, cout, 32, (cout // 32) * h * w, gn2.weight, gn2.bias, gn2.eps)
+    ss2_ref = ops.gn_finalize(ops.gn_stats(y, 32), n, cout, 32, (cout // 32) * h * w, gn2.weight, gn2.bias,
+                              gn2.eps)
+    assert (ss2 - ss2_ref).abs().max().item() <= 2e-5
+    with torch.no_grad():
+        want = torch.relu(gn2(y))
+    got = torch.relu(y * ss2[..., 0, None, None] + ss2[..., 1, None, None])
+    assert (got - want).abs().max().item() <= 5e-5
+
+
+def test_conv3x3_rejects_unsupported_shapes():
+    from monoport_amd import ops
+    from monoport_amd._lib import MonoportError
+    assert not ops.conv3x3_supported(3, 64, 512, 512)     # Cin % 16
+    assert not ops.conv3x3_supported(64, 48, 64, 64)      # Cout % 32
+    assert not ops.conv3x3_supported(64, 64, 24, 24)      # W not a power of two >= 32
+    x = torch.zeros((1, 64, 24, 24), device=DEV)
+    packed = ops.PackedConv3x3(torch.zeros((64, 64, 3, 3), device=DEV))
+    with pytest.raises(MonoportError):
+        ops.conv3x3_gn(x, None, packed)
+
+
+def test_convblock_fused_equals_unfused_module(monkeypatch):
+    """The pyramid block on the fused kernels vs the same module on MIOpen convolutions + the
+    stand-alone GroupNorm kernel."""
+    from monoport_amd.modeling import backbones
+    for c_in, c_out, hw, n in ((256, 256, 128, 2), (128, 256, 64, 1), (64, 128, 256, 1), (256, 256, 32, 3)):
+        blk = backbones.ConvBlock(c_in, c_out)
+        shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+        blk.load_state_dict({k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, 5).items()})
+        blk.to(DEV).eval()
+        x = torch.randn((n, c_in, hw, hw), generator=torch.Generator().manual_seed(c_in + hw)).to(DEV)
+        with torch.no_grad():
+            monkeypatch.setattr(backbones, "ENCODER_CONV", "hip")
+            assert blk._fused_ok(x)
+            fused = blk(x)
+            monkeypatch.setattr(backbones, "ENCODER_CONV", "miopen")
+            assert not blk._fused_ok(x)
+            plain = blk(x)
+        err = (fused - plain).abs().max().item()
+        print("ConvBlock(%d,%d)@%d: |fused - miopen| %.3g (max %.3g)" % (c_in, c_out, hw, err, plain.abs().max().item()))
+        assert err <= 1e-4 * max(1.0, plain.abs().max().item())
+
+
+def test_encoder_with_fused_convs_vs_reference_golden():
+    """The whole hourglass encoder on the fused kernels against the REFERENCE's CPU run of the
+    same seeded weights (fixture G0-G3), and against the MIOpen path."""
+    from monoport_amd.modeling import PIFuNetG, backbones
+    assert backbones.ENCODER_CONV == "hip"
+    g = load_golden("encoders")
+    net = PIFuNetG().eval()
+    shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
+    net.image_filter.load_state_dict(
+        {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, 71).items()})
+    net.image_filter.to(DEV)
+    img = torch.from_numpy(syn.synthetic_image(73))[None].to(DEV)
+    with torch.no_grad():
+        fg = net.filter(img)
+    for i in range(4):
+        err = float(np.abs(fg[i][0][0, ::8, ::8, ::8].cpu().numpy() - g["G%d" % i]).max())
+        print("HGFilter stack %d on fused convs vs reference: %.3g" % (i, err))
+        assert err <= 1e-4
