@@ -723,10 +723,12 @@ int mp_conv3x3_supported(int cin, int cout, int h, int w) { return conv3x3_suppo
 
 int mp_gn_stat_slices(void) { return gn_stat_slices(); }
 
-int mp_conv3x3_stat_slices(int cout, int h, int w) {
-  if (cout < 32 || cout % 32 || h < 1 || w < 32) return 0;
-  return conv3x3_stat_slices(cout, h, w);
+int mp_conv3x3_stat_slices(int cout, int n, int h, int w) {
+  if (cout < 32 || cout % 32 || n < 1 || h < 1 || w < 32) return 0;
+  return conv3x3_stat_slices(cout, n, h, w);
 }
+
+void mp_conv3x3_tune(int nr) { conv3x3_set_nr(nr); }
 
 int mp_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss, int relu,
                   const float *packed, int cout, float *y, double *stats, mp_stream stream) {

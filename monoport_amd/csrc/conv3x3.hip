@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(ConvArgs p) {
   const float *ssn = p.ss ? p.ss + (long long)img * p.cin * 2 : nullptr;
 
   f32x4 stg[kStageIters];
+  float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};  // wave-uniform (SGPRs)
   auto stage_load = [&](int chunk) {
     const float *pl = xin + (long long)(chunk * kCK + 4 * wv) * hw;
 #pragma unroll
@@ -105,9 +106,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(ConvArgs p) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) stg[it][k] = pl[(long long)k * hw + o];
     }
-  };
-  auto stage_store = [&](int chunk, unsigned char *buf) {
-    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (ssn) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -115,6 +113,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(ConvArgs p) {
         sh[k] = ssn[2 * (chunk * kCK + 4 * wv + k) + 1];
       }
     }
+  };
+  auto stage_store = [&](unsigned char *buf) {
 #pragma unroll
     for (int it = 0; it < kStageIters; ++it) {
       const int lp = lane + 64 * it;
@@ -154,15 +154,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(ConvArgs p) {
   for (int k = 0; k < 6; ++k) ring[k] = wload128(ws, a_base + min(k, kgt - 1) * 64);
 
   stage_load(0);
-  stage_store(0, smem);
+  stage_store(smem);
   __syncthreads();
 
   int kg0 = 0;  // first K group of the current row-step
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     const unsigned char *buf = smem + (chunk & 1) * buf_bytes;
     const bool more = chunk + 1 < n_chunks;
-    if (more) stage_load(chunk + 1);  // lands under this chunk's 72 NR MFMAs
-#pragma unroll 1
+    // the three kernel rows are unrolled so that every s_waitcnt vmcnt is counted for its own
+    // position: the next chunk's activations are requested at the END of row 0 -- the weight
+    // fragments row 1 waits for are older, and by row 2 they have had a whole row-step to land
+#pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int row_off = (ky - 1) * PW;
       // B operand of the first group of this row-step
@@ -199,8 +201,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(ConvArgs p) {
         }
       }
       kg0 += 6;
+      if (ky == 0 && more) stage_load(chunk + 1);
     }
-    if (more) stage_store(chunk + 1, smem + ((chunk + 1) & 1) * buf_bytes);
+    if (more) stage_store(smem + ((chunk + 1) & 1) * buf_bytes);
     __syncthreads();
   }
 
@@ -291,27 +294,41 @@ int launch_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *w
   return MP_OK;
 }
 
-// Tile shape of the kernel instantiation that serves `cout`: pixels per workgroup and the number
-// of statistics slots per image.
-static void conv_shape(int cout, int h, int w, int &rbw, int &px, int &tw, int &th, int &slots) {
+// Tile shape of the kernel instantiation that serves `cout`: RBW waves split the output channels
+// (32 each), the other 4 / RBW split the pixels; NR = 32-pixel column blocks per wave.  Smaller NR
+// = more, smaller workgroups (better balance over 256 CUs x 2 slots, more weight re-streaming).
+static int g_conv_nr = 0;  // 0 = heuristic; tools/conv_probe.py overrides it for A/B runs
+
+void conv3x3_set_nr(int nr) { g_conv_nr = nr; }
+
+static void conv_shape(int cout, int n, int h, int w, int &rbw, int &nr, int &tw, int &th, int &slots) {
   rbw = cout % 128 == 0 ? 4 : cout % 64 == 0 ? 2 : 1;
-  px = rbw == 4 ? 128 : 256;
+  const int cw = 4 / rbw;
+  nr = rbw == 1 ? 2 : 4;
+  if (g_conv_nr > 0) {
+    nr = g_conv_nr;
+  } else {
+    // halve the tile while the launch has fewer than ~3 workgroups per slot (512 slots)
+    while (nr > 1 && (long long)n * h * w / (32 * nr * cw) * (cout / (32 * rbw)) < 1024) nr >>= 1;
+  }
+  if (rbw == 1 && nr > 2) nr = 2;
+  const int px = 32 * nr * cw;
   tw = w < 128 ? w : 128;
+  if (tw > px) tw = px;
   th = px / tw;
-  slots = (h / th) * (w / tw) * (4 / rbw);
+  slots = (h / th) * (w / tw) * cw;
 }
 
-int conv3x3_stat_slices(int cout, int h, int w) {
-  int rbw, px, tw, th, slots;
-  conv_shape(cout, h, w, rbw, px, tw, th, slots);
+int conv3x3_stat_slices(int cout, int n, int h, int w) {
+  int rbw, nr, tw, th, slots;
+  conv_shape(cout, n, h, w, rbw, nr, tw, th, slots);
   return slots * (cout / 32);
 }
 
 bool conv3x3_supported(int cin, int cout, int h, int w) {
-  if (cin % kCK || cout % 32 || cin < kCK || cout < 32 || w < 32 || (w & (w - 1)) || h < 1) return false;
-  int rbw, px, tw, th, slots;
-  conv_shape(cout, h, w, rbw, px, tw, th, slots);
-  return th >= 1 && h % th == 0 && w % tw == 0 && (th + 2) * (tw + 2) <= kMaxHalo;
+  if (cin % kCK || cout % 32 || cin < kCK || cout < 32 || w < 32 || (w & (w - 1)) || h < 8 || (h & (h - 1)))
+    return false;
+  return true;
 }
 
 template <int RBW, int NR>
@@ -334,7 +351,7 @@ int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w,
                       int relu, const float *wp, int cout, float *y, double *stats, hipStream_t st) {
   if (!conv3x3_supported(cin, cout, h, w))
     return fail(ctx, MP_ERR_UNSUPPORTED,
-                "conv3x3: needs Cin %% 16 == 0, Cout %% 32 == 0, W a power of two >= 32 (got %d -> %d at %dx%d)",
+                "conv3x3: needs Cin %% 16 == 0, Cout %% 32 == 0, H and W powers of two (W >= 32, H >= 8); got %d -> %d at %dx%d",
                 cin, cout, h, w);
   ConvArgs a;
   a.x = x;
@@ -349,12 +366,23 @@ int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w,
   a.w = w;
   a.relu = relu;
   a.wp_floats = cout * cin * 9;
-  int rbw, px, slots;
-  conv_shape(cout, h, w, rbw, px, a.tw, a.th, slots);
+  int rbw, nr, slots;
+  conv_shape(cout, n, h, w, rbw, nr, a.tw, a.th, slots);
+  if (a.th > h || (a.th + 2) * (a.tw + 2) > kMaxHalo)
+    return fail(ctx, MP_ERR_UNSUPPORTED, "conv3x3: %dx%d map too small for a %dx%d tile", h, w, a.th, a.tw);
   const int tiles = (h / a.th) * (w / a.tw);
-  if (rbw == 4) return launch_conv_t<4, 4>(ctx, a, tiles, st);
-  if (rbw == 2) return launch_conv_t<2, 4>(ctx, a, tiles, st);
-  return launch_conv_t<1, 2>(ctx, a, tiles, st);
+#define MP_CONV_CASE(R, N) \
+  if (rbw == R && nr == N) return launch_conv_t<R, N>(ctx, a, tiles, st);
+  MP_CONV_CASE(4, 4)
+  MP_CONV_CASE(4, 2)
+  MP_CONV_CASE(4, 1)
+  MP_CONV_CASE(2, 4)
+  MP_CONV_CASE(2, 2)
+  MP_CONV_CASE(2, 1)
+  MP_CONV_CASE(1, 2)
+  MP_CONV_CASE(1, 1)
+#undef MP_CONV_CASE
+  return fail(ctx, MP_ERR_UNSUPPORTED, "conv3x3: no instantiation for rbw %d nr %d", rbw, nr);
 }
 
 int launch_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int groups, int slices,

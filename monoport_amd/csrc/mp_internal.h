@@ -200,7 +200,8 @@ int launch_marching_cubes(mp_ctx *ctx, void *scratch, const float *vol, int r, f
 
 // conv3x3.hip
 int launch_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *wp, hipStream_t st);
-int conv3x3_stat_slices(int cout, int h, int w);
+int conv3x3_stat_slices(int cout, int n, int h, int w);
+void conv3x3_set_nr(int nr);
 bool conv3x3_supported(int cin, int cout, int h, int w);
 int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss,
                       int relu, const float *wp, int cout, float *y, double *stats, hipStream_t st);

@@ -22,6 +22,9 @@ _GROUPS = 32  # GroupNorm(32, C) everywhere (HGFilters.py:23-27, ResBlkFilters.p
 # "hip" (default): the pyramid blocks' GroupNorm -> ReLU -> conv3x3 chains run as the fused f32-MFMA
 # kernels of csrc/conv3x3.hip; "miopen": stock convolutions + the stand-alone GroupNorm kernel
 ENCODER_CONV = os.environ.get("MONOPORT_ENCODER_CONV", "hip")
+# ... on feature maps of at least this height: below it a batch of a few frames cannot fill 256 CUs
+# with 128-pixel tiles and MIOpen's kernels win (tools/conv_probe.py)
+ENCODER_CONV_MIN_H = int(os.environ.get("MONOPORT_ENCODER_CONV_MIN_H", "128"))
 
 
 class _GroupNorm(nn.GroupNorm):
@@ -106,7 +109,7 @@ class ConvBlock(nn.Module):
         if self.training or ENCODER_CONV != "hip" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
             return False
         h, w = x.shape[2], x.shape[3]
-        return ((h * w) % 4 == 0 and all(ops.conv3x3_supported(c.in_channels, c.out_channels, h, w)
+        return (h >= ENCODER_CONV_MIN_H and (h * w) % 4 == 0 and all(ops.conv3x3_supported(c.in_channels, c.out_channels, h, w)
                                          for c in (self.conv1, self.conv2, self.conv3)))
 
     def _forward_fused(self, x):

@@ -624,7 +624,7 @@ def conv3x3_gn(x, ss, packed, relu=True, want_stats=False):
     y = torch.empty((n, packed.cout, h, w), dtype=torch.float32, device=x.device)
     stats = None
     if want_stats:
-        s = ctx.lib.mp_conv3x3_stat_slices(packed.cout, h, w)
+        s = ctx.lib.mp_conv3x3_stat_slices(packed.cout, n, h, w)
         stats = (torch.empty((n, 32, s, 2), dtype=torch.float64, device=x.device), s)
     ctx.check(ctx.lib.mp_conv3x3_gn(ctx.handle, _ptr(x), n, cin, h, w,
                                     _ptr(ss) if ss is not None else None, int(bool(relu)),

@@ -94,6 +94,7 @@ def test_convblock_fused_equals_unfused_module(monkeypatch):
         x = torch.randn((n, c_in, hw, hw), generator=torch.Generator().manual_seed(c_in + hw)).to(DEV)
         with torch.no_grad():
             monkeypatch.setattr(backbones, "ENCODER_CONV", "hip")
+            monkeypatch.setattr(backbones, "ENCODER_CONV_MIN_H", 32)
             assert blk._fused_ok(x)
             fused = blk(x)
             monkeypatch.setattr(backbones, "ENCODER_CONV", "miopen")
