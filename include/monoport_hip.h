@@ -282,6 +282,16 @@ int mp_conv3x3_stat_slices(int cout, int n, int h, int w);
 void mp_conv3x3_tune(int nr);
 int mp_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss, int relu,
                   const float *packed, int cout, float *y, double *stats, mp_stream stream);
+/* The same convolution on split-f16 operands ("f16x3": every operand hi + lo, three
+ * v_mfma_f32_32x32x16_f16 per product term, f32 accumulation; f32-class accuracy, the arithmetic of
+ * MP_PREC_F16X3).  mp_conv3x3_pack16 writes the pre-split weights (Cout*Cin*9*4 bytes) and
+ * max|W| (device float[1], from which pack and convolution derive the same power-of-two operand
+ * scale); fully asynchronous. */
+int mp_conv3x3_pack16(mp_ctx *ctx, const float *w, int cout, int cin, void *packed16, float *wmax,
+                      mp_stream stream);
+int mp_conv3x3_gn16(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss, int relu,
+                    const void *packed16, const float *wmax, int cout, float *y, double *stats,
+                    mp_stream stream);
 /* GroupNorm statistics as two steps.  mp_gn_stats: partial (sum, sum of squares) of x [N,C,HW] per
  * (image, group, slice) -> double [N*groups, mp_gn_stat_slices(), 2] (one read pass; for tensors
  * that do not come out of mp_conv3x3_gn).  mp_gn_finalize: partial sums (either source) -> ss [N,C,2] =

@@ -719,6 +719,31 @@ int mp_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *packe
   return launch_conv3x3_pack(ctx, w, cout, cin, packed, (hipStream_t)stream);
 }
 
+int mp_conv3x3_pack16(mp_ctx *ctx, const float *w, int cout, int cin, void *packed16, float *wmax,
+                      mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!w || !packed16 || !wmax || cout <= 0 || cin <= 0)
+    return fail(ctx, MP_ERR_ARG, "mp_conv3x3_pack16: bad argument");
+  if (cin % 16 || cout % 32)
+    return fail(ctx, MP_ERR_UNSUPPORTED, "mp_conv3x3_pack16: needs Cin %% 16 == 0 and Cout %% 32 == 0");
+  DeviceGuard g(ctx->device);
+  return launch_conv3x3_pack16(ctx, w, cout, cin, packed16, wmax, (hipStream_t)stream);
+}
+
+int mp_conv3x3_gn16(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss, int relu,
+                    const void *packed16, const float *wmax, int cout, float *y, double *stats,
+                    mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!x || !packed16 || !wmax || !y || n <= 0 || n > 65535 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0)
+    return fail(ctx, MP_ERR_ARG, "mp_conv3x3_gn16: bad argument");
+  if (!aligned16(packed16)) return fail(ctx, MP_ERR_ARG, "mp_conv3x3_gn16: packed weights must be 16-byte aligned");
+  DeviceGuard g(ctx->device);
+  return launch_conv3x3_gn(ctx, x, n, cin, h, w, ss, relu, static_cast<const float *>(packed16), wmax, cout,
+                           y, stats, (hipStream_t)stream);
+}
+
 int mp_conv3x3_supported(int cin, int cout, int h, int w) { return conv3x3_supported(cin, cout, h, w) ? 1 : 0; }
 
 int mp_gn_stat_slices(void) { return gn_stat_slices(); }
@@ -738,7 +763,8 @@ int mp_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, con
     return fail(ctx, MP_ERR_ARG, "mp_conv3x3_gn: bad argument");
   if (!aligned16(packed)) return fail(ctx, MP_ERR_ARG, "mp_conv3x3_gn: packed weights must be 16-byte aligned");
   DeviceGuard g(ctx->device);
-  return launch_conv3x3_gn(ctx, x, n, cin, h, w, ss, relu, packed, cout, y, stats, (hipStream_t)stream);
+  return launch_conv3x3_gn(ctx, x, n, cin, h, w, ss, relu, packed, nullptr, cout, y, stats,
+                           (hipStream_t)stream);
 }
 
 int mp_gn_stats(mp_ctx *ctx, const float *x, int n, int c, int64_t hw, int groups, double *partial,

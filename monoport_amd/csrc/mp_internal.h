@@ -203,8 +203,11 @@ int launch_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *w
 int conv3x3_stat_slices(int cout, int n, int h, int w);
 void conv3x3_set_nr(int nr);
 bool conv3x3_supported(int cin, int cout, int h, int w);
+int launch_conv3x3_pack16(mp_ctx *ctx, const float *w, int cout, int cin, void *wp, float *wmax,
+                          hipStream_t st);
 int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss,
-                      int relu, const float *wp, int cout, float *y, double *stats, hipStream_t st);
+                      int relu, const float *wp, const float *wmax16, int cout, float *y,
+                      double *stats, hipStream_t st);
 int launch_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int groups, int slices,
                        double count, const float *gamma, const float *beta, float eps, float *ss,
                        hipStream_t st);

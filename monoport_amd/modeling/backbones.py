@@ -25,6 +25,19 @@ ENCODER_CONV = os.environ.get("MONOPORT_ENCODER_CONV", "hip")
 # ... on feature maps of at least this height: below it a batch of a few frames cannot fill 256 CUs
 # with 128-pixel tiles and MIOpen's kernels win (tools/conv_probe.py)
 ENCODER_CONV_MIN_H = int(os.environ.get("MONOPORT_ENCODER_CONV_MIN_H", "128"))
+# arithmetic of those kernels: "f32" (exact f32 MFMA) or "f16x3" (f32 emulated on f16 MFMA: every
+# operand split into two halves, three MFMAs per product term, f32 accumulation -- the encoder-side
+# counterpart of SurfaceClassifier.set_precision("f16x3"))
+ENCODER_CONV_PRECISION = os.environ.get("MONOPORT_ENCODER_CONV_PRECISION", "f32")
+
+
+def set_encoder_conv_precision(precision):
+    """Process-wide switch for the fused 3x3 convolutions ("f32" / "f16x3"); takes effect on the
+    next forward (captured hipGraphs must be re-captured: FrameSlot.prepare())."""
+    global ENCODER_CONV_PRECISION
+    if precision not in ("f32", "f16x3"):
+        raise ValueError("encoder conv precision must be 'f32' or 'f16x3'")
+    ENCODER_CONV_PRECISION = precision
 
 
 class _GroupNorm(nn.GroupNorm):
@@ -98,10 +111,10 @@ class ConvBlock(nn.Module):
         """conv's weight in MFMA fragment order, re-packed when the parameter changes."""
         cache = self.__dict__.setdefault("_packed_cache", {})
         w = conv.weight
-        key = (w.data_ptr(), w._version, str(w.device))
+        key = (w.data_ptr(), w._version, str(w.device), ENCODER_CONV_PRECISION)
         hit = cache.get(id(conv))
         if hit is None or hit[0] != key:
-            hit = (key, ops.PackedConv3x3(w))
+            hit = (key, ops.PackedConv3x3(w, ENCODER_CONV_PRECISION))
             cache[id(conv)] = hit
         return hit[1]
 
@@ -109,7 +122,8 @@ class ConvBlock(nn.Module):
         if self.training or ENCODER_CONV != "hip" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
             return False
         h, w = x.shape[2], x.shape[3]
-        return (h >= ENCODER_CONV_MIN_H and (h * w) % 4 == 0 and all(ops.conv3x3_supported(c.in_channels, c.out_channels, h, w)
+        min_h = ENCODER_CONV_MIN_H if ENCODER_CONV_PRECISION == "f32" else min(ENCODER_CONV_MIN_H, 32)
+        return (h >= min_h and (h * w) % 4 == 0 and all(ops.conv3x3_supported(c.in_channels, c.out_channels, h, w)
                                          for c in (self.conv1, self.conv2, self.conv3)))
 
     def _forward_fused(self, x):

@@ -70,6 +70,52 @@ def test_conv3x3_gn_matches_torch(n, cin, cout, h, w):
     assert (got - want).abs().max().item() <= 5e-5
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", SHAPES[:8])
+def test_conv3x3_f16x3_is_f32_class(n, cin, cout, h, w):
+    """The split-f16 variant (three f16 MFMAs per product, f32 accumulation) against the fp64
+    reference: held to the SAME bound as the exact-f32 kernel."""
+    from monoport_amd import ops
+    g = torch.Generator().manual_seed(n * 1000 + cin + cout + h)
+    x = (torch.randn((n, cin, h, w), generator=g) * 2 + 0.3).to(DEV)
+    wt = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).to(DEV)
+    gn = torch.nn.GroupNorm(32, cin).to(DEV) if cin % 32 == 0 else None
+    ss = None
+    if gn is not None:
+        with torch.no_grad():
+            gn.weight.uniform_(0.5, 1.5)
+            gn.bias.uniform_(-0.5, 0.5)
+        ss = ops.gn_finalize(ops.gn_stats(x, 32), n, cin, 32, (cin // 32) * h * w, gn.weight, gn.bias, gn.eps)
+    y16, st16 = ops.conv3x3_gn(x, ss, ops.PackedConv3x3(wt, "f16x3"), relu=gn is not None, want_stats=True)
+    y32, st32 = ops.conv3x3_gn(x, ss, ops.PackedConv3x3(wt, "f32"), relu=gn is not None, want_stats=True)
+    ref = _ref_conv(x, gn, wt)
+    e16 = (y16.double() - ref).abs().max().item()
+    e32 = (y32.double() - ref).abs().max().item()
+    print("conv f16x3 %s: |f16x3 - f64| %.3g, |f32 - f64| %.3g, |f16x3 - f32| %.3g"
+          % ((n, cin, cout, h, w), e16, e32, (y16 - y32).abs().max().item()))
+    assert e16 <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert (st16[0] - st32[0]).abs().max().item() <= 1e-2  # sums over 128 values of O(1) numbers
+
+
+def test_encoder_f16x3_convs_vs_reference_golden(monkeypatch):
+    """The whole hourglass encoder with every pyramid-block convolution on the split-f16 kernels
+    (all map sizes) against the REFERENCE's CPU output: the same 1e-4 bar as fp32."""
+    from monoport_amd.modeling import PIFuNetG, backbones
+    monkeypatch.setattr(backbones, "ENCODER_CONV_PRECISION", "f16x3")
+    g = load_golden("encoders")
+    net = PIFuNetG().eval()
+    shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
+    net.image_filter.load_state_dict(
+        {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, 71).items()})
+    net.image_filter.to(DEV)
+    img = torch.from_numpy(syn.synthetic_image(73))[None].to(DEV)
+    with torch.no_grad():
+        fg = net.filter(img)
+    for i in range(4):
+        err = float(np.abs(fg[i][0][0, ::8, ::8, ::8].cpu().numpy() - g["G%d" % i]).max())
+        print("HGFilter stack %d on f16x3 convs vs reference: %.3g" % (i, err))
+        assert err <= 1e-4
+
+
 def test_conv3x3_rejects_unsupported_shapes():
     from monoport_amd import ops
     from monoport_amd._lib import MonoportError

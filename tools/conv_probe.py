@@ -46,15 +46,23 @@ with torch.no_grad():
             t_nr[nr] = timed(lambda: ops.conv3x3_gn(x, ss, packed, relu=True, want_stats=True))
         lib.mp_conv3x3_tune(0)
         t_hip = timed(lambda: ops.conv3x3_gn(x, ss, packed, relu=True, want_stats=True))
+        packed16 = ops.PackedConv3x3(w, "f16x3")
+        t16 = {}
+        for nr in (4, 2, 1, 0):
+            lib.mp_conv3x3_tune(nr)
+            t16[nr] = timed(lambda: ops.conv3x3_gn(x, ss, packed16, relu=True, want_stats=True))
+        tot_16 = globals().get("tot_16", 0.0) + t16[0] * count / B
+        globals()["tot_16"] = tot_16
         v = ops.group_norm(x, 32, gn.weight, gn.bias, gn.eps, relu=True)
         t_mi = timed(lambda: F.conv2d(v, w, padding=1))
         t_gn = timed(lambda: ops.group_norm(x, 32, gn.weight, gn.bias, gn.eps, relu=True))
         gf = 2.0 * 9 * cin * cout * hw * hw * B / 1e9
-        print("   NR 4/2/1: %.3f / %.3f / %.3f ms" % (t_nr[4], t_nr[2], t_nr[1]))
+        print("   NR 4/2/1: %.3f / %.3f / %.3f ms | f16x3 NR 4/2/1/auto: %.3f / %.3f / %.3f / %.3f ms = %.0f TFLOP/s-eq"
+              % (t_nr[4], t_nr[2], t_nr[1], t16[4], t16[2], t16[1], t16[0], 2.0 * 9 * cin * cout * hw * hw * B / 1e9 / t16[0]))
         print("%4d -> %3d @ %3d^2 x%d: hip %.3f ms = %6.1f TFLOP/s | MIOpen %.3f ms = %6.1f TFLOP/s (+ GroupNorm "
               "pass %.3f ms) | x%d per frame" % (cin, cout, hw, B, t_hip, gf / t_hip, t_mi, gf / t_mi, t_gn, count))
         tot_h += t_hip * count / B
         tot_m += (t_mi + t_gn) * count / B
         tot_f += gf * count / B
-print("per frame, all 3x3 convolutions (%.1f GFLOP): hip %.3f ms (%.1f TFLOP/s) | MIOpen + GroupNorm passes %.3f ms"
-      % (tot_f, tot_h, tot_f / tot_h, tot_m))
+print("per frame, all 3x3 convolutions (%.1f GFLOP): hip f32 %.3f ms (%.1f TFLOP/s) | hip f16x3 %.3f ms | MIOpen + GroupNorm "
+      "passes %.3f ms" % (tot_f, tot_h, tot_f / tot_h, globals().get("tot_16", 0.0), tot_m))
