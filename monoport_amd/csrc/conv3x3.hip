@@ -3,7 +3,7 @@
 //
 // The reference's pyramid block runs  conv(relu(GroupNorm(x)))  three times.  Under MIOpen that is,
 // per convolution, a statistics pass, a normalise+ReLU pass (read + write of the whole tensor) and
-// an fp32 Winograd kernel that reaches ~75 TFLOP/s direct-equivalent at these shapes.  Here:
+// an fp32 Winograd kernel (100-115 TFLOP/s direct-equivalent on the 128^2 maps, 20-60 on the small ones).  Here:
 //   * ONE kernel per convolution: implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32, FMA chain
 //     per output like the fused MLP kernel), M = output channels, N = pixels, K = (tap, cin);
 //   * GroupNorm + ReLU are applied to the INPUT while it is staged into LDS:
@@ -16,8 +16,8 @@
 //
 // Decomposition: workgroup = 4 waves = (32 RBW) output channels x (32 NR 4/RBW) pixels; wave =
 // one 32-row block x NR column blocks of 32 consecutive pixels of one image row.
-//   Cout = 128: RBW = 4, NR = 4 (128-pixel tile);  Cout = 64: RBW = 2, NR = 4 (256 pixels);
-//   Cout = 32:  RBW = 1, NR = 2 (256 pixels).
+//   Cout = 128: RBW = 4 (64 / 32-pixel tiles);  Cout = 64: RBW = 2 (128 / 64 pixels);
+//   Cout = 32:  RBW = 1 (256 / 128 pixels);  NR = 2, or 1 when the launch would be too small.
 // Algorithmic work: 2 * 9 * Cin * Cout FLOP per output pixel; roofline = f32 MFMA (157.3 TFLOP/s).
 #include "mp_internal.h"
 #include "query_common.h"
@@ -559,14 +559,13 @@ void conv3x3_set_nr(int nr) { g_conv_nr = nr; }
 static void conv_shape(int cout, int n, int h, int w, int &rbw, int &nr, int &tw, int &th, int &slots) {
   rbw = cout % 128 == 0 ? 4 : cout % 64 == 0 ? 2 : 1;
   const int cw = 4 / rbw;
-  nr = rbw == 1 ? 2 : 4;
-  if (g_conv_nr > 0) {
-    nr = g_conv_nr;
-  } else {
-    // halve the tile while the launch has fewer than ~3 workgroups per slot (512 slots)
-    while (nr > 1 && (long long)n * h * w / (32 * nr * cw) * (cout / (32 * rbw)) < 1024) nr >>= 1;
-  }
-  if (rbw == 1 && nr > 2) nr = 2;
+  // NR = 2 unless that leaves fewer than 2 workgroups per slot (512 slots); NR = 4 needs all 256
+  // VGPRs (spills) and measured slower at every shape, so it is not built
+  nr = 2;
+  if (g_conv_nr > 0)
+    nr = g_conv_nr > 2 ? 2 : g_conv_nr;
+  else if ((long long)n * h * w / (32 * nr * cw) * (cout / (32 * rbw)) < 1024)
+    nr = 1;
   const int px = 32 * nr * cw;
   tw = w < 128 ? w : 128;
   if (tw > px) tw = px;
@@ -661,10 +660,8 @@ int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w,
 #define MP_CONV_CASE(R, N)                                                                   \
   if (rbw == R && nr == N)                                                                   \
     return wmax16 ? launch_conv16_t<R, N>(ctx, a, wmax16, tiles, st) : launch_conv_t<R, N>(ctx, a, tiles, st);
-  MP_CONV_CASE(4, 4)
   MP_CONV_CASE(4, 2)
   MP_CONV_CASE(4, 1)
-  MP_CONV_CASE(2, 4)
   MP_CONV_CASE(2, 2)
   MP_CONV_CASE(2, 1)
   MP_CONV_CASE(1, 2)

@@ -74,6 +74,33 @@ def test_dense64_with_gpu_encoder_in_the_loop():
     assert fe <= 1e-4 and err.max() <= TOL_REF
 
 
+def test_dense64_all_f16x3_encoder_in_the_loop(monkeypatch):
+    """The complete opt-in f16x3 path -- the encoder's pyramid-block convolutions AND the MLP on
+    split-f16 MFMA -- against the reference's fp32 CPU run of image -> netG.filter -> netG.query
+    on the dense 64^3 grid: the north star's 1e-4 on the SDF holds."""
+    from monoport_amd.modeling import PIFuNetG, backbones
+    monkeypatch.setattr(backbones, "ENCODER_CONV_PRECISION", "f16x3")
+    g = load_golden("dense64")
+    net = PIFuNetG().eval()
+    _load_mlp(net, syn.rand_mlp("G", 91, 2.0))
+    net.surface_classifier.set_precision("f16x3")
+    shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
+    net.image_filter.load_state_dict(
+        {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, 71).items()})
+    net.to(DEV)
+    img = torch.from_numpy(syn.synthetic_image(74))[None].to(DEV)
+    with torch.no_grad():
+        feats = net.filter(img)
+    fe = float(np.abs(feats[-1][0][0, ::8, ::8, ::8].cpu().numpy() - g["enc_feat_slice"]).max())
+    pts = torch.from_numpy(dense_lattice(64))[None].to(DEV)
+    out = net.query(feats, pts, calibs=torch.from_numpy(g["calib"]).to(DEV))[0][0, 0].cpu().numpy()
+    err = np.abs(out - g["out_enc"])
+    print("f16x3 encoder convs + f16x3 MLP: max|feat - reference feat| = %.3g; SDF max %.3g, mean %.3g"
+          % (fe, err.max(), err.mean()))
+    assert np.array_equal(out == 0, g["out_enc"] == 0)
+    assert fe <= 1e-4 and err.max() <= TOL_REF
+
+
 def test_pipeline257_vs_reference():
     """BASELINE configs[1] size through the drop-in surface (RTL/main.py:169-195, :389-406):
     Seg3dLossless(17..257) + forward_vertices vs the reference's netG.query / forward_vertices run
