@@ -361,7 +361,7 @@ def main():
                    for _ in range(args.depth)]
     status_log = []
 
-    def run_batch(s0, s1, log):
+    def run_batch(pipe, s0, s1, log):
         """Frames s0 .. s1-1 (at most `batch`) as one slot submission."""
         slot = pipe.submit([images[s % len(images)] for s in range(s0, s1)],
                            [calibs[s] for s in range(s0, s1)])
@@ -380,24 +380,24 @@ def main():
             if log:
                 status_log.append(slot.status[:s1 - s0].clone())  # device-side copy, no sync
 
-    def timed_pass(log):
+    def timed_pass(pipe, log):
         """Warm-up batches, then EXACTLY --steps frames between barrier + synchronize pairs."""
         for s0 in range(0, n_warm, batch):
-            run_batch(s0, min(s0 + batch, n_warm), False)
+            run_batch(pipe, s0, min(s0 + batch, n_warm), False)
         pipe.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
         for s0 in range(n_warm, n_frames, batch):
-            run_batch(s0, min(s0 + batch, n_frames), log)
+            run_batch(pipe, s0, min(s0 + batch, n_frames), log)
         pipe.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         return time.perf_counter() - t0
 
-    elapsed = timed_pass(True)
+    elapsed = timed_pass(pipe, True)
 
     # informational second pass (N=1 only, never `value`): the same frames with the MLP on the
     # f32-accurate f16x3 kernel, plus the largest difference between the two volumes of one frame
@@ -405,20 +405,19 @@ def main():
     if world == 1 and args.precision == "f32" and not args.no_alt and not args.with_color:
         last_slot = pipe.slots[(pipe.n_submitted - 1) % len(pipe.slots)]
         vol_f32 = last_slot.volumes[last_slot.n_active - 1].clone()
-        head = pipe.slots[0].net.surface_classifier
-        set_precision_everywhere(head, "f16x3")
-        head.packed()  # re-pack now, on this stream, and drain before the slots' streams use it
-        torch.cuda.synchronize()
-        pipe.prepare()  # re-pack the encoder's convolution weights and re-capture its hipGraphs
-        alt_elapsed = timed_pass(False)
-        last_slot = pipe.slots[(pipe.n_submitted - 1) % len(pipe.slots)]
+        # a SECOND pipeline (own network copy, own captured graphs): the f32 pipeline and its graphs
+        # stay untouched for the roofline / breakdown legs below
+        pipe16 = make_pipeline(device, args.depth, use_graph, resolutions, False, "f16x3", batch)
+        alt_elapsed = timed_pass(pipe16, False)
+        last_slot = pipe16.slots[(pipe16.n_submitted - 1) % len(pipe16.slots)]
         vol_alt = last_slot.volumes[last_slot.n_active - 1]
         diff = (vol_alt - vol_f32).abs().max().item()
         flips = int(((vol_alt > 0.5) != (vol_f32 > 0.5)).sum().item())
-        set_precision_everywhere(head, "f32")
-        head.packed()
+        pipe16.close()
+        del pipe16, last_slot, vol_alt
+        from monoport_amd.modeling import backbones
+        backbones.set_encoder_conv_precision("f32")  # process-wide switch back for the eager legs
         torch.cuda.synchronize()
-        pipe.prepare()
         alt = {"precision": "f16x3 (f32 emulated on f16 MFMA, 3-term split, f32 accumulate) in the query "
                             "kernel AND in the encoder's 3x3 convolutions",
                "value": args.steps / alt_elapsed, "unit": "recon/s",

@@ -142,6 +142,7 @@ class FrameSlot:
         hipGraph.  The C-ABI stages stay eager: they are a handful of asynchronous calls, and a
         graph that also holds them faulted on ROCm 7.2 once tensors were allocated after
         capture."""
+        self.graph = None  # warm up eagerly with the CURRENT settings, then (re-)capture
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 self._chain()
