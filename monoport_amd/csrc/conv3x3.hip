@@ -553,8 +553,12 @@ int launch_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *w
 // (32 each), the other 4 / RBW split the pixels; NR = 32-pixel column blocks per wave.  Smaller NR
 // = more, smaller workgroups (better balance over 256 CUs x 2 slots, more weight re-streaming).
 static int g_conv_nr = 0;  // 0 = heuristic; tools/conv_probe.py overrides it for A/B runs
+static int g_conv_tw = 0;  // 0 = 32-pixel-wide tiles
 
-void conv3x3_set_nr(int nr) { g_conv_nr = nr; }
+void conv3x3_set_nr(int nr) {
+  g_conv_nr = nr & 0xff;
+  g_conv_tw = nr >> 8;  // measurement hook: bits 8.. = tile width
+}
 
 static void conv_shape(int cout, int n, int h, int w, int &rbw, int &nr, int &tw, int &th, int &slots) {
   rbw = cout % 128 == 0 ? 4 : cout % 64 == 0 ? 2 : 1;
@@ -567,9 +571,17 @@ static void conv_shape(int cout, int n, int h, int w, int &rbw, int &nr, int &tw
   else if ((long long)n * h * w / (32 * nr * cw) * (cout / (32 * rbw)) < 1024)
     nr = 1;
   const int px = 32 * nr * cw;
-  tw = w < 128 ? w : 128;
+  // 32-pixel-wide tiles, as tall as the workgroup's pixel count allows: the staged halo is
+  // (TH + 2) x 34 pixels, 1.3-2.1x the tile instead of 3x for one-row tiles (staging -- loads,
+  // normalisation, conversion, LDS stores -- is what the split-f16 variant is bound by)
+  tw = g_conv_tw > 0 ? g_conv_tw : 32;
+  if (tw > w) tw = w;
   if (tw > px) tw = px;
   th = px / tw;
+  while (th > h) {  // very small maps: wider, flatter tiles
+    tw *= 2;
+    th = px / tw;
+  }
   slots = (h / th) * (w / tw) * cw;
 }
 
