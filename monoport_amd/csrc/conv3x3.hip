@@ -26,8 +26,10 @@ namespace mp {
 
 constexpr int kCK = 16;           // input channels per LDS chunk
 constexpr int kPixBytes = kCK * 4;  // 64 bytes per staged pixel
-constexpr int kMaxHalo = 520;     // (TH + 2) * (TW + 2) <= 4 * 130
-constexpr int kStageIters = (kMaxHalo + 63) / 64;  // 9
+constexpr int kTileW = 32;        // tiles are 32 pixels wide and PX / 32 rows tall
+// staged pixels (tile + 1 halo) of a PX-pixel tile, and the 64-lane passes a wave needs for them
+constexpr int halo_pixels(int px) { return (px / kTileW + 2) * (kTileW + 2); }
+constexpr int stage_iters(int px) { return (halo_pixels(px) + 63) / 64; }
 
 struct ConvArgs {
   const float *x;    // [N, Cin, H, W]
@@ -62,6 +64,7 @@ __global__ void conv3x3_pack_kernel(const float *__restrict__ w, int cout, int c
 template <int RBW, int NR>
 __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(ConvArgs p) {
   constexpr int CW = 4 / RBW;
+  constexpr int kStageIters = stage_iters(32 * NR * CW);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -307,6 +310,7 @@ __device__ __forceinline__ h8 hload16(const WStream &w, int idx16) {
 template <int RBW, int NR>
 __global__ __launch_bounds__(256, 2) void conv3x3_gn16_kernel(ConvArgs p, const float *__restrict__ wmax) {
   constexpr int CW = 4 / RBW;
+  constexpr int kStageIters = stage_iters(32 * NR * CW);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -553,12 +557,8 @@ int launch_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *w
 // (32 each), the other 4 / RBW split the pixels; NR = 32-pixel column blocks per wave.  Smaller NR
 // = more, smaller workgroups (better balance over 256 CUs x 2 slots, more weight re-streaming).
 static int g_conv_nr = 0;  // 0 = heuristic; tools/conv_probe.py overrides it for A/B runs
-static int g_conv_tw = 0;  // 0 = 32-pixel-wide tiles
 
-void conv3x3_set_nr(int nr) {
-  g_conv_nr = nr & 0xff;
-  g_conv_tw = nr >> 8;  // measurement hook: bits 8.. = tile width
-}
+void conv3x3_set_nr(int nr) { g_conv_nr = nr; }
 
 static void conv_shape(int cout, int n, int h, int w, int &rbw, int &nr, int &tw, int &th, int &slots) {
   rbw = cout % 128 == 0 ? 4 : cout % 64 == 0 ? 2 : 1;
@@ -571,17 +571,10 @@ static void conv_shape(int cout, int n, int h, int w, int &rbw, int &nr, int &tw
   else if ((long long)n * h * w / (32 * nr * cw) * (cout / (32 * rbw)) < 1024)
     nr = 1;
   const int px = 32 * nr * cw;
-  // 32-pixel-wide tiles, as tall as the workgroup's pixel count allows: the staged halo is
-  // (TH + 2) x 34 pixels, 1.3-2.1x the tile instead of 3x for one-row tiles (staging -- loads,
-  // normalisation, conversion, LDS stores -- is what the split-f16 variant is bound by)
-  tw = g_conv_tw > 0 ? g_conv_tw : 32;
-  if (tw > w) tw = w;
-  if (tw > px) tw = px;
+  // 32-pixel-wide tiles, PX / 32 rows tall: the staged halo is (TH + 2) x 34 pixels (1.3-2.1x the
+  // tile; one-row tiles would stage 3x) and a wave stages it in 2-6 passes of 64 pixels
+  tw = kTileW;
   th = px / tw;
-  while (th > h) {  // very small maps: wider, flatter tiles
-    tw *= 2;
-    th = px / tw;
-  }
   slots = (h / th) * (w / tw) * cw;
 }
 
@@ -592,9 +585,8 @@ int conv3x3_stat_slices(int cout, int n, int h, int w) {
 }
 
 bool conv3x3_supported(int cin, int cout, int h, int w) {
-  if (cin % kCK || cout % 32 || cin < kCK || cout < 32 || w < 32 || (w & (w - 1)) || h < 8 || (h & (h - 1)))
-    return false;
-  return true;
+  return !(cin % kCK || cout % 32 || cin < kCK || cout < 32 || w < 32 || (w & (w - 1)) || h < 8 ||
+           (h & (h - 1)));
 }
 
 int launch_absmax(mp_ctx *ctx, const float *src, long long n, unsigned int *out_bits, hipStream_t st);
@@ -619,7 +611,7 @@ static int launch_conv16_t(mp_ctx *ctx, const ConvArgs &a, const float *wmax, in
   const void *kern_id = reinterpret_cast<const void *>(kern);
   if (!ctx->lds_attr_done.count(kern_id)) {
     MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * kMaxHalo * kPixBytes));
+                                    2 * halo_pixels(32 * NR * (4 / RBW)) * kPixBytes));
     ctx->lds_attr_done.insert(kern_id);
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * a.n_img), (unsigned)(a.cout / (32 * RBW))), dim3(256),
@@ -635,7 +627,7 @@ static int launch_conv_t(mp_ctx *ctx, const ConvArgs &a, int tiles, hipStream_t 
   const void *kern_id = reinterpret_cast<const void *>(kern);
   if (!ctx->lds_attr_done.count(kern_id)) {
     MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * kMaxHalo * kPixBytes));
+                                    2 * halo_pixels(32 * NR * (4 / RBW)) * kPixBytes));
     ctx->lds_attr_done.insert(kern_id);
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * a.n_img), (unsigned)(a.cout / (32 * RBW))), dim3(256),
@@ -666,7 +658,7 @@ int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w,
   a.wp_floats = cout * cin * 9;
   int rbw, nr, slots;
   conv_shape(cout, n, h, w, rbw, nr, a.tw, a.th, slots);
-  if (a.th > h || (a.th + 2) * (a.tw + 2) > kMaxHalo)
+  if (a.th > h)
     return fail(ctx, MP_ERR_UNSUPPORTED, "conv3x3: %dx%d map too small for a %dx%d tile", h, w, a.th, a.tw);
   const int tiles = (h / a.th) * (w / a.tw);
 #define MP_CONV_CASE(R, N)                                                                   \

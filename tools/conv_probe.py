@@ -51,14 +51,6 @@ with torch.no_grad():
         for nr in (4, 2, 1, 0):
             lib.mp_conv3x3_tune(nr)
             t16[nr] = timed(lambda: ops.conv3x3_gn(x, ss, packed16, relu=True, want_stats=True))
-        tw = {}
-        for w_ in (32, 64, 128):
-            lib.mp_conv3x3_tune((w_ << 8) | 2)
-            tw[w_] = (timed(lambda: ops.conv3x3_gn(x, ss, packed16, relu=True, want_stats=True)),
-                      timed(lambda: ops.conv3x3_gn(x, ss, packed, relu=True, want_stats=True)))
-        lib.mp_conv3x3_tune(0)
-        print("   tile width 32/64/128 at NR=2: f16x3 %.3f / %.3f / %.3f ms, f32 %.3f / %.3f / %.3f ms"
-              % (tw[32][0], tw[64][0], tw[128][0], tw[32][1], tw[64][1], tw[128][1]))
         tot_16 = globals().get("tot_16", 0.0) + t16[0] * count / B
         globals()["tot_16"] = tot_16
         v = ops.group_norm(x, 32, gn.weight, gn.bias, gn.eps, relu=True)
