@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmonoport_hip.so")
+# MONOPORT_HIP_LIB: measurement hook (tools/ablate.py side builds); the product loads lib/libmonoport_hip.so
+LIB_PATH = os.environ.get("MONOPORT_HIP_LIB") or os.path.join(_HERE, "lib", "libmonoport_hip.so")
 
 c_int = ctypes.c_int
 c_i64 = ctypes.c_int64

@@ -26,6 +26,9 @@ namespace mp {
 
 constexpr int kCK = 16;           // input channels per LDS chunk
 constexpr int kPixBytes = kCK * 4;  // 64 bytes per staged pixel
+#ifndef MP_CONV_WPS
+#define MP_CONV_WPS 2  // waves per SIMD the register allocator is held to (tools/ablate.py A/B)
+#endif
 constexpr int kTileW = 32;        // tiles are 32 pixels wide and PX / 32 rows tall
 // staged pixels (tile + 1 halo) of a PX-pixel tile, and the 64-lane passes a wave needs for them
 constexpr int halo_pixels(int px) { return (px / kTileW + 2) * (kTileW + 2); }
@@ -62,7 +65,7 @@ __global__ void conv3x3_pack_kernel(const float *__restrict__ w, int cout, int c
 }
 
 template <int RBW, int NR>
-__global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p) {
   constexpr int CW = 4 / RBW;
   constexpr int kStageIters = stage_iters(32 * NR * CW);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -308,7 +311,7 @@ __device__ __forceinline__ h8 hload16(const WStream &w, int idx16) {
 }
 
 template <int RBW, int NR>
-__global__ __launch_bounds__(256, 2) void conv3x3_gn16_kernel(ConvArgs p, const float *__restrict__ wmax) {
+__global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs p, const float *__restrict__ wmax) {
   constexpr int CW = 4 / RBW;
   constexpr int kStageIters = stage_iters(32 * NR * CW);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
