@@ -22,9 +22,10 @@ _GROUPS = 32  # GroupNorm(32, C) everywhere (HGFilters.py:23-27, ResBlkFilters.p
 # "hip" (default): the pyramid blocks' GroupNorm -> ReLU -> conv3x3 chains run as the fused f32-MFMA
 # kernels of csrc/conv3x3.hip; "miopen": stock convolutions + the stand-alone GroupNorm kernel
 ENCODER_CONV = os.environ.get("MONOPORT_ENCODER_CONV", "hip")
-# ... on feature maps of at least this height: below it a batch of a few frames cannot fill 256 CUs
-# with 128-pixel tiles and MIOpen's kernels win (tools/conv_probe.py)
-ENCODER_CONV_MIN_H = int(os.environ.get("MONOPORT_ENCODER_CONV_MIN_H", "128"))
+# ... on feature maps of at least this height (all of the hourglass's maps: with 32-pixel tiles the
+# kernels match or beat MIOpen's convolution alone down to 32x32 and save its GroupNorm pass,
+# tools/conv_probe.py / profiles/r02m_conv_probe.txt)
+ENCODER_CONV_MIN_H = int(os.environ.get("MONOPORT_ENCODER_CONV_MIN_H", "32"))
 # arithmetic of those kernels: "f32" (exact f32 MFMA) or "f16x3" (f32 emulated on f16 MFMA: every
 # operand split into two halves, three MFMAs per product term, f32 accumulation -- the encoder-side
 # counterpart of SurfaceClassifier.set_precision("f16x3"))
