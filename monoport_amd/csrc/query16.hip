@@ -43,6 +43,12 @@ constexpr int kHRow = 256;       // bytes per point in the hidden chunk: 8 hi sl
 #ifndef MP16_NB
 #define MP16_NB 4  // tile shape the launcher instantiates (see pifu_query16_kernel)
 #endif
+#ifndef MP16_PIPE
+#define MP16_PIPE (MP16_NB == 4)  // software-pipelined layer-0/1 loop (0: the sequential round-1 loop)
+#endif
+#ifndef MP16_SGB
+#define MP16_SGB 1  // sched_group_barrier interleave of the conversion with the layer-1 MFMAs
+#endif
 
 struct AFrag {
   h8 hi, lo;
@@ -213,6 +219,29 @@ __device__ __forceinline__ void store_hidden16(unsigned char *hb, const f32x16 &
   }
 }
 
+// 32-row chunk buffers of the pipelined layer-0/1 loop: 128 bytes per point = 4 hi slots | 4 lo
+// slots, slot index XORed with (p >> 1) & 7 (rows of 128 B: two points per 256-byte bank row, so
+// the pair index is what must differ between the 16 lanes of a ds_read_b128 group).
+constexpr int kHRow32 = 128;
+__device__ __forceinline__ int swz32(int p) { return (p >> 1) & 7; }
+
+// registers 4q .. 4q+3 of a C-layout tile = rows 8q + 4hh + {0..3} of point p = 32 cb + j
+__device__ __forceinline__ void store_hidden32_q(unsigned char *hb, const f32x16 &v, int q, int cb, int j,
+                                                 int hh, float inv_scale) {
+  const int p = 32 * cb + j;
+  f32x4 f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float y = v[4 * q + i] * inv_scale;
+    f[i] = y > 0.0f ? y : y * 0.01f;  // SurfaceClassifier.py:58
+  }
+  h4 hi, lo;
+  split4(f, hi, lo);
+  unsigned char *row = hb + p * kHRow32 + 8 * hh;
+  *reinterpret_cast<h4 *>(row + ((q ^ swz32(p)) << 4)) = hi;
+  *reinterpret_cast<h4 *>(row + (((4 + q) ^ swz32(p)) << 4)) = lo;
+}
+
 // Layers 2 and 3 read their K in chunks of 64 = 16 rows from EACH wave (pack.hip permutes the
 // weights to match), so all four waves convert and write a quarter of every chunk in parallel:
 // rows 16 half .. +15 of a C-layout tile are registers 8 half .. 8 half + 7; wave `grp` fills K
@@ -367,6 +396,106 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
       const int rs1 = (kHidden[0] / 16) * 128;  // row-block stride of layer 1's hidden segment
       const int a1 = mlp.ah[1] + (4 * wv) * rs1;
       const float inv0 = 1.0f / mlp.scale[0];
+#if MP16_PIPE
+      // Software pipeline over 32-row chunks of layer 0 (one row block; wave wv owns column block
+      // wv): while the layer-1 MFMAs of chunk ck run, the wave converts chunk ck+1 (whose layer-0
+      // MFMAs were issued just before) -- rescale, leaky ReLU, hi/lo split, LDS stores -- in their
+      // shadow, into the other half of the double-buffered chunk buffer.  One barrier per chunk.
+      // With one wave per SIMD nobody else could use the matrix pipe during that VALU work: the
+      // sequential version left it idle for ~15 % of the loop.
+      static_assert(NB == 4, "the pipelined layer-0/1 loop is written for the 128-point tile");
+      constexpr int NCK = kHidden[0] / 32;
+      const unsigned char *x0row = xrow + wv * 32 * kXRow;  // this wave's column block of xs
+      const int pj = 32 * wv + j;                           // its point for the hidden stores
+      const unsigned char *hrow32 = hb + j * kHRow32;       // B rows of column block 0 (+ n * 32 * kHRow32)
+      const int sw32 = hh ^ swz32(j);  // swz32(32 n + j) == swz32(j)
+      ZPair z0[1] = {zc[wv]};
+      AFrag ring0[4][1];
+      f32x16 acc0[1][1];
+      auto l0_begin = [&](int rbk) {
+        seg_prefetch16<1, 3, TERMS>(ring0, ws, a0 + rbk * NGX * 128, 0, NGX);
+        init_from_bias16(acc0[0][0], w32, mlp32.bias[0] + 32 * rbk, mlp.scale[0]);
+      };
+      auto l0_mfma = [&](int rbk) {
+        seg_main16<1, 1, 3, kXRow, 32, TERMS>(acc0, ring0, ws, a0 + rbk * NGX * 128, 0, NGX, x0row, swz);
+        gemm_z16<1, 1, TERMS>(acc0, ws, mlp.az[0] + rbk * 128, z0);
+      };
+      // prologue: chunk 0 -> buffer 0
+      l0_begin(0);
+      l0_mfma(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) store_hidden32_q(hb, acc0[0][0], q, wv, j, hh, inv0);
+      l0_begin(1);
+      // layer-1 A fragments of chunk 0, group 0 (2 k16 groups per chunk)
+      AFrag a1f[2][4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        a1f[0][m].hi = hload(ws, a1 + m * rs1);
+        if (TERMS == 3) a1f[0][m].lo = hload(ws, a1 + m * rs1 + 64);
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int ck = 0; ck < NCK; ++ck) {
+        const unsigned char *hcur = hrow32 + (ck & 1) * (P * kHRow32);
+        unsigned char *hnxt = hb + ((ck + 1) & 1) * (P * kHRow32);
+        // branch-free body: after the last chunk one more (unused) layer-0 chunk is computed and
+        // converted into the idle buffer -- 1/32 of layer 0, but the loop body stays one basic
+        // block, which is what lets the scheduler interleave the conversion with the MFMAs
+        // (A) layer-0 MFMAs of chunk ck + 1 (operands were prefetched during chunk ck - 1 / the prologue)
+        l0_mfma(min(ck + 1, NCK - 1));
+        // (B) layer-1 MFMAs of chunk ck, group by group, with chunk ck + 1's conversion interleaved
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          h8 bh[NB], bl[NB];
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            bh[n] = *reinterpret_cast<const h8 *>(hcur + n * 32 * kHRow32 + (((2 * g) ^ sw32) << 4));
+            if (TERMS >= 2)
+              bl[n] = *reinterpret_cast<const h8 *>(hcur + n * 32 * kHRow32 + (((4 + 2 * g) ^ sw32) << 4));
+          }
+          // next group's A fragments: group 1 of this chunk, or group 0 of the next chunk
+          const int gn = min(2 * ck + g + 1, 2 * NCK - 1);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            a1f[(g + 1) & 1][m].hi = hload(ws, a1 + m * rs1 + gn * 128);
+            if (TERMS == 3) a1f[(g + 1) & 1][m].lo = hload(ws, a1 + m * rs1 + gn * 128 + 64);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+              acc1[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1f[g][m].hi, bh[n], acc1[m][n], 0, 0, 0);
+            if (TERMS >= 2) {
+#pragma unroll
+              for (int n = 0; n < NB; ++n)
+                acc1[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1f[g][m].hi, bl[n], acc1[m][n], 0, 0, 0);
+            }
+            if (TERMS == 3) {
+#pragma unroll
+              for (int n = 0; n < NB; ++n)
+                acc1[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1f[g][m].lo, bh[n], acc1[m][n], 0, 0, 0);
+            }
+            // a quarter of chunk ck + 1's conversion inside each block of 12 MFMAs of group 0
+            if (g == 0) {
+              store_hidden32_q(hnxt, acc0[0][0], m, wv, j, hh, inv0);
+#if MP16_SGB
+              // 1 MFMA : 3 VALU, the two LDS stores at the end (cdna_hip_programming.md T19)
+#pragma unroll
+              for (int r = 0; r < (TERMS * NB); ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+              }
+              __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+#endif
+            }
+          }
+          if (g == 0) l0_begin(min(ck + 2, NCK - 1));  // operands of chunk ck + 2 under group 1
+        }
+        __syncthreads();
+      }
+      (void)pj;
+#else
       ZPair z0[NR0];
 #pragma unroll
       for (int n = 0; n < NR0; ++n) z0[n] = zc[NR0 * cp0 + n];
@@ -400,6 +529,7 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
         seg_main16<4, NB, 1, kHRow, 8, TERMS>(acc1, ring1, ws, a1 + ck * 4 * 128, rs1, 4, hrow, swz);
         __syncthreads();
       }
+#endif
       // skip segment + z column of layer 1
       const int a1x = mlp.ax[1] + (4 * wv) * NGX * 128;
       AFrag ring1[2][4];
