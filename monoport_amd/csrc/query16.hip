@@ -44,7 +44,12 @@ constexpr int kHRow = 256;       // bytes per point in the hidden chunk: 8 hi sl
 #define MP16_NB 4  // tile shape the launcher instantiates (see pifu_query16_kernel)
 #endif
 #ifndef MP16_PIPE
-#define MP16_PIPE (MP16_NB == 4)  // software-pipelined layer-0/1 loop (0: the sequential round-1 loop)
+// 1 = software-pipelined layer-0/1 loop (32-row chunks, conversion of chunk k+1 under the layer-1
+// MFMAs of chunk k).  Correct (the f16 tests pass with it) but MEASURED SLOWER, so it is off:
+// 1 M points f16x3 6.97 ms vs 6.65 ms sequential (8.05 without the sched_group_barrier
+// interleave) -- with 32-row chunks every wave streams the same layer-0 row block (4x instead of
+// 2x redundant weight loads) and feeds only 3 MFMAs per fragment pair.  Kept for tools/ablate.py.
+#define MP16_PIPE 0
 #endif
 #ifndef MP16_SGB
 #define MP16_SGB 1  // sched_group_barrier interleave of the conversion with the layer-1 MFMAs

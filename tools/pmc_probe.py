@@ -5,6 +5,7 @@ import torch
 from monoport_amd import synthetic as syn, ops
 dev = "cuda:0"
 mlp = ops.PackedMLP.from_layers(dev, syn.body_mlp("G", noise=0.05, seed=1), 1)
+mlp.set_precision(os.environ.get("MP_PROBE_PREC", "f32"))
 fh = ops.pack_features(torch.from_numpy(syn.body_feat(256, 128, 128, 2))[None].to(dev))
 cal = torch.eye(4, device=dev)[None]
 for n in [int(a) for a in sys.argv[1:]] or [64, 4913, 262144]:
