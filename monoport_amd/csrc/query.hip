@@ -148,7 +148,7 @@ __device__ __forceinline__ void init_from_bias(f32x16 &v, const WStream &ws, int
 __device__ __forceinline__ void lrelu(f32x16 &v) {
 #pragma unroll
   for (int t = 0; t < 16; ++t)
-    v[t] = v[t] > 0.0f ? v[t] : v[t] * 0.01f;  // F.leaky_relu default slope, SurfaceClassifier.py:58
+    v[t] = fmaxf(v[t], v[t] * 0.01f);  // = v > 0 ? v : 0.01 v (F.leaky_relu, SurfaceClassifier.py:58), bit for bit
 }
 
 // Store a C-layout 32x32 tile into the hidden-chunk buffer, point-major: rows 8q+4h..+3 of a

@@ -21,12 +21,15 @@
 // out of the f16 subnormals; accumulators start at bias * S and are multiplied by 1/S (exact)
 // before the leaky ReLU.  Activations larger than 65504 would saturate -- PIFu activations are O(1-100).
 //
-// Status (round 1): 143 M points/s on a 1 M-point launch (2.6x the f32 kernel), 0.2 of the
-// three-MFMA-per-product roof.  Ablation builds (-DMP16_ABLATE=1..3 stop after the gather / layers
-// 0+1 / layer 2) put 65 % of the time in the fused layer-0/1 loop at ~45 % MFMA utilisation;
-// re-reading one cached weight chunk instead of streaming all of them changes nothing, so the
-// limit is in-core: hipcc spills ~300 registers around the 256-register accumulator tile and
-// drains the prefetch queues at every reload.  Next step: hand-allocated registers for that loop.
+// Status (round 2): 1 M points in 6.65 ms = 158 M points/s (2.6x the f32 kernel) = 372
+// TFLOP/s-equivalent = 0.45 of the three-MFMA-per-product roof (2.5 PFLOP/s / 3).  PMC pass of that
+// launch (profiles/r02p_pmc_f16x3.txt): matrix pipe busy 52 % of the cycles at 2.09 GHz; of a wave's
+// cycles 44 % wait on the MFMA pipe, 20 % are parked at s_waitcnt / barriers (half of that is the
+// gather, which nothing overlaps with one workgroup per CU), 35 % issue instructions (20 % VALU:
+// rescale, leaky ReLU and the hi/lo split of 1920 activations per point); LDS bank conflicts are
+// 12 % of the LDS cycles.  The weight stream goes through buffer resources (query_common.h), the
+// inner loops are spill-free.  A software-pipelined layer-0/1 loop exists (MP16_PIPE) and measured
+// slower -- see its comment.
 #include "mp_internal.h"
 #include "query_common.h"
 
@@ -203,7 +206,7 @@ __device__ __forceinline__ void finish16(f32x16 &v, float inv_scale) {
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const float y = v[t] * inv_scale;
-    v[t] = y > 0.0f ? y : y * 0.01f;  // SurfaceClassifier.py:58
+    v[t] = fmaxf(y, y * 0.01f);  // = y > 0 ? y : 0.01 y (SurfaceClassifier.py:58), one op less
   }
 }
 
@@ -238,7 +241,7 @@ __device__ __forceinline__ void store_hidden32_q(unsigned char *hb, const f32x16
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float y = v[4 * q + i] * inv_scale;
-    f[i] = y > 0.0f ? y : y * 0.01f;  // SurfaceClassifier.py:58
+    f[i] = fmaxf(y, y * 0.01f);  // SurfaceClassifier.py:58
   }
   h4 hi, lo;
   split4(f, hi, lo);
