@@ -744,6 +744,31 @@ int mp_conv3x3_gn16(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, c
                            y, stats, (hipStream_t)stream);
 }
 
+int mp_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, int c2, int f16,
+                    void *packed, float *wmax, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!w1 || !packed || c1 <= 0 || c2 < 0 || (c2 > 0 && !w2) || (f16 && !wmax))
+    return fail(ctx, MP_ERR_ARG, "mp_conv1x1_pack: bad argument");
+  if (c1 % 64 || c2 % 64) return fail(ctx, MP_ERR_UNSUPPORTED, "mp_conv1x1_pack: channel counts must be multiples of 64");
+  DeviceGuard g(ctx->device);
+  return launch_conv1x1_pack(ctx, w1, c1, w2, c2, f16, packed, wmax, (hipStream_t)stream);
+}
+
+int mp_conv1x1(mp_ctx *ctx, const float *x1, const float *ss1, int relu1, const float *x2, int n, int c1,
+               int c2, int64_t hw, const void *packed, int f16, const float *wmax, const float *bias,
+               const float *res, float *y, float *y_hwc, double *stats, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!x1 || !packed || n <= 0 || hw <= 0 || (!y && !y_hwc) || (f16 && !wmax))
+    return fail(ctx, MP_ERR_ARG, "mp_conv1x1: bad argument");
+  if (!aligned16(packed) || (y_hwc && !aligned16(y_hwc)))
+    return fail(ctx, MP_ERR_ARG, "mp_conv1x1: packed weights / y_hwc must be 16-byte aligned");
+  DeviceGuard g(ctx->device);
+  return launch_conv1x1_raw(ctx, x1, ss1, relu1, x2, n, c1, c2, hw, packed, f16, wmax, bias, res, y, y_hwc,
+                            stats, (hipStream_t)stream);
+}
+
 int mp_conv3x3_supported(int cin, int cout, int h, int w) { return conv3x3_supported(cin, cout, h, w) ? 1 : 0; }
 
 int mp_gn_stat_slices(void) { return gn_stat_slices(); }

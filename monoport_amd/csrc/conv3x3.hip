@@ -686,4 +686,359 @@ int launch_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int gro
   return MP_OK;
 }
 
+// ---- 1x1 convolutions of the hourglass tail (HGFilters.py:184-204) ------------------------------
+//   conv_last (+ bias) -> bn_end -> ReLU -> l (+ bias) = the stack's feature map
+//   x_next = x + bl(relu(bn_end(.))) + al(l(.))                      (stacks 0..2)
+// as GEMMs on the same MFMA scheme: M = 256 output channels (each wave two 32-row blocks), N = 64
+// consecutive pixels of the flattened image (a 1x1 convolution has no halo), K = one or TWO input
+// tensors (the second K segment is what turns bl(.) + al(.) into one GEMM, like the skip-concat of
+// the MLP).  GroupNorm + ReLU of segment 1 are applied while staging; the epilogue adds the bias
+// and an optional residual, writes NCHW and / or the channels-last [H*W, C] map the query kernels
+// read (through LDS, so that every pixel row leaves as one 1 KB burst), and can emit the
+// GroupNorm statistics of its output (bn_end).  F16 = split-f16 ("f16x3") operands as in
+// conv3x3_gn16_kernel.
+struct Conv1Args {
+  const float *x1, *ss1;  // [N,C1,HW], [N,C1,2] or nullptr
+  const float *x2;        // [N,C2,HW] or nullptr (plain second K segment)
+  const float *wp;        // packed [8 row blocks][K/8 groups][64][4] f32, or [8][K/16][hi|lo][64] h8
+  const float *bias;      // [256]
+  const float *res;       // [N,256,HW] or nullptr
+  float *y;               // [N,256,HW] or nullptr
+  float *y_hwc;           // [N,HW,256] or nullptr
+  double *stats;          // nullptr or [N,32,S,2], S = (HW/64) * 8
+  int n_img, c1, c2, hw, relu1, wp_floats;
+};
+
+constexpr int kC1K = 64;          // channels per staged chunk
+constexpr int kC1Px = 64;         // pixels per workgroup
+constexpr int kC1Row = kC1K * 4;  // bytes per staged pixel (f32, or 32 hi + 32 lo halves... 128 + 128)
+
+// W = [Cout][K] row-major with K = C1 + C2 (segment 1 first) -> fragment order
+__global__ void conv1x1_pack_kernel(const float *__restrict__ w1, int c1, const float *__restrict__ w2,
+                                    int c2, float *__restrict__ wp) {
+  const int k = c1 + c2, kgt = k / 8;
+  const long long total = 256LL * k;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t & 3), lane = (int)((t >> 2) & 63);
+    const long long q = t >> 8;
+    const int kg = (int)(q % kgt), rb = (int)(q / kgt);
+    const int co = 32 * rb + (lane & 31);
+    const int ci = 8 * kg + 4 * (lane >> 5) + i;
+    wp[t] = ci < c1 ? w1[(long long)co * c1 + ci] : w2[(long long)co * c2 + (ci - c1)];
+  }
+}
+
+__global__ void conv1x1_pack16_kernel(const float *__restrict__ w1, int c1, const float *__restrict__ w2,
+                                      int c2, const float *__restrict__ wmax, _Float16 *__restrict__ wp) {
+  const float S = conv16_scale(*wmax);
+  const int k = c1 + c2, kst = k / 16;
+  const long long total = 256LL * k;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(t & 7), lane = (int)((t >> 3) & 63);
+    const long long q = t >> 9;
+    const int ks = (int)(q % kst), rb = (int)(q / kst);
+    const int co = 32 * rb + (lane & 31);
+    const int ci = 16 * ks + 8 * (lane >> 5) + e;
+    const float v = (ci < c1 ? w1[(long long)co * c1 + ci] : w2[(long long)co * c2 + (ci - c1)]) * S;
+    const _Float16 hi = (_Float16)v;
+    const long long base = ((q * 2) * 64 + lane) * 8 + e;
+    wp[base] = hi;
+    wp[base + 64 * 8] = (_Float16)(v - (float)hi);
+  }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const float *__restrict__ wmax) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x 16 KB stage (64 KB with y_hwc)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int tiles = p.hw / kC1Px;
+  const int tile = blockIdx.x % tiles, img = blockIdx.x / tiles;
+  const int px0 = tile * kC1Px;
+  const int ktot = p.c1 + p.c2;
+  const int n_chunks = ktot / kC1K;
+  const WStream ws = make_wstream(p.wp, p.wp_floats, lane);
+  constexpr int buf_bytes = kC1Px * kC1Row;  // 16 KB
+
+  // staging: lane = pixel, wave wv = channels 16 wv .. 16 wv + 15 of the chunk
+  f32x4 stg[4];
+  float sc[16], sh[16];
+  auto stage_load = [&](int chunk) {
+    const int c0 = chunk * kC1K + 16 * wv;  // first channel in the concatenated K
+    const bool seg2 = c0 >= p.c1;
+    const float *pl = seg2 ? p.x2 + ((long long)img * p.c2 + (c0 - p.c1)) * p.hw
+                           : p.x1 + ((long long)img * p.c1 + c0) * p.hw;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) stg[q][k] = pl[(long long)(4 * q + k) * p.hw + px0 + lane];
+    const bool norm = !seg2 && p.ss1 != nullptr;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      sc[k] = norm ? p.ss1[2 * ((long long)img * p.c1 + c0 + k)] : 1.0f;
+      sh[k] = norm ? p.ss1[2 * ((long long)img * p.c1 + c0 + k) + 1] : 0.0f;
+    }
+  };
+  auto stage_store = [&](int chunk, unsigned char *buf) {
+    const bool act = chunk * kC1K < p.c1 && p.relu1;
+    unsigned char *row = buf + lane * kC1Row;
+    const int sw = lane & 15;
+    if constexpr (!F16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float t = fmaf(stg[q][k], sc[4 * q + k], sh[4 * q + k]);
+          v[k] = act ? fmaxf(t, 0.0f) : t;
+        }
+        *reinterpret_cast<f32x4 *>(row + (((4 * wv + q) ^ sw) << 4)) = v;
+      }
+    } else {
+      // 16 channels -> hi slots 2 wv, 2 wv + 1 and lo slots 8 + 2 wv, 8 + 2 wv + 1 (8 halves each)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = 8 * half + e;
+          float t = fmaf(stg[c >> 2][c & 3], sc[c], sh[c]);
+          t = act ? fmaxf(t, 0.0f) : t;
+          hi[e] = (_Float16)t;
+          lo[e] = (_Float16)(t - (float)hi[e]);
+        }
+        *reinterpret_cast<h8 *>(row + (((2 * wv + half) ^ sw) << 4)) = hi;
+        *reinterpret_cast<h8 *>(row + (((8 + 2 * wv + half) ^ sw) << 4)) = lo;
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[m][n][t] = 0.0f;
+
+  // K steps per chunk: 8 groups of 8 (f32) / 4 steps of 16 (f16); fragments of row block rb, step s:
+  //   f32: ((rb * kgt + s) * 64 + lane) float4;  f16: ((rb * kst + s) * 2 + part) * 64 + lane h8
+  constexpr int SPC = F16 ? kC1K / 16 : kC1K / 8;   // steps per chunk
+  constexpr int FPS = F16 ? 2 : 1;                  // 16-byte fragments per step and row block
+  const int steps = n_chunks * SPC;
+  const int rb_stride = steps * FPS * 64;
+  const int a_base = (2 * wv) * rb_stride;
+  auto a_load = [&](int m, int s, int part) {
+    return wload128(ws, a_base + m * rb_stride + (min(s, steps - 1) * FPS + part) * 64);
+  };
+  f32x4 ring[2][2][FPS];  // [slot][m][part], one step ahead
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int part = 0; part < FPS; ++part) ring[0][m][part] = a_load(m, 0, part);
+
+  stage_load(0);
+  stage_store(0, smem);
+  __syncthreads();
+
+  const int swj = j & 15;
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    const unsigned char *buf = smem + (chunk & 1) * buf_bytes;
+    const bool more = chunk + 1 < n_chunks;
+    if (more) stage_load(chunk + 1);
+#pragma unroll
+    for (int s = 0; s < SPC; ++s) {
+      const int gs = chunk * SPC + s;
+      // next step's A fragments
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int part = 0; part < FPS; ++part) ring[(s + 1) & 1][m][part] = a_load(m, gs + 1, part);
+      if constexpr (!F16) {
+        f32x4 b[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          b[n] = *reinterpret_cast<const f32x4 *>(buf + (32 * n + j) * kC1Row + (((2 * s + h) ^ swj) << 4));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[s & 1][m][0][i], b[n][i], acc[m][n], 0, 0, 0);
+      } else {
+        h8 bh[2], bl[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const unsigned char *row = buf + (32 * n + j) * kC1Row;
+          bh[n] = *reinterpret_cast<const h8 *>(row + (((2 * s + h) ^ swj) << 4));
+          bl[n] = *reinterpret_cast<const h8 *>(row + (((8 + 2 * s + h) ^ swj) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const h8 ah = __builtin_bit_cast(h8, ring[s & 1][m][0]);
+          const h8 al = __builtin_bit_cast(h8, ring[s & 1][m][FPS - 1]);
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[n], acc[m][n], 0, 0, 0);
+        }
+      }
+    }
+    if (more) stage_store(chunk + 1, smem + ((chunk + 1) & 1) * buf_bytes);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const float inv_scale = F16 ? 1.0f / conv16_scale(*wmax) : 1.0f;
+  float s1[2][16], s2[2][16];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int rb = 2 * wv + m;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int co = 32 * rb + (t & 3) + 8 * (t >> 2) + 4 * h;
+      const float b = p.bias ? p.bias[co] : 0.0f;
+      s1[m][t] = s2[m][t] = 0.0f;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const long long o = ((long long)img * 256 + co) * p.hw + px0 + 32 * n + j;
+        float v = acc[m][n][t] * inv_scale + b;
+        if (p.res) v += p.res[o];
+        if (p.y) p.y[o] = v;
+        acc[m][n][t] = v;
+        s1[m][t] += v;
+        s2[m][t] = fmaf(v, v, s2[m][t]);
+      }
+    }
+  }
+  if (p.stats) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          s1[m][t] += __shfl_xor(s1[m][t], o);
+          s2[m][t] += __shfl_xor(s2[m][t], o);
+        }
+      }
+    if (j == 0) {
+      const int S = tiles * 8;  // 8 channels per GroupNorm(32, 256) group, one slot per tile
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int co = 32 * (2 * wv + m) + (t & 3) + 8 * (t >> 2) + 4 * h;
+          double *dst = p.stats + (((long long)img * 32 + (co >> 3)) * S + tile * 8 + (co & 7)) * 2;
+          dst[0] = (double)s1[m][t];
+          dst[1] = (double)s2[m][t];
+        }
+    }
+  }
+  if (p.y_hwc) {
+    // [64 px][256 ch] f32 = 64 KB through LDS (16-byte slots swizzled with the pixel), then every
+    // pixel row leaves as one 1 KB burst: wave wv writes pixels wv, wv + 4, ...
+    float *tr = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int px = 32 * n + j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int slot = (32 * (2 * wv + m) + 8 * q + 4 * h) >> 2;  // 4 consecutive channels
+          const f32x4 v = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+          *reinterpret_cast<f32x4 *>(reinterpret_cast<unsigned char *>(tr) + px * 1024 + ((slot ^ (px & 63)) << 4)) = v;
+        }
+      }
+    __syncthreads();
+    float *dst = p.y_hwc + ((long long)img * p.hw + px0) * 256;
+    for (int px = wv; px < kC1Px; px += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<unsigned char *>(tr) + px * 1024 +
+                                                        ((lane ^ (px & 63)) << 4));
+      *reinterpret_cast<f32x4 *>(dst + (long long)px * 256 + 4 * lane) = v;
+    }
+  }
+}
+
+int launch_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, int c2, int f16, void *wp,
+                        float *wmax, hipStream_t st) {
+  const long long total = 256LL * (c1 + c2);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (!f16) {
+    hipLaunchKernelGGL(conv1x1_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w1, c1, w2, c2,
+                       static_cast<float *>(wp));
+  } else {
+    // max|W| over both segments: two absmax passes into the same word (atomicMax keeps the larger)
+    MP_HIP(ctx, hipMemsetAsync(wmax, 0, sizeof(float), st));
+    int rc = launch_absmax_accumulate(ctx, w1, 256LL * c1, reinterpret_cast<unsigned int *>(wmax), st);
+    if (rc == MP_OK && c2 > 0)
+      rc = launch_absmax_accumulate(ctx, w2, 256LL * c2, reinterpret_cast<unsigned int *>(wmax), st);
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(conv1x1_pack16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w1, c1, w2, c2, wmax,
+                       static_cast<_Float16 *>(wp));
+  }
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+static int launch_conv1x1(mp_ctx *ctx, const Conv1Args &a, int f16, const float *wmax, hipStream_t st);
+
+int launch_conv1x1_raw(mp_ctx *ctx, const float *x1, const float *ss1, int relu1, const float *x2, int n,
+                       int c1, int c2, long long hw, const void *wp, int f16, const float *wmax,
+                       const float *bias, const float *res, float *y, float *y_hwc, double *stats,
+                       hipStream_t st) {
+  if (c1 <= 0 || c1 % kC1K || c2 < 0 || c2 % kC1K || hw % kC1Px || (c2 > 0) != (x2 != nullptr))
+    return fail(ctx, MP_ERR_UNSUPPORTED,
+                "conv1x1: needs C1, C2 multiples of 64, H*W a multiple of 64 and 256 output channels (got %d + %d, %lld)",
+                c1, c2, hw);
+  Conv1Args a;
+  a.x1 = x1;
+  a.ss1 = ss1;
+  a.x2 = x2;
+  a.wp = static_cast<const float *>(wp);
+  a.bias = bias;
+  a.res = res;
+  a.y = y;
+  a.y_hwc = y_hwc;
+  a.stats = stats;
+  a.n_img = n;
+  a.c1 = c1;
+  a.c2 = c2;
+  a.hw = (int)hw;
+  a.relu1 = relu1;
+  a.wp_floats = 256 * (c1 + c2);
+  return launch_conv1x1(ctx, a, f16, wmax, st);
+}
+
+static int launch_conv1x1(mp_ctx *ctx, const Conv1Args &a, int f16, const float *wmax, hipStream_t st) {
+  const int lds = a.y_hwc ? kC1Px * 1024 : 2 * kC1Px * kC1Row;
+  const void *kern_id = f16 ? reinterpret_cast<const void *>(conv1x1_kernel<true>)
+                            : reinterpret_cast<const void *>(conv1x1_kernel<false>);
+  if (!ctx->lds_attr_done.count(kern_id)) {
+    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, kC1Px * 1024));
+    ctx->lds_attr_done.insert(kern_id);
+  }
+  const dim3 grid((unsigned)((a.hw / kC1Px) * a.n_img));
+  if (f16)
+    hipLaunchKernelGGL(conv1x1_kernel<true>, grid, dim3(256), lds, st, a, wmax);
+  else
+    hipLaunchKernelGGL(conv1x1_kernel<false>, grid, dim3(256), lds, st, a, wmax);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
 }  // namespace mp

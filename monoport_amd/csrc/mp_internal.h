@@ -153,6 +153,8 @@ int launch_pack_layer(mp_ctx *ctx, Mlp &m, int layer, const float *w, const floa
 int launch_pack_layer16(mp_ctx *ctx, Mlp &m, int layer, const float *w, hipStream_t st);
 int launch_copy(mp_ctx *ctx, const float *src, float *dst, long long n, hipStream_t st);
 int launch_absmax(mp_ctx *ctx, const float *src, long long n, unsigned int *out_bits, hipStream_t st);
+int launch_absmax_accumulate(mp_ctx *ctx, const float *src, long long n, unsigned int *out_bits,
+                             hipStream_t st);
 // query16.hip
 int launch_query16(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
                    long long max_points, bool device_counts, hipStream_t st);
@@ -208,6 +210,12 @@ int launch_conv3x3_pack16(mp_ctx *ctx, const float *w, int cout, int cin, void *
 int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss,
                       int relu, const float *wp, const float *wmax16, int cout, float *y,
                       double *stats, hipStream_t st);
+int launch_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, int c2, int f16, void *wp,
+                        float *wmax, hipStream_t st);
+int launch_conv1x1_raw(mp_ctx *ctx, const float *x1, const float *ss1, int relu1, const float *x2, int n,
+                       int c1, int c2, long long hw, const void *wp, int f16, const float *wmax,
+                       const float *bias, const float *res, float *y, float *y_hwc, double *stats,
+                       hipStream_t st);
 int launch_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int groups, int slices,
                        double count, const float *gamma, const float *beta, float eps, float *ss,
                        hipStream_t st);

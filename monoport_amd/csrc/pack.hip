@@ -152,6 +152,14 @@ int launch_absmax(mp_ctx *ctx, const float *src, long long n, unsigned int *out_
   return MP_OK;
 }
 
+// like launch_absmax without zeroing the word first (maximum over several tensors)
+int launch_absmax_accumulate(mp_ctx *ctx, const float *src, long long n, unsigned int *out_bits,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, src, n, out_bits);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
 int launch_copy(mp_ctx *ctx, const float *src, float *dst, long long n, hipStream_t st) {
   hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)),
                      dim3(256), 0, st, src, dst, n);

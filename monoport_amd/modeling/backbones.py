@@ -209,15 +209,63 @@ class HGFilter(nn.Module):
                 self.add_module("bl%d" % i, nn.Conv2d(256, 256, 1))
                 self.add_module("al%d" % i, nn.Conv2d(dim, 256, 1))
 
-    def forward(self, x, last_only=False):
+    def _tail_packed(self, i):
+        """Fragment-order weights of stack i's 1x1 convolutions: conv_last, l and [bl | al]."""
+        cache = self.__dict__.setdefault("_tail_cache", {})
+        mods = [getattr(self, "conv_last%d" % i), getattr(self, "l%d" % i)]
+        if i < self.num_stack - 1:
+            mods += [getattr(self, "bl%d" % i), getattr(self, "al%d" % i)]
+        key = tuple((p.data_ptr(), p._version) for m in mods for p in (m.weight, m.bias)) + (ENCODER_CONV_PRECISION,)
+        hit = cache.get(i)
+        if hit is None or hit[0] != key:
+            pr = ENCODER_CONV_PRECISION
+            packs = [ops.PackedConv1x1(mods[0].weight, mods[0].bias, precision=pr),
+                     ops.PackedConv1x1(mods[1].weight, mods[1].bias, precision=pr)]
+            if len(mods) == 4:
+                packs.append(ops.PackedConv1x1(mods[2].weight, mods[2].bias, mods[3].weight, mods[3].bias,
+                                               precision=pr))
+            hit = (key, packs)
+            cache[i] = hit
+        return hit[1]
+
+    def _tail_fused(self, i, y, x, hwc_out, want_nchw):
+        """conv_last -> bn_end -> ReLU -> l, and x + bl(.) + al(.), as three fused GEMMs
+        (csrc/conv3x3.hip: conv1x1_kernel): bn_end's statistics come out of conv_last's epilogue,
+        its normalisation + ReLU are applied while l / [bl | al] stage their input, biases and the
+        residual are added in the epilogues, and the last stack's features can be written straight
+        into the channels-last map the query kernels read (HGFilters.py:184-204)."""
+        packs = self._tail_packed(i)
+        bn = getattr(self, "bn_end%d" % i)
+        n, _, h, w = y.shape
+        t, st = ops.conv1x1(y, None, False, None, packs[0], want_stats=True)
+        ss = ops.gn_finalize(st, n, 256, _GROUPS, 8 * h * w, bn.weight, bn.bias, bn.eps)
+        last = i == self.num_stack - 1
+        out, _ = ops.conv1x1(t, ss, True, None, packs[1], want_nchw=want_nchw or not last,
+                             y_hwc=hwc_out if last else None)
+        if not last:
+            x, _ = ops.conv1x1(t, ss, True, out, packs[2], res=x)
+        return out, x
+
+    def forward(self, x, last_only=False, hwc_out=None):
         """``last_only=True`` skips materialising the per-stack outputs nobody reads in eval mode
-        (MonoPortNet.py:63-64 keeps feats_stages[-1] only); the default matches the reference."""
+        (MonoPortNet.py:63-64 keeps feats_stages[-1] only); the default matches the reference.
+        ``hwc_out`` ([B,H,W,256], fused path only): the LAST stack's features are written there in
+        channels-last layout by the producing kernel (no NCHW -> HWC pass); with ``last_only`` the
+        NCHW copy is then skipped and the returned entry is None."""
         x = self.bn1(self.conv1(x), relu=True)
         x = F.avg_pool2d(self.conv2(x), 2, stride=2)
         x = self.conv4(self.conv3(x))
+        fused = (not self.training and ENCODER_CONV == "hip" and ops.conv1x1_supported(x)
+                 and x.shape[1] == 256)
+        if hwc_out is not None and not fused:
+            raise RuntimeError("HGFilter.forward(hwc_out=...) needs the fused convolution path")
         outputs = []
         for i in range(self.num_stack):
             y = getattr(self, "top_m_%d" % i)(getattr(self, "m%d" % i)(x))
+            if fused:
+                out, x = self._tail_fused(i, y, x, hwc_out, want_nchw=not (last_only and hwc_out is not None))
+                outputs.append((out,))
+                continue
             y = getattr(self, "bn_end%d" % i)(getattr(self, "conv_last%d" % i)(y), relu=True)
             out = getattr(self, "l%d" % i)(y)
             outputs.append((out,))

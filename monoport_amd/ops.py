@@ -650,6 +650,70 @@ def conv3x3_gn(x, ss, packed, relu=True, want_stats=False):
     return y, stats
 
 
+class PackedConv1x1:
+    """Weights of one fused 1x1 convolution of the hourglass tail in MFMA fragment order: W1
+    [256,C1(,1,1)] and optionally W2 [256,C2(,1,1)] (second K segment), biases summed."""
+
+    def __init__(self, w1, b1, w2=None, b2=None, precision="f32"):
+        w1 = _f32c(w1.detach().reshape(w1.shape[0], -1))
+        if w1.shape[0] != 256:
+            raise ValueError("conv1x1 is built for 256 output channels, got %d" % w1.shape[0])
+        self.c1, self.c2 = int(w1.shape[1]), 0
+        if w2 is not None:
+            w2 = _f32c(w2.detach().reshape(w2.shape[0], -1))
+            self.c2 = int(w2.shape[1])
+        self.precision = precision
+        ctx = get_context(w1.device)
+        self.data = torch.empty((256 * (self.c1 + self.c2),), dtype=torch.float32, device=w1.device)
+        self.wmax = torch.zeros((1,), dtype=torch.float32, device=w1.device)
+        bias = b1.detach().float()
+        if b2 is not None:
+            bias = bias + b2.detach().float()
+        self.bias = bias.contiguous()
+        ctx.check(ctx.lib.mp_conv1x1_pack(ctx.handle, _ptr(w1), self.c1, _ptr(w2) if w2 is not None else None,
+                                          self.c2, int(precision == "f16x3"), _ptr(self.data),
+                                          _ptr(self.wmax), _stream(w1)), "mp_conv1x1_pack")
+        stream = torch.cuda.current_stream(w1.device)
+        w1.record_stream(stream)
+        if w2 is not None:
+            w2.record_stream(stream)
+
+
+def conv1x1_supported(x):
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[1] % 64 == 0
+            and (x.shape[2] * x.shape[3]) % 64 == 0)
+
+
+def conv1x1(x1, ss1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=None, want_stats=False):
+    """y = W [relu?(x1 * scale + shift) ; x2] + bias (+ res) as one fused GEMM (mp_conv1x1).
+    Returns (y [N,256,H,W] or None, stats or None); ``y_hwc`` [N,H,W,256] is filled when given."""
+    ctx = get_context(x1.device)
+    x1 = x1.contiguous()
+    n, c1, h, w = x1.shape
+    hw = h * w
+    if c1 != packed.c1 or (x2 is None) != (packed.c2 == 0) or (x2 is not None and x2.shape[1] != packed.c2):
+        raise ValueError("conv1x1: inputs do not match the packed weights")
+    if x2 is not None:
+        x2 = x2.contiguous()
+    if res is not None:
+        res = res.contiguous()
+    y = torch.empty((n, 256, h, w), dtype=torch.float32, device=x1.device) if want_nchw else None
+    stats = None
+    if want_stats:
+        s = (hw // 64) * 8
+        stats = (torch.empty((n, 32, s, 2), dtype=torch.float64, device=x1.device), s)
+    if y_hwc is not None:
+        assert y_hwc.is_contiguous() and y_hwc.numel() == n * hw * 256 and y_hwc.dtype == torch.float32
+    ctx.check(ctx.lib.mp_conv1x1(
+        ctx.handle, _ptr(x1), _ptr(ss1) if ss1 is not None else None, int(bool(relu1)),
+        _ptr(x2) if x2 is not None else None, n, c1, packed.c2, hw, _ptr(packed.data),
+        int(packed.precision == "f16x3"), _ptr(packed.wmax), _ptr(packed.bias),
+        _ptr(res) if res is not None else None, _ptr(y) if y is not None else None,
+        _ptr(y_hwc) if y_hwc is not None else None, _ptr(stats[0]) if stats else None, _stream(x1)),
+        "mp_conv1x1")
+    return y, stats
+
+
 def gn_stats(x, groups):
     """One read pass over x [N,C,H,W]: (partial sums double [N*groups, S, 2], S)."""
     ctx = get_context(x.device)

@@ -116,6 +116,69 @@ def test_encoder_f16x3_convs_vs_reference_golden(monkeypatch):
         assert err <= 1e-4
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_conv1x1_fused_tail_matches_torch(precision):
+    """conv1x1_kernel: plain / GroupNorm-fused input, bias, second K segment + residual, the
+    statistics epilogue and the channels-last output, against fp64 torch ops."""
+    from monoport_amd import ops
+    g = torch.Generator().manual_seed(11)
+    n, h, w = 2, 64, 64
+    y = (torch.randn((n, 256, h, w), generator=g) * 1.5).to(DEV)
+    x = torch.randn((n, 256, h, w), generator=g).to(DEV)
+    convs = [torch.nn.Conv2d(256, 256, 1).to(DEV) for _ in range(4)]  # conv_last, l, bl, al
+    gn = torch.nn.GroupNorm(32, 256).to(DEV)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.5, 0.5)
+        p_last = ops.PackedConv1x1(convs[0].weight, convs[0].bias, precision=precision)
+        p_l = ops.PackedConv1x1(convs[1].weight, convs[1].bias, precision=precision)
+        p_blal = ops.PackedConv1x1(convs[2].weight, convs[2].bias, convs[3].weight, convs[3].bias,
+                                   precision=precision)
+        t, st = ops.conv1x1(y, None, False, None, p_last, want_stats=True)
+        t_ref = torch.nn.functional.conv2d(y.double(), convs[0].weight.double(), convs[0].bias.double())
+        assert (t.double() - t_ref).abs().max().item() <= 2e-5 * max(1.0, t_ref.abs().max().item())
+        ss = ops.gn_finalize(st, n, 256, 32, 8 * h * w, gn.weight, gn.bias, gn.eps)
+        ss_ref = ops.gn_finalize(ops.gn_stats(t, 32), n, 256, 32, 8 * h * w, gn.weight, gn.bias, gn.eps)
+        assert (ss - ss_ref).abs().max().item() <= 2e-5
+        v = torch.relu(gn.double()(t_ref)) if False else torch.relu(
+            torch.nn.functional.group_norm(t_ref, 32, gn.weight.double(), gn.bias.double(), gn.eps))
+        hwc = torch.empty((n, h, w, 256), device=DEV)
+        out, _ = ops.conv1x1(t, ss, True, None, p_l, y_hwc=hwc)
+        out_ref = torch.nn.functional.conv2d(v, convs[1].weight.double(), convs[1].bias.double())
+        e_out = (out.double() - out_ref).abs().max().item()
+        assert e_out <= 5e-5 * max(1.0, out_ref.abs().max().item())
+        assert torch.equal(hwc, out.permute(0, 2, 3, 1).contiguous())  # same values, channels-last
+        only_hwc, _ = ops.conv1x1(t, ss, True, None, p_l, want_nchw=False, y_hwc=hwc)
+        assert only_hwc is None
+        xn, _ = ops.conv1x1(t, ss, True, out, p_blal, res=x)
+        xn_ref = (x.double() + torch.nn.functional.conv2d(v, convs[2].weight.double(), convs[2].bias.double())
+                  + torch.nn.functional.conv2d(out_ref, convs[3].weight.double(), convs[3].bias.double()))
+        e_x = (xn.double() - xn_ref).abs().max().item()
+        print("conv1x1 %s: |conv_last| ok, |l| %.3g, |x + bl + al| %.3g" % (precision, e_out, e_x))
+        assert e_x <= 5e-5 * max(1.0, xn_ref.abs().max().item())
+
+
+def test_encoder_hwc_output_equals_packed_nchw():
+    """HGFilter.forward(hwc_out=...): the last stack's features written channels-last by the
+    producing kernel equal mp_feat_pack_hwc of the NCHW output, bit for bit."""
+    from monoport_amd import ops
+    from monoport_amd.modeling import PIFuNetG
+    net = PIFuNetG().eval()
+    shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
+    net.image_filter.load_state_dict(
+        {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, 71).items()})
+    net.image_filter.to(DEV)
+    img = torch.stack([torch.from_numpy(syn.synthetic_image(s)) for s in (73, 74)]).to(DEV)
+    hwc = torch.empty((2, 128, 128, 256), device=DEV)
+    with torch.no_grad():
+        outs = net.image_filter(img, hwc_out=hwc)
+        assert len(outs) == 4
+        for b in range(2):
+            assert torch.equal(hwc[b], ops.pack_features(outs[-1][0][b:b + 1]))
+        only = net.image_filter(img, last_only=True, hwc_out=torch.empty_like(hwc))
+        assert only[-1][0] is None
+
+
 def test_conv3x3_rejects_unsupported_shapes():
     from monoport_amd import ops
     from monoport_amd._lib import MonoportError
