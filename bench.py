@@ -87,6 +87,13 @@ def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, 
         # other 254 channels are the encoder's output (consumed through the seeded-noise weights)
         feat[:, 0:2].copy_(planes[None].expand(feat.shape[0], -1, -1, -1))
 
+    planes_hwc = planes.permute(1, 2, 0).contiguous()
+
+    def body_planes_hook_hwc(feat_hwc):  # the same edit on the channels-last [B,H,W,C] map
+        feat_hwc[..., 0:2].copy_(planes_hwc[None].expand(feat_hwc.shape[0], -1, -1, -1))
+
+    body_planes_hook.hwc = body_planes_hook_hwc
+
     pipe = FramePipeline(net, device, depth=depth, batch=batch, resolutions=resolutions or RESOLUTIONS,
                          b_min=B_MIN, b_max=B_MAX, balance=0.5, feature_hook=body_planes_hook,
                          use_graph=use_graph, netC=build_netc(device) if with_color else None)

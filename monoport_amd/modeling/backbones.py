@@ -246,12 +246,12 @@ class HGFilter(nn.Module):
             x, _ = ops.conv1x1(t, ss, True, out, packs[2], res=x)
         return out, x
 
-    def forward(self, x, last_only=False, hwc_out=None):
+    def forward(self, x, last_only=False, hwc_out=None, keep_nchw=False):
         """``last_only=True`` skips materialising the per-stack outputs nobody reads in eval mode
         (MonoPortNet.py:63-64 keeps feats_stages[-1] only); the default matches the reference.
         ``hwc_out`` ([B,H,W,256], fused path only): the LAST stack's features are written there in
         channels-last layout by the producing kernel (no NCHW -> HWC pass); with ``last_only`` the
-        NCHW copy is then skipped and the returned entry is None."""
+        NCHW copy is then skipped and the returned entry is None, unless ``keep_nchw``."""
         x = self.bn1(self.conv1(x), relu=True)
         x = F.avg_pool2d(self.conv2(x), 2, stride=2)
         x = self.conv4(self.conv3(x))
@@ -263,7 +263,8 @@ class HGFilter(nn.Module):
         for i in range(self.num_stack):
             y = getattr(self, "top_m_%d" % i)(getattr(self, "m%d" % i)(x))
             if fused:
-                out, x = self._tail_fused(i, y, x, hwc_out, want_nchw=not (last_only and hwc_out is not None))
+                out, x = self._tail_fused(i, y, x, hwc_out,
+                                          want_nchw=keep_nchw or not (last_only and hwc_out is not None))
                 outputs.append((out,))
                 continue
             y = getattr(self, "bn_end%d" % i)(getattr(self, "conv_last%d" % i)(y), relu=True)

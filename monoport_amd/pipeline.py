@@ -47,8 +47,16 @@ class FrameSlot:
         self.stream = torch.cuda.Stream(device=dev)
         self.image = torch.zeros((b, 3, 512, 512), dtype=torch.float32, device=dev)
         self.calib = torch.eye(4, dtype=torch.float32, device=dev)[None].repeat(b, 1, 1).contiguous()
-        self.feats_hwc = [torch.empty((128, 128, 256), dtype=torch.float32, device=dev)
-                          for _ in range(b)]
+        # one [B,128,128,256] channels-last map; feats_hwc[b] are its per-frame views
+        self.feat_hwc_all = torch.empty((b, 128, 128, 256), dtype=torch.float32, device=dev)
+        self.feats_hwc = [self.feat_hwc_all[i] for i in range(b)]
+        # the hourglass encoder can write its last stack's features straight into that map
+        # (HGFilter.forward(hwc_out=...), csrc/conv3x3.hip: conv1x1_kernel); a feature_hook must
+        # then come with a channels-last twin, ``feature_hook.hwc(feat_hwc_all)``
+        from .modeling import backbones
+        self.hwc_direct = (isinstance(netG.image_filter, backbones.HGFilter)
+                           and backbones.ENCODER_CONV == "hip"
+                           and (feature_hook is None or hasattr(feature_hook, "hwc")))
         # one volume per frame of the batch: results stay readable until the next submit
         self.volumes = [torch.empty((r, r, r), dtype=torch.float32, device=dev) for _ in range(b)]
         self.status = torch.zeros((b, 1 + len(self.res)), dtype=torch.int32, device=dev)
@@ -84,9 +92,17 @@ class FrameSlot:
     @torch.no_grad()
     def _encode(self):
         """Both encoders on the slot's image buffers: (featG [B,256,128,128], featC or None)."""
-        feat = self.net.image_filter(self.image, last_only=True)[-1][0]
-        if self.feature_hook is not None:
-            self.feature_hook(feat)
+        if self.hwc_direct:
+            feat = self.net.image_filter(self.image, last_only=True, hwc_out=self.feat_hwc_all,
+                                         keep_nchw=self.netC is not None)[-1][0]
+            if self.feature_hook is not None:
+                self.feature_hook.hwc(self.feat_hwc_all)
+                if feat is not None:
+                    self.feature_hook(feat)
+        else:
+            feat = self.net.image_filter(self.image, last_only=True)[-1][0]
+            if self.feature_hook is not None:
+                self.feature_hook(feat)
         feat_c = None
         if self.netC is not None:
             feat_c = self.netC.image_filter(self.image_c)[-1][0]  # [B,256,128,128]
@@ -104,8 +120,9 @@ class FrameSlot:
             mlp_c = self.netC.surface_classifier.packed()
         r = self.res[-1]
         n = self.n_active
-        for b in range(n):
-            ops.pack_features(feat[b:b + 1], out=self.feats_hwc[b])
+        if not self.hwc_direct:
+            for b in range(n):
+                ops.pack_features(feat[b:b + 1], out=self.feats_hwc[b])
         # the octree of all frames of the slot level by level: one fused-query launch per level
         # covers every frame (mp_recon_batch takes up to MAX_RECON_BATCH frames per call)
         for b0 in range(0, n, MAX_RECON_BATCH):
