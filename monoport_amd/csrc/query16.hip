@@ -46,6 +46,9 @@ constexpr int kHRow = 256;       // bytes per point in the hidden chunk: 8 hi sl
 #ifndef MP16_NB
 #define MP16_NB 4  // tile shape the launcher instantiates (see pifu_query16_kernel)
 #endif
+#ifndef MP16_CS
+#define MP16_CS (MP16_NB == 4 ? 2 : 1)  // column split: 2 = eight waves (two per SIMD), see the kernel
+#endif
 #ifndef MP16_PIPE
 // 1 = software-pipelined layer-0/1 loop (32-row chunks, conversion of chunk k+1 under the layer-1
 // MFMAs of chunk k).  Correct (the f16 tests pass with it) but MEASURED SLOWER, so it is off:
@@ -275,24 +278,38 @@ __device__ __forceinline__ void store_hidden16_part(unsigned char *hb, const f32
 // CU (the partner hides barriers and epilogues, at twice the weight bytes per point).  Measured
 // (1 M points, -DMP16_NB=2): f16x3 11.3 ms vs 7.4 ms, plain f16 4.4 vs 4.0 -- weight streaming wins,
 // the launcher instantiates NB = 4.
-template <int COUT, int TERMS, int NB>
-__global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kernel(
+//
+// CS = column split: 1 = four waves, each with all NB column blocks of its rows (one wave per SIMD,
+// 512 registers); 2 = EIGHT waves -- wave (rg, cg) owns row group rg (as before) but only the column
+// blocks [cg NB/2, +NB/2) -- so every SIMD holds two waves of 256 registers: while one converts a
+// chunk (VALU) or waits at a barrier / for the gather, the other keeps the matrix pipe busy.  Both
+// waves of a row group stream the same weight fragments (the second one hits the CU's L1); LDS
+// traffic, MFMA count and the chunk-buffer layout are unchanged.
+template <int COUT, int TERMS, int NB, int CS>
+__global__ __launch_bounds__(kThreads16 * CS, NB == 4 ? CS : 2) void pifu_query16_kernel(
     MlpPack mlp32, MlpPack16 mlp, int fh, int fw, float z_scale, int act, QuerySet set) {
   constexpr int C = 256;
-  constexpr int NGX = C / 16;  // k16 groups of the feature segment
-  constexpr int P = 32 * NB;   // points per tile
-  constexpr int NR0 = NB / 2;  // column blocks per wave in a layer-0 chunk
-  constexpr int PW = P / 4;    // points gathered per wave
+  constexpr int NGX = C / 16;        // k16 groups of the feature segment
+  constexpr int P = 32 * NB;         // points per tile
+  constexpr int THREADS = kThreads16 * CS;
+  constexpr int NBW = NB / CS;       // column blocks per wave in layers 1-3
+  constexpr int NR0 = NB / 2 / CS;   // column blocks per wave in a layer-0 chunk (8 tiles / waves)
+  constexpr int PW = P / (4 * CS);   // points gathered per wave
+  static_assert(CS == 1 || (CS == 2 && NB == 4), "column split is built for the 128-point tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *xs = smem;
   unsigned char *hb = smem + P * kXRow;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3 = row group of layers 1-3
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = wave & 3;           // 0..3 = row group of layers 1-3
+  const int cbase = (wave >> 2) * NBW;  // first column block of this wave in layers 1-3
   const int j = lane & 31, hh = lane >> 5;
   const int swz = hh ^ (j & 15);
-  const int rb0 = wv >> 1, cp0 = wv & 1;  // layer-0 chunk: row block / column-block pair
+  // layer-0 chunk (2 row blocks x NB column blocks): row block / first column block of this wave
+  const int rb0 = CS == 1 ? wv >> 1 : wave & 1;
+  const int c0 = CS == 1 ? NR0 * (wv & 1) : wave >> 1;
 
   // The tiles of all frames of the set form one index space: frame f owns the next
   // ceil(n_f / tile) global tiles.  The owner of a global tile is looked up from the (device-side)
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
         Taps t[GB];
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
-          const long long n = n0 + PW * wv + i0 + u;
+          const long long n = n0 + PW * wave + i0 + u;
           const bool live_n = n < n_pts;
           float px = 0, py = 0, pz = 0, x, y, z;
           uint32_t code;
@@ -358,7 +375,7 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
             v[u][k] = *reinterpret_cast<const f32x4 *>(feat + t[u].o[k] + 4 * lane);
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
-          const int p = PW * wv + i0 + u;
+          const int p = PW * wave + i0 + u;
           const f32x4 r = blend(v[u][0], v[u][1], v[u][2], v[u][3], t[u]);
           h4 hi, lo;
           split4(r, hi, lo);
@@ -388,16 +405,20 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
       continue;
     }
 #endif
-    const unsigned char *xrow = xs + j * kXRow;  // column block 0; + 32 * cb * kXRow for block cb
-    const unsigned char *hrow = hb + j * kHRow;
+    const unsigned char *xrow = xs + (32 * cbase + j) * kXRow;  // this wave's first column block
+    const unsigned char *hrow = hb + (32 * cbase + j) * kHRow;
+    const unsigned char *xrow0 = xs + j * kXRow;                // column block 0 (layer-0 chunks)
+    ZPair zw[NBW];  // z_feat of this wave's column blocks
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) zw[n] = zc[cbase + n];
 
     // ---------------- layers 0 + 1, fused over 64-row chunks of layer 0 ----------------
-    f32x16 acc1[4][NB];  // layer-1 rows [128 wv, +128) x all points: 256 accumulator registers at NB = 4
+    f32x16 acc1[4][NBW];  // layer-1 rows [128 wv, +128) x this wave's points (256 / CS registers)
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       init_from_bias16(acc1[m][0], w32, mlp32.bias[1] + 32 * (4 * wv + m), mlp.scale[1]);
 #pragma unroll
-      for (int n = 1; n < NB; ++n) acc1[m][n] = acc1[m][0];
+      for (int n = 1; n < NBW; ++n) acc1[m][n] = acc1[m][0];
     }
     {
       const int a0 = mlp.ax[0];                 // [rb][g][part][lane]
@@ -411,7 +432,7 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
       // shadow, into the other half of the double-buffered chunk buffer.  One barrier per chunk.
       // With one wave per SIMD nobody else could use the matrix pipe during that VALU work: the
       // sequential version left it idle for ~15 % of the loop.
-      static_assert(NB == 4, "the pipelined layer-0/1 loop is written for the 128-point tile");
+      static_assert(NB == 4 && CS == 1, "the pipelined layer-0/1 loop is written for the 4-wave 128-point tile");
       constexpr int NCK = kHidden[0] / 32;
       const unsigned char *x0row = xrow + wv * 32 * kXRow;  // this wave's column block of xs
       const int pj = 32 * wv + j;                           // its point for the hidden stores
@@ -506,7 +527,7 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
 #else
       ZPair z0[NR0];
 #pragma unroll
-      for (int n = 0; n < NR0; ++n) z0[n] = zc[NR0 * cp0 + n];
+      for (int n = 0; n < NR0; ++n) z0[n] = zc[c0 + n];
       AFrag ring0[4][1];
       f32x16 acc0[1][NR0];
       seg_prefetch16<1, 3, TERMS>(ring0, ws, a0 + rb0 * NGX * 128, 0, NGX);
@@ -518,14 +539,14 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
         // layer-0 rows [64 ck + 32 rb0, +32) x column blocks [NR0 cp0, +NR0)
         const int rb = 2 * ck + rb0;
         seg_main16<1, NR0, 3, kXRow, 32, TERMS>(acc0, ring0, ws, a0 + rb * NGX * 128, 0, NGX,
-                                         xrow + (NR0 * cp0) * 32 * kXRow, swz);
+                                         xrow0 + c0 * 32 * kXRow, swz);
         AFrag ring1[2][4];
         seg_prefetch16<4, 1, TERMS>(ring1, ws, a1 + ck * 4 * 128, rs1, 4);
         gemm_z16<1, NR0, TERMS>(acc0, ws, mlp.az[0] + rb * 128, z0);
 #pragma unroll
         for (int n = 0; n < NR0; ++n) {
           finish16(acc0[0][n], inv0);
-          store_hidden16(hb, acc0[0][n], rb0, NR0 * cp0 + n, j, hh);
+          store_hidden16(hb, acc0[0][n], rb0, c0 + n, j, hh);
         }
         // next chunk's layer-0 operands stream in underneath the layer-1 MFMAs
         const int rbn = min(rb + 2, kHidden[0] / 32 - 2 + rb0);
@@ -534,7 +555,7 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
 #pragma unroll
         for (int n = 1; n < NR0; ++n) acc0[0][n] = acc0[0][0];
         __syncthreads();
-        seg_main16<4, NB, 1, kHRow, 8, TERMS>(acc1, ring1, ws, a1 + ck * 4 * 128, rs1, 4, hrow, swz);
+        seg_main16<4, NBW, 1, kHRow, 8, TERMS>(acc1, ring1, ws, a1 + ck * 4 * 128, rs1, 4, hrow, swz);
         __syncthreads();
       }
 #endif
@@ -542,13 +563,13 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
       const int a1x = mlp.ax[1] + (4 * wv) * NGX * 128;
       AFrag ring1[2][4];
       seg_prefetch16<4, 1, TERMS>(ring1, ws, a1x, NGX * 128, NGX);
-      seg_main16<4, NB, 1, kXRow, 32, TERMS>(acc1, ring1, ws, a1x, NGX * 128, NGX, xrow, swz);
-      gemm_z16<4, NB, TERMS>(acc1, ws, mlp.az[1] + (4 * wv) * 128, zc);
+      seg_main16<4, NBW, 1, kXRow, 32, TERMS>(acc1, ring1, ws, a1x, NGX * 128, NGX, xrow, swz);
+      gemm_z16<4, NBW, TERMS>(acc1, ws, mlp.az[1] + (4 * wv) * 128, zw);
       const float inv1 = 1.0f / mlp.scale[1];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < NB; ++n) finish16(acc1[m][n], inv1);
+        for (int n = 0; n < NBW; ++n) finish16(acc1[m][n], inv1);
     }
 
 #ifdef MP16_ABLATE
@@ -557,19 +578,19 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < NB; ++n) sink += acc1[m][n][0];
+        for (int n = 0; n < NBW; ++n) sink += acc1[m][n][0];
       if (sink == 12345.678f) out[0] = sink;
       __syncthreads();
       continue;
     }
 #endif
     // ---------------- layer 2: rows [64 wv, +64) x 128 points ----------------
-    f32x16 acc2[2][NB];
+    f32x16 acc2[2][NBW];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       init_from_bias16(acc2[m][0], w32, mlp32.bias[2] + 32 * (2 * wv + m), mlp.scale[2]);
 #pragma unroll
-      for (int n = 1; n < NB; ++n) acc2[m][n] = acc2[m][0];
+      for (int n = 1; n < NBW; ++n) acc2[m][n] = acc2[m][0];
     }
     {
       const int rs2 = (kHidden[1] / 16) * 128;
@@ -579,21 +600,21 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
 #pragma unroll
       for (int ck = 0; ck < 8; ++ck) {
 #pragma unroll
-        for (int n = 0; n < NB; ++n) store_hidden16_part(hb, acc1[ck >> 1][n], ck & 1, wv, n, j, hh);
+        for (int n = 0; n < NBW; ++n) store_hidden16_part(hb, acc1[ck >> 1][n], ck & 1, wv, cbase + n, j, hh);
         __syncthreads();
-        seg_main16<2, NB, 1, kHRow, 8, TERMS>(acc2, ring2, ws, a2 + ck * 4 * 128, rs2, 4, hrow, swz);
+        seg_main16<2, NBW, 1, kHRow, 8, TERMS>(acc2, ring2, ws, a2 + ck * 4 * 128, rs2, 4, hrow, swz);
         if (ck < 7) seg_prefetch16<2, 1, TERMS>(ring2, ws, a2 + (ck + 1) * 4 * 128, rs2, 4);
         __syncthreads();
       }
       const int a2x = mlp.ax[2] + (2 * wv) * NGX * 128;
       seg_prefetch16<2, 1, TERMS>(ring2, ws, a2x, NGX * 128, NGX);
-      seg_main16<2, NB, 1, kXRow, 32, TERMS>(acc2, ring2, ws, a2x, NGX * 128, NGX, xrow, swz);
-      gemm_z16<2, NB, TERMS>(acc2, ws, mlp.az[2] + (2 * wv) * 128, zc);
+      seg_main16<2, NBW, 1, kXRow, 32, TERMS>(acc2, ring2, ws, a2x, NGX * 128, NGX, xrow, swz);
+      gemm_z16<2, NBW, TERMS>(acc2, ws, mlp.az[2] + (2 * wv) * 128, zw);
       const float inv2 = 1.0f / mlp.scale[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < NB; ++n) finish16(acc2[m][n], inv2);
+        for (int n = 0; n < NBW; ++n) finish16(acc2[m][n], inv2);
     }
 
 #ifdef MP16_ABLATE
@@ -602,17 +623,17 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < NB; ++n) sink += acc2[m][n][0];
+        for (int n = 0; n < NBW; ++n) sink += acc2[m][n][0];
       if (sink == 12345.678f) out[0] = sink;
       __syncthreads();
       continue;
     }
 #endif
     // ---------------- layer 3: rows [32 wv, +32) x 128 points ----------------
-    f32x16 acc3[1][NB];
+    f32x16 acc3[1][NBW];
     init_from_bias16(acc3[0][0], w32, mlp32.bias[3] + 32 * wv, mlp.scale[3]);
 #pragma unroll
-    for (int n = 1; n < NB; ++n) acc3[0][n] = acc3[0][0];
+    for (int n = 1; n < NBW; ++n) acc3[0][n] = acc3[0][0];
     {
       const int a3 = mlp.ah[3] + wv * (kHidden[2] / 16) * 128;
       AFrag ring3[4][1];
@@ -620,24 +641,24 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
 #pragma unroll
       for (int ck = 0; ck < 4; ++ck) {
 #pragma unroll
-        for (int n = 0; n < NB; ++n) store_hidden16_part(hb, acc2[ck >> 1][n], ck & 1, wv, n, j, hh);
+        for (int n = 0; n < NBW; ++n) store_hidden16_part(hb, acc2[ck >> 1][n], ck & 1, wv, cbase + n, j, hh);
         __syncthreads();
-        seg_main16<1, NB, 3, kHRow, 8, TERMS>(acc3, ring3, ws, a3 + ck * 4 * 128, 0, 4, hrow, swz);
+        seg_main16<1, NBW, 3, kHRow, 8, TERMS>(acc3, ring3, ws, a3 + ck * 4 * 128, 0, 4, hrow, swz);
         if (ck < 3) seg_prefetch16<1, 3, TERMS>(ring3, ws, a3 + (ck + 1) * 4 * 128, 0, 4);
         __syncthreads();
       }
       const int a3x = mlp.ax[3] + wv * NGX * 128;
       seg_prefetch16<1, 3, TERMS>(ring3, ws, a3x, 0, NGX);
-      seg_main16<1, NB, 3, kXRow, 32, TERMS>(acc3, ring3, ws, a3x, 0, NGX, xrow, swz);
-      gemm_z16<1, NB, TERMS>(acc3, ws, mlp.az[3] + wv * 128, zc);
+      seg_main16<1, NBW, 3, kXRow, 32, TERMS>(acc3, ring3, ws, a3x, 0, NGX, xrow, swz);
+      gemm_z16<1, NBW, TERMS>(acc3, ws, mlp.az[3] + wv * 128, zw);
       const float inv3 = 1.0f / mlp.scale[3];
 #pragma unroll
-      for (int n = 0; n < NB; ++n) finish16(acc3[0][n], inv3);
+      for (int n = 0; n < NBW; ++n) finish16(acc3[0][n], inv3);
     }
 
     // ---------------- layer 4 (Cout x (128 + C + 1)) on the VALU, f32 ----------------
     // red[part][o][p]: parts 0-3 = hidden rows of wave `part`, parts 4.. = slices of the features
-    constexpr int FP = kThreads16 / P;  // feature slices (threads per point)
+    constexpr int FP = THREADS / P;     // feature slices (threads per point)
     constexpr int SL = 32 / FP;         // 8-channel slots per slice
     float *red = reinterpret_cast<float *>(hb);
     constexpr int K4 = (kHidden[3] + C + 1 + 3) & ~3;  // padded row stride (pack.hip)
@@ -645,21 +666,21 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
 #pragma unroll
       for (int o = 0; o < COUT; ++o) {
         const float *w4 = wbase + mlp32.w4 + o * K4 + 32 * wv + 4 * hh;
-        float sv[NB];
+        float sv[NBW];
 #pragma unroll
-        for (int n = 0; n < NB; ++n) sv[n] = 0.0f;
+        for (int n = 0; n < NBW; ++n) sv[n] = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 wq = *reinterpret_cast<const f32x4 *>(w4 + 8 * q);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int n = 0; n < NB; ++n) sv[n] = fmaf(wq[i], acc3[0][n][4 * q + i], sv[n]);
+            for (int n = 0; n < NBW; ++n) sv[n] = fmaf(wq[i], acc3[0][n][4 * q + i], sv[n]);
         }
 #pragma unroll
-        for (int n = 0; n < NB; ++n) {
+        for (int n = 0; n < NBW; ++n) {
           sv[n] += __shfl_xor(sv[n], 32);
-          if (hh == 0) red[(wv * COUT + o) * P + 32 * n + j] = sv[n];
+          if (hh == 0) red[(wv * COUT + o) * P + 32 * (cbase + n) + j] = sv[n];
         }
       }
       // feature part: thread = (point, slice of the channels); x = hi + lo
@@ -683,7 +704,7 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
       for (int o = 0; o < COUT; ++o) red[((4 + hf) * COUT + o) * P + p] = sx[o];
     }
     __syncthreads();
-    for (int idx = tid; idx < COUT * P; idx += kThreads16) {
+    for (int idx = tid; idx < COUT * P; idx += THREADS) {
       const int o = idx / P, p = idx % P;
       const long long n = n0 + p;
       if (n < n_pts) {
@@ -711,13 +732,13 @@ __global__ __launch_bounds__(kThreads16, NB == 4 ? 1 : 2) void pifu_query16_kern
   }
 }
 
-template <int COUT, int TERMS, int NB>
+template <int COUT, int TERMS, int NB, int CS>
 static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w,
                             float z_scale, long long max_points, bool device_counts,
                             hipStream_t st) {
   constexpr int P = 32 * NB;
   constexpr int lds = P * (kXRow + kHRow);
-  auto kern = pifu_query16_kernel<COUT, TERMS, NB>;
+  auto kern = pifu_query16_kernel<COUT, TERMS, NB, CS>;
   const void *kern_id = reinterpret_cast<const void *>(kern);
   if (!ctx->lds_attr_done.count(kern_id)) {  // once per kernel and context (= device)
     MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -730,7 +751,7 @@ static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int 
                                        : (tiles < 8 * resident ? tiles : 8 * resident);
   const bool prof = 2 * (ctx->prof_used + 1) <= (int)ctx->prof_events.size();
   if (prof) MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], st));
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads16), lds, st, m.pack(), m.pack16(),
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads16 * CS), lds, st, m.pack(), m.pack16(),
                      h, w, z_scale, m.act, set);
   if (prof) {
     MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], st));
@@ -745,7 +766,7 @@ int launch_query16(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w,
   if (m.c != 256) return fail(ctx, MP_ERR_UNSUPPORTED, "f16x3 query kernel is built for C = 256");
 #define MP_Q16CASE(CO, PREC, TERMS)                                                         \
   if (m.cout == CO && m.precision == PREC)                                                 \
-    return launch_query16_t<CO, TERMS, MP16_NB>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
+    return launch_query16_t<CO, TERMS, MP16_NB, MP16_CS>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
   MP_Q16CASE(1, MP_PREC_F16X3, 3)
   MP_Q16CASE(3, MP_PREC_F16X3, 3)
   MP_Q16CASE(1, MP_PREC_F16W, 2)
