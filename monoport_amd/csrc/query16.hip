@@ -47,7 +47,12 @@ constexpr int kHRow = 256;       // bytes per point in the hidden chunk: 8 hi sl
 #define MP16_NB 4  // tile shape the launcher instantiates (see pifu_query16_kernel)
 #endif
 #ifndef MP16_CS
-#define MP16_CS (MP16_NB == 4 ? 2 : 1)  // column split: 2 = eight waves (two per SIMD), see the kernel
+// column split: 2 = eight waves, two per SIMD (see the kernel).  Correct (the f16 tests pass with
+// it) but MEASURED SLOWER for f16x3 -- 1 M points 9.3 ms vs 7.0 ms: 128 accumulator registers + the
+// A ring + double-buffered hi/lo B fragments do not fit 256 registers (103 spilled, scratch traffic
+// inside the chunk loop) and both waves of a row group load every weight fragment.  Plain f16 gains
+// 5 % (3.63 vs 3.82 ms).  Kept for tools/ablate.py; the product uses 1.
+#define MP16_CS 1
 #endif
 #ifndef MP16_PIPE
 // 1 = software-pipelined layer-0/1 loop (32-row chunks, conversion of chunk k+1 under the layer-1
