@@ -398,16 +398,11 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
     lpc[n] = (ty + 1) * PW + tx + j + 1;
   }
 
-  // NR == 1: two accumulators for the ONE output tile, used alternately, so that consecutive MFMAs
-  // never depend on each other (three dependent MFMAs per tap otherwise); summed in the epilogue
-  constexpr int NA = NR == 1 ? 2 : 1;
-  f32x16 acc[NA][NR];
+  f32x16 acc[NR];
 #pragma unroll
-  for (int a = 0; a < NA; ++a)
+  for (int n = 0; n < NR; ++n)
 #pragma unroll
-    for (int n = 0; n < NR; ++n)
-#pragma unroll
-      for (int t = 0; t < 16; ++t) acc[a][n][t] = 0.0f;
+    for (int t = 0; t < 16; ++t) acc[n][t] = 0.0f;
 
   // A ring: (hi, lo) fragments of the 3 taps of one kernel row, refilled one row-step ahead
   const int a_base = rb * kst * 128;  // 16-byte units: [ks][hi | lo][64 lanes]
@@ -454,15 +449,13 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
         // term-major order: consecutive MFMAs hit different accumulators
 #pragma unroll
         for (int n = 0; n < NR; ++n)
-          acc[(3 * kx) % NA][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[n], acc[(3 * kx) % NA][n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[n], acc[n], 0, 0, 0);
 #pragma unroll
         for (int n = 0; n < NR; ++n)
-          acc[(3 * kx + 1) % NA][n] =
-              __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[n], acc[(3 * kx + 1) % NA][n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[n], acc[n], 0, 0, 0);
 #pragma unroll
         for (int n = 0; n < NR; ++n)
-          acc[(3 * kx + 2) % NA][n] =
-              __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[n], acc[(3 * kx + 2) % NA][n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[n], acc[n], 0, 0, 0);
         if (kx < 2) {
 #pragma unroll
           for (int n = 0; n < NR; ++n) {
@@ -490,7 +483,7 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int r = (t & 3) + 8 * (t >> 2) + 4 * h;
-      const float v = (NA == 2 ? acc[0][n][t] + acc[NA - 1][n][t] : acc[0][n][t]) * inv_scale;
+      const float v = acc[n][t] * inv_scale;
       row[(long long)r * hw] = v;
       s1[t] += v;
       s2[t] = fmaf(v, v, s2[t]);
