@@ -138,12 +138,20 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
   };
 
   // ---- this wave's output pixels: column block n = 32 consecutive pixels of one tile row ----
-  int lpc[NR];  // linear halo-pixel index of this lane's pixel, per column block
+  // byte offset (inside a stage buffer) of this lane's B operand for each of the 9 taps and column
+  // blocks, K group 0 (slot h ^ swizzle); group 1 is the same address XOR 32 (slot ^ 2).  Computed
+  // once: the inner loop spends 2 VALU instructions per operand read instead of ~8.
+  int boff[NR][9];
 #pragma unroll
   for (int n = 0; n < NR; ++n) {
     const int cb = cwi * NR + n;
     const int ty = (32 * cb) / TW, tx = (32 * cb) - ty * TW;
-    lpc[n] = (ty + 1) * PW + tx + j + 1;
+    const int lpc = (ty + 1) * PW + tx + j + 1;  // linear halo-pixel index of this lane's pixel
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int lp = lpc + (tap / 3 - 1) * PW + (tap % 3 - 1);
+      boff[n][tap] = lp * kPixBytes + ((h ^ ((lp >> 2) & 3)) << 4);
+    }
   }
 
   f32x16 acc[NR];
@@ -172,14 +180,10 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
     // fragments row 1 waits for are older, and by row 2 they have had a whole row-step to land
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-      const int row_off = (ky - 1) * PW;
       // B operand of the first group of this row-step
       f32x4 bcur[NR];
 #pragma unroll
-      for (int n = 0; n < NR; ++n) {
-        const int lp = lpc[n] + row_off - 1;
-        bcur[n] = *reinterpret_cast<const f32x4 *>(buf + lp * kPixBytes + ((h ^ ((lp >> 2) & 3)) << 4));
-      }
+      for (int n = 0; n < NR; ++n) bcur[n] = *reinterpret_cast<const f32x4 *>(buf + boff[n][3 * ky]);
 #pragma unroll
       for (int s = 0; s < 6; ++s) {  // s = 2 * kx + g
         // next group's B operand (the first group of the next row-step is read at its top)
@@ -187,11 +191,8 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
         if (s < 5) {
           const int sn = s + 1;
 #pragma unroll
-          for (int n = 0; n < NR; ++n) {
-            const int lp = lpc[n] + row_off + (sn >> 1) - 1;
-            bnxt[n] = *reinterpret_cast<const f32x4 *>(
-                buf + lp * kPixBytes + (((2 * (sn & 1) + h) ^ ((lp >> 2) & 3)) << 4));
-          }
+          for (int n = 0; n < NR; ++n)
+            bnxt[n] = *reinterpret_cast<const f32x4 *>(buf + (boff[n][3 * ky + (sn >> 1)] ^ (32 * (sn & 1))));
         }
         const f32x4 a = ring[s];
         ring[s] = wload128(ws, a_base + min(kg0 + 6 + s, kgt - 1) * 64);
@@ -390,12 +391,19 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
     }
   };
 
-  int lpc[NR];
+  // byte offsets of this lane's hi B operand per tap and column block; the lo operand is the same
+  // address XOR 32 (slot ^ 2)
+  int boff[NR][9];
 #pragma unroll
   for (int n = 0; n < NR; ++n) {
     const int cb = cwi * NR + n;
     const int ty = (32 * cb) / TW, tx = (32 * cb) - ty * TW;
-    lpc[n] = (ty + 1) * PW + tx + j + 1;
+    const int lpc = (ty + 1) * PW + tx + j + 1;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int lp = lpc + (tap / 3 - 1) * PW + (tap % 3 - 1);
+      boff[n][tap] = lp * kPixBytes + ((h ^ ((lp >> 2) & 3)) << 4);
+    }
   }
 
   f32x16 acc[NR];
@@ -420,14 +428,11 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
     const bool more = chunk + 1 < n_chunks;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-      const int row_off = (ky - 1) * PW;
       h8 bh[NR], bl[NR];
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
-        const int lp = lpc[n] + row_off - 1;
-        const int sw = (lp >> 2) & 3;
-        bh[n] = *reinterpret_cast<const h8 *>(buf + lp * kPixBytes + ((h ^ sw) << 4));
-        bl[n] = *reinterpret_cast<const h8 *>(buf + lp * kPixBytes + (((2 + h) ^ sw) << 4));
+        bh[n] = *reinterpret_cast<const h8 *>(buf + boff[n][3 * ky]);
+        bl[n] = *reinterpret_cast<const h8 *>(buf + (boff[n][3 * ky] ^ 32));
       }
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
@@ -435,10 +440,8 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
         if (kx < 2) {
 #pragma unroll
           for (int n = 0; n < NR; ++n) {
-            const int lp = lpc[n] + row_off + kx;  // tap kx + 1: dx = kx
-            const int sw = (lp >> 2) & 3;
-            nh[n] = *reinterpret_cast<const h8 *>(buf + lp * kPixBytes + ((h ^ sw) << 4));
-            nl[n] = *reinterpret_cast<const h8 *>(buf + lp * kPixBytes + (((2 + h) ^ sw) << 4));
+            nh[n] = *reinterpret_cast<const h8 *>(buf + boff[n][3 * ky + kx + 1]);
+            nl[n] = *reinterpret_cast<const h8 *>(buf + (boff[n][3 * ky + kx + 1] ^ 32));
           }
         }
         const h8 ah = ring[2 * kx], al = ring[2 * kx + 1];
