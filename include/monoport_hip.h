@@ -271,14 +271,14 @@ int mp_concat3_add(mp_ctx *ctx, const float *a, int ca, const float *b, int cb, 
  * the normalised tensor -- as an implicit GEMM on v_mfma_f32_32x32x2_f32, and optionally emits the
  * partial sums the NEXT GroupNorm(32, Cout) needs.  x [N,Cin,H,W], y [N,Cout,H,W] contiguous NCHW;
  * ss [N,Cin,2] = (scale, shift) from mp_gn_finalize; packed = W re-ordered by mp_conv3x3_pack
- * (Cout*Cin*9 floats).  stats: NULL or double [N,32,S,2] with S = mp_conv3x3_stat_slices(Cout,N,H,W).
+ * (Cout*Cin*9 floats).  stats: NULL or double [N,32,S,2] with S = mp_conv3x3_stat_slices(Cout,N,H,W,f16) (f16 = 0 here, 1 for mp_conv3x3_gn16).
  * Needs Cin % 16 == 0, Cout % 32 == 0, H and W powers of two (W >= 32); else MP_ERR_UNSUPPORTED.
  * mp_conv3x3_tune(nr): measurement hook -- force nr (1, 2, 4) 32-pixel column blocks per wave
  * instead of the launch-size heuristic (0 restores it); process-wide, not for production use. */
 int mp_conv3x3_pack(mp_ctx *ctx, const float *w /*[Cout,Cin,3,3]*/, int cout, int cin, float *packed,
                     mp_stream stream);
 int mp_conv3x3_supported(int cin, int cout, int h, int w); /* 1 if the shape is built, else 0 */
-int mp_conv3x3_stat_slices(int cout, int n, int h, int w);
+int mp_conv3x3_stat_slices(int cout, int n, int h, int w, int f16);
 void mp_conv3x3_tune(int nr);
 int mp_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss, int relu,
                   const float *packed, int cout, float *y, double *stats, mp_stream stream);

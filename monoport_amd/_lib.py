@@ -64,7 +64,7 @@ SIGNATURES = {
                               c_vp]),
     "mp_upsample_bicubic2x": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "mp_conv3x3_pack": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
-    "mp_conv3x3_stat_slices": (c_int, [c_int, c_int, c_int, c_int]),
+    "mp_conv3x3_stat_slices": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mp_conv3x3_tune": (None, [c_int]),
     "mp_conv3x3_gn": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp,
                               c_vp, c_vp]),

@@ -773,9 +773,9 @@ int mp_conv3x3_supported(int cin, int cout, int h, int w) { return conv3x3_suppo
 
 int mp_gn_stat_slices(void) { return gn_stat_slices(); }
 
-int mp_conv3x3_stat_slices(int cout, int n, int h, int w) {
+int mp_conv3x3_stat_slices(int cout, int n, int h, int w, int f16) {
   if (cout < 32 || cout % 32 || n < 1 || h < 1 || w < 32) return 0;
-  return conv3x3_stat_slices(cout, n, h, w);
+  return conv3x3_stat_slices(cout, n, h, w, f16 != 0);
 }
 
 void mp_conv3x3_tune(int nr) { conv3x3_set_nr(nr); }

@@ -566,16 +566,18 @@ static int g_conv_nr = 0;  // 0 = heuristic; tools/conv_probe.py overrides it fo
 
 void conv3x3_set_nr(int nr) { g_conv_nr = nr; }
 
-static void conv_shape(int cout, int n, int h, int w, int &rbw, int &nr, int &tw, int &th, int &slots) {
+static void conv_shape(int cout, int n, int h, int w, bool f16, int &rbw, int &nr, int &tw, int &th,
+                       int &slots) {
   rbw = cout % 128 == 0 ? 4 : cout % 64 == 0 ? 2 : 1;
   const int cw = 4 / rbw;
   // NR = 2 unless that leaves fewer than 2 workgroups per slot (512 slots); NR = 4 needs all 256
   // VGPRs (spills) and measured slower at every shape, so it is not built
   nr = 2;
   if (g_conv_nr > 0)
-    nr = g_conv_nr > 2 ? 2 : g_conv_nr;
+    nr = g_conv_nr;
   else if ((long long)n * h * w / (32 * nr * cw) * (cout / (32 * rbw)) < 1024)
     nr = 1;
+  if (nr > 2 && (rbw == 1 || !f16)) nr = 2;  // NR = 4 is built for the split-f16 kernels only
   const int px = 32 * nr * cw;
   // 32-pixel-wide tiles, PX / 32 rows tall: the staged halo is (TH + 2) x 34 pixels (1.3-2.1x the
   // tile; one-row tiles would stage 3x) and a wave stages it in 2-6 passes of 64 pixels
@@ -584,9 +586,9 @@ static void conv_shape(int cout, int n, int h, int w, int &rbw, int &nr, int &tw
   slots = (h / th) * (w / tw) * cw;
 }
 
-int conv3x3_stat_slices(int cout, int n, int h, int w) {
+int conv3x3_stat_slices(int cout, int n, int h, int w, bool f16) {
   int rbw, nr, tw, th, slots;
-  conv_shape(cout, n, h, w, rbw, nr, tw, th, slots);
+  conv_shape(cout, n, h, w, f16, rbw, nr, tw, th, slots);
   return slots * (cout / 32);
 }
 
@@ -663,13 +665,17 @@ int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w,
   a.relu = relu;
   a.wp_floats = cout * cin * 9;
   int rbw, nr, slots;
-  conv_shape(cout, n, h, w, rbw, nr, a.tw, a.th, slots);
+  conv_shape(cout, n, h, w, wmax16 != nullptr, rbw, nr, a.tw, a.th, slots);
   if (a.th > h)
     return fail(ctx, MP_ERR_UNSUPPORTED, "conv3x3: %dx%d map too small for a %dx%d tile", h, w, a.th, a.tw);
   const int tiles = (h / a.th) * (w / a.tw);
 #define MP_CONV_CASE(R, N)                                                                   \
   if (rbw == R && nr == N)                                                                   \
     return wmax16 ? launch_conv16_t<R, N>(ctx, a, wmax16, tiles, st) : launch_conv_t<R, N>(ctx, a, tiles, st);
+  if (wmax16 && nr == 4) {
+    if (rbw == 4) return launch_conv16_t<4, 4>(ctx, a, wmax16, tiles, st);
+    if (rbw == 2) return launch_conv16_t<2, 4>(ctx, a, wmax16, tiles, st);
+  }
   MP_CONV_CASE(4, 2)
   MP_CONV_CASE(4, 1)
   MP_CONV_CASE(2, 2)

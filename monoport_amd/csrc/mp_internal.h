@@ -202,7 +202,7 @@ int launch_marching_cubes(mp_ctx *ctx, void *scratch, const float *vol, int r, f
 
 // conv3x3.hip
 int launch_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *wp, hipStream_t st);
-int conv3x3_stat_slices(int cout, int n, int h, int w);
+int conv3x3_stat_slices(int cout, int n, int h, int w, bool f16);
 void conv3x3_set_nr(int nr);
 bool conv3x3_supported(int cin, int cout, int h, int w);
 int launch_conv3x3_pack16(mp_ctx *ctx, const float *w, int cout, int cin, void *wp, float *wmax,

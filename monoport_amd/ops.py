@@ -634,7 +634,7 @@ def conv3x3_gn(x, ss, packed, relu=True, want_stats=False):
     y = torch.empty((n, packed.cout, h, w), dtype=torch.float32, device=x.device)
     stats = None
     if want_stats:
-        s = ctx.lib.mp_conv3x3_stat_slices(packed.cout, n, h, w)
+        s = ctx.lib.mp_conv3x3_stat_slices(packed.cout, n, h, w, int(packed.precision == "f16x3"))
         stats = (torch.empty((n, 32, s, 2), dtype=torch.float64, device=x.device), s)
     if packed.precision == "f32":
         ctx.check(ctx.lib.mp_conv3x3_gn(ctx.handle, _ptr(x), n, cin, h, w,
