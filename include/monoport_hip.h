@@ -281,7 +281,13 @@ int mp_conv3x3_supported(int cin, int cout, int h, int w); /* 1 if the shape is 
 int mp_conv3x3_stat_slices(int cout, int n, int h, int w, int f16);
 void mp_conv3x3_tune(int nr);
 int mp_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss, int relu,
-                  const float *packed, int cout, float *y, double *stats, mp_stream stream);
+                  int reflect, const float *packed, int cout, float *y, double *stats, mp_stream stream);
+/* reflect != 0: nn.ReflectionPad2d(1) + an unpadded 3x3 convolution (the residual blocks of the
+ * netC encoder, backbones/ResBlkFilters.py:28-84) instead of zero padding.
+ * mp_scale_shift_add: y = res + (t * scale[n,c] + shift[n,c]) -- x + GroupNorm(conv(.)) at the end of
+ * such a block (no ReLU), ss from mp_gn_finalize; t, res, y [N,C,HW], HW % 4 == 0. */
+int mp_scale_shift_add(mp_ctx *ctx, const float *t, const float *ss, const float *res, int n, int c,
+                       int64_t hw, float *y, mp_stream stream);
 /* The same convolution on split-f16 operands ("f16x3": every operand hi + lo, three
  * v_mfma_f32_32x32x16_f16 per product term, f32 accumulation; f32-class accuracy, the arithmetic of
  * MP_PREC_F16X3).  mp_conv3x3_pack16 writes the pre-split weights (Cout*Cin*9*4 bytes) and
@@ -290,7 +296,7 @@ int mp_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, con
 int mp_conv3x3_pack16(mp_ctx *ctx, const float *w, int cout, int cin, void *packed16, float *wmax,
                       mp_stream stream);
 int mp_conv3x3_gn16(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss, int relu,
-                    const void *packed16, const float *wmax, int cout, float *y, double *stats,
+                    int reflect, const void *packed16, const float *wmax, int cout, float *y, double *stats,
                     mp_stream stream);
 /* The 1x1 convolutions of the hourglass tail (backbones/HGFilters.py:184-204: conv_last, l, bl,
  * al; nn.Conv2d(C, 256, 1) with bias) as one fused GEMM each:

@@ -66,11 +66,12 @@ SIGNATURES = {
     "mp_conv3x3_pack": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "mp_conv3x3_stat_slices": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mp_conv3x3_tune": (None, [c_int]),
-    "mp_conv3x3_gn": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp,
+    "mp_conv3x3_gn": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp,
                               c_vp, c_vp]),
+    "mp_scale_shift_add": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_vp, c_vp]),
     "mp_conv3x3_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "mp_conv3x3_pack16": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
-    "mp_conv3x3_gn16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int,
+    "mp_conv3x3_gn16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int,
                                 c_vp, c_vp, c_vp]),
     "mp_conv1x1_pack": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "mp_conv1x1": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_i64, c_vp, c_int, c_vp,

@@ -732,7 +732,7 @@ int mp_conv3x3_pack16(mp_ctx *ctx, const float *w, int cout, int cin, void *pack
 }
 
 int mp_conv3x3_gn16(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss, int relu,
-                    const void *packed16, const float *wmax, int cout, float *y, double *stats,
+                    int reflect, const void *packed16, const float *wmax, int cout, float *y, double *stats,
                     mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -740,8 +740,8 @@ int mp_conv3x3_gn16(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, c
     return fail(ctx, MP_ERR_ARG, "mp_conv3x3_gn16: bad argument");
   if (!aligned16(packed16)) return fail(ctx, MP_ERR_ARG, "mp_conv3x3_gn16: packed weights must be 16-byte aligned");
   DeviceGuard g(ctx->device);
-  return launch_conv3x3_gn(ctx, x, n, cin, h, w, ss, relu, static_cast<const float *>(packed16), wmax, cout,
-                           y, stats, (hipStream_t)stream);
+  return launch_conv3x3_gn(ctx, x, n, cin, h, w, ss, relu, reflect, static_cast<const float *>(packed16),
+                           wmax, cout, y, stats, (hipStream_t)stream);
 }
 
 int mp_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, int c2, int f16,
@@ -769,6 +769,18 @@ int mp_conv1x1(mp_ctx *ctx, const float *x1, const float *ss1, int relu1, const 
                             stats, (hipStream_t)stream);
 }
 
+int mp_scale_shift_add(mp_ctx *ctx, const float *t, const float *ss, const float *res, int n, int c,
+                       int64_t hw, float *y, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!t || !ss || !res || !y || n <= 0 || c <= 0 || hw <= 0)
+    return fail(ctx, MP_ERR_ARG, "mp_scale_shift_add: bad argument");
+  if (hw % 4 || !aligned16(t) || !aligned16(res) || !aligned16(y))
+    return fail(ctx, MP_ERR_UNSUPPORTED, "mp_scale_shift_add: needs HW %% 4 == 0 and 16-byte aligned buffers");
+  DeviceGuard g(ctx->device);
+  return launch_scale_shift_add(ctx, t, ss, res, (long long)n * c, hw, y, (hipStream_t)stream);
+}
+
 int mp_conv3x3_supported(int cin, int cout, int h, int w) { return conv3x3_supported(cin, cout, h, w) ? 1 : 0; }
 
 int mp_gn_stat_slices(void) { return gn_stat_slices(); }
@@ -781,14 +793,14 @@ int mp_conv3x3_stat_slices(int cout, int n, int h, int w, int f16) {
 void mp_conv3x3_tune(int nr) { conv3x3_set_nr(nr); }
 
 int mp_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss, int relu,
-                  const float *packed, int cout, float *y, double *stats, mp_stream stream) {
+                  int reflect, const float *packed, int cout, float *y, double *stats, mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!x || !packed || !y || n <= 0 || n > 65535 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0)
     return fail(ctx, MP_ERR_ARG, "mp_conv3x3_gn: bad argument");
   if (!aligned16(packed)) return fail(ctx, MP_ERR_ARG, "mp_conv3x3_gn: packed weights must be 16-byte aligned");
   DeviceGuard g(ctx->device);
-  return launch_conv3x3_gn(ctx, x, n, cin, h, w, ss, relu, packed, nullptr, cout, y, stats,
+  return launch_conv3x3_gn(ctx, x, n, cin, h, w, ss, relu, reflect, packed, nullptr, cout, y, stats,
                            (hipStream_t)stream);
 }
 

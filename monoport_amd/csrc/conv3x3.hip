@@ -43,6 +43,8 @@ struct ConvArgs {
   int n_img, cin, cout, h, w;
   int tw, th;        // tile width / height in pixels (th * tw = 32 * NR * CW)
   int relu;          // apply ReLU to the (normalised) input
+  int reflect;       // 0: zero padding (HGFilters.py ConvBlock); 1: nn.ReflectionPad2d(1) in front of
+                     // the convolution (ResBlkFilters.py:28-84): halo pixels mirror the interior
   int wp_floats;     // size of wp
 };
 
@@ -95,8 +97,14 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
   for (int it = 0; it < kStageIters; ++it) {
     const int lp = lane + 64 * it;
     const int r = lp / PW, c = lp - r * PW;
-    const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-    const bool ok = lp < NPH && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+    int gy = y0 - 1 + r, gx = x0 - 1 + c;
+    bool ok = lp < NPH;
+    if (p.reflect) {  // -1 -> 1, H -> H - 2 (padding 1 never reaches further)
+      gy = gy < 0 ? -gy : (gy >= p.h ? 2 * p.h - 2 - gy : gy);
+      gx = gx < 0 ? -gx : (gx >= p.w ? 2 * p.w - 2 - gx : gx);
+    } else {
+      ok = ok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+    }
     goff[it] = ok ? gy * p.w + gx : -1;
   }
   const float *xin = p.x + (long long)img * p.cin * hw;
@@ -342,8 +350,14 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
   for (int it = 0; it < kStageIters; ++it) {
     const int lp = lane + 64 * it;
     const int r = lp / PW, c = lp - r * PW;
-    const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-    const bool ok = lp < NPH && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+    int gy = y0 - 1 + r, gx = x0 - 1 + c;
+    bool ok = lp < NPH;
+    if (p.reflect) {  // -1 -> 1, H -> H - 2 (padding 1 never reaches further)
+      gy = gy < 0 ? -gy : (gy >= p.h ? 2 * p.h - 2 - gy : gy);
+      gx = gx < 0 ? -gx : (gx >= p.w ? 2 * p.w - 2 - gx : gx);
+    } else {
+      ok = ok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+    }
     goff[it] = ok ? gy * p.w + gx : -1;
   }
   const float *xin = p.x + (long long)img * p.cin * hw;
@@ -550,6 +564,38 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const double *__restric
   }
 }
 
+// y = res + (t * scale[n,c] + shift[n,c]): the tail of a residual block whose last GroupNorm has no
+// ReLU (ResBlkFilters.py:75-84: out = x + conv_block(x)); hw % 4 == 0.
+__global__ __launch_bounds__(256) void scale_shift_add_kernel(const float *__restrict__ t,
+                                                              const float *__restrict__ ss,
+                                                              const float *__restrict__ res,
+                                                              long long hw4, long long total4,
+                                                              float *__restrict__ y) {
+  const f32x4 *t4 = reinterpret_cast<const f32x4 *>(t), *r4 = reinterpret_cast<const f32x4 *>(res);
+  f32x4 *y4 = reinterpret_cast<f32x4 *>(y);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long plane = i / hw4;  // image * C + channel
+    const float sc = ss[2 * plane], sh = ss[2 * plane + 1];
+    const f32x4 a = t4[i], r = r4[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = r[k] + (a[k] * sc + sh);
+    y4[i] = o;
+  }
+}
+
+int launch_scale_shift_add(mp_ctx *ctx, const float *t, const float *ss, const float *res, long long planes,
+                           long long hw, float *y, hipStream_t st) {
+  const long long total4 = planes * (hw / 4);
+  long long blocks = (total4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(scale_shift_add_kernel, dim3((unsigned)blocks), dim3(256), 0, st, t, ss, res, hw / 4,
+                     total4, y);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
 int launch_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *wp, hipStream_t st) {
   const long long total = (long long)cout * cin * 9;
   long long blocks = (total + 255) / 256;
@@ -645,8 +691,8 @@ static int launch_conv_t(mp_ctx *ctx, const ConvArgs &a, int tiles, hipStream_t 
 }
 
 int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss,
-                      int relu, const float *wp, const float *wmax16, int cout, float *y, double *stats,
-                      hipStream_t st) {
+                      int relu, int reflect, const float *wp, const float *wmax16, int cout, float *y,
+                      double *stats, hipStream_t st) {
   if (!conv3x3_supported(cin, cout, h, w))
     return fail(ctx, MP_ERR_UNSUPPORTED,
                 "conv3x3: needs Cin %% 16 == 0, Cout %% 32 == 0, H and W powers of two (W >= 32, H >= 8); got %d -> %d at %dx%d",
@@ -663,6 +709,7 @@ int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w,
   a.h = h;
   a.w = w;
   a.relu = relu;
+  a.reflect = reflect;
   a.wp_floats = cout * cin * 9;
   int rbw, nr, slots;
   conv_shape(cout, n, h, w, wmax16 != nullptr, rbw, nr, a.tw, a.th, slots);

@@ -208,8 +208,10 @@ bool conv3x3_supported(int cin, int cout, int h, int w);
 int launch_conv3x3_pack16(mp_ctx *ctx, const float *w, int cout, int cin, void *wp, float *wmax,
                           hipStream_t st);
 int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss,
-                      int relu, const float *wp, const float *wmax16, int cout, float *y,
+                      int relu, int reflect, const float *wp, const float *wmax16, int cout, float *y,
                       double *stats, hipStream_t st);
+int launch_scale_shift_add(mp_ctx *ctx, const float *t, const float *ss, const float *res, long long planes,
+                           long long hw, float *y, hipStream_t st);
 int launch_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, int c2, int f16, void *wp,
                         float *wmax, hipStream_t st);
 int launch_conv1x1_raw(mp_ctx *ctx, const float *x1, const float *ss1, int relu1, const float *x2, int n,

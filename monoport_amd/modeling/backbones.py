@@ -88,6 +88,19 @@ def _upsample2x_add(low, skip):
     return skip + F.interpolate(low, scale_factor=2, mode="bicubic", align_corners=True)
 
 
+def _packed_conv(owner, conv):
+    """conv's weight in MFMA fragment order (cached on ``owner``), re-packed when the parameter
+    or the encoder precision changes."""
+    cache = owner.__dict__.setdefault("_packed_cache", {})
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device), ENCODER_CONV_PRECISION)
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != key:
+        hit = (key, ops.PackedConv3x3(w, ENCODER_CONV_PRECISION))
+        cache[id(conv)] = hit
+    return hit[1]
+
+
 class ConvBlock(nn.Module):
     """Pre-activation pyramid block: three GN-ReLU-3x3 convs of widths C/2, C/4, C/4 whose
     outputs are concatenated and added to a (projected) shortcut (HGFilters.py:12-62)."""
@@ -109,15 +122,7 @@ class ConvBlock(nn.Module):
             self.downsample = None
 
     def _packed(self, conv):
-        """conv's weight in MFMA fragment order, re-packed when the parameter changes."""
-        cache = self.__dict__.setdefault("_packed_cache", {})
-        w = conv.weight
-        key = (w.data_ptr(), w._version, str(w.device), ENCODER_CONV_PRECISION)
-        hit = cache.get(id(conv))
-        if hit is None or hit[0] != key:
-            hit = (key, ops.PackedConv3x3(w, ENCODER_CONV_PRECISION))
-            cache[id(conv)] = hit
-        return hit[1]
+        return _packed_conv(self, conv)
 
     def _fused_ok(self, x):
         if self.training or ENCODER_CONV != "hip" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
@@ -291,7 +296,32 @@ class _ResBlock(nn.Module):
             layers.append(_gn(dim))
         self.conv_block = nn.Sequential(*layers)
 
+    def _fused_ok(self, x):
+        if self.training or ENCODER_CONV != "hip" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+            return False
+        c = self.conv_block[1]
+        return (x.shape[2] * x.shape[3]) % 4 == 0 and ops.conv3x3_supported(c.in_channels, c.out_channels,
+                                                                           x.shape[2], x.shape[3])
+
+    def _forward_fused(self, x):
+        """Two kernels + the residual: the reflection padding is index arithmetic in the staging
+        loop of csrc/conv3x3.hip, the first GroupNorm + ReLU is applied while the second
+        convolution stages its input, the last GroupNorm (no ReLU) is folded into the add."""
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        blk = self.conv_block
+        t, st = ops.conv3x3_gn(x, None, _packed_conv(self, blk[1]), relu=False, want_stats=True, reflect=True)
+        ss = ops.gn_finalize(st, n, c, _GROUPS, (c // _GROUPS) * h * w, blk[2].weight, blk[2].bias, blk[2].eps)
+        last = len(blk) == 6
+        u, st = ops.conv3x3_gn(t, ss, _packed_conv(self, blk[5]), relu=True, want_stats=not last, reflect=True)
+        if last:
+            return x + u
+        ss = ops.gn_finalize(st, n, c, _GROUPS, (c // _GROUPS) * h * w, blk[6].weight, blk[6].bias, blk[6].eps)
+        return ops.scale_shift_add(u, ss, x)
+
     def forward(self, x):
+        if self._fused_ok(x):
+            return self._forward_fused(x)
         return x + _run_sequential(self.conv_block, x)
 
 

@@ -623,9 +623,21 @@ def conv3x3_supported(cin, cout, h, w):
     return bool(_lib.load().mp_conv3x3_supported(int(cin), int(cout), int(h), int(w)))
 
 
-def conv3x3_gn(x, ss, packed, relu=True, want_stats=False):
-    """y = conv3x3(relu?(x * scale + shift)) (stride 1, zero padding 1, no bias) as one f32-MFMA
-    kernel; ``ss`` [N,Cin,2] from ``gn_finalize`` or None (plain x).  Returns (y, stats) where
+def scale_shift_add(t, ss, res):
+    """res + (t * scale + shift): x + GroupNorm(t) with (scale, shift) from ``gn_finalize``."""
+    ctx = get_context(t.device)
+    t, res = t.contiguous(), res.contiguous()
+    n, c = t.shape[0], t.shape[1]
+    y = torch.empty_like(t)
+    ctx.check(ctx.lib.mp_scale_shift_add(ctx.handle, _ptr(t), _ptr(ss), _ptr(res), n, c,
+                                         t.shape[2] * t.shape[3], _ptr(y), _stream(t)), "mp_scale_shift_add")
+    return y
+
+
+def conv3x3_gn(x, ss, packed, relu=True, want_stats=False, reflect=False):
+    """y = conv3x3(relu?(x * scale + shift)) (stride 1, zero padding 1 -- or ReflectionPad2d(1) with
+    ``reflect`` -- no bias) as one MFMA kernel; ``ss`` [N,Cin,2] from ``gn_finalize`` or None (plain
+    x).  Returns (y, stats) where
     stats = (partial sums double [N,32,S,2], S) of GroupNorm(32, Cout) over y, or None."""
     ctx = get_context(x.device)
     n, cin, h, w = x.shape
@@ -639,12 +651,13 @@ def conv3x3_gn(x, ss, packed, relu=True, want_stats=False):
     if packed.precision == "f32":
         ctx.check(ctx.lib.mp_conv3x3_gn(ctx.handle, _ptr(x), n, cin, h, w,
                                         _ptr(ss) if ss is not None else None, int(bool(relu)),
-                                        _ptr(packed.data), packed.cout, _ptr(y),
+                                        int(bool(reflect)), _ptr(packed.data), packed.cout, _ptr(y),
                                         _ptr(stats[0]) if stats else None, _stream(x)), "mp_conv3x3_gn")
     else:
         ctx.check(ctx.lib.mp_conv3x3_gn16(ctx.handle, _ptr(x), n, cin, h, w,
                                           _ptr(ss) if ss is not None else None, int(bool(relu)),
-                                          _ptr(packed.data), _ptr(packed.wmax), packed.cout, _ptr(y),
+                                          int(bool(reflect)), _ptr(packed.data), _ptr(packed.wmax),
+                                          packed.cout, _ptr(y),
                                           _ptr(stats[0]) if stats else None, _stream(x)),
                   "mp_conv3x3_gn16")
     return y, stats

@@ -70,6 +70,65 @@ def test_conv3x3_gn_matches_torch(n, cin, cout, h, w):
     assert (got - want).abs().max().item() <= 5e-5
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("n,c,h,w", [(1, 256, 128, 128), (2, 64, 32, 64)])
+def test_conv3x3_reflection_padding(precision, n, c, h, w):
+    """reflect=True is nn.ReflectionPad2d(1) + an unpadded 3x3 convolution -- the residual blocks
+    of the netC encoder (ResBlkFilters.py:28-84) -- with the GroupNorm + ReLU applied to the
+    mirrored halo as well; followed by the block's x + GroupNorm(.) tail."""
+    from monoport_amd import ops
+    g = torch.Generator().manual_seed(c + h)
+    x = (torch.randn((n, c, h, w), generator=g) * 2 + 0.3).to(DEV)
+    wt = (torch.randn((c, c, 3, 3), generator=g) * (2.0 / (9 * c)) ** 0.5).to(DEV)
+    gn = torch.nn.GroupNorm(32, c).to(DEV)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.5, 0.5)
+    packed = ops.PackedConv3x3(wt, precision)
+    pad = torch.nn.ReflectionPad2d(1)
+    for ss_on in (False, True):
+        ss = None
+        if ss_on:
+            ss = ops.gn_finalize(ops.gn_stats(x, 32), n, c, 32, (c // 32) * h * w, gn.weight, gn.bias, gn.eps)
+        y, stats = ops.conv3x3_gn(x, ss, packed, relu=ss_on, want_stats=True, reflect=True)
+        with torch.no_grad():
+            v = torch.relu(gn(x)) if ss_on else x
+            ref = torch.nn.functional.conv2d(pad(v).double(), wt.double())
+        err = (y.double() - ref).abs().max().item()
+        print("reflect conv %s %s gn=%d: max|d| %.3g" % (precision, (n, c, h, w), ss_on, err))
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item())
+        # zero padding must differ on the border and agree in the interior
+        y0, _ = ops.conv3x3_gn(x, ss, packed, relu=ss_on)
+        assert torch.equal(y0[:, :, 1:-1, 1:-1], y[:, :, 1:-1, 1:-1]) and not torch.equal(y0, y)
+    ss2 = ops.gn_finalize(stats, n, c, 32, (c // 32) * h * w, gn.weight, gn.bias, gn.eps)
+    out = ops.scale_shift_add(y, ss2, x)
+    with torch.no_grad():
+        want = x + gn(y)
+    assert (out - want).abs().max().item() <= 5e-5
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_resnet_filter_fused_equals_unfused(monkeypatch, precision):
+    """The netC encoder with its twelve 256->256 reflect-padded convolutions on csrc/conv3x3.hip
+    against the same module on the stock ops."""
+    from monoport_amd.modeling import backbones
+    net = backbones.ResnetFilter().eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, 5).items()})
+    net.to(DEV)
+    img = torch.from_numpy(syn.synthetic_image(6))[None].to(DEV)
+    monkeypatch.setattr(backbones, "ENCODER_CONV_PRECISION", precision)
+    with torch.no_grad():
+        monkeypatch.setattr(backbones, "ENCODER_CONV", "miopen")
+        ref = net(img)[0][0]
+        monkeypatch.setattr(backbones, "ENCODER_CONV", "hip")
+        assert net.model[-1]._fused_ok(ref)
+        got = net(img)[0][0]
+    err = (got - ref).abs().max().item()
+    print("ResnetFilter fused (%s) vs stock ops: %.3g (max|ref| %.3g)" % (precision, err, ref.abs().max().item()))
+    assert got.shape == (1, 256, 128, 128) and err <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w", SHAPES[:8])
 def test_conv3x3_f16x3_is_f32_class(n, cin, cout, h, w):
     """The split-f16 variant (three f16 MFMAs per product, f32 accumulation) against the fp64

@@ -122,10 +122,13 @@ def test_encoder_on_gpu_close_to_reference():
         assert np.abs(fg[i][0][0, ::8, ::8, ::8].cpu().numpy() - g["G%d" % i]).max() <= 1e-4
 
 
-def test_netc_encoder_on_gpu_close_to_reference():
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_netc_encoder_on_gpu_close_to_reference(monkeypatch, precision):
     """netC.filter (ResNet encoder + the nearest-resized, prior-first concat of MonoPortNet.py:41-45)
-    on the GPU vs the reference's CPU run of the same seeded weights (fixture C0)."""
-    from monoport_amd.modeling import PIFuNetC, PIFuNetG
+    on the GPU vs the reference's CPU run of the same seeded weights (fixture C0); its residual
+    blocks run on csrc/conv3x3.hip (reflection padding) in either precision."""
+    from monoport_amd.modeling import PIFuNetC, PIFuNetG, backbones
+    monkeypatch.setattr(backbones, "ENCODER_CONV_PRECISION", precision)
     g = load_golden("encoders")
     netg, netc = PIFuNetG().eval(), PIFuNetC().eval()
     for net, seed in ((netg, 71), (netc, 72)):
@@ -139,7 +142,7 @@ def test_netc_encoder_on_gpu_close_to_reference():
         fc = netc.filter(img, feat_prior=fg[-1][-1])
     assert len(fc) == 1 and fc[0][0].shape == (1, 512, 128, 128)
     err = float(np.abs(fc[0][0][0, ::8, ::8, ::8].cpu().numpy() - g["C0"]).max())
-    print("netC.filter on GPU vs reference: %.3g" % err)
+    print("netC.filter (%s convs) on GPU vs reference: %.3g" % (precision, err))
     assert err <= 1e-4
 
 
