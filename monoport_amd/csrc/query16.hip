@@ -7,35 +7,50 @@
 // instruction: 3 MFMAs of 32 cycles replace 8 MFMAs of 64 cycles per 16-deep k-step (5.3x).
 //
 // Everything that was "free" next to f32 MFMA now matters, so the decomposition changes:
-//   * one workgroup = 4 waves = a 128-point tile (weights are re-used over twice as many points:
-//     4.7 MB of weight traffic per 128 points keeps the L2 -> CU stream ~12 TB/s chip-wide);
-//   * one wave per SIMD with the whole 512-entry register file: layer 1's 128 rows x 128 points
-//     per wave are 256 accumulator registers, and the A ring / B fragments are deep enough to hide
-//     L2 latency without a partner wave;
-//   * LDS is used to the last byte: xs[128][hi 512 B | lo 512 B] = 128 KB + one 64-row hidden chunk
-//     [128][hi 128 B | lo 128 B] = 32 KB (160 KB, one workgroup per CU);
-//   * layer 0 is produced in 64-row chunks (32 rows x 64 points per wave), split into halves on
-//     the way to LDS and consumed by layer 1; layers 2 and 3 stream their inputs from the owning
-//     waves' registers the same way.
+//   * one workgroup = 4 waves = a 96-point tile, one wave per SIMD with the whole 512-entry register
+//     file: layer 1's 128 rows x 96 points per wave are 192 accumulator registers, a layer-0 chunk
+//     48 more -- 240, which fit the 256 AGPRs, so no accumulator tile ever moves between the two
+//     register files (the 128-point tile of round 1 needed 256 + 32 and the allocator shuffled
+//     tiles and spilled 100 registers; MP16_NB=4 still builds it);
+//   * LDS: xs[96][hi 512 B | lo 512 B] = 96 KB + one 128-row hidden chunk [96][hi 256 B | lo 256 B]
+//     = 48 KB (144 KB, one workgroup per CU);
+//   * layer 0 is produced in 128-row chunks -- one row block x all three column blocks per wave, so
+//     every weight fragment of layer 0 is loaded by exactly one wave and feeds 9 MFMAs (the
+//     128-point tile's 64-row chunks had two waves load each) -- split into halves on the way to
+//     LDS and consumed by layer 1 (8 k16 groups per chunk); layers 2 and 3 stream their inputs
+//     from the owning waves' registers in 64-row chunks made of 16 rows from each wave;
+//   * the prefetches of a k16 group (weight fragments, LDS reads of the next group's activations)
+//     are placed one behind each MFMA (sched_group_barrier) instead of in a clump in front of them.
 // Weights are pre-split and pre-scaled by a per-layer power of two S (pack.hip) so that lo stays
 // out of the f16 subnormals; accumulators start at bias * S and are multiplied by 1/S (exact)
 // before the leaky ReLU.  Activations larger than 65504 would saturate -- PIFu activations are O(1-100).
 //
-// Status (round 2): 1 M points in 6.65 ms = 158 M points/s (2.6x the f32 kernel) = 372
-// TFLOP/s-equivalent = 0.45 of the three-MFMA-per-product roof (2.5 PFLOP/s / 3).  PMC pass of that
-// launch (profiles/r02p_pmc_f16x3.txt): matrix pipe busy 52 % of the cycles at 2.09 GHz; of a wave's
-// cycles 44 % wait on the MFMA pipe, 20 % are parked at s_waitcnt / barriers (half of that is the
-// gather, which nothing overlaps with one workgroup per CU), 35 % issue instructions (20 % VALU:
-// rescale, leaky ReLU and the hi/lo split of 1920 activations per point); LDS bank conflicts are
-// 12 % of the LDS cycles.  The weight stream goes through buffer resources (query_common.h), the
-// inner loops are spill-free.  A software-pipelined layer-0/1 loop exists (MP16_PIPE) and measured
-// slower -- see its comment.
+// Status (round 2): 1 M points in 6.44-6.60 ms = 160 M points/s (2.7x the f32 kernel) = 375-385
+// TFLOP/s-equivalent = 0.45-0.46 of the three-MFMA-per-product roof (2.5 PFLOP/s / 3); 0.44 over a
+// reconstruction's launches (128-point tile: 0.42).
+// What bounds it (side builds, tools/ablate.py -DMP16_ABLATE=10..14, profiles/r02w_f16x3_ablation.txt):
+// removing the layer-0 conversion buys 2 %, the barriers 1.6 %, the LDS reads 4 % -- and removing
+// the WEIGHT LOADS 27 % (6.60 -> 4.81 ms; everything together 4.46).  It is not latency: deeper
+// rings (MP16_PF0 / MP16_PF1) are slower, and FETCH_SIZE says the weights come from L2.  It is the
+// CU's one vector-memory path: 4.7 MB of fragments per 96 points at 64 B/clk are 73 k of a tile's
+// ~300 k cycles, each buffer_load costs the issuing wave tens of cycles (MI355X_MICROARCH.md: ~60
+// cycles per 1-KB piece beside MFMAs) and with ONE wave per SIMD nobody issues MFMAs meanwhile.
+// The f32 kernel hides exactly this with its second wave per SIMD; here two waves per SIMD would
+// need either 64-point tiles (twice the weight bytes per point: measured 11.3 ms) or an eight-wave
+// split of the 96 / 128-point tile whose layer-0 chunks need a second chunk buffer the LDS does not
+// have (MP16_CS=2 duplicated the weight loads instead: 9.3 ms).  Also measured and dropped: a
+// software-pipelined layer-0/1 loop over 32-row chunks (6.97 vs 6.65 ms, round 2 history) and
+// MP16_FILL below.
 #include "mp_internal.h"
 #include "query_common.h"
 
 #pragma clang fp contract(off)
 
 namespace mp {
+
+#if defined(MP16_ABLATE) && (MP16_ABLATE == 12 || MP16_ABLATE == 14)  // timing experiment: no barriers (results are garbage)
+#define __syncthreads() ((void)0)
+#endif
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -44,7 +59,7 @@ constexpr int kThreads16 = 256;  // 4 waves = one per SIMD, each with the full 5
 constexpr int kXRow = 1024;      // bytes per point in xs: 32 hi slots | 32 lo slots (16 B each)
 constexpr int kHRow = 256;       // bytes per point in the hidden chunk: 8 hi slots | 8 lo slots
 #ifndef MP16_NB
-#define MP16_NB 4  // tile shape the launcher instantiates (see pifu_query16_kernel)
+#define MP16_NB 3  // tile shape the launcher instantiates (see pifu_query16_kernel)
 #endif
 #ifndef MP16_CS
 // column split: 2 = eight waves, two per SIMD (see the kernel).  Correct (the f16 tests pass with
@@ -54,13 +69,19 @@ constexpr int kHRow = 256;       // bytes per point in the hidden chunk: 8 hi sl
 // 5 % (3.63 vs 3.82 ms).  Kept for tools/ablate.py; the product uses 1.
 #define MP16_CS 1
 #endif
-#ifndef MP16_PIPE
-// 1 = software-pipelined layer-0/1 loop (32-row chunks, conversion of chunk k+1 under the layer-1
-// MFMAs of chunk k).  Correct (the f16 tests pass with it) but MEASURED SLOWER, so it is off:
-// 1 M points f16x3 6.97 ms vs 6.65 ms sequential (8.05 without the sched_group_barrier
-// interleave) -- with 32-row chunks every wave streams the same layer-0 row block (4x instead of
-// 2x redundant weight loads) and feeds only 3 MFMAs per fragment pair.  Kept for tools/ablate.py.
-#define MP16_PIPE 0
+#ifndef MP16_FILL
+// 1 = (96-point tile) the skip-connection k16 groups of layer 1 -- they depend on nothing but xs --
+// are spread over the chunk loop and issued while the wave rescales / splits / stores the chunk it
+// just produced, 6-8 VALU instructions behind each MFMA.  Correct and the interleave comes out as
+// written (tools/isa_loops.py), but MEASURED NEUTRAL: 6.60-6.62 ms vs 6.57-6.59 -- the conversion is
+// not what the matrix pipe waits for (see "What bounds it" in the header).  Off.
+#define MP16_FILL 0
+#endif
+#ifndef MP16_PF0
+#define MP16_PF0 3  // weight fragments in flight ahead of layer 0's MFMAs (96-point tile)
+#endif
+#ifndef MP16_PF1
+#define MP16_PF1 1  // the same for layer 1's hidden segment (4 row blocks per group)
 #endif
 #ifndef MP16_SGB
 #define MP16_SGB 1  // sched_group_barrier interleave of the conversion with the layer-1 MFMAs
@@ -84,6 +105,12 @@ __device__ __forceinline__ void split4(const f32x4 &v, h4 &hi, h4 &lo) {
 // TERMS selects the arithmetic: 3 = hi*hi + hi*lo + lo*hi (f32-class, "f16x3"); 2 = weights
 // rounded to f16, activations still split (hi*hi + hi*lo, "f16w"); 1 = plain f16 operands ("f16").
 __device__ __forceinline__ h8 hload(const WStream &w, int idx16) {
+#if defined(MP16_ABLATE) && (MP16_ABLATE == 11 || MP16_ABLATE == 14)  // timing experiment: no weight loads
+  h8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (_Float16)(float)(idx16 & 3);
+  return r;
+#endif
   return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.lane16, idx16 * 16, 0));
 }
 
@@ -134,10 +161,19 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
       h8 nh[NR], nl[NR];
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
+#if defined(MP16_ABLATE) && (MP16_ABLATE == 13 || MP16_ABLATE == 14)  // timing experiment: no LDS reads
+        nh[n] = bh[n];
+        nl[n] = bl[n];
+        (void)boff;
+        (void)boff_lo;
+        continue;
+#endif
         nh[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + boff);
         if (TERMS >= 2) nl[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + boff_lo);
       }
+#if !MP16_SGB
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above the MFMAs (see query.hip)
+#endif
       // term-major order: consecutive MFMAs hit different accumulators
 #pragma unroll
       for (int m = 0; m < MR; ++m)
@@ -163,6 +199,25 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
         bh[n] = nh[n];
         if (TERMS >= 2) bl[n] = nl[n];
       }
+#if MP16_SGB
+      // One wave per SIMD: whatever the wave issues between two runs of MFMAs is time the matrix
+      // pipe idles (nobody else feeds it).  So the prefetches of this group -- NV weight fragments,
+      // ND LDS reads -- go INTO the run, one behind each MFMA (32 cycles of shadow each).
+      {
+        constexpr int NV = MR * (TERMS == 3 ? 2 : 1), ND = NR * (TERMS >= 2 ? 2 : 1), NM = MR * NR * TERMS;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (NM > NV + ND) __builtin_amdgcn_sched_group_barrier(0x008, NM - NV - ND, 0);
+      }
+#endif
     }
   }
 }
@@ -235,15 +290,16 @@ __device__ __forceinline__ void store_hidden16(unsigned char *hb, const f32x16 &
   }
 }
 
-// 32-row chunk buffers of the pipelined layer-0/1 loop: 128 bytes per point = 4 hi slots | 4 lo
-// slots, slot index XORed with (p >> 1) & 7 (rows of 128 B: two points per 256-byte bank row, so
-// the pair index is what must differ between the 16 lanes of a ds_read_b128 group).
-constexpr int kHRow32 = 128;
-__device__ __forceinline__ int swz32(int p) { return (p >> 1) & 7; }
-
-// registers 4q .. 4q+3 of a C-layout tile = rows 8q + 4hh + {0..3} of point p = 32 cb + j
-__device__ __forceinline__ void store_hidden32_q(unsigned char *hb, const f32x16 &v, int q, int cb, int j,
-                                                 int hh, float inv_scale) {
+// registers 4q .. 4q+3 of a C-layout tile (rows 32 rb_local + 8q + 4hh + i of point p = 32 cb + j):
+// y = lrelu(acc / S), split, store into the 128-row chunk buffer of the 96-point tile: 512 bytes
+// per point = 16 hi slots | 16 lo slots, row block rb_local (= the wave) owns slots 4 rb_local .. +3
+constexpr int kHRow128 = 512;
+__device__ __forceinline__ void convert_store_q128(unsigned char *hb, const f32x16 &v, int q, int rb_local,
+                                                   int cb, int j, int hh, float inv_scale) {
+#if defined(MP16_ABLATE) && (MP16_ABLATE == 10 || MP16_ABLATE == 14)  // timing experiment: no conversion
+  if (v[4 * q] == 12345.0f) hb[0] = 1;
+  return;
+#endif
   const int p = 32 * cb + j;
   f32x4 f;
 #pragma unroll
@@ -253,9 +309,63 @@ __device__ __forceinline__ void store_hidden32_q(unsigned char *hb, const f32x16
   }
   h4 hi, lo;
   split4(f, hi, lo);
-  unsigned char *row = hb + p * kHRow32 + 8 * hh;
-  *reinterpret_cast<h4 *>(row + ((q ^ swz32(p)) << 4)) = hi;
-  *reinterpret_cast<h4 *>(row + (((4 + q) ^ swz32(p)) << 4)) = lo;
+  unsigned char *row = hb + p * kHRow128 + 8 * hh;
+  const int slot = 4 * rb_local + q;
+  *reinterpret_cast<h4 *>(row + ((slot ^ (p & 15)) << 4)) = hi;
+  *reinterpret_cast<h4 *>(row + (((16 + slot) ^ (p & 15)) << 4)) = lo;
+}
+
+// One k16 group of a skip segment (A: MR row blocks, B: NBW column blocks of xs) with `piece(m)` --
+// a slice of VALU / LDS-store work that does not depend on these MFMAs -- scheduled between the
+// MFMAs of row block m: VPM VALU instructions after every MFMA, DSW LDS stores at the end.
+template <int MR, int NBW, int TERMS, int VPM, int DSW, class F>
+__device__ __forceinline__ void fill_group16(f32x16 (&acc)[MR][NBW], const AFrag (&a)[MR],
+                                             const h8 (&bh)[NBW], const h8 (&bl)[NBW], F &&piece) {
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+#pragma unroll
+    for (int n = 0; n < NBW; ++n)
+      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m].hi, bh[n], acc[m][n], 0, 0, 0);
+    if (TERMS >= 2) {
+#pragma unroll
+      for (int n = 0; n < NBW; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m].hi, bl[n], acc[m][n], 0, 0, 0);
+    }
+    if (TERMS == 3) {
+#pragma unroll
+      for (int n = 0; n < NBW; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m].lo, bh[n], acc[m][n], 0, 0, 0);
+    }
+    piece(m);
+#if MP16_SGB
+#pragma unroll
+    for (int r = 0; r < TERMS * NBW; ++r) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x200, DSW, 0);
+#endif
+  }
+}
+
+// skip-segment operands of k16 group g: A fragments of MR row blocks, B fragments of NBW column blocks
+template <int MR, int TERMS>
+__device__ __forceinline__ void skip_load_a(AFrag (&a)[MR], const WStream &ws, int ax, int rb_stride, int g) {
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    a[m].hi = hload(ws, ax + m * rb_stride + g * 128);
+    if (TERMS == 3) a[m].lo = hload(ws, ax + m * rb_stride + g * 128 + 64);
+  }
+}
+
+template <int NBW, int TERMS>
+__device__ __forceinline__ void skip_load_b(h8 (&bh)[NBW], h8 (&bl)[NBW], const unsigned char *xrow, int swz,
+                                            int g) {
+#pragma unroll
+  for (int n = 0; n < NBW; ++n) {
+    bh[n] = *reinterpret_cast<const h8 *>(xrow + n * 32 * kXRow + (((2 * g) ^ swz) << 4));
+    if (TERMS >= 2) bl[n] = *reinterpret_cast<const h8 *>(xrow + n * 32 * kXRow + (((32 + 2 * g) ^ swz) << 4));
+  }
 }
 
 // Layers 2 and 3 read their K in chunks of 64 = 16 rows from EACH wave (pack.hip permutes the
@@ -278,11 +388,12 @@ __device__ __forceinline__ void store_hidden16_part(unsigned char *hb, const f32
   }
 }
 
-// NB = 32-point column blocks per tile: 4 = the 128-point tile described above (one workgroup per
-// CU); 2 = a 64-point tile with half the LDS and half the accumulators per wave, two workgroups per
-// CU (the partner hides barriers and epilogues, at twice the weight bytes per point).  Measured
-// (1 M points, -DMP16_NB=2): f16x3 11.3 ms vs 7.4 ms, plain f16 4.4 vs 4.0 -- weight streaming wins,
-// the launcher instantiates NB = 4.
+// NB = 32-point column blocks per tile: 3 = the 96-point tile described above (the product);
+// 4 = round 1's 128-point tile (160 KB of LDS, 64-row layer-0 chunks computed by two waves per row
+// block: 0.42 of the roof over a reconstruction vs 0.44); 2 = a 64-point tile with half the LDS,
+// two workgroups per CU (the partner hides barriers and epilogues, at twice the weight bytes per
+// point).  Measured (1 M points, -DMP16_NB=2): f16x3 11.3 ms, plain f16 4.4 vs 4.0 -- weight
+// streaming wins.
 //
 // CS = column split: 1 = four waves, each with all NB column blocks of its rows (one wave per SIMD,
 // 512 registers); 2 = EIGHT waves -- wave (rg, cg) owns row group rg (as before) but only the column
@@ -291,14 +402,14 @@ __device__ __forceinline__ void store_hidden16_part(unsigned char *hb, const f32
 // waves of a row group stream the same weight fragments (the second one hits the CU's L1); LDS
 // traffic, MFMA count and the chunk-buffer layout are unchanged.
 template <int COUT, int TERMS, int NB, int CS>
-__global__ __launch_bounds__(kThreads16 * CS, NB == 4 ? CS : 2) void pifu_query16_kernel(
+__global__ __launch_bounds__(kThreads16 * CS, NB >= 3 ? CS : 2) void pifu_query16_kernel(
     MlpPack mlp32, MlpPack16 mlp, int fh, int fw, float z_scale, int act, QuerySet set) {
   constexpr int C = 256;
   constexpr int NGX = C / 16;        // k16 groups of the feature segment
   constexpr int P = 32 * NB;         // points per tile
   constexpr int THREADS = kThreads16 * CS;
   constexpr int NBW = NB / CS;       // column blocks per wave in layers 1-3
-  constexpr int NR0 = NB / 2 / CS;   // column blocks per wave in a layer-0 chunk (8 tiles / waves)
+  constexpr int NR0 = NB == 3 ? 3 : NB / 2 / CS;  // column blocks per wave in a layer-0 chunk
   constexpr int PW = P / (4 * CS);   // points gathered per wave
   static_assert(CS == 1 || (CS == 2 && NB == 4), "column split is built for the 128-point tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -430,111 +541,63 @@ __global__ __launch_bounds__(kThreads16 * CS, NB == 4 ? CS : 2) void pifu_query1
       const int rs1 = (kHidden[0] / 16) * 128;  // row-block stride of layer 1's hidden segment
       const int a1 = mlp.ah[1] + (4 * wv) * rs1;
       const float inv0 = 1.0f / mlp.scale[0];
-#if MP16_PIPE
-      // Software pipeline over 32-row chunks of layer 0 (one row block; wave wv owns column block
-      // wv): while the layer-1 MFMAs of chunk ck run, the wave converts chunk ck+1 (whose layer-0
-      // MFMAs were issued just before) -- rescale, leaky ReLU, hi/lo split, LDS stores -- in their
-      // shadow, into the other half of the double-buffered chunk buffer.  One barrier per chunk.
-      // With one wave per SIMD nobody else could use the matrix pipe during that VALU work: the
-      // sequential version left it idle for ~15 % of the loop.
-      static_assert(NB == 4 && CS == 1, "the pipelined layer-0/1 loop is written for the 4-wave 128-point tile");
-      constexpr int NCK = kHidden[0] / 32;
-      const unsigned char *x0row = xrow + wv * 32 * kXRow;  // this wave's column block of xs
-      const int pj = 32 * wv + j;                           // its point for the hidden stores
-      const unsigned char *hrow32 = hb + j * kHRow32;       // B rows of column block 0 (+ n * 32 * kHRow32)
-      const int sw32 = hh ^ swz32(j);  // swz32(32 n + j) == swz32(j)
-      ZPair z0[1] = {zc[wv]};
-      AFrag ring0[4][1];
-      f32x16 acc0[1][1];
-      auto l0_begin = [&](int rbk) {
-        seg_prefetch16<1, 3, TERMS>(ring0, ws, a0 + rbk * NGX * 128, 0, NGX);
-        init_from_bias16(acc0[0][0], w32, mlp32.bias[0] + 32 * rbk, mlp.scale[0]);
-      };
-      auto l0_mfma = [&](int rbk) {
-        seg_main16<1, 1, 3, kXRow, 32, TERMS>(acc0, ring0, ws, a0 + rbk * NGX * 128, 0, NGX, x0row, swz);
-        gemm_z16<1, 1, TERMS>(acc0, ws, mlp.az[0] + rbk * 128, z0);
-      };
-      // prologue: chunk 0 -> buffer 0
-      l0_begin(0);
-      l0_mfma(0);
+      AFrag ring0[(NB == 3 ? MP16_PF0 : 3) + 1][1];
+      f32x16 acc0[1][NR0];
+      const int a1x = mlp.ax[1] + (4 * wv) * NGX * 128;
+      constexpr bool kFill = MP16_FILL && NB == 3;
+      if constexpr (NB == 3) {
+        // 96-point tile: a chunk is 128 rows of layer 0 = one row block x all three column blocks
+        // per wave -- every layer-0 weight fragment is loaded by exactly one wave and feeds 9 MFMAs
+        // -- and 8 k16 groups of layer 1; 240 accumulator registers (192 + 48) fit the AGPR file.
+        static_assert(CS == 1, "the 96-point tile has no column split");
+        const unsigned char *hrow1 = hb + j * kHRow128;
+        seg_prefetch16<1, MP16_PF0, TERMS>(ring0, ws, a0 + wv * NGX * 128, 0, NGX);
+        init_from_bias16(acc0[0][0], w32, mlp32.bias[0] + 32 * wv, mlp.scale[0]);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) store_hidden32_q(hb, acc0[0][0], q, wv, j, hh, inv0);
-      l0_begin(1);
-      // layer-1 A fragments of chunk 0, group 0 (2 k16 groups per chunk)
-      AFrag a1f[2][4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        a1f[0][m].hi = hload(ws, a1 + m * rs1);
-        if (TERMS == 3) a1f[0][m].lo = hload(ws, a1 + m * rs1 + 64);
-      }
-      __syncthreads();
+        for (int n = 1; n < NB; ++n) acc0[0][n] = acc0[0][0];
 #pragma unroll 1
-      for (int ck = 0; ck < NCK; ++ck) {
-        const unsigned char *hcur = hrow32 + (ck & 1) * (P * kHRow32);
-        unsigned char *hnxt = hb + ((ck + 1) & 1) * (P * kHRow32);
-        // branch-free body: after the last chunk one more (unused) layer-0 chunk is computed and
-        // converted into the idle buffer -- 1/32 of layer 0, but the loop body stays one basic
-        // block, which is what lets the scheduler interleave the conversion with the MFMAs
-        // (A) layer-0 MFMAs of chunk ck + 1 (operands were prefetched during chunk ck - 1 / the prologue)
-        l0_mfma(min(ck + 1, NCK - 1));
-        // (B) layer-1 MFMAs of chunk ck, group by group, with chunk ck + 1's conversion interleaved
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          h8 bh[NB], bl[NB];
-#pragma unroll
-          for (int n = 0; n < NB; ++n) {
-            bh[n] = *reinterpret_cast<const h8 *>(hcur + n * 32 * kHRow32 + (((2 * g) ^ sw32) << 4));
-            if (TERMS >= 2)
-              bl[n] = *reinterpret_cast<const h8 *>(hcur + n * 32 * kHRow32 + (((4 + 2 * g) ^ sw32) << 4));
-          }
-          // next group's A fragments: group 1 of this chunk, or group 0 of the next chunk
-          const int gn = min(2 * ck + g + 1, 2 * NCK - 1);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            a1f[(g + 1) & 1][m].hi = hload(ws, a1 + m * rs1 + gn * 128);
-            if (TERMS == 3) a1f[(g + 1) & 1][m].lo = hload(ws, a1 + m * rs1 + gn * 128 + 64);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
+        for (int ck = 0; ck < kHidden[0] / 128; ++ck) {
+          const int rb = 4 * ck + wv;
+          AFrag sa[4], sa2[4];  // layer 1, skip groups 2 ck and 2 ck + 1
+          if (kFill) skip_load_a<4, TERMS>(sa, ws, a1x, NGX * 128, 2 * ck);
+          seg_main16<1, NB, MP16_PF0, kXRow, 32, TERMS>(acc0, ring0, ws, a0 + rb * NGX * 128, 0, NGX, xrow0, swz);
+          AFrag ring1[MP16_PF1 + 1][4];
+          seg_prefetch16<4, MP16_PF1, TERMS>(ring1, ws, a1 + ck * 8 * 128, rs1, 8);
+          if (kFill) {
+            h8 sbh[NB], sbl[NB];
+            skip_load_b<NB, TERMS>(sbh, sbl, xrow, swz, 2 * ck);
+            skip_load_a<4, TERMS>(sa2, ws, a1x, NGX * 128, 2 * ck + 1);
+            gemm_z16<1, NB, TERMS>(acc0, ws, mlp.az[0] + rb * 128, zc);
+            // 12 quarter-tiles over 8 slots: two under each row block of the first group, one
+            // under each of the second
+            fill_group16<4, NB, TERMS, 24 / TERMS, 4>(acc1, sa, sbh, sbl, [&](int m) {
+              convert_store_q128(hb, acc0[0][m >> 1], 2 * (m & 1), wv, m >> 1, j, hh, inv0);
+              convert_store_q128(hb, acc0[0][m >> 1], 2 * (m & 1) + 1, wv, m >> 1, j, hh, inv0);
+            });
+            skip_load_b<NB, TERMS>(sbh, sbl, xrow, swz, 2 * ck + 1);
+            fill_group16<4, NB, TERMS, 12 / TERMS, 2>(acc1, sa2, sbh, sbl, [&](int m) {
+              convert_store_q128(hb, acc0[0][2], m, wv, 2, j, hh, inv0);
+            });
+          } else {
+            gemm_z16<1, NB, TERMS>(acc0, ws, mlp.az[0] + rb * 128, zc);
 #pragma unroll
             for (int n = 0; n < NB; ++n)
-              acc1[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1f[g][m].hi, bh[n], acc1[m][n], 0, 0, 0);
-            if (TERMS >= 2) {
 #pragma unroll
-              for (int n = 0; n < NB; ++n)
-                acc1[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1f[g][m].hi, bl[n], acc1[m][n], 0, 0, 0);
-            }
-            if (TERMS == 3) {
-#pragma unroll
-              for (int n = 0; n < NB; ++n)
-                acc1[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1f[g][m].lo, bh[n], acc1[m][n], 0, 0, 0);
-            }
-            // a quarter of chunk ck + 1's conversion inside each block of 12 MFMAs of group 0
-            if (g == 0) {
-              store_hidden32_q(hnxt, acc0[0][0], m, wv, j, hh, inv0);
-#if MP16_SGB
-              // 1 MFMA : 3 VALU, the two LDS stores at the end (cdna_hip_programming.md T19)
-#pragma unroll
-              for (int r = 0; r < (TERMS * NB); ++r) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-              }
-              __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-#endif
-            }
+              for (int q = 0; q < 4; ++q) convert_store_q128(hb, acc0[0][n], q, wv, n, j, hh, inv0);
           }
-          if (g == 0) l0_begin(min(ck + 2, NCK - 1));  // operands of chunk ck + 2 under group 1
+          const int rbn = min(rb + 4, kHidden[0] / 32 - 4 + wv);
+          seg_prefetch16<1, MP16_PF0, TERMS>(ring0, ws, a0 + rbn * NGX * 128, 0, NGX);
+          init_from_bias16(acc0[0][0], w32, mlp32.bias[0] + 32 * rbn, mlp.scale[0]);
+#pragma unroll
+          for (int n = 1; n < NB; ++n) acc0[0][n] = acc0[0][0];
+          __syncthreads();
+          seg_main16<4, NB, MP16_PF1, kHRow128, 16, TERMS>(acc1, ring1, ws, a1 + ck * 8 * 128, rs1, 8, hrow1, swz);
+          __syncthreads();
         }
-        __syncthreads();
-      }
-      (void)pj;
-#else
+      } else {
       ZPair z0[NR0];
 #pragma unroll
       for (int n = 0; n < NR0; ++n) z0[n] = zc[c0 + n];
-      AFrag ring0[4][1];
-      f32x16 acc0[1][NR0];
       seg_prefetch16<1, 3, TERMS>(ring0, ws, a0 + rb0 * NGX * 128, 0, NGX);
       init_from_bias16(acc0[0][0], w32, mlp32.bias[0] + 32 * rb0, mlp.scale[0]);
 #pragma unroll
@@ -563,12 +626,13 @@ __global__ __launch_bounds__(kThreads16 * CS, NB == 4 ? CS : 2) void pifu_query1
         seg_main16<4, NBW, 1, kHRow, 8, TERMS>(acc1, ring1, ws, a1 + ck * 4 * 128, rs1, 4, hrow, swz);
         __syncthreads();
       }
-#endif
-      // skip segment + z column of layer 1
-      const int a1x = mlp.ax[1] + (4 * wv) * NGX * 128;
-      AFrag ring1[2][4];
-      seg_prefetch16<4, 1, TERMS>(ring1, ws, a1x, NGX * 128, NGX);
-      seg_main16<4, NBW, 1, kXRow, 32, TERMS>(acc1, ring1, ws, a1x, NGX * 128, NGX, xrow, swz);
+      }
+      // skip segment (unless it went into the chunk loop) + z column of layer 1
+      if (!kFill) {
+        AFrag ring1[2][4];
+        seg_prefetch16<4, 1, TERMS>(ring1, ws, a1x, NGX * 128, NGX);
+        seg_main16<4, NBW, 1, kXRow, 32, TERMS>(acc1, ring1, ws, a1x, NGX * 128, NGX, xrow, swz);
+      }
       gemm_z16<4, NBW, TERMS>(acc1, ws, mlp.az[1] + (4 * wv) * 128, zw);
       const float inv1 = 1.0f / mlp.scale[1];
 #pragma unroll
@@ -689,12 +753,12 @@ __global__ __launch_bounds__(kThreads16 * CS, NB == 4 ? CS : 2) void pifu_query1
         }
       }
       // feature part: thread = (point, slice of the channels); x = hi + lo
-      const int p = tid & (P - 1), hf = tid / P;
+      const int p = tid % P, hf = tid / P;  // threads past FP * P (96-point tile: 192 .. 255) sit out
       float sx[COUT];
 #pragma unroll
       for (int o = 0; o < COUT; ++o) sx[o] = 0.0f;
 #pragma unroll 2
-      for (int s = 0; s < SL; ++s) {
+      for (int s = 0; s < (hf < FP ? SL : 0); ++s) {
         const int slot = SL * hf + s;  // 8 channels per slot
         const h8 xh = *reinterpret_cast<const h8 *>(xs + p * kXRow + ((slot ^ (p & 15)) << 4));
         const h8 xl = *reinterpret_cast<const h8 *>(xs + p * kXRow + (((32 + slot) ^ (p & 15)) << 4));
@@ -706,7 +770,8 @@ __global__ __launch_bounds__(kThreads16 * CS, NB == 4 ? CS : 2) void pifu_query1
         }
       }
 #pragma unroll
-      for (int o = 0; o < COUT; ++o) red[((4 + hf) * COUT + o) * P + p] = sx[o];
+      for (int o = 0; o < COUT; ++o)
+        if (hf < FP) red[((4 + hf) * COUT + o) * P + p] = sx[o];
     }
     __syncthreads();
     for (int idx = tid; idx < COUT * P; idx += THREADS) {
@@ -742,7 +807,7 @@ static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int 
                             float z_scale, long long max_points, bool device_counts,
                             hipStream_t st) {
   constexpr int P = 32 * NB;
-  constexpr int lds = P * (kXRow + kHRow);
+  constexpr int lds = P * (kXRow + (NB == 3 ? kHRow128 : kHRow));
   auto kern = pifu_query16_kernel<COUT, TERMS, NB, CS>;
   const void *kern_id = reinterpret_cast<const void *>(kern);
   if (!ctx->lds_attr_done.count(kern_id)) {  // once per kernel and context (= device)
@@ -751,7 +816,7 @@ static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int 
   }
   if (max_points <= 0) return MP_OK;
   const long long tiles = (max_points + P - 1) / P + (set.n - 1);
-  const long long resident = (long long)ctx->n_cu * (NB == 4 ? 1 : 2);  // 160 KB / 80 KB of LDS each
+  const long long resident = (long long)ctx->n_cu * (NB >= 3 ? 1 : 2);  // 160 / 144 / 80 KB of LDS each
   const long long grid = device_counts ? (tiles < resident ? tiles : resident)
                                        : (tiles < 8 * resident ? tiles : 8 * resident);
   const bool prof = 2 * (ctx->prof_used + 1) <= (int)ctx->prof_events.size();
