@@ -268,7 +268,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--depth", type=int, default=3, help="pipeline slots (streams) per GPU")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=10,
                     help="frames per slot (upper bound): their encoder passes run as one batch and "
                          "their octree levels as one fused-query launch; depth x batch frames are in "
                          "flight.  The largest divisor of --steps not above this is used, so no slot "

@@ -134,7 +134,7 @@ int mp_query_counted(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, 
                      const float *points, int64_t capacity, const int32_t *count,
                      const float *calib, float z_scale, float *out, mp_stream stream);
 
-/* mp_query_counted over n_frames (1..8) independent frames in ONE launch (the per-vertex colour
+/* mp_query_counted over n_frames (1..16) independent frames in ONE launch (the per-vertex colour
  * queries of all frames of a pipeline slot: ~14 k points each cannot fill 256 CUs alone).
  * feat_hwc / points / count / calib / out are HOST arrays of n_frames device pointers, each as in
  * mp_query_counted (one `capacity` for all); results are identical to n_frames separate calls. */
@@ -155,7 +155,7 @@ int mp_recon(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, c
              const int *resolutions /*host*/, int n_levels, float balance, float *volume,
              int32_t *status, mp_stream stream);
 
-/* mp_recon over n_frames (1..8) independent frames sharing the MLP, box and resolutions: every
+/* mp_recon over n_frames (1..16) independent frames sharing the MLP, box and resolutions: every
  * octree level evaluates the selected nodes of ALL frames in one fused-query launch, so the coarse
  * levels (5-25 k nodes per frame) fill the 256 CUs together.  feat_hwc / calib / volume / status
  * are HOST arrays of n_frames device pointers, each as in mp_recon; results are identical to

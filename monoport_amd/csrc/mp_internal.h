@@ -63,7 +63,7 @@ struct PointSrc {
 // One launch of the fused query kernels serves up to kMaxFrames independent frames (their own
 // feature map, calibration, points and output): the tiles of all frames form one index space, so
 // the small coarse levels of several frames fill the machine together.
-constexpr int kMaxFrames = 8;
+constexpr int kMaxFrames = 16;
 struct QueryItem {
   const float *feat;   // channels-last feature map [H,W,C]
   const float *calib;  // [3,4] rows of the 4x4

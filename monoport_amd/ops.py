@@ -226,7 +226,7 @@ def query_counted(mlp, feat_hwc, points, count, calib, z_scale, out=None):
 
 
 def query_counted_batch(mlp, feats_hwc, points, counts, calibs, z_scale, outs=None):
-    """mp_query_counted_batch: one fused-query launch for up to 8 frames.  feats_hwc / points
+    """mp_query_counted_batch: one fused-query launch for up to 16 frames.  feats_hwc / points
     ([3,cap] each, one cap) / counts (int32[1] each) / calibs: lists of per-frame device tensors
     -> list of [Cout,cap]."""
     ctx = mlp.ctx
@@ -276,7 +276,7 @@ def recon(mlp, feat_hwc, calib, z_scale, b_min, b_max, resolutions, balance=0.5,
 
 def recon_batch(mlp, feats_hwc, calibs, z_scale, b_min, b_max, resolutions, balance=0.5,
                 volumes=None, status=None):
-    """``recon`` over up to 8 independent frames in one call: every octree level evaluates the
+    """``recon`` over up to 16 independent frames in one call: every octree level evaluates the
     selected nodes of all frames in ONE fused-query launch (the coarse levels of a single frame
     cannot fill 256 CUs).  feats_hwc: list of [H,W,C] maps; calibs: [B,4,4] (or list of [1,4,4]);
     volumes: list of [R,R,R]; status: [B, 1+levels] int32.  Results equal B separate ``recon``

@@ -25,7 +25,7 @@ from . import ops
 from .synthetic import Z_SCALE
 
 RESOLUTIONS = (17, 33, 65, 129, 257)  # RTL/main.py:187
-MAX_RECON_BATCH = 8  # kMaxFrames of the C-ABI (include/monoport_hip.h, mp_recon_batch)
+MAX_RECON_BATCH = 16  # kMaxFrames of the C-ABI (include/monoport_hip.h, mp_recon_batch)
 
 
 class FrameSlot:
@@ -142,7 +142,7 @@ class FrameSlot:
                 pts_all.append(ops.vertex_points(x, y, z, count, r, self.mat_color))
         if self.netC is not None:
             # netC.query on the visible vertices (RTL/main.py:231-248) of ALL frames of the slot:
-            # one fused-query launch per chunk of 8 frames (14 k points per frame alone would
+            # one fused-query launch per chunk of 16 frames (14 k points per frame alone would
             # leave most CUs idle)
             for b0 in range(0, n, MAX_RECON_BATCH):
                 b1 = min(b0 + MAX_RECON_BATCH, n)

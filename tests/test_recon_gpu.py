@@ -415,10 +415,24 @@ def test_recon_batch_equals_single_frames(ops, oracle, precision):
     assert len({tuple(r) for r in st[:, 2:].tolist()}) > 1  # the frames really differ
 
 
+def test_recon_batch_of_16_frames(ops, oracle):
+    """The full frame set of one launch (kMaxFrames = 16), every frame with its own camera."""
+    mlp = ops.PackedMLP.from_layers(DEV, syn.body_mlp("G", noise=0.05, seed=1), 1)
+    fh = ops.pack_features(torch.from_numpy(syn.body_feat(256, 128, 128, 2))[None].to(DEV))
+    res = [9, 17, 33, 65]
+    cals = [torch.from_numpy(oracle.pifu_calib(*syn.scene_camera(11 * i))).to(DEV) for i in range(16)]
+    vols, status = ops.recon_batch(mlp, [fh] * 16, cals, syn.Z_SCALE, BMIN, BMAX, res)
+    st = status.cpu().numpy()
+    assert (st[:, 0] == 1).all() and len({tuple(r) for r in st[:, 2:].tolist()}) > 8
+    for i in (0, 7, 8, 15):
+        v1, s1 = ops.recon(mlp, fh, cals[i], syn.Z_SCALE, BMIN, BMAX, res)
+        assert np.array_equal(s1.cpu().numpy(), st[i]) and torch.equal(v1, vols[i]), i
+
+
 def test_recon_batch_rejects_too_many_frames(ops, body):
     from monoport_amd._lib import MonoportError
     with pytest.raises(MonoportError):
-        ops.recon_batch(body["mlp"], [body["fh"]] * 9, [body["cal"]] * 9, syn.Z_SCALE, BMIN, BMAX,
+        ops.recon_batch(body["mlp"], [body["fh"]] * 17, [body["cal"]] * 17, syn.Z_SCALE, BMIN, BMAX,
                         [9, 17])
 
 

@@ -1,6 +1,6 @@
 """Workload for the rocprofv3 --pmc passes behind bench.py's roofline.traffic.
 
-    run   : one pipeline slot, 4 frames per batch, 2 timed-style batches (after warm-up) --
+    run   : one pipeline slot, 10 frames per batch, 2 timed-style batches (after warm-up) --
             the LAST 10 pifu_query_kernel dispatches are 2 batches x 5 octree levels
     parse : counter_collection.csv of the FETCH_SIZE and WRITE_SIZE passes -> profiles/*.json
 
@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-BATCH, LEVELS = 5, 5  # bench.py default: --steps 20 -> 5 frames per slot submission / launch
+BATCH, LEVELS = 10, 5  # bench.py default: --steps 20 -> 10 frames per slot submission / launch
 
 
 def run():
