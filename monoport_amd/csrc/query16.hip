@@ -28,19 +28,24 @@
 // Status (round 2): 1 M points in 6.44-6.60 ms = 160 M points/s (2.7x the f32 kernel) = 375-385
 // TFLOP/s-equivalent = 0.45-0.46 of the three-MFMA-per-product roof (2.5 PFLOP/s / 3); 0.44 over a
 // reconstruction's launches (128-point tile: 0.42).
-// What bounds it (side builds, tools/ablate.py -DMP16_ABLATE=10..14, profiles/r02w_f16x3_ablation.txt):
+// What bounds it (side builds, tools/ablate.py -DMP16_ABLATE=..., profiles/r02w_f16x3_ablation.txt):
 // removing the layer-0 conversion buys 2 %, the barriers 1.6 %, the LDS reads 4 % -- and removing
-// the WEIGHT LOADS 27 % (6.60 -> 4.81 ms; everything together 4.46).  It is not latency: deeper
-// rings (MP16_PF0 / MP16_PF1) are slower, and FETCH_SIZE says the weights come from L2.  It is the
-// CU's one vector-memory path: 4.7 MB of fragments per 96 points at 64 B/clk are 73 k of a tile's
-// ~300 k cycles, each buffer_load costs the issuing wave tens of cycles (MI355X_MICROARCH.md: ~60
-// cycles per 1-KB piece beside MFMAs) and with ONE wave per SIMD nobody issues MFMAs meanwhile.
-// The f32 kernel hides exactly this with its second wave per SIMD; here two waves per SIMD would
-// need either 64-point tiles (twice the weight bytes per point: measured 11.3 ms) or an eight-wave
-// split of the 96 / 128-point tile whose layer-0 chunks need a second chunk buffer the LDS does not
-// have (MP16_CS=2 duplicated the weight loads instead: 9.3 ms).  Also measured and dropped: a
-// software-pipelined layer-0/1 loop over 32-row chunks (6.97 vs 6.65 ms, round 2 history) and
-// MP16_FILL below.
+// the WEIGHT LOADS 27 % (6.60 -> 4.81 ms; layers 0-1 alone 4.42 -> 3.03 ms against a 2.69 ms MFMA
+// floor).  The loads' cost is ADDITIVE, ~76 cycles of a SIMD's matrix-pipe time per 1-KB fragment
+// (50 M fragments per 1 M points), and nothing tried moves it:
+//   * deeper prefetch rings (MP16_PF0 / MP16_PF1): slower -- it is not latency;
+//   * eight waves per workgroup, two per SIMD, rows split so that every wave streams half as much
+//     and no fragment is loaded twice (built, tests green, removed): 6.9 ms, layers 0-1 4.36 ms --
+//     it is neither the per-wave streaming cap (tools/probes/l2_stream_probe.hip: ~8 KB in flight
+//     = 7.7 B/clk per wave, which one wave per SIMD does sit at) nor something a partner wave hides;
+//   * group-major fragment order (contiguous blocks for the waves of a workgroup): no change -- not
+//     L2 channel camping; sc0 / sc1 / nt cache policies (MP16_AUX): equal or slower.
+// With that cost fixed, cycles per point = 1729 (MFMA) + 76 x fragments per point per SIMD (942 at
+// 96 points per tile, 707 at 128): 0.45-0.47 of the roof here; 0.6 would need a tile of >= 240 points
+// = 240 KB of split features in LDS.  The f32 kernel streams the same bytes per point but spends 4x
+// the matrix-pipe time per fragment, which is why it sits at 0.91.  Also measured and dropped: a
+// software-pipelined layer-0/1 loop over 32-row chunks (6.97 vs 6.65 ms), MP16_CS=2 (column split,
+// duplicated loads: 9.3 ms) and MP16_FILL below.
 #include "mp_internal.h"
 #include "query_common.h"
 
@@ -77,6 +82,9 @@ constexpr int kHRow = 256;       // bytes per point in the hidden chunk: 8 hi sl
 // not what the matrix pipe waits for (see "What bounds it" in the header).  Off.
 #define MP16_FILL 0
 #endif
+#ifndef MP16_AUX
+#define MP16_AUX 0  // cache-policy bits of the weight loads (1 = sc0, 2 = nt, 16 = sc1); no variant measured faster
+#endif
 #ifndef MP16_PF0
 #define MP16_PF0 3  // weight fragments in flight ahead of layer 0's MFMAs (96-point tile)
 #endif
@@ -105,13 +113,13 @@ __device__ __forceinline__ void split4(const f32x4 &v, h4 &hi, h4 &lo) {
 // TERMS selects the arithmetic: 3 = hi*hi + hi*lo + lo*hi (f32-class, "f16x3"); 2 = weights
 // rounded to f16, activations still split (hi*hi + hi*lo, "f16w"); 1 = plain f16 operands ("f16").
 __device__ __forceinline__ h8 hload(const WStream &w, int idx16) {
-#if defined(MP16_ABLATE) && (MP16_ABLATE == 11 || MP16_ABLATE == 14)  // timing experiment: no weight loads
+#if defined(MP16_ABLATE) && (MP16_ABLATE == 11 || MP16_ABLATE == 14 || MP16_ABLATE == 22)  // timing experiment: no weight loads
   h8 r;
 #pragma unroll
   for (int e = 0; e < 8; ++e) r[e] = (_Float16)(float)(idx16 & 3);
   return r;
 #endif
-  return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.lane16, idx16 * 16, 0));
+  return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.lane16, idx16 * 16, MP16_AUX));
 }
 
 template <int MR, int PF, int TERMS>
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(kThreads16 * CS, NB >= 3 ? CS : 2) void pifu_query1
     }
 
 #ifdef MP16_ABLATE
-    if (MP16_ABLATE == 2) {  // timing experiment only: stop after layers 0+1
+    if (MP16_ABLATE == 2 || MP16_ABLATE == 22) {  // timing experiment only: stop after layers 0+1
       float sink = 0.f;
 #pragma unroll
       for (int m = 0; m < 4; ++m)
