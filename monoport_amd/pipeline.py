@@ -172,6 +172,10 @@ class FrameSlot:
                 self._graph_feat = self._encode()
             self.stream.synchronize()
             self.graph = graph
+            # first launch of an instantiated graph uploads it: keep that out of the caller's first frame
+            with torch.cuda.stream(self.stream):
+                self.graph.replay()
+            self.stream.synchronize()
 
     def submit(self, images, calibs, images_c=None):
         """Enqueue the reconstruction of n <= ``batch`` frames: ``images`` [n,3,512,512] (or a list
