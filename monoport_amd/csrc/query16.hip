@@ -33,19 +33,21 @@
 // the WEIGHT LOADS 27 % (6.60 -> 4.81 ms; layers 0-1 alone 4.42 -> 3.03 ms against a 2.69 ms MFMA
 // floor).  The loads' cost is ADDITIVE, ~76 cycles of a SIMD's matrix-pipe time per 1-KB fragment
 // (50 M fragments per 1 M points), and nothing tried moves it:
-//   * deeper prefetch rings (MP16_PF0 / MP16_PF1): slower -- it is not latency;
+//   * deeper prefetch rings (layer 0: 7 instead of 3 groups, layer 1: 3 instead of 1): slower -- it
+//     is not latency;
 //   * eight waves per workgroup, two per SIMD, rows split so that every wave streams half as much
 //     and no fragment is loaded twice (built, tests green, removed): 6.9 ms, layers 0-1 4.36 ms --
 //     it is neither the per-wave streaming cap (tools/probes/l2_stream_probe.hip: ~8 KB in flight
 //     = 7.7 B/clk per wave, which one wave per SIMD does sit at) nor something a partner wave hides;
 //   * group-major fragment order (contiguous blocks for the waves of a workgroup): no change -- not
-//     L2 channel camping; sc0 / sc1 / nt cache policies (MP16_AUX): equal or slower.
+//     L2 channel camping; sc0 / sc1 / nt cache policies on the weight loads: equal or slower.
 // With that cost fixed, cycles per point = 1729 (MFMA) + 76 x fragments per point per SIMD (942 at
 // 96 points per tile, 707 at 128): 0.45-0.47 of the roof here; 0.6 would need a tile of >= 240 points
 // = 240 KB of split features in LDS.  The f32 kernel streams the same bytes per point but spends 4x
 // the matrix-pipe time per fragment, which is why it sits at 0.91.  Also measured and dropped: a
 // software-pipelined layer-0/1 loop over 32-row chunks (6.97 vs 6.65 ms), MP16_CS=2 (column split,
-// duplicated loads: 9.3 ms) and MP16_FILL below.
+// duplicated loads: 9.3 ms) and the skip-connection MFMAs of layer 1 issued under the layer-0
+// conversion (correct, the interleave comes out as written, neutral: 6.60-6.62 vs 6.57-6.59 ms).
 #include "mp_internal.h"
 #include "query_common.h"
 
@@ -74,25 +76,8 @@ constexpr int kHRow = 256;       // bytes per point in the hidden chunk: 8 hi sl
 // 5 % (3.63 vs 3.82 ms).  Kept for tools/ablate.py; the product uses 1.
 #define MP16_CS 1
 #endif
-#ifndef MP16_FILL
-// 1 = (96-point tile) the skip-connection k16 groups of layer 1 -- they depend on nothing but xs --
-// are spread over the chunk loop and issued while the wave rescales / splits / stores the chunk it
-// just produced, 6-8 VALU instructions behind each MFMA.  Correct and the interleave comes out as
-// written (tools/isa_loops.py), but MEASURED NEUTRAL: 6.60-6.62 ms vs 6.57-6.59 -- the conversion is
-// not what the matrix pipe waits for (see "What bounds it" in the header).  Off.
-#define MP16_FILL 0
-#endif
-#ifndef MP16_AUX
-#define MP16_AUX 0  // cache-policy bits of the weight loads (1 = sc0, 2 = nt, 16 = sc1); no variant measured faster
-#endif
-#ifndef MP16_PF0
-#define MP16_PF0 3  // weight fragments in flight ahead of layer 0's MFMAs (96-point tile)
-#endif
-#ifndef MP16_PF1
-#define MP16_PF1 1  // the same for layer 1's hidden segment (4 row blocks per group)
-#endif
 #ifndef MP16_SGB
-#define MP16_SGB 1  // sched_group_barrier interleave of the conversion with the layer-1 MFMAs
+#define MP16_SGB 1  // 1: a k16 group's prefetches interleaved with its MFMAs (seg_main16); 0: in a clump before them
 #endif
 
 struct AFrag {
@@ -113,13 +98,13 @@ __device__ __forceinline__ void split4(const f32x4 &v, h4 &hi, h4 &lo) {
 // TERMS selects the arithmetic: 3 = hi*hi + hi*lo + lo*hi (f32-class, "f16x3"); 2 = weights
 // rounded to f16, activations still split (hi*hi + hi*lo, "f16w"); 1 = plain f16 operands ("f16").
 __device__ __forceinline__ h8 hload(const WStream &w, int idx16) {
-#if defined(MP16_ABLATE) && (MP16_ABLATE == 11 || MP16_ABLATE == 14 || MP16_ABLATE == 22)  // timing experiment: no weight loads
+#if defined(MP16_ABLATE) && (MP16_ABLATE == 11 || MP16_ABLATE == 14)  // timing experiment: no weight loads
   h8 r;
 #pragma unroll
   for (int e = 0; e < 8; ++e) r[e] = (_Float16)(float)(idx16 & 3);
   return r;
 #endif
-  return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.lane16, idx16 * 16, MP16_AUX));
+  return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.lane16, idx16 * 16, 0));
 }
 
 template <int MR, int PF, int TERMS>
@@ -323,59 +308,6 @@ __device__ __forceinline__ void convert_store_q128(unsigned char *hb, const f32x
   *reinterpret_cast<h4 *>(row + (((16 + slot) ^ (p & 15)) << 4)) = lo;
 }
 
-// One k16 group of a skip segment (A: MR row blocks, B: NBW column blocks of xs) with `piece(m)` --
-// a slice of VALU / LDS-store work that does not depend on these MFMAs -- scheduled between the
-// MFMAs of row block m: VPM VALU instructions after every MFMA, DSW LDS stores at the end.
-template <int MR, int NBW, int TERMS, int VPM, int DSW, class F>
-__device__ __forceinline__ void fill_group16(f32x16 (&acc)[MR][NBW], const AFrag (&a)[MR],
-                                             const h8 (&bh)[NBW], const h8 (&bl)[NBW], F &&piece) {
-#pragma unroll
-  for (int m = 0; m < MR; ++m) {
-#pragma unroll
-    for (int n = 0; n < NBW; ++n)
-      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m].hi, bh[n], acc[m][n], 0, 0, 0);
-    if (TERMS >= 2) {
-#pragma unroll
-      for (int n = 0; n < NBW; ++n)
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m].hi, bl[n], acc[m][n], 0, 0, 0);
-    }
-    if (TERMS == 3) {
-#pragma unroll
-      for (int n = 0; n < NBW; ++n)
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m].lo, bh[n], acc[m][n], 0, 0, 0);
-    }
-    piece(m);
-#if MP16_SGB
-#pragma unroll
-    for (int r = 0; r < TERMS * NBW; ++r) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x200, DSW, 0);
-#endif
-  }
-}
-
-// skip-segment operands of k16 group g: A fragments of MR row blocks, B fragments of NBW column blocks
-template <int MR, int TERMS>
-__device__ __forceinline__ void skip_load_a(AFrag (&a)[MR], const WStream &ws, int ax, int rb_stride, int g) {
-#pragma unroll
-  for (int m = 0; m < MR; ++m) {
-    a[m].hi = hload(ws, ax + m * rb_stride + g * 128);
-    if (TERMS == 3) a[m].lo = hload(ws, ax + m * rb_stride + g * 128 + 64);
-  }
-}
-
-template <int NBW, int TERMS>
-__device__ __forceinline__ void skip_load_b(h8 (&bh)[NBW], h8 (&bl)[NBW], const unsigned char *xrow, int swz,
-                                            int g) {
-#pragma unroll
-  for (int n = 0; n < NBW; ++n) {
-    bh[n] = *reinterpret_cast<const h8 *>(xrow + n * 32 * kXRow + (((2 * g) ^ swz) << 4));
-    if (TERMS >= 2) bl[n] = *reinterpret_cast<const h8 *>(xrow + n * 32 * kXRow + (((32 + 2 * g) ^ swz) << 4));
-  }
-}
-
 // Layers 2 and 3 read their K in chunks of 64 = 16 rows from EACH wave (pack.hip permutes the
 // weights to match), so all four waves convert and write a quarter of every chunk in parallel:
 // rows 16 half .. +15 of a C-layout tile are registers 8 half .. 8 half + 7; wave `grp` fills K
@@ -549,57 +481,37 @@ __global__ __launch_bounds__(kThreads16 * CS, NB >= 3 ? CS : 2) void pifu_query1
       const int rs1 = (kHidden[0] / 16) * 128;  // row-block stride of layer 1's hidden segment
       const int a1 = mlp.ah[1] + (4 * wv) * rs1;
       const float inv0 = 1.0f / mlp.scale[0];
-      AFrag ring0[(NB == 3 ? MP16_PF0 : 3) + 1][1];
+      AFrag ring0[4][1];
       f32x16 acc0[1][NR0];
       const int a1x = mlp.ax[1] + (4 * wv) * NGX * 128;
-      constexpr bool kFill = MP16_FILL && NB == 3;
       if constexpr (NB == 3) {
         // 96-point tile: a chunk is 128 rows of layer 0 = one row block x all three column blocks
         // per wave -- every layer-0 weight fragment is loaded by exactly one wave and feeds 9 MFMAs
         // -- and 8 k16 groups of layer 1; 240 accumulator registers (192 + 48) fit the AGPR file.
         static_assert(CS == 1, "the 96-point tile has no column split");
         const unsigned char *hrow1 = hb + j * kHRow128;
-        seg_prefetch16<1, MP16_PF0, TERMS>(ring0, ws, a0 + wv * NGX * 128, 0, NGX);
+        seg_prefetch16<1, 3, TERMS>(ring0, ws, a0 + wv * NGX * 128, 0, NGX);
         init_from_bias16(acc0[0][0], w32, mlp32.bias[0] + 32 * wv, mlp.scale[0]);
 #pragma unroll
         for (int n = 1; n < NB; ++n) acc0[0][n] = acc0[0][0];
 #pragma unroll 1
         for (int ck = 0; ck < kHidden[0] / 128; ++ck) {
           const int rb = 4 * ck + wv;
-          AFrag sa[4], sa2[4];  // layer 1, skip groups 2 ck and 2 ck + 1
-          if (kFill) skip_load_a<4, TERMS>(sa, ws, a1x, NGX * 128, 2 * ck);
-          seg_main16<1, NB, MP16_PF0, kXRow, 32, TERMS>(acc0, ring0, ws, a0 + rb * NGX * 128, 0, NGX, xrow0, swz);
-          AFrag ring1[MP16_PF1 + 1][4];
-          seg_prefetch16<4, MP16_PF1, TERMS>(ring1, ws, a1 + ck * 8 * 128, rs1, 8);
-          if (kFill) {
-            h8 sbh[NB], sbl[NB];
-            skip_load_b<NB, TERMS>(sbh, sbl, xrow, swz, 2 * ck);
-            skip_load_a<4, TERMS>(sa2, ws, a1x, NGX * 128, 2 * ck + 1);
-            gemm_z16<1, NB, TERMS>(acc0, ws, mlp.az[0] + rb * 128, zc);
-            // 12 quarter-tiles over 8 slots: two under each row block of the first group, one
-            // under each of the second
-            fill_group16<4, NB, TERMS, 24 / TERMS, 4>(acc1, sa, sbh, sbl, [&](int m) {
-              convert_store_q128(hb, acc0[0][m >> 1], 2 * (m & 1), wv, m >> 1, j, hh, inv0);
-              convert_store_q128(hb, acc0[0][m >> 1], 2 * (m & 1) + 1, wv, m >> 1, j, hh, inv0);
-            });
-            skip_load_b<NB, TERMS>(sbh, sbl, xrow, swz, 2 * ck + 1);
-            fill_group16<4, NB, TERMS, 12 / TERMS, 2>(acc1, sa2, sbh, sbl, [&](int m) {
-              convert_store_q128(hb, acc0[0][2], m, wv, 2, j, hh, inv0);
-            });
-          } else {
-            gemm_z16<1, NB, TERMS>(acc0, ws, mlp.az[0] + rb * 128, zc);
+          seg_main16<1, NB, 3, kXRow, 32, TERMS>(acc0, ring0, ws, a0 + rb * NGX * 128, 0, NGX, xrow0, swz);
+          AFrag ring1[2][4];
+          seg_prefetch16<4, 1, TERMS>(ring1, ws, a1 + ck * 8 * 128, rs1, 8);
+          gemm_z16<1, NB, TERMS>(acc0, ws, mlp.az[0] + rb * 128, zc);
 #pragma unroll
-            for (int n = 0; n < NB; ++n)
+          for (int n = 0; n < NB; ++n)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) convert_store_q128(hb, acc0[0][n], q, wv, n, j, hh, inv0);
-          }
+            for (int q = 0; q < 4; ++q) convert_store_q128(hb, acc0[0][n], q, wv, n, j, hh, inv0);
           const int rbn = min(rb + 4, kHidden[0] / 32 - 4 + wv);
-          seg_prefetch16<1, MP16_PF0, TERMS>(ring0, ws, a0 + rbn * NGX * 128, 0, NGX);
+          seg_prefetch16<1, 3, TERMS>(ring0, ws, a0 + rbn * NGX * 128, 0, NGX);
           init_from_bias16(acc0[0][0], w32, mlp32.bias[0] + 32 * rbn, mlp.scale[0]);
 #pragma unroll
           for (int n = 1; n < NB; ++n) acc0[0][n] = acc0[0][0];
           __syncthreads();
-          seg_main16<4, NB, MP16_PF1, kHRow128, 16, TERMS>(acc1, ring1, ws, a1 + ck * 8 * 128, rs1, 8, hrow1, swz);
+          seg_main16<4, NB, 1, kHRow128, 16, TERMS>(acc1, ring1, ws, a1 + ck * 8 * 128, rs1, 8, hrow1, swz);
           __syncthreads();
         }
       } else {
@@ -635,12 +547,10 @@ __global__ __launch_bounds__(kThreads16 * CS, NB >= 3 ? CS : 2) void pifu_query1
         __syncthreads();
       }
       }
-      // skip segment (unless it went into the chunk loop) + z column of layer 1
-      if (!kFill) {
-        AFrag ring1[2][4];
-        seg_prefetch16<4, 1, TERMS>(ring1, ws, a1x, NGX * 128, NGX);
-        seg_main16<4, NBW, 1, kXRow, 32, TERMS>(acc1, ring1, ws, a1x, NGX * 128, NGX, xrow, swz);
-      }
+      // skip segment + z column of layer 1
+      AFrag ring1[2][4];
+      seg_prefetch16<4, 1, TERMS>(ring1, ws, a1x, NGX * 128, NGX);
+      seg_main16<4, NBW, 1, kXRow, 32, TERMS>(acc1, ring1, ws, a1x, NGX * 128, NGX, xrow, swz);
       gemm_z16<4, NBW, TERMS>(acc1, ws, mlp.az[1] + (4 * wv) * 128, zw);
       const float inv1 = 1.0f / mlp.scale[1];
 #pragma unroll
@@ -650,7 +560,7 @@ __global__ __launch_bounds__(kThreads16 * CS, NB >= 3 ? CS : 2) void pifu_query1
     }
 
 #ifdef MP16_ABLATE
-    if (MP16_ABLATE == 2 || MP16_ABLATE == 22) {  // timing experiment only: stop after layers 0+1
+    if (MP16_ABLATE == 2) {  // timing experiment only: stop after layers 0+1
       float sink = 0.f;
 #pragma unroll
       for (int m = 0; m < 4; ++m)
