@@ -330,7 +330,8 @@ __device__ __forceinline__ void store_hidden16_part(unsigned char *hb, const f32
 
 // NB = 32-point column blocks per tile: 3 = the 96-point tile described above (the product);
 // 4 = round 1's 128-point tile (160 KB of LDS, 64-row layer-0 chunks computed by two waves per row
-// block: 0.42 of the roof over a reconstruction vs 0.44); 2 = a 64-point tile with half the LDS,
+// block: 0.42 of the roof over a reconstruction vs 0.44; build it with -DMP16_SGB=0, the
+// interleaved prefetches spill next to its 288 accumulator registers: 9.7 ms); 2 = a 64-point tile with half the LDS,
 // two workgroups per CU (the partner hides barriers and epilogues, at twice the weight bytes per
 // point).  Measured (1 M points, -DMP16_NB=2): f16x3 11.3 ms, plain f16 4.4 vs 4.0 -- weight
 // streaming wins.
