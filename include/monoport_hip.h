@@ -299,21 +299,23 @@ int mp_conv3x3_gn16(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, c
                     int reflect, const void *packed16, const float *wmax, int cout, float *y, double *stats,
                     mp_stream stream);
 /* The 1x1 convolutions of the hourglass tail (backbones/HGFilters.py:184-204: conv_last, l, bl,
- * al; nn.Conv2d(C, 256, 1) with bias) as one fused GEMM each:
+ * al; nn.Conv2d(C, 256, 1) with bias) and the 1x1 projection of a pyramid block whose channel
+ * count changes (HGFilters.py:47-52: GroupNorm, ReLU, Conv2d(Cin, Cout, 1, bias=False)) as one
+ * fused GEMM each:
  *     y = W [relu?(x1 * scale + shift) ; x2] + bias (+ res)
- * Cout = 256; x1 [N,C1,HW] with optional fused GroupNorm (ss1 [N,C1,2]) + ReLU; x2 [N,C2,HW] an
+ * cout = 256, or 128 (then no stats / y_hwc); bias may be NULL; x1 [N,C1,HW] with optional fused GroupNorm (ss1 [N,C1,2]) + ReLU; x2 [N,C2,HW] an
  * optional second K segment (bl(y) + al(out) is ONE call with W = [W_bl | W_al], bias = b_bl +
  * b_al, res = x); outputs: y [N,256,HW] and / or y_hwc [N,HW,256] (the channels-last map the
  * query kernels read, written in 1 KB bursts) -- at least one; stats: NULL or the partial sums of
  * GroupNorm(32, 256) over the output, double [N,32,(HW/64)*8,2].  mp_conv1x1_pack re-orders
- * W1 [256,C1] (and W2 [256,C2]) into fragment order: 256*(C1+C2) floats, or the same number of
+ * W1 [cout,C1] (and W2 [cout,C2]) into fragment order: cout*(C1+C2) floats, or the same number of
  * (hi, lo) f16 pairs when f16 != 0 (then wmax, device float[1], receives max|W|).  C1, C2 and HW
  * must be multiples of 64. */
-int mp_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, int c2, int f16,
+int mp_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, int c2, int cout, int f16,
                     void *packed, float *wmax, mp_stream stream);
 int mp_conv1x1(mp_ctx *ctx, const float *x1, const float *ss1, int relu1, const float *x2, int n, int c1,
-               int c2, int64_t hw, const void *packed, int f16, const float *wmax, const float *bias,
-               const float *res, float *y, float *y_hwc, double *stats, mp_stream stream);
+               int c2, int cout, int64_t hw, const void *packed, int f16, const float *wmax,
+               const float *bias, const float *res, float *y, float *y_hwc, double *stats, mp_stream stream);
 /* GroupNorm statistics as two steps.  mp_gn_stats: partial (sum, sum of squares) of x [N,C,HW] per
  * (image, group, slice) -> double [N*groups, mp_gn_stat_slices(), 2] (one read pass; for tensors
  * that do not come out of mp_conv3x3_gn).  mp_gn_finalize: partial sums (either source) -> ss [N,C,2] =

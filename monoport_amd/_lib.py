@@ -73,9 +73,9 @@ SIGNATURES = {
     "mp_conv3x3_pack16": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "mp_conv3x3_gn16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int,
                                 c_vp, c_vp, c_vp]),
-    "mp_conv1x1_pack": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
-    "mp_conv1x1": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_i64, c_vp, c_int, c_vp,
-                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mp_conv1x1_pack": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "mp_conv1x1": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_int,
+                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mp_gn_stat_slices": (c_int, []),
     "mp_gn_stats": (c_int, [c_vp, c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp]),
     "mp_gn_finalize": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp, c_f32, c_vp,

@@ -744,19 +744,21 @@ int mp_conv3x3_gn16(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, c
                            wmax, cout, y, stats, (hipStream_t)stream);
 }
 
-int mp_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, int c2, int f16,
+int mp_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, int c2, int cout, int f16,
                     void *packed, float *wmax, mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!w1 || !packed || c1 <= 0 || c2 < 0 || (c2 > 0 && !w2) || (f16 && !wmax))
     return fail(ctx, MP_ERR_ARG, "mp_conv1x1_pack: bad argument");
-  if (c1 % 64 || c2 % 64) return fail(ctx, MP_ERR_UNSUPPORTED, "mp_conv1x1_pack: channel counts must be multiples of 64");
+  if (c1 % 64 || c2 % 64 || (cout != 128 && cout != 256))
+    return fail(ctx, MP_ERR_UNSUPPORTED,
+                "mp_conv1x1_pack: input channel counts must be multiples of 64, output channels 128 or 256");
   DeviceGuard g(ctx->device);
-  return launch_conv1x1_pack(ctx, w1, c1, w2, c2, f16, packed, wmax, (hipStream_t)stream);
+  return launch_conv1x1_pack(ctx, w1, c1, w2, c2, cout, f16, packed, wmax, (hipStream_t)stream);
 }
 
 int mp_conv1x1(mp_ctx *ctx, const float *x1, const float *ss1, int relu1, const float *x2, int n, int c1,
-               int c2, int64_t hw, const void *packed, int f16, const float *wmax, const float *bias,
+               int c2, int cout, int64_t hw, const void *packed, int f16, const float *wmax, const float *bias,
                const float *res, float *y, float *y_hwc, double *stats, mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -765,8 +767,8 @@ int mp_conv1x1(mp_ctx *ctx, const float *x1, const float *ss1, int relu1, const 
   if (!aligned16(packed) || (y_hwc && !aligned16(y_hwc)))
     return fail(ctx, MP_ERR_ARG, "mp_conv1x1: packed weights / y_hwc must be 16-byte aligned");
   DeviceGuard g(ctx->device);
-  return launch_conv1x1_raw(ctx, x1, ss1, relu1, x2, n, c1, c2, hw, packed, f16, wmax, bias, res, y, y_hwc,
-                            stats, (hipStream_t)stream);
+  return launch_conv1x1_raw(ctx, x1, ss1, relu1, x2, n, c1, c2, cout, hw, packed, f16, wmax, bias, res, y,
+                            y_hwc, stats, (hipStream_t)stream);
 }
 
 int mp_scale_shift_add(mp_ctx *ctx, const float *t, const float *ss, const float *res, int n, int c,

@@ -763,6 +763,7 @@ struct Conv1Args {
   float *y_hwc;           // [N,HW,256] or nullptr
   double *stats;          // nullptr or [N,32,S,2], S = (HW/64) * 8
   int n_img, c1, c2, hw, relu1, wp_floats;
+  int cout;  // 256 (each wave two 32-row blocks) or 128 (one): the 1x1 projection of a pyramid block
 };
 
 constexpr int kC1K = 64;          // channels per staged chunk
@@ -771,9 +772,9 @@ constexpr int kC1Row = kC1K * 4;  // bytes per staged pixel (f32, or 32 hi + 32 
 
 // W = [Cout][K] row-major with K = C1 + C2 (segment 1 first) -> fragment order
 __global__ void conv1x1_pack_kernel(const float *__restrict__ w1, int c1, const float *__restrict__ w2,
-                                    int c2, float *__restrict__ wp) {
+                                    int c2, int cout, float *__restrict__ wp) {
   const int k = c1 + c2, kgt = k / 8;
-  const long long total = 256LL * k;
+  const long long total = (long long)cout * k;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
     const int i = (int)(t & 3), lane = (int)((t >> 2) & 63);
@@ -786,10 +787,11 @@ __global__ void conv1x1_pack_kernel(const float *__restrict__ w1, int c1, const 
 }
 
 __global__ void conv1x1_pack16_kernel(const float *__restrict__ w1, int c1, const float *__restrict__ w2,
-                                      int c2, const float *__restrict__ wmax, _Float16 *__restrict__ wp) {
+                                      int c2, int cout, const float *__restrict__ wmax,
+                                      _Float16 *__restrict__ wp) {
   const float S = conv16_scale(*wmax);
   const int k = c1 + c2, kst = k / 16;
-  const long long total = 256LL * k;
+  const long long total = (long long)cout * k;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
     const int e = (int)(t & 7), lane = (int)((t >> 3) & 63);
@@ -805,7 +807,7 @@ __global__ void conv1x1_pack16_kernel(const float *__restrict__ w1, int c1, cons
   }
 }
 
-template <bool F16>
+template <bool F16, int MRW>
 __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const float *__restrict__ wmax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x 16 KB stage (64 KB with y_hwc)
   const int tid = threadIdx.x;
@@ -873,9 +875,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MRW][2];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MRW; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -887,13 +889,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
   constexpr int FPS = F16 ? 2 : 1;                  // 16-byte fragments per step and row block
   const int steps = n_chunks * SPC;
   const int rb_stride = steps * FPS * 64;
-  const int a_base = (2 * wv) * rb_stride;
+  const int a_base = (MRW * wv) * rb_stride;
   auto a_load = [&](int m, int s, int part) {
     return wload128(ws, a_base + m * rb_stride + (min(s, steps - 1) * FPS + part) * 64);
   };
-  f32x4 ring[2][2][FPS];  // [slot][m][part], one step ahead
+  f32x4 ring[2][MRW][FPS];  // [slot][m][part], one step ahead
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MRW; ++m)
 #pragma unroll
     for (int part = 0; part < FPS; ++part) ring[0][m][part] = a_load(m, 0, part);
 
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
       const int gs = chunk * SPC + s;
       // next step's A fragments
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MRW; ++m)
 #pragma unroll
         for (int part = 0; part < FPS; ++part) ring[(s + 1) & 1][m][part] = a_load(m, gs + 1, part);
       if constexpr (!F16) {
@@ -923,7 +925,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
+          for (int m = 0; m < MRW; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[s & 1][m][0][i], b[n][i], acc[m][n], 0, 0, 0);
@@ -937,7 +939,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < MRW; ++m) {
           const h8 ah = __builtin_bit_cast(h8, ring[s & 1][m][0]);
           const h8 al = __builtin_bit_cast(h8, ring[s & 1][m][FPS - 1]);
 #pragma unroll
@@ -958,10 +960,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
 
   // ---- epilogue ----
   const float inv_scale = F16 ? 1.0f / conv16_scale(*wmax) : 1.0f;
-  float s1[2][16], s2[2][16];
+  float s1[MRW][16], s2[MRW][16];
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int rb = 2 * wv + m;
+  for (int m = 0; m < MRW; ++m) {
+    const int rb = MRW * wv + m;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int co = 32 * rb + (t & 3) + 8 * (t >> 2) + 4 * h;
@@ -969,7 +971,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
       s1[m][t] = s2[m][t] = 0.0f;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        const long long o = ((long long)img * 256 + co) * p.hw + px0 + 32 * n + j;
+        const long long o = ((long long)img * p.cout + co) * p.hw + px0 + 32 * n + j;
         float v = acc[m][n][t] * inv_scale + b;
         if (p.res) v += p.res[o];
         if (p.y) p.y[o] = v;
@@ -979,9 +981,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
       }
     }
   }
-  if (p.stats) {
+  if (MRW == 2 && p.stats) {  // GroupNorm(32, 256) statistics: the launcher refuses them for 128 rows
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MRW; ++m)
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
 #pragma unroll
@@ -993,28 +995,28 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
     if (j == 0) {
       const int S = tiles * 8;  // 8 channels per GroupNorm(32, 256) group, one slot per tile
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MRW; ++m)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-          const int co = 32 * (2 * wv + m) + (t & 3) + 8 * (t >> 2) + 4 * h;
+          const int co = 32 * (MRW * wv + m) + (t & 3) + 8 * (t >> 2) + 4 * h;
           double *dst = p.stats + (((long long)img * 32 + (co >> 3)) * S + tile * 8 + (co & 7)) * 2;
           dst[0] = (double)s1[m][t];
           dst[1] = (double)s2[m][t];
         }
     }
   }
-  if (p.y_hwc) {
+  if (MRW == 2 && p.y_hwc) {
     // [64 px][256 ch] f32 = 64 KB through LDS (16-byte slots swizzled with the pixel), then every
     // pixel row leaves as one 1 KB burst: wave wv writes pixels wv, wv + 4, ...
     float *tr = reinterpret_cast<float *>(smem);
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MRW; ++m)
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         const int px = 32 * n + j;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int slot = (32 * (2 * wv + m) + 8 * q + 4 * h) >> 2;  // 4 consecutive channels
+          const int slot = (32 * (MRW * wv + m) + 8 * q + 4 * h) >> 2;  // 4 consecutive channels
           const f32x4 v = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
           *reinterpret_cast<f32x4 *>(reinterpret_cast<unsigned char *>(tr) + px * 1024 + ((slot ^ (px & 63)) << 4)) = v;
         }
@@ -1029,23 +1031,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
   }
 }
 
-int launch_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, int c2, int f16, void *wp,
-                        float *wmax, hipStream_t st) {
-  const long long total = 256LL * (c1 + c2);
+int launch_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, int c2, int cout, int f16,
+                        void *wp, float *wmax, hipStream_t st) {
+  const long long total = (long long)cout * (c1 + c2);
   long long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (!f16) {
-    hipLaunchKernelGGL(conv1x1_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w1, c1, w2, c2,
+    hipLaunchKernelGGL(conv1x1_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w1, c1, w2, c2, cout,
                        static_cast<float *>(wp));
   } else {
     // max|W| over both segments: two absmax passes into the same word (atomicMax keeps the larger)
     MP_HIP(ctx, hipMemsetAsync(wmax, 0, sizeof(float), st));
-    int rc = launch_absmax_accumulate(ctx, w1, 256LL * c1, reinterpret_cast<unsigned int *>(wmax), st);
+    int rc = launch_absmax_accumulate(ctx, w1, (long long)cout * c1, reinterpret_cast<unsigned int *>(wmax), st);
     if (rc == MP_OK && c2 > 0)
-      rc = launch_absmax_accumulate(ctx, w2, 256LL * c2, reinterpret_cast<unsigned int *>(wmax), st);
+      rc = launch_absmax_accumulate(ctx, w2, (long long)cout * c2, reinterpret_cast<unsigned int *>(wmax), st);
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(conv1x1_pack16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w1, c1, w2, c2, wmax,
-                       static_cast<_Float16 *>(wp));
+    hipLaunchKernelGGL(conv1x1_pack16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w1, c1, w2, c2, cout,
+                       wmax, static_cast<_Float16 *>(wp));
   }
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
@@ -1054,13 +1056,16 @@ int launch_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, i
 static int launch_conv1x1(mp_ctx *ctx, const Conv1Args &a, int f16, const float *wmax, hipStream_t st);
 
 int launch_conv1x1_raw(mp_ctx *ctx, const float *x1, const float *ss1, int relu1, const float *x2, int n,
-                       int c1, int c2, long long hw, const void *wp, int f16, const float *wmax,
+                       int c1, int c2, int cout, long long hw, const void *wp, int f16, const float *wmax,
                        const float *bias, const float *res, float *y, float *y_hwc, double *stats,
                        hipStream_t st) {
-  if (c1 <= 0 || c1 % kC1K || c2 < 0 || c2 % kC1K || hw % kC1Px || (c2 > 0) != (x2 != nullptr))
+  if (c1 <= 0 || c1 % kC1K || c2 < 0 || c2 % kC1K || hw % kC1Px || (c2 > 0) != (x2 != nullptr) ||
+      (cout != 256 && cout != 128))
     return fail(ctx, MP_ERR_UNSUPPORTED,
-                "conv1x1: needs C1, C2 multiples of 64, H*W a multiple of 64 and 256 output channels (got %d + %d, %lld)",
-                c1, c2, hw);
+                "conv1x1: needs C1, C2 multiples of 64, H*W a multiple of 64 and 128 or 256 output channels "
+                "(got %d + %d -> %d, %lld)", c1, c2, cout, hw);
+  if (cout != 256 && (stats || y_hwc))
+    return fail(ctx, MP_ERR_UNSUPPORTED, "conv1x1: statistics / channels-last output are built for 256 channels");
   Conv1Args a;
   a.x1 = x1;
   a.ss1 = ss1;
@@ -1076,23 +1081,23 @@ int launch_conv1x1_raw(mp_ctx *ctx, const float *x1, const float *ss1, int relu1
   a.c2 = c2;
   a.hw = (int)hw;
   a.relu1 = relu1;
-  a.wp_floats = 256 * (c1 + c2);
+  a.wp_floats = cout * (c1 + c2);
+  a.cout = cout;
   return launch_conv1x1(ctx, a, f16, wmax, st);
 }
 
 static int launch_conv1x1(mp_ctx *ctx, const Conv1Args &a, int f16, const float *wmax, hipStream_t st) {
   const int lds = a.y_hwc ? kC1Px * 1024 : 2 * kC1Px * kC1Row;
-  const void *kern_id = f16 ? reinterpret_cast<const void *>(conv1x1_kernel<true>)
-                            : reinterpret_cast<const void *>(conv1x1_kernel<false>);
+  void (*kern)(Conv1Args, const float *) =
+      a.cout == 256 ? (f16 ? conv1x1_kernel<true, 2> : conv1x1_kernel<false, 2>)
+                    : (f16 ? conv1x1_kernel<true, 1> : conv1x1_kernel<false, 1>);
+  const void *kern_id = reinterpret_cast<const void *>(kern);
   if (!ctx->lds_attr_done.count(kern_id)) {
     MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, kC1Px * 1024));
     ctx->lds_attr_done.insert(kern_id);
   }
   const dim3 grid((unsigned)((a.hw / kC1Px) * a.n_img));
-  if (f16)
-    hipLaunchKernelGGL(conv1x1_kernel<true>, grid, dim3(256), lds, st, a, wmax);
-  else
-    hipLaunchKernelGGL(conv1x1_kernel<false>, grid, dim3(256), lds, st, a, wmax);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, wmax);
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
 }

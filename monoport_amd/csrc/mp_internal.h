@@ -212,10 +212,10 @@ int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w,
                       double *stats, hipStream_t st);
 int launch_scale_shift_add(mp_ctx *ctx, const float *t, const float *ss, const float *res, long long planes,
                            long long hw, float *y, hipStream_t st);
-int launch_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, int c2, int f16, void *wp,
-                        float *wmax, hipStream_t st);
+int launch_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, int c2, int cout, int f16,
+                        void *wp, float *wmax, hipStream_t st);
 int launch_conv1x1_raw(mp_ctx *ctx, const float *x1, const float *ss1, int relu1, const float *x2, int n,
-                       int c1, int c2, long long hw, const void *wp, int f16, const float *wmax,
+                       int c1, int c2, int cout, long long hw, const void *wp, int f16, const float *wmax,
                        const float *bias, const float *res, float *y, float *y_hwc, double *stats,
                        hipStream_t st);
 int launch_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int groups, int slices,

@@ -140,7 +140,8 @@ class ConvBlock(nn.Module):
         x = x.contiguous()
         n, c_in, h, w = x.shape
         hw = h * w
-        ss = ops.gn_finalize(ops.gn_stats(x, _GROUPS), n, c_in, _GROUPS, (c_in // _GROUPS) * hw,
+        stats_x = ops.gn_stats(x, _GROUPS)
+        ss = ops.gn_finalize(stats_x, n, c_in, _GROUPS, (c_in // _GROUPS) * hw,
                              self.bn1.weight, self.bn1.bias, self.bn1.eps)
         a, st = ops.conv3x3_gn(x, ss, self._packed(self.conv1), relu=True, want_stats=True)
         ca = a.shape[1]
@@ -151,8 +152,27 @@ class ConvBlock(nn.Module):
         ss = ops.gn_finalize(st, n, cb, _GROUPS, (cb // _GROUPS) * hw, self.bn3.weight, self.bn3.bias,
                              self.bn3.eps)
         c, _ = ops.conv3x3_gn(b, ss, self._packed(self.conv3), relu=True, want_stats=False)
-        shortcut = x if self.downsample is None else _run_sequential(self.downsample, x)
+        if self.downsample is None:
+            shortcut = x
+        elif c_in % 64 == 0 and hw % 64 == 0 and self.downsample[2].out_channels in (128, 256):
+            # relu(bn4(x)) from the statistics bn1 already took (same input, other affine) applied
+            # while the 1x1 projection stages its input (csrc/conv3x3.hip conv1x1_kernel)
+            ss4 = ops.gn_finalize(stats_x, n, c_in, _GROUPS, (c_in // _GROUPS) * hw,
+                                  self.bn4.weight, self.bn4.bias, self.bn4.eps)
+            shortcut, _ = ops.conv1x1(x, ss4, True, None, self._packed_projection())
+        else:
+            shortcut = _run_sequential(self.downsample, x)
         return ops.concat3_add(a, b, c, shortcut)
+
+    def _packed_projection(self):
+        cache = self.__dict__.setdefault("_packed_cache", {})
+        w = self.downsample[2].weight
+        key = (w.data_ptr(), w._version, str(w.device), ENCODER_CONV_PRECISION)
+        hit = cache.get("projection")
+        if hit is None or hit[0] != key:
+            hit = (key, ops.PackedConv1x1(w, None, precision=ENCODER_CONV_PRECISION))
+            cache["projection"] = hit
+        return hit[1]
 
     def forward(self, x):
         if self._fused_ok(x):

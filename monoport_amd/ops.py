@@ -664,27 +664,29 @@ def conv3x3_gn(x, ss, packed, relu=True, want_stats=False, reflect=False):
 
 
 class PackedConv1x1:
-    """Weights of one fused 1x1 convolution of the hourglass tail in MFMA fragment order: W1
-    [256,C1(,1,1)] and optionally W2 [256,C2(,1,1)] (second K segment), biases summed."""
+    """Weights of one fused 1x1 convolution in MFMA fragment order: W1 [Cout,C1(,1,1)] and optionally
+    W2 [Cout,C2(,1,1)] (second K segment), biases summed (``b1`` may be None).  Cout = 256 (the
+    hourglass tail) or 128 / 256 (the projection shortcut of a pyramid block)."""
 
-    def __init__(self, w1, b1, w2=None, b2=None, precision="f32"):
+    def __init__(self, w1, b1=None, w2=None, b2=None, precision="f32"):
         w1 = _f32c(w1.detach().reshape(w1.shape[0], -1))
-        if w1.shape[0] != 256:
-            raise ValueError("conv1x1 is built for 256 output channels, got %d" % w1.shape[0])
+        self.cout = int(w1.shape[0])
+        if self.cout not in (128, 256):
+            raise ValueError("conv1x1 is built for 128 or 256 output channels, got %d" % self.cout)
         self.c1, self.c2 = int(w1.shape[1]), 0
         if w2 is not None:
             w2 = _f32c(w2.detach().reshape(w2.shape[0], -1))
             self.c2 = int(w2.shape[1])
         self.precision = precision
         ctx = get_context(w1.device)
-        self.data = torch.empty((256 * (self.c1 + self.c2),), dtype=torch.float32, device=w1.device)
+        self.data = torch.empty((self.cout * (self.c1 + self.c2),), dtype=torch.float32, device=w1.device)
         self.wmax = torch.zeros((1,), dtype=torch.float32, device=w1.device)
-        bias = b1.detach().float()
+        bias = None if b1 is None else b1.detach().float()
         if b2 is not None:
-            bias = bias + b2.detach().float()
-        self.bias = bias.contiguous()
+            bias = b2.detach().float() if bias is None else bias + b2.detach().float()
+        self.bias = None if bias is None else bias.contiguous()
         ctx.check(ctx.lib.mp_conv1x1_pack(ctx.handle, _ptr(w1), self.c1, _ptr(w2) if w2 is not None else None,
-                                          self.c2, int(precision == "f16x3"), _ptr(self.data),
+                                          self.c2, self.cout, int(precision == "f16x3"), _ptr(self.data),
                                           _ptr(self.wmax), _stream(w1)), "mp_conv1x1_pack")
         stream = torch.cuda.current_stream(w1.device)
         w1.record_stream(stream)
@@ -699,7 +701,7 @@ def conv1x1_supported(x):
 
 def conv1x1(x1, ss1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=None, want_stats=False):
     """y = W [relu?(x1 * scale + shift) ; x2] + bias (+ res) as one fused GEMM (mp_conv1x1).
-    Returns (y [N,256,H,W] or None, stats or None); ``y_hwc`` [N,H,W,256] is filled when given."""
+    Returns (y [N,Cout,H,W] or None, stats or None); ``y_hwc`` [N,H,W,256] is filled when given."""
     ctx = get_context(x1.device)
     x1 = x1.contiguous()
     n, c1, h, w = x1.shape
@@ -710,7 +712,7 @@ def conv1x1(x1, ss1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=None, wa
         x2 = x2.contiguous()
     if res is not None:
         res = res.contiguous()
-    y = torch.empty((n, 256, h, w), dtype=torch.float32, device=x1.device) if want_nchw else None
+    y = torch.empty((n, packed.cout, h, w), dtype=torch.float32, device=x1.device) if want_nchw else None
     stats = None
     if want_stats:
         s = (hw // 64) * 8
@@ -719,8 +721,9 @@ def conv1x1(x1, ss1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=None, wa
         assert y_hwc.is_contiguous() and y_hwc.numel() == n * hw * 256 and y_hwc.dtype == torch.float32
     ctx.check(ctx.lib.mp_conv1x1(
         ctx.handle, _ptr(x1), _ptr(ss1) if ss1 is not None else None, int(bool(relu1)),
-        _ptr(x2) if x2 is not None else None, n, c1, packed.c2, hw, _ptr(packed.data),
-        int(packed.precision == "f16x3"), _ptr(packed.wmax), _ptr(packed.bias),
+        _ptr(x2) if x2 is not None else None, n, c1, packed.c2, packed.cout, hw, _ptr(packed.data),
+        int(packed.precision == "f16x3"), _ptr(packed.wmax),
+        _ptr(packed.bias) if packed.bias is not None else None,
         _ptr(res) if res is not None else None, _ptr(y) if y is not None else None,
         _ptr(y_hwc) if y_hwc is not None else None, _ptr(stats[0]) if stats else None, _stream(x1)),
         "mp_conv1x1")

@@ -217,6 +217,33 @@ def test_conv1x1_fused_tail_matches_torch(precision):
         assert e_x <= 5e-5 * max(1.0, xn_ref.abs().max().item())
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("cin,cout,hw", [(64, 128, 128), (128, 256, 64)])
+def test_conv1x1_projection_shortcut(precision, cin, cout, hw):
+    """The 1x1 projection of a pyramid block whose channel count changes (HGFilters.py:47-52:
+    GroupNorm -> ReLU -> Conv2d(Cin, Cout, 1, bias=False)), 128 or 256 output channels, no bias."""
+    from monoport_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    n = 2
+    x = (torch.randn((n, cin, hw, hw), generator=g) * 1.3 + 0.2).to(DEV)
+    conv = torch.nn.Conv2d(cin, cout, 1, bias=False).to(DEV)
+    gn = torch.nn.GroupNorm(32, cin).to(DEV)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.5, 0.5)
+        packed = ops.PackedConv1x1(conv.weight, None, precision=precision)
+        ss = ops.gn_finalize(ops.gn_stats(x, 32), n, cin, 32, (cin // 32) * hw * hw, gn.weight, gn.bias, gn.eps)
+        y, st = ops.conv1x1(x, ss, True, None, packed)
+        ref = torch.nn.functional.conv2d(torch.relu(gn(x)).double(), conv.weight.double())
+        err = (y.double() - ref).abs().max().item()
+        print("conv1x1 projection %s %d -> %d: %.3g" % (precision, cin, cout, err))
+        assert st is None and y.shape == (n, cout, hw, hw) and err <= 2e-5 * max(1.0, ref.abs().max().item())
+        if cout == 128:  # statistics / channels-last output exist for 256 rows only
+            from monoport_amd._lib import MonoportError
+            with pytest.raises(MonoportError):
+                ops.conv1x1(x, ss, True, None, packed, want_stats=True)
+
+
 def test_encoder_hwc_output_equals_packed_nchw():
     """HGFilter.forward(hwc_out=...): the last stack's features written channels-last by the
     producing kernel equal mp_feat_pack_hwc of the NCHW output, bit for bit."""
