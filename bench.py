@@ -2,22 +2,33 @@
 """Headline benchmark: reconstructions/sec (512x512 image in, 256^3-effective octree grid out).
 
 One "step" = one full geometry reconstruction of one synthetic frame on one MI355X
-(BASELINE.json configs[1]): netG.filter (hourglass encoder, PyTorch-ROCm) -> channels-last pack
--> coarse-to-fine octree 17..257 driving the fused HIP query kernel -> forward_vertices ->
-normal render.  Inputs are resident in HBM before the timed region.  With --gpus N every rank
+(BASELINE.json configs[1]): netG.filter (hourglass encoder) -> channels-last features ->
+coarse-to-fine octree 17..257 driving the fused HIP query kernel -> forward_vertices -> normal
+render.  Inputs are resident in HBM before the timed region.  With --gpus N every rank
 reconstructs its own frames (frame-parallel, weak scaling) and the renders are gathered to rank 0
 over RCCL.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  "roofline":     the fused query kernel against the f32 MFMA peak (HIP-event timed, live)
-  "cpu_baseline": the CPU oracle path timed on this box's host cores (rank 0, N=1 only)
-
     python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks (one per
+GPU, ``python -m torch.distributed.run --standalone``-style on 127.0.0.1) and fails loudly when
+fewer than N GPUs are visible; under ``python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N ...`` it joins the ranks the launcher made.  Either way rank 0 prints ONE JSON
+line with the driver's contract fields plus
+
+  "roofline"      the fused query kernel against the f32 MFMA peak (HIP-event timed, live)
+  "cpu_baseline"  the CPU oracle path timed on this box's host cores (rank 0, N=1 only)
+  "passes"        the timed region is run 3 times (each EXACTLY --steps frames between barrier +
+                  synchronize pairs); `value` is the median pass, min / max are listed
+  "in_flight_8"   BASELINE configs[3]: 8 frames in flight across the node (8/N per rank)
+  "with_color" / "levels6_f16w" / "mesh" / "dropin" / "alt_precision"   (N=1 only) the other
+                  BASELINE configs and surfaces, each with its own timing and parity deltas
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,13 +40,25 @@ sys.path.insert(0, ROOT)
 
 from monoport_amd import ops, parallel, synthetic as syn  # noqa: E402
 from monoport_amd.modeling import PIFuNetC, PIFuNetG  # noqa: E402
-from monoport_amd.pipeline import FramePipeline  # noqa: E402
+from monoport_amd.pipeline import MAX_RECON_BATCH, FramePipeline  # noqa: E402
 from monoport_amd.recon import pifu_calib  # noqa: E402
 
 RESOLUTIONS = [17, 33, 65, 129, 257]  # RTL/main.py:187
 B_MIN, B_MAX = [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]  # RTL/main.py:185-186
 FLOP_PER_POINT = 2363906  # netG MLP, SURVEY.md section 8d / BASELINE.md section 2
+FLOP_PER_POINT_C = 3350022  # netC MLP (per-vertex colour query)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak
+N_IMAGES = 8  # distinct synthetic frames cycled through the timed region
+# the reference's OWN modules timed on CPU (oracle/time_reference.py, build container: the GPU box
+# has no /root/reference) -- a constant with its provenance, next to the live "port" baseline
+CPU_BASELINE_REFERENCE = {
+    "value": 0.123, "unit": "recon/s", "cores": 8, "kind": "reference",
+    "where": "build container (no GPU), 8 threads; not re-measured on the GPU box",
+    "source": "oracle/time_reference.py -> BASELINE.md section 4",
+    "sample": "1 reconstruction = netG.filter 0.565 s + 17..257 octree through the reference's "
+              "netG.query 7.49 s (280,936 points) + forward_vertices 0.092 s = 8.15 s",
+}
 
 
 def set_precision_everywhere(head, precision):
@@ -104,13 +127,13 @@ def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, 
 TRAFFIC_PROFILE = "r02_query_traffic.json"
 
 
-def traffic_from_profile(args, frames_per_launch):
+def traffic_from_profile(precision, levels, with_color, frames_per_launch):
     """HBM-side bytes per fused-query launch from the committed PMC pass (separate rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE runs of tools/traffic_probe.py, corrected as
     MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process, so the
     figure is reported ONLY for the configuration the pass covered (f32 kernel, 5 levels, geometry
     only, same frames per launch) and is None for every other run or when the profile is absent."""
-    if args.precision != "f32" or args.levels != 5 or args.with_color:
+    if precision != "f32" or levels != 5 or with_color:
         return None
     path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
     try:
@@ -123,12 +146,343 @@ def traffic_from_profile(args, frames_per_launch):
         return None
 
 
-def dropin_surface(device, n_frames, n_warm, resolutions):
+# ---------------------------------------------------------------------------------------------
+# launching the ranks
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """``python bench.py --gpus N`` (N > 1) outside a launcher: start N ranks of this script, one
+    per GPU, with torch.distributed.run on 127.0.0.1 and pass their output / exit code through.
+    Refuses (exit 2) when fewer than N GPUs are visible -- never a silent 1-GPU run."""
+    one_gpu_test = os.environ.get("MONOPORT_BENCH_ONE_GPU_TEST") == "1"
+    if not args.rendezvous_only:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs MI355X GPUs (no CPU fallback)")
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus and not one_gpu_test:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible on this node; "
+                             "refusing to run (a frame-parallel measurement needs one GPU per "
+                             "rank)\n" % (args.gpus, n_dev))
+            raise SystemExit(2)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env["MONOPORT_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+           str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("bench.py: launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def rank_devices(dist, device, world):
+    """(device index, PCI bus id, name) of every rank, gathered on all ranks."""
+    if device.type == "cuda":
+        props = torch.cuda.get_device_properties(device)
+        bus = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1),
+                                  getattr(props, "pci_device_id", -1))
+        mine = "%d|%s|%s" % (torch.cuda.current_device(), bus, props.name)
+    else:
+        mine = "cpu|pid%d" % os.getpid()
+    if dist is None:
+        return [mine]
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    return got
+
+
+def rendezvous_only(args):
+    """--rendezvous-only: every rank joins the process group, the device census and ONE gather of
+    a frame-sized payload run exactly as in a measurement, and rank 0 prints a JSON line -- no
+    reconstruction, no GPU kernels of ours.  It proves the launch path (self-launch or
+    torch.distributed.run) without spending a measurement, and runs on a box without GPUs (gloo;
+    tests/test_bench_launch_cpu.py)."""
+    have_gpu = torch.cuda.is_available()
+    one_gpu_test = os.environ.get("MONOPORT_BENCH_ONE_GPU_TEST") == "1"
+    local_rank = 0 if one_gpu_test else int(os.environ.get("LOCAL_RANK", "0"))
+    if have_gpu:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
+    backend = "nccl" if have_gpu and not one_gpu_test else "gloo"
+    rank, world = parallel.init_from_env(backend=backend, device=device if have_gpu else None)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+    devices = rank_devices(dist, device, world)
+    if world > 1 and have_gpu and not one_gpu_test:
+        assert len(set(devices)) == world, "ranks share a GPU: %s" % devices
+    gather = parallel.FrameGather((1, 257, 257, 3), device=device, store=False)
+    payload = torch.full((1, 257, 257, 3), float(rank), device=device)
+    gather.push(0, payload)
+    ok = True
+    if rank == 0 and world > 1:
+        ok = all(bool((gather.received(r) == float(r)).all()) for r in range(world))
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "backend": backend,
+                          "devices": devices, "gather_checked": bool(ok),
+                          "self_launched": os.environ.get("MONOPORT_BENCH_SELF_LAUNCHED") == "1"}),
+              flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
+# ---------------------------------------------------------------------------------------------
+# the measurement
+# ---------------------------------------------------------------------------------------------
+class Job:
+    """Rank identity and the synthetic inputs every leg shares."""
+
+    def __init__(self, device, rank, world, dist, one_gpu_test, steps, warm):
+        self.device, self.rank, self.world, self.dist = device, rank, world, dist
+        self.one_gpu_test = one_gpu_test
+        self.steps, self.warm = steps, warm
+        n_frames = steps + warm
+        # distinct frames per rank: frame id = step * world + rank (frame-parallel sharding)
+        self.images = [torch.from_numpy(syn.synthetic_image(s * world + rank))[None].to(device)
+                       for s in range(min(n_frames, N_IMAGES))]
+        self.calibs = [pifu_calib(*syn.scene_camera(3 * (s * world + rank)), device=device)
+                       for s in range(n_frames)]
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def reduce_max(self, values):
+        """Element-wise MAX over ranks of a list of floats (the slowest rank defines a pass)."""
+        if self.dist is None:
+            return [float(v) for v in values]
+        t = torch.tensor(values, dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    def gather_floats(self, value):
+        if self.dist is None:
+            return [float(value)]
+        got = [None] * self.world
+        self.dist.all_gather_object(got, float(value))
+        return got
+
+
+def pick_batch(steps, upper):
+    """The largest divisor of --steps not above `upper`: no slot submission is short (a short
+    batch would still pay the full-batch encoder)."""
+    return max(b for b in range(1, max(1, min(upper, steps)) + 1) if steps % b == 0)
+
+
+def timed_passes(job, pipe, batch, with_color, passes, collective=True, want_status=True):
+    """Warm-up, then `passes` timed regions of EXACTLY job.steps frames each, every one between
+    barrier + synchronize pairs; returns (per-pass seconds of THIS rank, status rows of the first
+    pass, gather_checked).  `collective=False` runs the same frames without the render gather and
+    the barriers (the single-rank leg of an N > 1 run)."""
+    world = job.world if collective else 1
+    depth = len(pipe.slots)
+    r_last = pipe.slots[0].res[-1]
+    n_warm, n_frames = job.warm, job.steps + job.warm
+    gather = parallel.FrameGather((batch, r_last, r_last, 3), device=job.device, store=False) \
+        if world > 1 else None
+    render_pack = [torch.zeros((batch, r_last, r_last, 3), dtype=torch.float32, device=job.device)
+                   for _ in range(depth)] if world > 1 else None
+    gather_checked = [False]
+    status_log = []
+
+    def run_batch(s0, s1, log):
+        """Frames s0 .. s1-1 (at most `batch`) as one slot submission."""
+        slot = pipe.submit([job.images[s % len(job.images)] for s in range(s0, s1)],
+                           [job.calibs[s] for s in range(s0, s1)])
+        with torch.cuda.stream(slot.stream):
+            if world > 1:
+                pack = render_pack[(pipe.n_submitted - 1) % depth]  # this slot's staging buffer
+                for b in range(s1 - s0):
+                    pack[b].copy_(slot.renders_tex[b] if with_color else slot.renders[b])
+                gather.push(s0 // batch, pack)
+                if not log and job.rank == 0 and not gather_checked[0]:
+                    # (warm-up only: this syncs) the gathered copy of rank 0's own frames must
+                    # equal what rank 0 rendered
+                    got = gather.received(0)[:s1 - s0].to(pack.device)
+                    assert torch.equal(got, pack[:s1 - s0]), "gather mismatch"
+                    gather_checked[0] = True
+            if log:
+                status_log.append(slot.status[:s1 - s0].clone())  # device-side copy, no sync
+
+    def bracket():
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        if collective:
+            job.barrier()
+
+    for s0 in range(0, n_warm, batch):
+        run_batch(s0, min(s0 + batch, n_warm), False)
+    elapsed = []
+    for p in range(passes):
+        bracket()
+        t0 = time.perf_counter()
+        for s0 in range(n_warm, n_frames, batch):
+            run_batch(s0, min(s0 + batch, n_frames), want_status and p == 0)
+        bracket()
+        elapsed.append(time.perf_counter() - t0)
+    statuses = torch.cat(status_log).cpu().numpy() if status_log else None
+    return elapsed, statuses, gather_checked[0]
+
+
+def roofline_leg(job, pipe, batch, resolutions, with_color):
+    """The same frames again on ONE stream with every fused-query launch bracketed by HIP events on
+    its launch stream (concurrent slots would share CUs) -> per-launch durations and point counts
+    of the dominant kernel (and of the netC colour launches with `with_color`)."""
+    n_warm, n_frames = job.warm, job.steps + job.warm
+    slot = pipe.slots[0]
+    prof_status, prof_vcount = [], []
+    cap = 8 * job.steps + 64
+    ops.profile_begin(job.device, max_records=cap)
+    for s0 in range(n_warm, n_frames, batch):
+        s1 = min(s0 + batch, n_frames)
+        slot.submit([job.images[s % len(job.images)] for s in range(s0, s1)],
+                    [job.calibs[s] for s in range(s0, s1)])
+        with torch.cuda.stream(slot.stream):
+            prof_status.append(slot.status[:s1 - s0].clone())
+            if with_color:
+                prof_vcount.append(torch.cat([slot.vertices[b][4].reshape(1) for b in range(s1 - s0)]))
+    slot.wait()
+    all_ms = ops.profile_end(job.device, capacity=cap)
+    # launch order per submission of n frames: for every chunk of <= 16 frames one launch per level
+    # (its points = that level's nodes summed over the chunk, pipeline.py / mp_recon_batch); with
+    # colour one netC launch per chunk follows the octree launches of the whole submission
+    launch_ms, launch_pts, c_ms, c_pts, cursor = [], [], [], [], 0
+    for i, st in enumerate(prof_status):
+        counts = st.cpu().numpy()[:, 1:]
+        for b0 in range(0, counts.shape[0], MAX_RECON_BATCH):
+            launch_pts.append(counts[b0:b0 + MAX_RECON_BATCH].sum(0))
+            launch_ms.append(all_ms[cursor:cursor + len(resolutions)])
+            cursor += len(resolutions)
+        if with_color:
+            vc = prof_vcount[i].cpu().numpy()
+            for b0 in range(0, counts.shape[0], MAX_RECON_BATCH):
+                c_pts.append(int(vc[b0:b0 + MAX_RECON_BATCH].sum()))
+                c_ms.append(float(all_ms[cursor]))
+                cursor += 1
+    launch_ms = np.concatenate(launch_ms)
+    launch_pts = np.stack(launch_pts)
+    n_launch = min(len(launch_ms), launch_pts.size)
+    flops = launch_pts.reshape(-1)[:n_launch].astype(np.float64) * FLOP_PER_POINT
+    achieved = flops.sum() / (launch_ms[:n_launch].sum() * 1e-3) / 1e12 if n_launch else 0.0
+    out = {"achieved": achieved, "launches": int(n_launch), "launch_ms": launch_ms[:n_launch],
+           "launch_pts": launch_pts.reshape(-1)[:n_launch], "points_per_level": launch_pts.sum(0)}
+    if with_color and c_ms:
+        out["color_achieved"] = (np.sum(c_pts, dtype=np.float64) * FLOP_PER_POINT_C
+                                 / (np.sum(c_ms) * 1e-3) / 1e12)
+        out["color_points_per_frame"] = float(np.sum(c_pts)) / job.steps
+    return out
+
+
+def breakdown_leg(job, pipe, batch, resolutions):
+    """encoder-only and encoder-excluded time per frame, one stream."""
+    slot = pipe.slots[0]
+    r_last = resolutions[-1]
+
+    def timed(fn, n):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(slot.stream):
+            fn()
+            ev0.record(slot.stream)
+            for _ in range(n):
+                fn()
+            ev1.record(slot.stream)
+        slot.stream.synchronize()
+        return ev0.elapsed_time(ev1) / n
+
+    def recon_only():
+        mlp = slot.net.surface_classifier.packed()
+        ops.recon(mlp, slot.feats_hwc[0], slot.calib[0:1], syn.Z_SCALE, B_MIN, B_MAX,
+                  resolutions, 0.5, volume=slot.volume, status=slot.status[0])
+        x, y, z, nrm, count = ops.forward_vertices_raw(slot.volume, "front")
+        ops.paint(x, y, nrm, 0, count, r_last, 0.5, 0.5, 0.0, 1.0)
+
+    def recon_batched():
+        """What a slot does after its encoder: the octree of its frames level by level, then per
+        frame forward_vertices + render (monoport_amd/pipeline.py)."""
+        mlp = slot.net.surface_classifier.packed()
+        nb = min(batch, MAX_RECON_BATCH)
+        ops.recon_batch(mlp, slot.feats_hwc[:nb], slot.calib[:nb], syn.Z_SCALE, B_MIN, B_MAX,
+                        resolutions, 0.5, volumes=slot.volumes[:nb], status=slot.status[:nb])
+        for b in range(nb):
+            x, y, z, nrm, count = ops.forward_vertices_raw(slot.volumes[b], "front")
+            ops.paint(x, y, nrm, 0, count, r_last, 0.5, 0.5, 0.0, 1.0)
+
+    with torch.no_grad():
+        # the last submission may have been a short batch: refill the slot so every entry is live
+        slot.submit([job.images[s % len(job.images)] for s in range(batch)], job.calibs[:batch])
+        slot.wait()
+        enc_ms = timed(lambda: slot.net.image_filter(slot.image, last_only=True), 10) / batch
+        enc1_ms = timed(lambda: slot.net.image_filter(slot.image[:1], last_only=True), 10)
+        rec_ms = timed(recon_only, 10)
+        rec_batched_ms = timed(recon_batched, 5) / min(batch, MAX_RECON_BATCH)
+    return {
+        "encoder_ms_per_frame": enc_ms, "encoder_ms_batch1": enc1_ms,
+        "recon_vertices_render_ms": rec_ms,
+        "recon_vertices_render_ms_per_frame_batched": rec_batched_ms,
+        "recon_per_s_encoder_excluded": 1e3 / rec_batched_ms,
+        "recon_per_s_encoder_excluded_single_frame": 1e3 / rec_ms,
+        "note": "single stream, no overlap; encoder eager at the bench batch size (and at batch 1); "
+                "batched = mp_recon_batch over the slot's frames, as the pipeline runs it",
+    }
+
+
+def mesh_leg(job, volume, resolutions):
+    """North star's mesh output: marching cubes (csrc/mcubes.hip) of one reconstructed volume at the
+    full resolution, HIP-event timed.  HBM-bound; algorithmic bytes = one read of the volume + 12 B
+    per vertex + 12 B per face.  SELF-PARITY: the reference has no marching cubes, connectivity is
+    checked against our own CPU oracle (tests/test_recon_gpu.py, 257^3 included)."""
+    r = resolutions[-1]
+    torch.cuda.synchronize()
+    verts, faces, counts = ops.marching_cubes_raw(volume, 0.5, B_MIN, B_MAX)
+    nv, nf = (int(c) for c in counts.cpu())
+    if nv > verts.shape[0] or nf > faces.shape[0]:
+        return {"error": "capacity guess too small (%d verts, %d faces)" % (nv, nf)}
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    ev0.record()
+    for _ in range(reps):
+        ops.marching_cubes_raw(volume, 0.5, B_MIN, B_MAX)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    alg_bytes = 4.0 * r ** 3 + 12.0 * nv + 12.0 * nf
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    f = faces[:nf].long()
+    return {
+        "kernel": "marching cubes: mc_count / mc_scan / mc_vertices / mc_triangles (csrc/mcubes.hip)",
+        "resolution": r, "mesh_ms": ms, "vertices": nv, "faces": nf,
+        "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes},
+        "euler_characteristic": int(nv - torch.unique(torch.sort(torch.cat(
+            [f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), 1).values, dim=0).shape[0] + nf),
+        "parity": "self-parity: identical connectivity to our CPU oracle (the reference has no "
+                  "marching cubes, SURVEY.md section 0)",
+    }
+
+
+def dropin_surface(device, n_frames, n_warm, resolutions, passes=3):
     """The reference's own call surface, as RTL/main.py:326-452 drives it: the processors=[...]
     list (H2D, camera, pifu_calib, input normalisation, netG.filter, reconEngine =
     Seg3dLossless(query_func) with its per-frame host sync, forward_vertices with its .item(),
     colorization) on the thread-per-stage pipeline -- one frame per call, batch 1, eager encoder.
-    Returns recon/s through that surface and the latency of a single frame run stage by stage."""
+    Returns recon/s through that surface (median of `passes` runs) and the latency of a single
+    frame run stage by stage."""
     from monoport_amd.implicit_seg.functional import Seg3dLossless
     from monoport_amd.recon import colorization, forward_vertices
     from monoport_amd.stage_pipeline import StagePipeline
@@ -174,62 +528,56 @@ def dropin_surface(device, n_frames, n_warm, resolutions):
         ]
 
     frames = []
-    for i in range(4):
+    for i in range(N_IMAGES):
         img = torch.from_numpy(syn.synthetic_image(i))
         mask = (img.abs().sum(0, keepdim=True) > 0).float()
         frames.append(torch.cat([img, mask], 0)[None].pin_memory())
 
     # single-frame latency: one frame through the stages, one after the other, nothing else on
-    # the GPU; median of 5 after a warm-up
+    # the GPU; median of 7 after a warm-up
     procs = processors([0])
     lat = []
     with torch.no_grad():
-        for i in range(2 + 5):
+        for i in range(3 + 7):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            d = frames[i % 4]
+            d = frames[i % N_IMAGES]
             for p in procs:
                 d = p(d)
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t0)
     assert d["render_norm"] is not None
-    latency_ms = float(np.median(lat[2:])) * 1e3
+    latency_ms = float(np.median(lat[3:])) * 1e3
 
     # throughput: the same list on the stage pipeline (thread + stream per stage, FIFO order)
-    def source():
-        for i in range(n_warm + n_frames):
-            yield frames[i % 4]
+    def one_pass():
+        def source():
+            for i in range(n_warm + n_frames):
+                yield frames[i % N_IMAGES]
 
-    out_count, t0 = 0, None
-    with torch.no_grad():
-        for d in StagePipeline(source(), processors([0]), device=device, max_in_flight=8):
-            out_count += 1
-            if out_count == n_warm:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    assert out_count == n_warm + n_frames and engine.last_path == "fused"
+        out_count, t0 = 0, None
+        with torch.no_grad():
+            for d in StagePipeline(source(), processors([0]), device=device, max_in_flight=8):
+                out_count += 1
+                if out_count == n_warm:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        assert out_count == n_warm + n_frames and engine.last_path == "fused"
+        return elapsed
+
+    runs = sorted(one_pass() for _ in range(passes))
+    elapsed = runs[len(runs) // 2]
     return {
         "surface": "RTL/main.py processors list on StagePipeline: Seg3dLossless(query_func) + "
                    "forward_vertices + colorization, batch 1, eager encoder, 8 frames in flight",
         "value": n_frames / elapsed, "unit": "recon/s", "ms_per_step": elapsed / n_frames * 1e3,
+        "passes": {"n": passes, "value_min": n_frames / runs[-1], "value_max": n_frames / runs[0]},
         "latency_ms_single_frame": latency_ms,
+        "latency_ms_min": float(np.min(lat[3:])) * 1e3,
         "frames": n_frames,
     }
-
-
-def rank_devices(dist, device, world):
-    """(device index, PCI bus id, uuid-ish name) of every rank, gathered on all ranks."""
-    props = torch.cuda.get_device_properties(device)
-    bus = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1),
-                              getattr(props, "pci_device_id", -1))
-    mine = "%d|%s|%s" % (torch.cuda.current_device(), bus, props.name)
-    if dist is None:
-        return [mine]
-    got = [None] * world
-    dist.all_gather_object(got, mine)
-    return got
 
 
 def cpu_baseline(threads):
@@ -262,7 +610,74 @@ def cpu_baseline(threads):
     }
 
 
-def main():
+def in_flight_layout(k_total, world):
+    """--in-flight K: K frames in flight across the node = K / N per rank, as (slots, frames per
+    slot).  One frame per rank (configs[3] on 8 GPUs) is one slot of one frame; an even share is
+    split over two slots so that one slot's encoder overlaps the other's octree."""
+    if k_total % world != 0:
+        raise SystemExit("--in-flight %d is not a multiple of --gpus %d" % (k_total, world))
+    per_rank = k_total // world
+    depth = 2 if per_rank >= 2 and per_rank % 2 == 0 else 1
+    return depth, per_rank // depth
+
+
+def build_pipeline(job, depth, batch, use_graph, resolutions, with_color, precision):
+    """make_pipeline on every rank, agreed: if hipGraph capture fails on ANY rank (it can next to an
+    initialised RCCL communicator, whose watchdog thread touches the runtime) all ranks rebuild
+    with eager encoder launches rather than lose the run.  Returns (pipeline, use_graph)."""
+    pipe, ok = None, 1
+    try:
+        pipe = make_pipeline(job.device, depth, use_graph, resolutions, with_color, precision, batch)
+    except RuntimeError as e:
+        if not use_graph:
+            raise
+        sys.stderr.write("bench: hipGraph capture failed (%s); falling back to --no-graph\n" % e)
+        torch.cuda.synchronize()
+        ok = 0
+    if job.dist is not None:  # all ranks run the same variant
+        flag = torch.tensor([ok], device=job.device)
+        job.dist.all_reduce(flag, op=job.dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    if not ok:
+        if pipe is not None:
+            pipe.close()
+        use_graph = False
+        pipe = make_pipeline(job.device, depth, False, resolutions, with_color, precision, batch)
+    return pipe, use_graph
+
+
+def measure_config(job, depth, batch, use_graph, resolutions, with_color, precision, passes,
+                   roofline=True):
+    """Build a pipeline for one configuration, run the timed passes (+ the roofline leg), return
+    (summary dict, pipeline).  The caller closes the pipeline."""
+    pipe, use_graph = build_pipeline(job, depth, batch, use_graph, resolutions, with_color, precision)
+    elapsed, statuses, checked = timed_passes(job, pipe, batch, with_color, passes)
+    # a pass is as slow as its slowest rank; the median pass is the reported one
+    per_pass = job.reduce_max(elapsed)
+    order = sorted(per_pass)
+    med = order[len(order) // 2]
+    pts = float(statuses[:, 1:].sum()) if statuses is not None else 0.0
+    ok = bool((statuses[:, 0] == 1).all()) if statuses is not None else True
+    if job.dist is not None:
+        t = torch.tensor([pts, float(ok)], dtype=torch.float64, device=job.device)
+        job.dist.all_reduce(t, op=job.dist.ReduceOp.SUM)
+        pts, ok = float(t[0].item()), int(t[1].item()) == job.world
+    assert ok, "synthetic body must be non-empty"
+    res = {
+        "value": job.steps * job.world / med, "ms_per_step": med / job.steps * 1e3,
+        "elapsed": med, "points": pts, "gather_checked": checked, "use_graph": use_graph,
+        "passes": {"n": passes, "value_min": job.steps * job.world / order[-1],
+                   "value_max": job.steps * job.world / order[0],
+                   "ms_per_step_all": [e / job.steps * 1e3 for e in per_pass]},
+        "ms_per_step_per_rank": [e / job.steps * 1e3
+                                 for e in job.gather_floats(sorted(elapsed)[len(elapsed) // 2])],
+    }
+    if roofline:
+        res["roof"] = roofline_leg(job, pipe, batch, resolutions, with_color)
+    return res, pipe
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -273,6 +688,12 @@ def main():
                          "their octree levels as one fused-query launch; depth x batch frames are in "
                          "flight.  The largest divisor of --steps not above this is used, so no slot "
                          "submission is short (a short batch would still pay the full-batch encoder)")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="K > 0: exactly K frames in flight across the node (K / --gpus per rank; "
+                         "BASELINE configs[3] is K = 8) instead of --depth x --batch per GPU; the "
+                         "default run reports this configuration as `in_flight_8` next to `value`")
+    ap.add_argument("--passes", type=int, default=3,
+                    help="timed regions of exactly --steps frames each; `value` is the median")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the encoder eagerly instead of replaying it as a hipGraph")
     ap.add_argument("--with-color", action="store_true",
@@ -288,12 +709,34 @@ def main():
                          "host sync; dropin: `value` is measured through the reference's call surface "
                          "(StagePipeline + Seg3dLossless + forward_vertices), as the default run's "
                          "`dropin` object")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline measurement + roofline (skips every leg below)")
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip the drop-in-surface pass a default N=1 run appends")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the informational f16x3 pass that a default N=1 run appends")
-    args = ap.parse_args()
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the with_color / levels6_f16w / in_flight_8 / mesh legs")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="join the ranks, census the devices, one frame-sized gather, print JSON; no "
+                         "measurement (launch-path check; runs without GPUs over gloo)")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, argv)  # does not return
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE")))
+    if args.rendezvous_only:
+        return rendezvous_only(args)
+    if args.no_extras:
+        args.no_dropin = args.no_cpu_baseline = args.no_alt = args.no_configs = True
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # test hook (tests/test_dropin_gpu.py): exercise the N > 1 code path on a ONE-GPU box -- every
@@ -301,14 +744,15 @@ def main():
     one_gpu_test = os.environ.get("MONOPORT_BENCH_ONE_GPU_TEST") == "1"
     if one_gpu_test:
         local_rank = 0
-    if int(os.environ.get("WORLD_SIZE", "1")) not in (1, args.gpus):
-        raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ["WORLD_SIZE"]))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank with LOCAL_RANK=%d but only %d GPU(s) visible"
+                         % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    rank, world = parallel.init_from_env(backend="gloo" if one_gpu_test else "nccl",
-                                         device=device)  # nccl = RCCL on ROCm
+    backend = "gloo" if one_gpu_test else "nccl"  # nccl = RCCL on ROCm
+    rank, world = parallel.init_from_env(backend=backend, device=device)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -322,100 +766,70 @@ def main():
     resolutions = RESOLUTIONS + ([513] if args.levels == 6 else [])
     if args.mode == "dropin":
         assert world == 1, "--mode dropin is a single-GPU measurement"
-        res = dropin_surface(device, args.steps, args.warmup, resolutions)
+        res = dropin_surface(device, args.steps, args.warmup, resolutions, args.passes)
         print(json.dumps({
             "metric": "reconstructions/sec (512^2 in, %d^3 grid) through the drop-in surface" % (resolutions[-1] - 1),
             "value": res["value"], "unit": "recon/s", "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": res["surface"]},
+            "config": {"workload": res["surface"]}, "passes": res["passes"],
             "latency_ms_single_frame": res["latency_ms_single_frame"]}), flush=True)
         return
-    batch = max(b for b in range(1, max(1, min(args.batch, args.steps)) + 1) if args.steps % b == 0)
-    use_graph = not args.no_graph
-    try:
-        pipe = make_pipeline(device, args.depth, use_graph, resolutions, args.with_color,
-                             args.precision, batch)
-    except RuntimeError as e:
-        # hipGraph capture can fail next to an initialised RCCL communicator (its watchdog thread
-        # touches the runtime): fall back to eager encoder launches rather than lose the run
-        if not use_graph:
-            raise
-        sys.stderr.write("bench: hipGraph capture failed (%s); falling back to --no-graph\n" % e)
-        torch.cuda.synchronize()
-        use_graph = False
-        pipe = make_pipeline(device, args.depth, False, resolutions, args.with_color,
-                             args.precision, batch)
-    if dist is not None:  # all ranks run the same variant
-        flag = torch.tensor([int(use_graph)], device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if use_graph and int(flag.item()) == 0:
-            use_graph = False
-            pipe = make_pipeline(device, args.depth, False, resolutions, args.with_color,
-                                 args.precision, batch)
-    n_warm = args.warmup
-    n_frames = args.steps + n_warm
-    # distinct frames per rank: frame id = step * world + rank (frame-parallel sharding)
-    images = [torch.from_numpy(syn.synthetic_image(s * world + rank))[None].to(device)
-              for s in range(min(n_frames, 4))]
-    calibs = [pifu_calib(*syn.scene_camera(3 * (s * world + rank)), device=device)
-              for s in range(n_frames)]
+
+    job = Job(device, rank, world, dist, one_gpu_test, args.steps, args.warmup)
+    if args.in_flight > 0:
+        depth, batch = in_flight_layout(args.in_flight, world)
+        if args.steps % batch != 0:
+            raise SystemExit("--steps %d is not a multiple of the %d frames per slot that "
+                             "--in-flight %d gives" % (args.steps, batch, args.in_flight))
+    else:
+        depth, batch = args.depth, pick_batch(args.steps, args.batch)
+    main_res, pipe = measure_config(job, depth, batch, not args.no_graph, resolutions,
+                                    args.with_color, args.precision, args.passes)
+    use_graph = main_res["use_graph"]
+    roof = main_res["roof"]
     r_last = resolutions[-1]
-    # one gather per slot submission: [batch, R, R, 3] renders to rank 0 (a no-op on one GPU)
-    gather = parallel.FrameGather((batch, r_last, r_last, 3), device=device, store=False)
-    gather_checked = [False]
-    render_pack = [torch.zeros((batch, r_last, r_last, 3), dtype=torch.float32, device=device)
-                   for _ in range(args.depth)]
-    status_log = []
+    extras = {}
 
-    def run_batch(pipe, s0, s1, log):
-        """Frames s0 .. s1-1 (at most `batch`) as one slot submission."""
-        slot = pipe.submit([images[s % len(images)] for s in range(s0, s1)],
-                           [calibs[s] for s in range(s0, s1)])
-        with torch.cuda.stream(slot.stream):
-            if world > 1:
-                pack = render_pack[(pipe.n_submitted - 1) % args.depth]  # this slot's staging buffer
-                for b in range(s1 - s0):
-                    pack[b].copy_(slot.renders_tex[b] if args.with_color else slot.renders[b])
-                gather.push(s0 // batch, pack)
-                if not log and rank == 0 and not gather_checked[0]:
-                    # (warm-up only: this syncs) the gathered copy of rank 0's own frames must
-                    # equal what rank 0 rendered
-                    got = gather.received(0)[:s1 - s0].to(pack.device)
-                    assert torch.equal(got, pack[:s1 - s0]), "gather mismatch"
-                    gather_checked[0] = True
-            if log:
-                status_log.append(slot.status[:s1 - s0].clone())  # device-side copy, no sync
+    # single-rank leg of an N > 1 run: rank 0 repeats the passes alone (no gather, no barriers)
+    # while the other ranks wait -> scaling efficiency against a line measured in THIS run
+    if world > 1:
+        job.barrier()
+        if rank == 0:
+            el, _, _ = timed_passes(job, pipe, batch, args.with_color, args.passes, collective=False,
+                                    want_status=False)
+            single = args.steps / sorted(el)[len(el) // 2]
+            extras["scaling_vs_single_rank"] = {
+                "single_rank_value": single, "efficiency": main_res["value"] / (world * single),
+                "note": "rank 0 alone on its GPU, same frames, other ranks idle at a barrier; the "
+                        "driver computes its own efficiency from separate --gpus 1 runs"}
+        job.barrier()
 
-    def timed_pass(pipe, log):
-        """Warm-up batches, then EXACTLY --steps frames between barrier + synchronize pairs."""
-        for s0 in range(0, n_warm, batch):
-            run_batch(pipe, s0, min(s0 + batch, n_warm), False)
-        pipe.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for s0 in range(n_warm, n_frames, batch):
-            run_batch(pipe, s0, min(s0 + batch, n_frames), log)
-        pipe.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        return time.perf_counter() - t0
+    # BASELINE configs[3]: 8 frames in flight across the node, at every N that divides 8
+    if not args.no_configs and args.in_flight == 0 and 8 % world == 0 and not args.with_color \
+            and args.precision == "f32" and args.levels == 5:
+        d8, b8 = in_flight_layout(8, world)
+        if args.steps % b8 == 0:
+            r8, p8 = measure_config(job, d8, b8, use_graph, resolutions, False, "f32", args.passes,
+                                    roofline=False)
+            p8.close()
+            del p8
+            extras["in_flight_8"] = {
+                "config": "BASELINE configs[3]: 8 frames in flight across %d GPU(s) = %d slot(s) x %d "
+                          "frame(s) per rank" % (world, d8, b8),
+                "value": r8["value"], "unit": "recon/s", "ms_per_step": r8["ms_per_step"],
+                "passes": r8["passes"], "ms_per_step_per_rank": r8["ms_per_step_per_rank"]}
 
-    elapsed = timed_pass(pipe, True)
-
-    # informational second pass (N=1 only, never `value`): the same frames with the MLP on the
-    # f32-accurate f16x3 kernel, plus the largest difference between the two volumes of one frame
     alt = None
     if world == 1 and args.precision == "f32" and not args.no_alt and not args.with_color:
+        # informational second configuration (never `value`): the same frames with the MLP on the
+        # f32-accurate f16x3 kernel, plus the largest difference between the two volumes of one frame
         last_slot = pipe.slots[(pipe.n_submitted - 1) % len(pipe.slots)]
         vol_f32 = last_slot.volumes[last_slot.n_active - 1].clone()
         # a SECOND pipeline (own network copy, own captured graphs): the f32 pipeline and its graphs
-        # stay untouched for the roofline / breakdown legs below
-        pipe16 = make_pipeline(device, args.depth, use_graph, resolutions, False, "f16x3", batch)
-        alt_elapsed = timed_pass(pipe16, False)
+        # stay untouched for the breakdown leg below
+        r16, pipe16 = measure_config(job, depth, batch, use_graph, resolutions, False, "f16x3",
+                                     args.passes, roofline=False)
         last_slot = pipe16.slots[(pipe16.n_submitted - 1) % len(pipe16.slots)]
         vol_alt = last_slot.volumes[last_slot.n_active - 1]
         diff = (vol_alt - vol_f32).abs().max().item()
@@ -427,108 +841,70 @@ def main():
         torch.cuda.synchronize()
         alt = {"precision": "f16x3 (f32 emulated on f16 MFMA, 3-term split, f32 accumulate) in the query "
                             "kernel AND in the encoder's 3x3 convolutions",
-               "value": args.steps / alt_elapsed, "unit": "recon/s",
-               "ms_per_step": alt_elapsed / args.steps * 1e3,
+               "value": r16["value"], "unit": "recon/s", "ms_per_step": r16["ms_per_step"],
+               "passes": r16["passes"],
                "max_abs_diff_vs_f32_volume": diff, "thresholded_voxels_differing": flips,
                "voxels": int(vol_f32.numel()),
                "note": "opt-in (--precision f16x3); not the headline"}
 
-    # roofline leg: the same frames again on ONE stream with every fused-query launch bracketed by
-    # HIP events on its launch stream (concurrent slots would share CUs) -> per-launch durations
-    # of the dominant kernel
-    from monoport_amd.pipeline import MAX_RECON_BATCH
-    prof_slot = pipe.slots[0]
-    prof_status = []
-    ops.profile_begin(device, max_records=8 * args.steps + 8)
-    for s0 in range(n_warm, n_frames, batch):
-        s1 = min(s0 + batch, n_frames)
-        prof_slot.submit([images[s % len(images)] for s in range(s0, s1)],
-                         [calibs[s] for s in range(s0, s1)])
-        with torch.cuda.stream(prof_slot.stream):
-            prof_status.append(prof_slot.status[:s1 - s0].clone())
-    prof_slot.wait()
-    all_ms = ops.profile_end(device, capacity=8 * args.steps + 8)
-    # launch order per submission of n frames: for every chunk of <= 8 frames one launch per level
-    # (its points = that level's nodes summed over the chunk, pipeline.py / mp_recon_batch); with
-    # --with-color one netC launch per chunk follows, which the netG roofline skips
-    launch_ms, prof_pts, cursor = [], [], 0
-    for st in prof_status:
-        counts = st.cpu().numpy()[:, 1:]
-        for b0 in range(0, counts.shape[0], MAX_RECON_BATCH):
-            prof_pts.append(counts[b0:b0 + MAX_RECON_BATCH].sum(0))
-            launch_ms.append(all_ms[cursor:cursor + len(resolutions)])
-            cursor += len(resolutions)
-        if args.with_color:  # one netC launch per chunk of <= 8 frames follows (skipped here)
-            cursor += (counts.shape[0] + MAX_RECON_BATCH - 1) // MAX_RECON_BATCH
-    launch_ms = np.concatenate(launch_ms)
-    prof_pts = np.stack(prof_pts)
+    breakdown = None
+    if rank == 0 or world == 1:
+        breakdown = breakdown_leg(job, pipe, batch, resolutions)
+        breakdown["points_per_level"] = [float(v) / args.steps for v in roof["points_per_level"]]
 
-    # breakdown leg: encoder-only and encoder-excluded time per frame, one
-    # stream, features of the last frame
-    def timed(fn, n):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(prof_slot.stream):
-            fn()
-            ev0.record(prof_slot.stream)
-            for _ in range(n):
-                fn()
-            ev1.record(prof_slot.stream)
-        prof_slot.stream.synchronize()
-        return ev0.elapsed_time(ev1) / n
+    if world == 1 and not args.no_configs and not args.with_color and args.levels == 5:
+        slot = pipe.slots[0]
+        extras["mesh"] = mesh_leg(job, slot.volumes[0], resolutions)
 
-    def recon_only():
-        mlp = prof_slot.net.surface_classifier.packed()
-        ops.recon(mlp, prof_slot.feats_hwc[0], prof_slot.calib[0:1], syn.Z_SCALE, B_MIN, B_MAX,
-                  resolutions, 0.5, volume=prof_slot.volume, status=prof_slot.status[0])
-        x, y, z, nrm, count = ops.forward_vertices_raw(prof_slot.volume, "front")
-        ops.paint(x, y, nrm, 0, count, r_last, 0.5, 0.5, 0.0, 1.0)
-
-    def recon_batched():
-        """What a slot does after its encoder: the octree of its frames level by level, then per
-        frame forward_vertices + render (monoport_amd/pipeline.py)."""
-        mlp = prof_slot.net.surface_classifier.packed()
-        nb = min(batch, MAX_RECON_BATCH)
-        ops.recon_batch(mlp, prof_slot.feats_hwc[:nb], prof_slot.calib[:nb], syn.Z_SCALE, B_MIN, B_MAX,
-                        resolutions, 0.5, volumes=prof_slot.volumes[:nb], status=prof_slot.status[:nb])
-        for b in range(nb):
-            x, y, z, nrm, count = ops.forward_vertices_raw(prof_slot.volumes[b], "front")
-            ops.paint(x, y, nrm, 0, count, r_last, 0.5, 0.5, 0.0, 1.0)
-
-    with torch.no_grad():
-        # the last submission may have been a short batch: refill the slot so every entry is live
-        prof_slot.submit([images[s % len(images)] for s in range(batch)], calibs[:batch])
-        prof_slot.wait()
-        enc_ms = timed(lambda: prof_slot.net.image_filter(prof_slot.image, last_only=True), 10) / batch
-        rec_ms = timed(recon_only, 10)
-        rec_batched_ms = timed(recon_batched, 5) / min(batch, MAX_RECON_BATCH)
-
-    statuses = torch.cat(status_log).cpu().numpy()
-    assert (statuses[:, 0] == 1).all(), "synthetic body must be non-empty"
-    level_pts = statuses[:, 1:]
-    pts_total = int(level_pts.sum())
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    p = torch.tensor([pts_total], dtype=torch.float64, device=device)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(p, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    pts_all = float(p.item())
+    if world == 1 and not args.no_configs and not args.with_color and args.levels == 5 \
+            and args.precision == "f32" and args.in_flight == 0:
+        # BASELINE configs[2]: geometry + netC colour
+        rc, pc = measure_config(job, depth, batch, use_graph, resolutions, True, "f32", args.passes)
+        pc.close()
+        del pc
+        extras["with_color"] = {
+            "config": "BASELINE configs[2]: netG + netC (ResNet encoder + per-vertex colour MLP)",
+            "value": rc["value"], "unit": "recon/s", "ms_per_step": rc["ms_per_step"],
+            "passes": rc["passes"],
+            "roofline_frac_netG_query": rc["roof"]["achieved"] / F32_MFMA_PEAK_TFLOPS,
+            "roofline_frac_netC_query": (rc["roof"].get("color_achieved", 0.0) / F32_MFMA_PEAK_TFLOPS),
+            "colour_points_per_frame": rc["roof"].get("color_points_per_frame")}
+        # BASELINE configs[4]: 513^3, fp16 weights; parity deltas against the exact-f32 kernel on
+        # the same features and camera
+        res6 = RESOLUTIONS + [513]
+        r6, p6 = measure_config(job, depth, batch, use_graph, res6, False, "f16w", args.passes)
+        s6 = p6.slots[0]
+        s6.wait()
+        mlp32 = ops.PackedMLP.from_layers(device, syn.body_mlp("G", noise=0.05, seed=1),
+                                          syn.LAST_OP["G"])
+        vol32, st32 = ops.recon(mlp32, s6.feats_hwc[0], s6.calib[0:1], syn.Z_SCALE, B_MIN, B_MAX, res6)
+        v16 = s6.volumes[0]
+        inter = ((vol32 > 0.5) & (v16 > 0.5)).sum().item()
+        union = ((vol32 > 0.5) | (v16 > 0.5)).sum().item()
+        extras["levels6_f16w"] = {
+            "config": "BASELINE configs[4]: octree 17..513, fp16 MLP weights x split-f16 activations "
+                      "(two f16 MFMAs per product, f32 accumulate)",
+            "value": r6["value"], "unit": "recon/s", "ms_per_step": r6["ms_per_step"],
+            "passes": r6["passes"], "points_per_recon": r6["points"] / args.steps,
+            "roofline_frac": r6["roof"]["achieved"] / (2500.0 / 2), "roofline_peak_tflops": 2500.0 / 2,
+            "iou_vs_f32_volume": inter / max(union, 1),
+            "max_abs_diff_vs_f32_volume": (vol32 - v16).abs().max().item(),
+            "same_points_per_level": bool(torch.equal(st32.cpu(), s6.status[0].cpu()))}
+        p6.close()
+        del p6, s6, vol32, v16, mlp32
 
     if rank == 0:
         # the f16 variants spend 3 / 2 / 1 f16 MFMAs (2.5 PFLOP/s dense peak) per algorithmic product
         terms = {"f32": 0, "f16x3": 3, "f16w": 2, "f16": 1}[args.precision]
         peak_tflops = F32_MFMA_PEAK_TFLOPS if terms == 0 else 2500.0 / terms
-        n_launch = min(len(launch_ms), prof_pts.size)
-        flops = prof_pts.reshape(-1)[:n_launch].astype(np.float64) * FLOP_PER_POINT
-        achieved = flops.sum() / (launch_ms[:n_launch].sum() * 1e-3) / 1e12 if n_launch else 0.0
         out = {
             "metric": "reconstructions/sec (512^2 in, %d^3 grid)" % (r_last - 1),
-            "value": args.steps * world / elapsed,
+            "value": main_res["value"],
             "unit": "recon/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -546,53 +922,62 @@ def main():
                                 if args.with_color else
                                 "geometry only (+forward_vertices, normal render)")),
                 "frames_per_rank": args.steps,
+                "distinct_images": len(job.images),
                 "devices": devices,
-                "gather_checked": bool(gather_checked[0]) if world > 1 else None,
+                "backend": ("none (single process)" if world == 1 else
+                            "gloo (one-GPU test hook)" if one_gpu_test else "nccl (RCCL)"),
+                "self_launched": os.environ.get("MONOPORT_BENCH_SELF_LAUNCHED") == "1",
+                "gather_checked": bool(main_res["gather_checked"]) if world > 1 else None,
+                "frames_in_flight_per_rank": depth * batch,
                 "parallelism": "frame-parallel x%d (one process per GPU, renders gathered to rank 0 "
                                "over %s); per GPU %d slots x %d frames in flight, encoder "
                                "batched per slot%s"
                                % (world, "gloo (one-GPU test hook)" if one_gpu_test else "RCCL",
-                                  args.depth, batch,
+                                  depth, batch,
                                   " and replayed as a hipGraph" if use_graph else ""),
                 "fixture": "F-body analytic head, seeded encoder (monoport_amd/synthetic.py)",
-                "points_per_recon": pts_all / (args.steps * world),
+                "points_per_recon": main_res["points"] / (args.steps * world),
             },
-            "mpts_per_s": pts_all / elapsed / 1e6,
-            "breakdown": {
-                "encoder_ms_per_frame": enc_ms, "recon_vertices_render_ms": rec_ms,
-                "recon_vertices_render_ms_per_frame_batched": rec_batched_ms,
-                "recon_per_s_encoder_excluded": 1e3 / rec_batched_ms,
-                "recon_per_s_encoder_excluded_single_frame": 1e3 / rec_ms,
-                "points_per_level": [float(v) / args.steps for v in prof_pts.sum(0)],
-                "note": "single stream, no overlap; encoder eager at the bench batch size; batched = "
-                        "mp_recon_batch over the slot's frames, as the pipeline runs it",
-            },
+            "passes": main_res["passes"],
+            "ms_per_step_per_rank": main_res["ms_per_step_per_rank"],
+            "mpts_per_s": main_res["points"] / main_res["elapsed"] / 1e6,
+            "breakdown": breakdown,
             "roofline": {
                 "kernel": ("pifu_query_kernel<256,1> (fused gather + MLP)" if args.precision == "f32"
                            else "pifu_query16_kernel<1,%d> (fused gather + MLP, %s)" % (terms, args.precision)),
                 "bound": "mfma",
-                "achieved": achieved,
+                "achieved": roof["achieved"],
                 "peak": peak_tflops,
                 "unit": "TFLOP/s",
-                "frac": achieved / peak_tflops,
-                "traffic": traffic_from_profile(args, min(batch, MAX_RECON_BATCH)),
+                "frac": roof["achieved"] / peak_tflops,
+                "traffic": traffic_from_profile(args.precision, args.levels, args.with_color,
+                                                min(batch, MAX_RECON_BATCH)),
                 "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                    "this configuration)" % TRAFFIC_PROFILE),
-                "launches": int(n_launch),
+                "launches": roof["launches"],
                 "frames_per_launch": min(batch, MAX_RECON_BATCH),
-                "avg_launch_ms": float(launch_ms[:n_launch].mean()) if n_launch else None,
+                "avg_launch_ms": float(roof["launch_ms"].mean()) if roof["launches"] else None,
                 "flop_per_point": FLOP_PER_POINT,
             },
         }
+        out.update(extras)
         if alt is not None:
             out["alt_precision"] = alt
         if world == 1 and not args.no_dropin and not args.with_color and args.precision == "f32":
-            out["dropin"] = dropin_surface(device, args.steps, args.warmup, resolutions)
+            out["dropin"] = dropin_surface(device, args.steps, args.warmup, resolutions, args.passes)
             out["latency_ms_single_frame"] = out["dropin"]["latency_ms_single_frame"]
         if world == 1 and not args.no_cpu_baseline and not args.with_color and args.levels == 5:
             # bounded thread count: torch-CPU convs at batch 1 collapse when oversubscribed
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))
+            out["cpu_baseline_reference"] = CPU_BASELINE_REFERENCE
+        launch_log = os.environ.get("MONOPORT_BENCH_LAUNCH_LOG")
+        if launch_log:  # tools/profile_summary.py: per-launch (ms, points) of the roofline leg
+            with open(launch_log, "w") as f:
+                json.dump({"launch_ms": [float(v) for v in roof["launch_ms"]],
+                           "launch_points": [int(v) for v in roof["launch_pts"]],
+                           "levels": len(resolutions), "frames_per_launch": min(batch, MAX_RECON_BATCH)}, f)
         print(json.dumps(out), flush=True)
+    pipe.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,84 @@
+"""bench.py's launch path without a GPU: ``python bench.py --gpus N`` outside a launcher starts its
+own N ranks (it used to run ONE rank silently and print n_gpus 1), joins the ranks a
+launcher made otherwise, and refuses to measure when the GPUs are not there.  ``--rendezvous-only``
+runs everything up to the measurement (process group, device census, one frame-sized gather to
+rank 0) over gloo."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(cmd, **env):
+    e = dict(os.environ, **env)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    return subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+
+
+def _json_lines(stdout):
+    return [json.loads(l) for l in stdout.splitlines() if l.startswith("{")]
+
+
+def test_self_launch_two_ranks():
+    res = _run([sys.executable, BENCH, "--gpus", "2", "--rendezvous-only"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = _json_lines(res.stdout)
+    assert len(lines) == 1  # rank 0 only
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["self_launched"] is True and out["gather_checked"] is True
+    assert len(out["devices"]) == 2 and len(set(out["devices"])) == 2
+    assert "launching 2 ranks" in res.stderr
+
+
+def test_under_torchrun_joins_the_launchers_ranks():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2",
+                "--rendezvous-only"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = _json_lines(res.stdout)
+    assert len(out) == 1 and out[0]["n_gpus"] == 2 and out[0]["self_launched"] is False
+
+
+def test_world_size_mismatch_is_an_error():
+    res = _run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1",
+                "--nproc-per-node", "2", BENCH, "--gpus", "4", "--rendezvous-only"])
+    assert res.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in res.stderr
+
+
+def test_measurement_refuses_without_enough_gpus():
+    """A real run (no --rendezvous-only) with fewer GPUs than ranks must fail loudly, never fall
+    back to fewer ranks or to the CPU."""
+    res = _run([sys.executable, BENCH, "--gpus", "64", "--steps", "2", "--warmup", "1"])
+    assert res.returncode != 0
+    assert not _json_lines(res.stdout)
+    if torch.cuda.is_available():
+        assert "only %d GPU(s) are visible" % torch.cuda.device_count() in res.stderr
+    else:
+        assert "needs MI355X" in res.stderr
+
+
+def test_in_flight_layout():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.in_flight_layout(8, 8) == (1, 1)  # configs[3]: one frame per rank
+    assert bench.in_flight_layout(8, 4) == (2, 1)
+    assert bench.in_flight_layout(8, 2) == (2, 2)
+    assert bench.in_flight_layout(8, 1) == (2, 4)
+    assert bench.pick_batch(20, 10) == 10 and bench.pick_batch(7, 10) == 7 and bench.pick_batch(22, 10) == 2
+    try:
+        bench.in_flight_layout(8, 3)
+    except SystemExit:
+        pass
+    else:
+        raise AssertionError("8 frames over 3 ranks must be refused")

@@ -400,21 +400,29 @@ def test_prepare_inputs_bit_exact_vs_reference_expressions():
 
 def test_bench_two_ranks_on_one_gpu():
     """bench.py's N > 1 path (rank-sharded frames, barriers, gather to rank 0, MAX-over-ranks
-    timing) with two processes on this box's single GPU: the test hook swaps RCCL for gloo, the
-    rest of the code is what the 8-GPU run executes."""
+    timing) with two processes on this box's single GPU, launched the way the driver launched its
+    N = 1 run -- plain ``python bench.py --gpus 2``, no torchrun: bench.py starts its own ranks.
+    The test hook swaps RCCL for gloo; the rest of the code is what the 8-GPU run executes."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MONOPORT_BENCH_ONE_GPU_TEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29713", os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "4", "--warmup", "2", "--depth", "1", "--batch", "2"]
-    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "2", "--depth", "1", "--batch", "2", "--passes", "2"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # rank 0 only
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
     assert out["value"] > 0 and "cpu_baseline" not in out and 0 < out["roofline"]["frac"] < 1
+    cfg = out["config"]
+    assert cfg["self_launched"] is True and cfg["gather_checked"] is True and len(cfg["devices"]) == 2
+    assert len(out["ms_per_step_per_rank"]) == 2 and out["passes"]["n"] == 2
+    assert out["passes"]["value_min"] <= out["value"] <= out["passes"]["value_max"]
+    assert 0 < out["scaling_vs_single_rank"]["efficiency"]
+    # configs[3] at N = 2: 8 frames in flight = 2 slots x 2 frames per rank
+    assert out["in_flight_8"]["value"] > 0 and "2 slot(s) x 2 frame(s)" in out["in_flight_8"]["config"]
