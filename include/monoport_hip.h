@@ -271,10 +271,12 @@ int mp_concat3_add(mp_ctx *ctx, const float *a, int ca, const float *b, int cb, 
  * the normalised tensor -- as an implicit GEMM on v_mfma_f32_32x32x2_f32, and optionally emits the
  * partial sums the NEXT GroupNorm(32, Cout) needs.  x [N,Cin,H,W], y [N,Cout,H,W] contiguous NCHW;
  * ss [N,Cin,2] = (scale, shift) from mp_gn_finalize; packed = W re-ordered by mp_conv3x3_pack
- * (Cout*Cin*9 floats).  stats: NULL or double [N,32,S,2] with S = mp_conv3x3_stat_slices(Cout,N,H,W,f16) (f16 = 0 here, 1 for mp_conv3x3_gn16).
+ * (Cout*Cin*9 floats).  stats: NULL or double [N,32,S,2] (per image, group and tile) with S = mp_conv3x3_stat_slices(Cout,N,H,W,f16) (f16 = 0 here, 1 for mp_conv3x3_gn16).
  * Needs Cin % 16 == 0, Cout % 32 == 0, H and W powers of two (W >= 32); else MP_ERR_UNSUPPORTED.
  * mp_conv3x3_tune(nr): measurement hook -- force nr (1, 2, 4) 32-pixel column blocks per wave
- * instead of the launch-size heuristic (0 restores it); process-wide, not for production use. */
+ * instead of the launch-size heuristic (0 restores it); | 0x100 forces the large-tile kernel, | 0x200
+ * the split-K kernel, | mrw << 12 the row blocks per wave of mp_conv1x1; process-wide, not for
+ * production use. */
 int mp_conv3x3_pack(mp_ctx *ctx, const float *w /*[Cout,Cin,3,3]*/, int cout, int cin, float *packed,
                     mp_stream stream);
 int mp_conv3x3_supported(int cin, int cout, int h, int w); /* 1 if the shape is built, else 0 */
@@ -307,7 +309,7 @@ int mp_conv3x3_gn16(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, c
  * optional second K segment (bl(y) + al(out) is ONE call with W = [W_bl | W_al], bias = b_bl +
  * b_al, res = x); outputs: y [N,256,HW] and / or y_hwc [N,HW,256] (the channels-last map the
  * query kernels read, written in 1 KB bursts) -- at least one; stats: NULL or the partial sums of
- * GroupNorm(32, 256) over the output, double [N,32,(HW/64)*8,2].  mp_conv1x1_pack re-orders
+ * GroupNorm(32, 256) over the output, double [N,32,mp_conv1x1_stat_slices(HW),2].  mp_conv1x1_pack re-orders
  * W1 [cout,C1] (and W2 [cout,C2]) into fragment order: cout*(C1+C2) floats, or the same number of
  * (hi, lo) f16 pairs when f16 != 0 (then wmax, device float[1], receives max|W|).  C1, C2 and HW
  * must be multiples of 64. */
@@ -327,6 +329,118 @@ int mp_gn_stats(mp_ctx *ctx, const float *x, int n, int c, int64_t hw, int group
 int mp_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int groups, int slices,
                    int64_t count, const float *gamma, const float *beta, float eps, float *ss,
                    mp_stream stream);
+
+/* ---- GroupNorm statistics taken by the producing kernel (round 3) ------------------------------
+ * Every GroupNorm(32, C) of the encoders (backbones/HGFilters.py:23-27, ResBlkFilters.py:19) needs
+ * the statistics of a whole (image, group) before the first normalised value exists.  The kernels
+ * below publish the partial sums of the tensor they WRITE and the last workgroup to finish turns
+ * them -- in a fixed order, no floating-point atomics -- into ss [N,C,2] = (gamma rstd, beta - mean
+ * gamma rstd) for the one or two GroupNorm modules that will read the tensor; the consumer applies
+ * ss while it stages its input (ss arguments of the convolutions), so a normalised tensor never
+ * exists in memory and a GroupNorm costs no launch.
+ *   partial          scratch, `partial_doubles` doubles, at least N * 32 * slices * 2 with slices =
+ *                    mp_conv3x3_stat_slices / mp_conv1x1_stat_slices / mp_convk_stat_slices /
+ *                    mp_gn_stat_slices of the launch (checked); NULL = no statistics
+ *   counters         int32 [N * 32], ALL ZERO before the first launch that uses it; every launch
+ *                    leaves it zero, so one buffer serves all launches of a stream (two requests of
+ *                    ONE launch -- fin and fin2 of mp_conv3x3_ex -- need separate buffers); unused
+ *                    when n_sets == 0
+ *   n_sets           0: partial sums only (finalise with mp_gn_finalize); 1 or 2 consumers
+ *   gamma/beta/eps   affine parameters of consumer k; ss[k]: out [N,C,2] */
+typedef struct mp_gn_fin {
+  double *partial;
+  int64_t partial_doubles;
+  int32_t *counters;
+  int n_sets;
+  const float *gamma[2];
+  const float *beta[2];
+  float eps[2];
+  float *ss[2];
+} mp_gn_fin;
+
+/* mp_conv3x3_gn / mp_conv3x3_gn16 with the pyramid block's tail and the GroupNorm hand-over fused in
+ * (backbones/HGFilters.py:40-62).  wmax == NULL: packed by mp_conv3x3_pack (exact f32); else by
+ * mp_conv3x3_pack16.  y may be NULL when y2 is given.  y2 / res [N, y2_channels, H, W]:
+ *     y2[n, y2_offset + c] = conv[n, c] + res[n, y2_offset + c]
+ * -- torch.cat((out1, out2, out3), 1) + residual (HGFilters.py:57-60) written by the three
+ * convolutions themselves.  fin: GroupNorm(32, Cout) over y (the next convolution of the block);
+ * fin2: this launch's groups of GroupNorm(32, y2_channels) over y2 (the next block; groups must not
+ * straddle launches: y2_offset % (y2_channels / 32) == 0).  Launches too small to fill the chip run
+ * a split-K variant (the four waves of a workgroup share one 32-channel x 32/64-pixel tile). */
+typedef struct mp_conv3x3_args {
+  const float *x;
+  int n, cin, h, w;
+  const float *ss;
+  int relu, reflect;
+  const void *packed;
+  const float *wmax;
+  int cout;
+  float *y;
+  float *y2;
+  const float *res;
+  int y2_channels, y2_offset;
+  mp_gn_fin fin, fin2;
+} mp_conv3x3_args;
+int mp_conv3x3_ex(mp_ctx *ctx, const mp_conv3x3_args *args, mp_stream stream);
+
+/* mp_conv1x1 with the GroupNorm hand-over: fin = GroupNorm(32, 256) over the output (res included),
+ * i.e. bn_end after conv_last and the first GroupNorm of the next stack after x + bl(.) + al(.)
+ * (HGFilters.py:184-204).  Same tensors and restrictions as mp_conv1x1. */
+typedef struct mp_conv1x1_args {
+  const float *x1;
+  const float *ss1;
+  int relu1;
+  const float *x2;
+  int n, c1, c2, cout;
+  int64_t hw;
+  const void *packed;
+  int f16;
+  const float *wmax;
+  const float *bias;
+  const float *res;
+  float *y;
+  float *y_hwc;
+  mp_gn_fin fin;
+} mp_conv1x1_args;
+int mp_conv1x1_ex(mp_ctx *ctx, const mp_conv1x1_args *args, mp_stream stream);
+int mp_conv1x1_stat_slices(int64_t hw);
+
+/* The encoders' other convolutions on the same MFMA scheme (csrc/convim2col.hip), with an explicit
+ * im2col tile in LDS: ks = 7, 3 -> 64 channels, stride 2 + zero padding 3 + bias (the hourglass stem,
+ * HGFilters.py:125, :168) or stride 1 + nn.ReflectionPad2d(3) (netC's stem, ResBlkFilters.py:111-113);
+ * ks = 3, stride 2, zero padding 1, Cin % 16 == 0, Cout % 128 == 0 (netC's two down-sampling
+ * convolutions, ResBlkFilters.py:115-121).  y [N, Cout, H/stride, W/stride], W/stride % 64 == 0.
+ * ss / relu: GroupNorm (+ReLU) of the INPUT applied while gathering, as in mp_conv3x3_gn; bias may be
+ * NULL; fin: GroupNorm(32, Cout) over y.  packed: mp_convk_packed_floats floats from mp_convk_pack. */
+typedef struct mp_convk_args {
+  const float *x;
+  int n, cin, h, w;
+  const float *ss;
+  int relu, reflect;
+  const float *packed;
+  const float *bias;
+  int cout, ks, stride;
+  float *y;
+  mp_gn_fin fin;
+} mp_convk_args;
+int mp_convk_supported(int cin, int cout, int ks, int stride, int h, int w);
+int64_t mp_convk_packed_floats(int cin, int cout, int ks);
+int mp_convk_stat_slices(int ks, int stride, int h, int w);
+int mp_convk_pack(mp_ctx *ctx, const float *w /*[Cout,Cin,ks,ks]*/, int cout, int cin, int ks, float *packed,
+                  mp_stream stream);
+int mp_convk(mp_ctx *ctx, const mp_convk_args *args, mp_stream stream);
+
+/* The tensors between the convolutions, written together with their statistics (fin may be NULL;
+ * slices = mp_gn_stat_slices(); C % 32 == 0):
+ *   mp_avgpool2_gn            y [N,C,H/2,W/2] = avg_pool2d(x, 2, stride 2)  (HGFilters.py:93, :171), W % 8 == 0
+ *   mp_upsample_bicubic2x_gn  y [N,C,2H,2W] = add + bicubic_x2(x)           (HGFilters.py:108-111), add may be NULL
+ *   mp_gn_apply               y = relu?(x * scale + shift), ss [N,C,2]      (the stem's GroupNorm + ReLU, :168) */
+int mp_avgpool2_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, float *y, const mp_gn_fin *fin,
+                   mp_stream stream);
+int mp_upsample_bicubic2x_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, const float *add, float *y,
+                             const mp_gn_fin *fin, mp_stream stream);
+int mp_gn_apply(mp_ctx *ctx, const float *x, const float *ss, int relu, int n, int c, int64_t hw, float *y,
+                const mp_gn_fin *fin, mp_stream stream);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Brackets every fused-query kernel launch made through this context with a pair of HIP events

@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "mp_internal.h"
+#include "encoder_kernels.h"
 
 namespace mp {
 
@@ -792,7 +793,10 @@ int mp_conv3x3_stat_slices(int cout, int n, int h, int w, int f16) {
   return conv3x3_stat_slices(cout, n, h, w, f16 != 0);
 }
 
-void mp_conv3x3_tune(int nr) { conv3x3_set_nr(nr); }
+void mp_conv3x3_tune(int nr) {
+  conv3x3_set_nr(nr & 0xfff);
+  conv1x1_set_mrw((nr >> 12) & 3);
+}
 
 int mp_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss, int relu,
                   int reflect, const float *packed, int cout, float *y, double *stats, mp_stream stream) {
@@ -829,6 +833,171 @@ int mp_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int groups,
   DeviceGuard g(ctx->device);
   return launch_gn_finalize(ctx, partial, n, c, groups, slices, (double)count, gamma, beta, eps, ss,
                             (hipStream_t)stream);
+}
+
+// mp_gn_fin (C-ABI) -> GnFin (kernel argument); the launchers fill c / S / count
+static GnFin to_fin(const mp_gn_fin *f) {
+  GnFin g = gn_fin_none();
+  if (!f || !f->partial) return g;
+  g.partial = f->partial;
+  g.counter = f->counters;
+  g.n_sets = f->n_sets;
+  for (int k = 0; k < 2; ++k) g.set[k] = GnSet{f->gamma[k], f->beta[k], f->ss[k], f->eps[k]};
+  return g;
+}
+static long long fin_cap(const mp_gn_fin *f) { return f && f->partial ? (long long)f->partial_doubles : -1; }
+
+int mp_conv3x3_ex(mp_ctx *ctx, const mp_conv3x3_args *q, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!q || !q->x || !q->packed || (!q->y && !q->y2) || q->n <= 0 || q->n > 65535 || q->cin <= 0 || q->cout <= 0 ||
+      q->h <= 0 || q->w <= 0)
+    return fail(ctx, MP_ERR_ARG, "mp_conv3x3_ex: bad argument");
+  if (!aligned16(q->packed)) return fail(ctx, MP_ERR_ARG, "mp_conv3x3_ex: packed weights must be 16-byte aligned");
+  DeviceGuard g(ctx->device);
+  ConvArgs a;
+  a.x = q->x;
+  a.ss = q->ss;
+  a.wp = static_cast<const float *>(q->packed);
+  a.y = q->y;
+  a.y2 = q->y2;
+  a.res = q->res;
+  a.y2_c = q->y2 ? q->y2_channels : 32;
+  a.y2_off = q->y2 ? q->y2_offset : 0;
+  a.fin = to_fin(&q->fin);
+  a.fin2 = to_fin(&q->fin2);
+  a.n_img = q->n;
+  a.cin = q->cin;
+  a.cout = q->cout;
+  a.h = q->h;
+  a.w = q->w;
+  a.relu = q->relu;
+  a.reflect = q->reflect;
+  const long long cap[2] = {fin_cap(&q->fin), fin_cap(&q->fin2)};
+  return launch_conv3x3(ctx, a, q->wmax, cap, (hipStream_t)stream);
+}
+
+int mp_conv1x1_ex(mp_ctx *ctx, const mp_conv1x1_args *q, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!q || !q->x1 || !q->packed || q->n <= 0 || q->hw <= 0 || (!q->y && !q->y_hwc) || (q->f16 && !q->wmax))
+    return fail(ctx, MP_ERR_ARG, "mp_conv1x1_ex: bad argument");
+  if (!aligned16(q->packed) || (q->y_hwc && !aligned16(q->y_hwc)))
+    return fail(ctx, MP_ERR_ARG, "mp_conv1x1_ex: packed weights / y_hwc must be 16-byte aligned");
+  DeviceGuard g(ctx->device);
+  Conv1Args a;
+  a.x1 = q->x1;
+  a.ss1 = q->ss1;
+  a.x2 = q->x2;
+  a.wp = static_cast<const float *>(q->packed);
+  a.bias = q->bias;
+  a.res = q->res;
+  a.y = q->y;
+  a.y_hwc = q->y_hwc;
+  a.fin = to_fin(&q->fin);
+  a.n_img = q->n;
+  a.c1 = q->c1;
+  a.c2 = q->c2;
+  a.hw = (int)q->hw;
+  a.relu1 = q->relu1;
+  a.cout = q->cout;
+  return launch_conv1x1(ctx, a, q->f16, q->wmax, fin_cap(&q->fin), (hipStream_t)stream);
+}
+
+int mp_conv1x1_stat_slices(int64_t hw) { return hw > 0 ? conv1x1_stat_slices(hw) : 0; }
+
+int mp_convk_supported(int cin, int cout, int ks, int stride, int h, int w) {
+  return convk_supported(cin, cout, ks, stride, h, w) ? 1 : 0;
+}
+
+int64_t mp_convk_packed_floats(int cin, int cout, int ks) {
+  if (cin <= 0 || cout <= 0 || (ks != 3 && ks != 7) || cin % (ks == 7 ? 3 : 16)) return 0;
+  return convk_packed_floats(cin, cout, ks);
+}
+
+int mp_convk_stat_slices(int ks, int stride, int h, int w) {
+  if ((ks != 3 && ks != 7) || stride < 1 || stride > 2 || h <= 0 || w <= 0) return 0;
+  return convk_stat_slices(ks, stride, h, w);
+}
+
+int mp_convk_pack(mp_ctx *ctx, const float *w, int cout, int cin, int ks, float *packed, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!w || !packed || mp_convk_packed_floats(cin, cout, ks) <= 0 || cout % 32)
+    return fail(ctx, MP_ERR_ARG, "mp_convk_pack: bad argument");
+  DeviceGuard g(ctx->device);
+  return launch_convk_pack(ctx, w, cout, cin, ks, packed, (hipStream_t)stream);
+}
+
+int mp_convk(mp_ctx *ctx, const mp_convk_args *q, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!q || !q->x || !q->packed || !q->y || q->n <= 0 || q->n > 65535 || q->cin <= 0 || q->cout <= 0 ||
+      q->h <= 0 || q->w <= 0)
+    return fail(ctx, MP_ERR_ARG, "mp_convk: bad argument");
+  if (!aligned16(q->packed)) return fail(ctx, MP_ERR_ARG, "mp_convk: packed weights must be 16-byte aligned");
+  DeviceGuard g(ctx->device);
+  ConvKArgs a;
+  a.x = q->x;
+  a.ss = q->ss;
+  a.wp = q->packed;
+  a.bias = q->bias;
+  a.y = q->y;
+  a.fin = to_fin(&q->fin);
+  a.n_img = q->n;
+  a.cin = q->cin;
+  a.cout = q->cout;
+  a.h = q->h;
+  a.w = q->w;
+  a.ho = a.wo = 0;
+  a.ks = q->ks;
+  a.stride = q->stride;
+  a.pad = q->ks / 2;
+  a.reflect = q->reflect;
+  a.relu = q->relu;
+  a.wp_floats = 0;
+  return launch_convk(ctx, a, fin_cap(&q->fin), (hipStream_t)stream);
+}
+
+static int check_ew(mp_ctx *ctx, const char *who, const void *x, const void *y, int n, int c, long long hw_out) {
+  if (!x || !y || n <= 0 || n > 4096 || c <= 0 || hw_out <= 0) return fail(ctx, MP_ERR_ARG, "%s: bad argument", who);
+  if (c % 32 || hw_out % 4 || !aligned16(x) || !aligned16(y))
+    return fail(ctx, MP_ERR_UNSUPPORTED, "%s: needs C %% 32 == 0, output H*W %% 4 == 0, 16-byte aligned buffers", who);
+  return MP_OK;
+}
+
+int mp_avgpool2_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, float *y, const mp_gn_fin *fin,
+                   mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (h < 2 || w < 8 || h % 2 || w % 8) return fail(ctx, MP_ERR_UNSUPPORTED, "mp_avgpool2_gn: needs H %% 2 == 0, W %% 8 == 0");
+  int rc = check_ew(ctx, "mp_avgpool2_gn", x, y, n, c, (long long)(h / 2) * (w / 2));
+  if (rc != MP_OK) return rc;
+  DeviceGuard g(ctx->device);
+  return launch_avgpool2_gn(ctx, x, n, c, h, w, y, to_fin(fin), fin_cap(fin), (hipStream_t)stream);
+}
+
+int mp_upsample_bicubic2x_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, const float *add, float *y,
+                             const mp_gn_fin *fin, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (h < 2 || w < 2 || w % 2) return fail(ctx, MP_ERR_UNSUPPORTED, "mp_upsample_bicubic2x_gn: needs H, W >= 2, W %% 2 == 0");
+  int rc = check_ew(ctx, "mp_upsample_bicubic2x_gn", x, y, n, c, 4LL * h * w);
+  if (rc != MP_OK) return rc;
+  if (add && !aligned16(add)) return fail(ctx, MP_ERR_UNSUPPORTED, "mp_upsample_bicubic2x_gn: add must be 16-byte aligned");
+  DeviceGuard g(ctx->device);
+  return launch_upsample_add_gn(ctx, x, n, c, h, w, add, y, to_fin(fin), fin_cap(fin), (hipStream_t)stream);
+}
+
+int mp_gn_apply(mp_ctx *ctx, const float *x, const float *ss, int relu, int n, int c, int64_t hw, float *y,
+                const mp_gn_fin *fin, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ss) return fail(ctx, MP_ERR_ARG, "mp_gn_apply: bad argument");
+  int rc = check_ew(ctx, "mp_gn_apply", x, y, n, c, hw);
+  if (rc != MP_OK) return rc;
+  DeviceGuard g(ctx->device);
+  return launch_gn_apply_gn(ctx, x, ss, relu, n, c, hw, y, to_fin(fin), fin_cap(fin), (hipStream_t)stream);
 }
 
 int mp_profile_begin(mp_ctx *ctx, int max_records) {

@@ -21,6 +21,7 @@
 // Algorithmic work: 2 * 9 * Cin * Cout FLOP per output pixel; roofline = f32 MFMA (157.3 TFLOP/s).
 #include "mp_internal.h"
 #include "query_common.h"
+#include "gn_tail.h"
 
 namespace mp {
 
@@ -33,20 +34,6 @@ constexpr int kTileW = 32;        // tiles are 32 pixels wide and PX / 32 rows t
 // staged pixels (tile + 1 halo) of a PX-pixel tile, and the 64-lane passes a wave needs for them
 constexpr int halo_pixels(int px) { return (px / kTileW + 2) * (kTileW + 2); }
 constexpr int stage_iters(int px) { return (halo_pixels(px) + 63) / 64; }
-
-struct ConvArgs {
-  const float *x;    // [N, Cin, H, W]
-  const float *ss;   // [N, Cin, 2] (scale, shift) of the fused GroupNorm, or nullptr: plain input
-  const float *wp;   // packed weights [Cout/32][Cin/16 * 18][64][4]
-  float *y;          // [N, Cout, H, W]
-  double *stats;     // nullptr or [N, 32, S, 2] partial (sum, sumsq), S = slots * (Cout/32)
-  int n_img, cin, cout, h, w;
-  int tw, th;        // tile width / height in pixels (th * tw = 32 * NR * CW)
-  int relu;          // apply ReLU to the (normalised) input
-  int reflect;       // 0: zero padding (HGFilters.py ConvBlock); 1: nn.ReflectionPad2d(1) in front of
-                     // the convolution (ResBlkFilters.py:28-84): halo pixels mirror the interior
-  int wp_floats;     // size of wp
-};
 
 // W [Cout][Cin][3][3] -> fragment order: group kg = (chunk * 9 + tap) * 2 + g holds, for lane
 // (r = lane & 31, hh = lane >> 5), the 4 weights W[32 rb + r][16 chunk + 8 g + 4 hh + i][tap].
@@ -63,6 +50,93 @@ __global__ void conv3x3_pack_kernel(const float *__restrict__ w, int cout, int c
     const int co = 32 * rb + (lane & 31);
     const int ci = kCK * chunk + 8 * g + 4 * (lane >> 5) + i;
     wp[t] = w[((long long)co * cin + ci) * 9 + tap];
+  }
+}
+
+
+// ---- epilogue shared by the 3x3 kernels ------------------------------------------------------
+// A wave holds rows r(t) = (t & 3) + 8 (t >> 2) + 4 h, t in [t0, t0 + TN), of the 32-row block
+// `rbi` of its workgroup (NCH output channels, CW pixel-column waves), for NR column blocks of 32
+// consecutive pixels of one tile row.  Writes the raw output (y), the pyramid-block tail
+// y2 = conv + res (optional) and publishes the GroupNorm statistics of either (gn_tail.h): the
+// per-channel sums of all waves meet in LDS, threads 0..ng-1 fold them into the workgroup's
+// per-group partials in a fixed order.  smem: the kernel's dynamic LDS, idle by now (>= 8.5 KB).
+template <int NCH, int CW, int NR, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &p, const float (&v)[NR][TN], int t0, int img,
+                                              int tile, int tiles, int y0, int x0, int rbi, int cwi, int lane,
+                                              unsigned char *smem) {
+  const int j = lane & 31, h = lane >> 5;
+  const int hw = p.h * p.w;
+  const int ch0 = NCH * blockIdx.y + 32 * rbi;
+  const long long o1 = ((long long)img * p.cout + ch0) * hw;
+  const long long o2 = ((long long)img * p.y2_c + p.y2_off + ch0) * hw;
+  const bool cat = p.y2 != nullptr;
+  float s1[TN], s2[TN], q1[TN], q2[TN];
+#pragma unroll
+  for (int tt = 0; tt < TN; ++tt) s1[tt] = s2[tt] = q1[tt] = q2[tt] = 0.0f;
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
+    const int cb = cwi * NR + n;
+    const int ty = (32 * cb) / p.tw, tx = (32 * cb) - ty * p.tw;
+    const long long pix = (long long)(y0 + ty) * p.w + x0 + tx + j;
+#pragma unroll
+    for (int tt = 0; tt < TN; ++tt) {
+      const int t = t0 + tt;
+      const long long ro = (long long)((t & 3) + 8 * (t >> 2) + 4 * h) * hw + pix;
+      const float val = v[n][tt];
+      if (p.y) p.y[o1 + ro] = val;
+      s1[tt] += val;
+      s2[tt] = fmaf(val, val, s2[tt]);
+      if (cat) {
+        const float u = val + p.res[o2 + ro];
+        p.y2[o2 + ro] = u;
+        q1[tt] += u;
+        q2[tt] = fmaf(u, u, q2[tt]);
+      }
+    }
+  }
+  double *cs = reinterpret_cast<double *>(smem);  // [CW][NCH][2] per-channel (sum, sum of squares)
+  unsigned char *tail = smem + 4096;
+  const int tid = threadIdx.x;
+  const int cidx = img * gridDim.y + blockIdx.y;
+  auto publish = [&](const GnFin &f, float (&a1)[TN], float (&a2)[TN], int c_off) {
+    // sum over the 32 lanes that share h (the pixels); lanes j == 0 then hold the row sums
+#pragma unroll
+    for (int tt = 0; tt < TN; ++tt) {
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        a1[tt] += __shfl_xor(a1[tt], o);
+        a2[tt] += __shfl_xor(a2[tt], o);
+      }
+    }
+    if (j == 0) {
+#pragma unroll
+      for (int tt = 0; tt < TN; ++tt) {
+        const int t = t0 + tt;
+        const int idx = cwi * NCH + 32 * rbi + (t & 3) + 8 * (t >> 2) + 4 * h;
+        cs[2 * idx] = (double)a1[tt];
+        cs[2 * idx + 1] = (double)a2[tt];
+      }
+    }
+    __syncthreads();
+    const int cpg = f.c / 32;  // channels per group of the normalised tensor
+    const int ng = NCH / cpg;  // groups this workgroup covers
+    const int g0 = (c_off + NCH * (int)blockIdx.y) / cpg;
+    double a = 0.0, b = 0.0;
+    if (tid < ng) {
+      for (int cw = 0; cw < CW; ++cw)
+        for (int ch = 0; ch < cpg; ++ch) {
+          const int idx = cw * NCH + tid * cpg + ch;
+          a += cs[2 * idx];
+          b += cs[2 * idx + 1];
+        }
+    }
+    gn_publish<256>(f, img, g0, ng, tile, cidx, tiles, a, b, tail);
+  };
+  if (p.fin.partial) publish(p.fin, s1, s2, 0);
+  if (cat && p.fin2.partial) {
+    if (p.fin.partial) __syncthreads();  // cs is reused
+    publish(p.fin2, q1, q2, p.y2_off);
   }
 }
 
@@ -222,50 +296,207 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
     __syncthreads();
   }
 
-  // ---- epilogue: NCHW store + per-channel statistics of this wave's 32 x (32 NR) tile ----
-  float *yb = p.y + ((long long)img * p.cout + 32 * rb) * hw;
-  float s1[16], s2[16];
+  // ---- epilogue: stores + GroupNorm statistics (conv_epilogue) ----
+  float v[NR][16];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) s1[t] = s2[t] = 0.0f;
+  for (int n = 0; n < NR; ++n)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[n][t] = acc[n][t];
+  conv_epilogue<32 * RBW, CW, NR, 16>(p, v, 0, img, tile, tiles, y0, x0, rbi, cwi, lane, smem);
+}
+
+// ---- small-launch variant: the four waves of a workgroup split K ---------------------------------
+// The kernel above gives a wave a whole K = 9 Cin loop, so a launch takes at least one such loop
+// (31 us for 256 -> 128 channels) however small the map is, and a 64^2 / 32^2 map or a single frame
+// yields fewer workgroups than the chip has slots (profiles/r02x_encoder_kernel_stats_b1.txt: the
+// 32^2 convolutions took as long as the 128^2 ones).  Here a workgroup is ONE 32-channel row block
+// x 32 NR pixels and wave ks takes the 16-channel chunks ks, ks + 4, ... of the input -- staged by
+// itself into its own double-buffered LDS tile, so there is no workgroup barrier inside the K loop
+// -- and the four partial accumulators meet in LDS at the end, added in wave order (deterministic).
+// 4 x (Cout / 32) / RBW times as many workgroups, each a quarter as long; the price is that every
+// wave stages all 16 channels of its chunks (the halo is staged once per row block instead of once
+// per workgroup), which the launcher only pays when the large-tile launch would not fill the chip.
+template <int NR>
+__global__ __launch_bounds__(256, 2) void conv3x3_gn_sk_kernel(ConvArgs p) {
+  constexpr int kStageIters = stage_iters(32 * NR);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // = K split index
+  const int j = lane & 31, h = lane >> 5;
+
+  const int TW = p.tw, TH = p.th, PW = TW + 2;
+  const int NPH = (TH + 2) * PW;
+  const int buf_bytes = NPH * kPixBytes;
+  const int tiles_x = p.w / TW, tiles = tiles_x * (p.h / TH);
+  const int tile = blockIdx.x % tiles, img = blockIdx.x / tiles;
+  const int y0 = (tile / tiles_x) * TH, x0 = (tile % tiles_x) * TW;
+  const int rb = blockIdx.y;
+  const int hw = p.h * p.w;
+  const int n_chunks = p.cin / kCK;
+  const int kgt = n_chunks * 18;
+  unsigned char *mybuf = smem + wv * 2 * buf_bytes;
+
+  const WStream ws = make_wstream(p.wp, p.wp_floats, lane);
+
+  int goff[kStageIters];
+#pragma unroll
+  for (int it = 0; it < kStageIters; ++it) {
+    const int lp = lane + 64 * it;
+    const int r = lp / PW, c = lp - r * PW;
+    int gy = y0 - 1 + r, gx = x0 - 1 + c;
+    bool ok = lp < NPH;
+    if (p.reflect) {
+      gy = gy < 0 ? -gy : (gy >= p.h ? 2 * p.h - 2 - gy : gy);
+      gx = gx < 0 ? -gx : (gx >= p.w ? 2 * p.w - 2 - gx : gx);
+    } else {
+      ok = ok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+    }
+    goff[it] = ok ? gy * p.w + gx : -1;
+  }
+  const float *xin = p.x + (long long)img * p.cin * hw;
+  const float *ssn = p.ss ? p.ss + (long long)img * p.cin * 2 : nullptr;
+
+  // lane = pixel, all 16 channels of the chunk
+  f32x4 stg[kStageIters][4];
+  float sc[16], sh[16];  // wave-uniform
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    sc[k] = 1.0f;
+    sh[k] = 0.0f;
+  }
+  // activations through a buffer resource: lane part = the pixel's offset inside a plane (one VGPR
+  // per pass), plane = wave-uniform scalar offset -- 64-bit flat addresses made hipcc hoist 16 plane
+  // pointers per pass out of the loop and spill (the weight stream's story, query_common.h)
+  const __amdgpu_buffer_rsrc_t xs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xin), 0, p.cin * hw * 4, 0x00020000);
+  auto stage_load = [&](int chunk) {
+    const int plane0 = chunk * kCK * hw * 4;  // bytes
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+      const int o = (goff[it] < 0 ? 0 : goff[it]) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          stg[it][q][k] = __builtin_bit_cast(
+              float, __builtin_amdgcn_raw_buffer_load_b32(xs, o, plane0 + (4 * q + k) * hw * 4, 0));
+    }
+    if (ssn) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        sc[k] = ssn[2 * (chunk * kCK + k)];
+        sh[k] = ssn[2 * (chunk * kCK + k) + 1];
+      }
+    }
+  };
+  auto stage_store = [&](unsigned char *buf) {
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+      const int lp = lane + 64 * it;
+      if (lp < NPH) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float t = fmaf(stg[it][q][k], sc[4 * q + k], sh[4 * q + k]);
+            if (p.relu) t = fmaxf(t, 0.0f);
+            v[k] = goff[it] < 0 ? 0.0f : t;
+          }
+          *reinterpret_cast<f32x4 *>(buf + lp * kPixBytes + ((q ^ ((lp >> 2) & 3)) << 4)) = v;
+        }
+      }
+    }
+  };
+
+  int boff[NR][9];
 #pragma unroll
   for (int n = 0; n < NR; ++n) {
-    const int cb = cwi * NR + n;
-    const int ty = (32 * cb) / TW, tx = (32 * cb) - ty * TW;
-    float *row = yb + (long long)(y0 + ty) * p.w + x0 + tx + j;
+    const int ty = (32 * n) / TW, tx = (32 * n) - ty * TW;
+    const int lpc = (ty + 1) * PW + tx + j + 1;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int r = (t & 3) + 8 * (t >> 2) + 4 * h;
-      const float v = acc[n][t];
-      row[(long long)r * hw] = v;
-      s1[t] += v;
-      s2[t] = fmaf(v, v, s2[t]);
+    for (int tap = 0; tap < 9; ++tap) {
+      const int lp = lpc + (tap / 3 - 1) * PW + (tap % 3 - 1);
+      boff[n][tap] = lp * kPixBytes + ((h ^ ((lp >> 2) & 3)) << 4);
     }
   }
-  if (p.stats) {
-    // sum over the 32 lanes that share h (the pixels); lanes j == 0 then hold the row sums
+
+  f32x16 acc[NR];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+  for (int n = 0; n < NR; ++n)
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-        s1[t] += __shfl_xor(s1[t], o);
-        s2[t] += __shfl_xor(s2[t], o);
+    for (int t = 0; t < 16; ++t) acc[n][t] = 0.0f;
+
+  if (wv < n_chunks) {
+    const int a_base = rb * kgt * 64;
+    f32x4 ring[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ring[k] = wload128(ws, a_base + (wv * 18 + k) * 64);
+    stage_load(wv);
+    stage_store(mybuf);
+    int it_n = 0;
+    for (int chunk = wv; chunk < n_chunks; chunk += 4, ++it_n) {
+      const unsigned char *buf = mybuf + (it_n & 1) * buf_bytes;
+      const bool more = chunk + 4 < n_chunks;
+      __builtin_amdgcn_wave_barrier();  // this wave's LDS tile was written by its own lanes
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        // first K group of the NEXT row-step (the next chunk of this wave after the last row)
+        const int kg_next = ky < 2 ? chunk * 18 + 6 * (ky + 1) : (chunk + 4) * 18;
+        f32x4 bcur[NR];
+#pragma unroll
+        for (int n = 0; n < NR; ++n) bcur[n] = *reinterpret_cast<const f32x4 *>(buf + boff[n][3 * ky]);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+          f32x4 bnxt[NR];
+          if (s < 5) {
+            const int sn = s + 1;
+#pragma unroll
+            for (int n = 0; n < NR; ++n)
+              bnxt[n] = *reinterpret_cast<const f32x4 *>(buf + (boff[n][3 * ky + (sn >> 1)] ^ (32 * (sn & 1))));
+          }
+          const f32x4 a = ring[s];
+          ring[s] = wload128(ws, a_base + min(kg_next + s, kgt - 1) * 64);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n = 0; n < NR; ++n)
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[n][i], acc[n], 0, 0, 0);
+          if (s < 5) {
+#pragma unroll
+            for (int n = 0; n < NR; ++n) bcur[n] = bnxt[n];
+          }
+        }
+        if (ky == 0 && more) stage_load(chunk + 4);
       }
-    }
-    if (j == 0) {
-      const int cpg = p.cout / 32;                 // channels per GroupNorm(32, Cout) group
-      const int slots = tiles * CW;
-      const int S = slots * cpg;
-      const int slot = tile * CW + cwi;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int co = 32 * rb + (t & 3) + 8 * (t >> 2) + 4 * h;
-        const int grp = co / cpg, s = slot * cpg + (co - grp * cpg);
-        double *dst = p.stats + (((long long)img * 32 + grp) * S + s) * 2;
-        dst[0] = (double)s1[t];
-        dst[1] = (double)s2[t];
-      }
+      if (more) stage_store(mybuf + ((it_n + 1) & 1) * buf_bytes);
     }
   }
+
+  // ---- the four partial accumulators meet in LDS; wave wv finishes rows t = 4 wv .. 4 wv + 3 ----
+  __syncthreads();
+  float *red = reinterpret_cast<float *>(smem);  // [4][NR][16][64]
+#pragma unroll
+  for (int n = 0; n < NR; ++n)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) red[((wv * NR + n) * 16 + t) * 64 + lane] = acc[n][t];
+  __syncthreads();
+  float v[NR][4];
+#pragma unroll
+  for (int n = 0; n < NR; ++n)
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int t = 4 * wv + tt;
+      float sum = red[((0 * NR + n) * 16 + t) * 64 + lane];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) sum += red[((k * NR + n) * 16 + t) * 64 + lane];
+      v[n][tt] = sum;
+    }
+  __syncthreads();
+  conv_epilogue<32, 1, NR, 4>(p, v, 4 * wv, img, tile, tiles, y0, x0, 0, 0, lane, smem);
 }
 
 // ---- split-f16 ("f16x3") variant ----------------------------------------------------------------
@@ -488,48 +719,12 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
     __syncthreads();
   }
 
-  float *yb = p.y + ((long long)img * p.cout + 32 * rb) * hw;
-  float s1[16], s2[16];
+  float v[NR][16];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) s1[t] = s2[t] = 0.0f;
+  for (int n = 0; n < NR; ++n)
 #pragma unroll
-  for (int n = 0; n < NR; ++n) {
-    const int cb = cwi * NR + n;
-    const int ty = (32 * cb) / TW, tx = (32 * cb) - ty * TW;
-    float *row = yb + (long long)(y0 + ty) * p.w + x0 + tx + j;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int r = (t & 3) + 8 * (t >> 2) + 4 * h;
-      const float v = acc[n][t] * inv_scale;
-      row[(long long)r * hw] = v;
-      s1[t] += v;
-      s2[t] = fmaf(v, v, s2[t]);
-    }
-  }
-  if (p.stats) {
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-        s1[t] += __shfl_xor(s1[t], o);
-        s2[t] += __shfl_xor(s2[t], o);
-      }
-    }
-    if (j == 0) {
-      const int cpg = p.cout / 32;
-      const int slots = tiles * CW;
-      const int S = slots * cpg;
-      const int slot = tile * CW + cwi;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int co = 32 * rb + (t & 3) + 8 * (t >> 2) + 4 * h;
-        const int grp = co / cpg, s = slot * cpg + (co - grp * cpg);
-        double *dst = p.stats + (((long long)img * 32 + grp) * S + s) * 2;
-        dst[0] = (double)s1[t];
-        dst[1] = (double)s2[t];
-      }
-    }
-  }
+    for (int t = 0; t < 16; ++t) v[n][t] = acc[n][t] * inv_scale;
+  conv_epilogue<32 * RBW, CW, NR, 16>(p, v, 0, img, tile, tiles, y0, x0, rbi, cwi, lane, smem);
 }
 
 // (scale, shift) of GroupNorm(groups, C) from partial sums: ss[n][c] = (gamma[c] rstd,
@@ -605,38 +800,58 @@ int launch_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *w
   return MP_OK;
 }
 
-// Tile shape of the kernel instantiation that serves `cout`: RBW waves split the output channels
-// (32 each), the other 4 / RBW split the pixels; NR = 32-pixel column blocks per wave.  Smaller NR
-// = more, smaller workgroups (better balance over 256 CUs x 2 slots, more weight re-streaming).
+// Tile shape of the kernel instantiation that serves a launch.  Large launches: RBW waves split the
+// output channels (32 each), the other 4 / RBW split the pixels, NR = 32-pixel column blocks per
+// wave (smaller NR = more, smaller workgroups: better balance over 256 CUs x 2 slots, more weight
+// re-streaming).  Launches that would leave workgroup slots empty take the split-K kernel (sk):
+// one 32-channel row block x 32 NR pixels per workgroup, K split over its four waves.
 static int g_conv_nr = 0;  // 0 = heuristic; tools/conv_probe.py overrides it for A/B runs
+static int g_conv_sk = -1; // -1 = heuristic; 0 / 1 force the large-tile / the split-K kernel
 
-void conv3x3_set_nr(int nr) { g_conv_nr = nr; }
+void conv3x3_set_nr(int nr) {
+  g_conv_nr = nr & 0xff;
+  g_conv_sk = (nr >> 8) == 0 ? -1 : (nr >> 8) - 1;  // mp_conv3x3_tune(nr | 0x100: large tiles, | 0x200: split-K)
+}
 
-static void conv_shape(int cout, int n, int h, int w, bool f16, int &rbw, int &nr, int &tw, int &th,
-                       int &slots) {
-  rbw = cout % 128 == 0 ? 4 : cout % 64 == 0 ? 2 : 1;
-  const int cw = 4 / rbw;
+struct ConvPlan {
+  int rbw, nr, tw, th, tiles;  // tiles per image
+  bool sk;
+};
+
+static ConvPlan conv_plan(int cout, int n, int h, int w, bool f16) {
+  ConvPlan c;
+  c.rbw = cout % 128 == 0 ? 4 : cout % 64 == 0 ? 2 : 1;
+  const int cw = 4 / c.rbw;
+  const long long pix = (long long)n * h * w;
   // NR = 2 unless that leaves fewer than 2 workgroups per slot (512 slots); NR = 4 needs all 256
   // VGPRs (spills) and measured slower at every shape, so it is not built
-  nr = 2;
+  c.nr = 2;
   if (g_conv_nr > 0)
-    nr = g_conv_nr;
-  else if ((long long)n * h * w / (32 * nr * cw) * (cout / (32 * rbw)) < 1024)
-    nr = 1;
-  if (nr > 2 && (rbw == 1 || !f16)) nr = 2;  // NR = 4 is built for the split-f16 kernels only
-  const int px = 32 * nr * cw;
-  // 32-pixel-wide tiles, PX / 32 rows tall: the staged halo is (TH + 2) x 34 pixels (1.3-2.1x the
-  // tile; one-row tiles would stage 3x) and a wave stages it in 2-6 passes of 64 pixels
-  tw = kTileW;
-  th = px / tw;
-  slots = (h / th) * (w / tw) * cw;
+    c.nr = g_conv_nr;
+  else if (pix / (32 * c.nr * cw) * (cout / (32 * c.rbw)) < 1024)
+    c.nr = 1;
+  if (c.nr > 2 && (c.rbw == 1 || !f16)) c.nr = 2;  // NR = 4 is built for the split-f16 kernels only
+  // split-K when even the smallest large-tile launch does not give every slot a workgroup
+  const long long wg_large = pix / (32 * c.nr * cw) * (cout / (32 * c.rbw));
+  c.sk = !f16 && (g_conv_sk >= 0 ? g_conv_sk == 1 : wg_large < 512);
+  if (c.sk) {
+    c.rbw = 1;
+    c.nr = g_conv_nr > 0 ? (g_conv_nr > 2 ? 2 : g_conv_nr) : (pix / 64 * (cout / 32) >= 512 ? 2 : 1);
+    if (h < c.nr) c.nr = 1;
+    c.tw = kTileW;
+    c.th = c.nr;
+  } else {
+    // 32-pixel-wide tiles, PX / 32 rows tall: the staged halo is (TH + 2) x 34 pixels (1.3-2.1x the
+    // tile; one-row tiles would stage 3x) and a wave stages it in 2-6 passes of 64 pixels
+    c.tw = kTileW;
+    c.th = 32 * c.nr * cw / c.tw;
+  }
+  c.tiles = (h / c.th) * (w / c.tw);
+  return c;
 }
 
-int conv3x3_stat_slices(int cout, int n, int h, int w, bool f16) {
-  int rbw, nr, tw, th, slots;
-  conv_shape(cout, n, h, w, f16, rbw, nr, tw, th, slots);
-  return slots * (cout / 32);
-}
+// slots per (image, group) of the statistics a launch publishes = its tiles per image
+int conv3x3_stat_slices(int cout, int n, int h, int w, bool f16) { return conv_plan(cout, n, h, w, f16).tiles; }
 
 bool conv3x3_supported(int cin, int cout, int h, int w) {
   return !(cin % kCK || cout % 32 || cin < kCK || cout < 32 || w < 32 || (w & (w - 1)) || h < 8 ||
@@ -658,16 +873,20 @@ int launch_conv3x3_pack16(mp_ctx *ctx, const float *w, int cout, int cin, void *
   return MP_OK;
 }
 
+static int raise_lds_limit(mp_ctx *ctx, const void *kern_id, int bytes) {
+  if (!ctx->lds_attr_done.count(kern_id)) {
+    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    ctx->lds_attr_done.insert(kern_id);
+  }
+  return MP_OK;
+}
+
 template <int RBW, int NR>
 static int launch_conv16_t(mp_ctx *ctx, const ConvArgs &a, const float *wmax, int tiles, hipStream_t st) {
   const int lds = 2 * (a.th + 2) * (a.tw + 2) * kPixBytes;
   auto kern = conv3x3_gn16_kernel<RBW, NR>;
-  const void *kern_id = reinterpret_cast<const void *>(kern);
-  if (!ctx->lds_attr_done.count(kern_id)) {
-    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * halo_pixels(32 * NR * (4 / RBW)) * kPixBytes));
-    ctx->lds_attr_done.insert(kern_id);
-  }
+  int rc = raise_lds_limit(ctx, reinterpret_cast<const void *>(kern), 2 * halo_pixels(32 * NR * (4 / RBW)) * kPixBytes);
+  if (rc != MP_OK) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * a.n_img), (unsigned)(a.cout / (32 * RBW))), dim3(256),
                      lds, st, a, wmax);
   MP_HIP(ctx, hipGetLastError());
@@ -678,44 +897,67 @@ template <int RBW, int NR>
 static int launch_conv_t(mp_ctx *ctx, const ConvArgs &a, int tiles, hipStream_t st) {
   const int lds = 2 * (a.th + 2) * (a.tw + 2) * kPixBytes;
   auto kern = conv3x3_gn_kernel<RBW, NR>;
-  const void *kern_id = reinterpret_cast<const void *>(kern);
-  if (!ctx->lds_attr_done.count(kern_id)) {
-    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * halo_pixels(32 * NR * (4 / RBW)) * kPixBytes));
-    ctx->lds_attr_done.insert(kern_id);
-  }
+  int rc = raise_lds_limit(ctx, reinterpret_cast<const void *>(kern), 2 * halo_pixels(32 * NR * (4 / RBW)) * kPixBytes);
+  if (rc != MP_OK) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * a.n_img), (unsigned)(a.cout / (32 * RBW))), dim3(256),
                      lds, st, a);
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
 }
 
-int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss,
-                      int relu, int reflect, const float *wp, const float *wmax16, int cout, float *y,
-                      double *stats, hipStream_t st) {
+template <int NR>
+static int launch_conv_sk_t(mp_ctx *ctx, const ConvArgs &a, int tiles, hipStream_t st) {
+  const int lds = 8 * halo_pixels(32 * NR) * kPixBytes;  // 4 waves x 2 buffers
+  auto kern = conv3x3_gn_sk_kernel<NR>;
+  int rc = raise_lds_limit(ctx, reinterpret_cast<const void *>(kern), lds);
+  if (rc != MP_OK) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * a.n_img), (unsigned)(a.cout / 32)), dim3(256), lds, st, a);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+// Fills in what the launcher derives (tile shape, slots, group sizes) and checks the statistics
+// request against the launch: `a` arrives with x / ss / wp / y / y2 / res / fin / fin2 as the caller
+// gave them (fin.c, fin.S, fin.count unset).  partial_cap[k]: doubles the caller allocated for
+// fin / fin2 (-1 = unchecked legacy entry points).
+int launch_conv3x3(mp_ctx *ctx, ConvArgs a, const float *wmax16, const long long partial_cap[2], hipStream_t st) {
+  const int n = a.n_img, cin = a.cin, cout = a.cout, h = a.h, w = a.w;
   if (!conv3x3_supported(cin, cout, h, w))
     return fail(ctx, MP_ERR_UNSUPPORTED,
                 "conv3x3: needs Cin %% 16 == 0, Cout %% 32 == 0, H and W powers of two (W >= 32, H >= 8); got %d -> %d at %dx%d",
                 cin, cout, h, w);
-  ConvArgs a;
-  a.x = x;
-  a.ss = ss;
-  a.wp = wp;
-  a.y = y;
-  a.stats = stats;
-  a.n_img = n;
-  a.cin = cin;
-  a.cout = cout;
-  a.h = h;
-  a.w = w;
-  a.relu = relu;
-  a.reflect = reflect;
   a.wp_floats = cout * cin * 9;
-  int rbw, nr, slots;
-  conv_shape(cout, n, h, w, wmax16 != nullptr, rbw, nr, a.tw, a.th, slots);
+  const ConvPlan c = conv_plan(cout, n, h, w, wmax16 != nullptr);
+  a.tw = c.tw;
+  a.th = c.th;
   if (a.th > h)
     return fail(ctx, MP_ERR_UNSUPPORTED, "conv3x3: %dx%d map too small for a %dx%d tile", h, w, a.th, a.tw);
-  const int tiles = (h / a.th) * (w / a.tw);
+  if (a.y2) {
+    if (!a.res || a.y2_c % 32 || a.y2_off < 0 || a.y2_off + cout > a.y2_c || a.y2_off % (a.y2_c / 32) ||
+        32 % (a.y2_c / 32))
+      return fail(ctx, MP_ERR_ARG, "conv3x3: bad fused-tail request (%d channels at offset %d of %d)", cout,
+                  a.y2_off, a.y2_c);
+  } else if (!a.y) {
+    return fail(ctx, MP_ERR_ARG, "conv3x3: no output buffer");
+  }
+  for (int k = 0; k < 2; ++k) {
+    GnFin &f = k ? a.fin2 : a.fin;
+    if (!f.partial) continue;
+    if (k && !a.y2) return fail(ctx, MP_ERR_ARG, "conv3x3: statistics of y2 requested without y2");
+    f.c = k ? a.y2_c : cout;
+    f.S = c.tiles;
+    f.count = (double)(f.c / 32) * h * w;
+    if (partial_cap[k] >= 0 && partial_cap[k] < (long long)n * 32 * f.S * 2)
+      return fail(ctx, MP_ERR_ARG, "conv3x3: statistics buffer holds %lld doubles, the launch writes %lld",
+                  partial_cap[k], (long long)n * 32 * f.S * 2);
+    if (f.n_sets < 0 || f.n_sets > 2 || (f.n_sets > 0 && !f.counter))
+      return fail(ctx, MP_ERR_ARG, "conv3x3: bad GroupNorm consumer request");
+    for (int q = 0; q < f.n_sets; ++q)
+      if (!f.set[q].gamma || !f.set[q].beta || !f.set[q].ss)
+        return fail(ctx, MP_ERR_ARG, "conv3x3: GroupNorm consumer %d lacks gamma / beta / ss", q);
+  }
+  if (c.sk) return c.nr == 2 ? launch_conv_sk_t<2>(ctx, a, c.tiles, st) : launch_conv_sk_t<1>(ctx, a, c.tiles, st);
+  const int rbw = c.rbw, nr = c.nr, tiles = c.tiles;
 #define MP_CONV_CASE(R, N)                                                                   \
   if (rbw == R && nr == N)                                                                   \
     return wmax16 ? launch_conv16_t<R, N>(ctx, a, wmax16, tiles, st) : launch_conv_t<R, N>(ctx, a, tiles, st);
@@ -731,6 +973,33 @@ int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w,
   MP_CONV_CASE(1, 1)
 #undef MP_CONV_CASE
   return fail(ctx, MP_ERR_UNSUPPORTED, "conv3x3: no instantiation for rbw %d nr %d", rbw, nr);
+}
+
+// legacy form: plain output + optional partial sums (finalised by mp_gn_finalize)
+int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss,
+                      int relu, int reflect, const float *wp, const float *wmax16, int cout, float *y,
+                      double *stats, hipStream_t st) {
+  ConvArgs a;
+  a.x = x;
+  a.ss = ss;
+  a.wp = wp;
+  a.y = y;
+  a.y2 = nullptr;
+  a.res = nullptr;
+  a.y2_c = 32;
+  a.y2_off = 0;
+  a.fin = gn_fin_none();
+  a.fin2 = gn_fin_none();
+  a.fin.partial = stats;
+  a.n_img = n;
+  a.cin = cin;
+  a.cout = cout;
+  a.h = h;
+  a.w = w;
+  a.relu = relu;
+  a.reflect = reflect;
+  const long long cap[2] = {-1, -1};
+  return launch_conv3x3(ctx, a, wmax16, cap, st);
 }
 
 int launch_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int groups, int slices,
@@ -753,19 +1022,6 @@ int launch_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int gro
 // read (through LDS, so that every pixel row leaves as one 1 KB burst), and can emit the
 // GroupNorm statistics of its output (bn_end).  F16 = split-f16 ("f16x3") operands as in
 // conv3x3_gn16_kernel.
-struct Conv1Args {
-  const float *x1, *ss1;  // [N,C1,HW], [N,C1,2] or nullptr
-  const float *x2;        // [N,C2,HW] or nullptr (plain second K segment)
-  const float *wp;        // packed [8 row blocks][K/8 groups][64][4] f32, or [8][K/16][hi|lo][64] h8
-  const float *bias;      // [256]
-  const float *res;       // [N,256,HW] or nullptr
-  float *y;               // [N,256,HW] or nullptr
-  float *y_hwc;           // [N,HW,256] or nullptr
-  double *stats;          // nullptr or [N,32,S,2], S = (HW/64) * 8
-  int n_img, c1, c2, hw, relu1, wp_floats;
-  int cout;  // 256 (each wave two 32-row blocks) or 128 (one): the 1x1 projection of a pyramid block
-};
-
 constexpr int kC1K = 64;          // channels per staged chunk
 constexpr int kC1Px = 64;         // pixels per workgroup
 constexpr int kC1Row = kC1K * 4;  // bytes per staged pixel (f32, or 32 hi + 32 lo halves... 128 + 128)
@@ -889,7 +1145,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
   constexpr int FPS = F16 ? 2 : 1;                  // 16-byte fragments per step and row block
   const int steps = n_chunks * SPC;
   const int rb_stride = steps * FPS * 64;
-  const int a_base = (MRW * wv) * rb_stride;
+  const int rb0 = (int)blockIdx.y * (4 * MRW) + MRW * wv;  // first 32-row block of this wave
+  const int a_base = rb0 * rb_stride;
   auto a_load = [&](int m, int s, int part) {
     return wload128(ws, a_base + m * rb_stride + (min(s, steps - 1) * FPS + part) * 64);
   };
@@ -963,10 +1220,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
   float s1[MRW][16], s2[MRW][16];
 #pragma unroll
   for (int m = 0; m < MRW; ++m) {
-    const int rb = MRW * wv + m;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-      const int co = 32 * rb + (t & 3) + 8 * (t >> 2) + 4 * h;
+      const int co = 32 * (rb0 + m) + (t & 3) + 8 * (t >> 2) + 4 * h;
       const float b = p.bias ? p.bias[co] : 0.0f;
       s1[m][t] = s2[m][t] = 0.0f;
 #pragma unroll
@@ -981,7 +1237,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
       }
     }
   }
-  if (MRW == 2 && p.stats) {  // GroupNorm(32, 256) statistics: the launcher refuses them for 128 rows
+  constexpr int NCH = 128 * MRW;  // output channels of this workgroup
+  if (p.fin.partial) {
+    // GroupNorm(32, Cout) statistics of the output (bn_end after conv_last; the first GroupNorm of the
+    // next stack after x + bl(.) + al(.)): per-channel sums meet in LDS, gn_tail.h does the rest
 #pragma unroll
     for (int m = 0; m < MRW; ++m)
 #pragma unroll
@@ -992,23 +1251,34 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
           s2[m][t] += __shfl_xor(s2[m][t], o);
         }
       }
+    double *cs = reinterpret_cast<double *>(smem);  // [NCH][2]
     if (j == 0) {
-      const int S = tiles * 8;  // 8 channels per GroupNorm(32, 256) group, one slot per tile
 #pragma unroll
       for (int m = 0; m < MRW; ++m)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-          const int co = 32 * (MRW * wv + m) + (t & 3) + 8 * (t >> 2) + 4 * h;
-          double *dst = p.stats + (((long long)img * 32 + (co >> 3)) * S + tile * 8 + (co & 7)) * 2;
-          dst[0] = (double)s1[m][t];
-          dst[1] = (double)s2[m][t];
+          const int lc = 32 * (MRW * wv + m) + (t & 3) + 8 * (t >> 2) + 4 * h;
+          cs[2 * lc] = (double)s1[m][t];
+          cs[2 * lc + 1] = (double)s2[m][t];
         }
     }
+    __syncthreads();
+    const int cpg = p.cout / 32, ng = NCH / cpg;
+    double a = 0.0, b = 0.0;
+    if (tid < ng)
+      for (int ch = 0; ch < cpg; ++ch) {
+        a += cs[2 * (tid * cpg + ch)];
+        b += cs[2 * (tid * cpg + ch) + 1];
+      }
+    gn_publish<256>(p.fin, img, (NCH * (int)blockIdx.y) / cpg, ng, tile, img * gridDim.y + blockIdx.y, tiles, a, b,
+                    smem + 4096);
   }
-  if (MRW == 2 && p.y_hwc) {
-    // [64 px][256 ch] f32 = 64 KB through LDS (16-byte slots swizzled with the pixel), then every
-    // pixel row leaves as one 1 KB burst: wave wv writes pixels wv, wv + 4, ...
-    float *tr = reinterpret_cast<float *>(smem);
+  if (p.y_hwc) {
+    // [64 px][NCH ch] f32 through LDS (16-byte slots swizzled with the pixel), then every pixel row
+    // leaves as one burst of NCH * 4 bytes: wave wv writes pixels wv, wv + 4, ...
+    if (p.fin.partial) __syncthreads();
+    constexpr int kRow = NCH * 4, kSlots = NCH / 4;
+    unsigned char *tr = smem;
 #pragma unroll
     for (int m = 0; m < MRW; ++m)
 #pragma unroll
@@ -1018,16 +1288,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
         for (int q = 0; q < 4; ++q) {
           const int slot = (32 * (MRW * wv + m) + 8 * q + 4 * h) >> 2;  // 4 consecutive channels
           const f32x4 v = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
-          *reinterpret_cast<f32x4 *>(reinterpret_cast<unsigned char *>(tr) + px * 1024 + ((slot ^ (px & 63)) << 4)) = v;
+          *reinterpret_cast<f32x4 *>(tr + px * kRow + ((slot ^ (px & (kSlots - 1))) << 4)) = v;
         }
       }
     __syncthreads();
-    float *dst = p.y_hwc + ((long long)img * p.hw + px0) * 256;
-    for (int px = wv; px < kC1Px; px += 4) {
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<unsigned char *>(tr) + px * 1024 +
-                                                        ((lane ^ (px & 63)) << 4));
-      *reinterpret_cast<f32x4 *>(dst + (long long)px * 256 + 4 * lane) = v;
-    }
+    float *dst = p.y_hwc + ((long long)img * p.hw + px0) * p.cout + NCH * (int)blockIdx.y;
+    if (lane < kSlots)
+      for (int px = wv; px < kC1Px; px += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(tr + px * kRow + ((lane ^ (px & (kSlots - 1))) << 4));
+        *reinterpret_cast<f32x4 *>(dst + (long long)px * p.cout + 4 * lane) = v;
+      }
   }
 }
 
@@ -1053,19 +1323,59 @@ int launch_conv1x1_pack(mp_ctx *ctx, const float *w1, int c1, const float *w2, i
   return MP_OK;
 }
 
-static int launch_conv1x1(mp_ctx *ctx, const Conv1Args &a, int f16, const float *wmax, hipStream_t st);
+static int g_conv1_mrw = 0;  // 0 = heuristic; measurement hook (mp_conv3x3_tune(nr | mrw << 12))
 
+void conv1x1_set_mrw(int mrw) { g_conv1_mrw = mrw; }
+
+// slots per (image, group) of the statistics a 1x1 launch publishes
+int conv1x1_stat_slices(long long hw) { return (int)(hw / kC1Px); }
+
+// `a` arrives with the tensors, cout, fin.{partial, counter, sets} as the caller gave them;
+// partial_cap: doubles allocated for fin.partial (-1 = unchecked legacy entry point)
+int launch_conv1x1(mp_ctx *ctx, Conv1Args a, int f16, const float *wmax, long long partial_cap, hipStream_t st) {
+  if (a.c1 <= 0 || a.c1 % kC1K || a.c2 < 0 || a.c2 % kC1K || a.hw % kC1Px || (a.c2 > 0) != (a.x2 != nullptr) ||
+      (a.cout != 256 && a.cout != 128))
+    return fail(ctx, MP_ERR_UNSUPPORTED,
+                "conv1x1: needs C1, C2 multiples of 64, H*W a multiple of 64 and 128 or 256 output channels "
+                "(got %d + %d -> %d, %d)", a.c1, a.c2, a.cout, a.hw);
+  if (a.cout != 256 && (a.fin.partial || a.y_hwc))
+    return fail(ctx, MP_ERR_UNSUPPORTED, "conv1x1: statistics / channels-last output are built for 256 channels");
+  a.wp_floats = a.cout * (a.c1 + a.c2);
+  const int tiles = a.hw / kC1Px;
+  if (a.fin.partial) {
+    a.fin.c = a.cout;
+    a.fin.S = tiles;
+    a.fin.count = (double)(a.cout / 32) * a.hw;
+    if (partial_cap >= 0 && partial_cap < (long long)a.n_img * 32 * tiles * 2)
+      return fail(ctx, MP_ERR_ARG, "conv1x1: statistics buffer holds %lld doubles, the launch writes %lld",
+                  partial_cap, (long long)a.n_img * 32 * tiles * 2);
+    if (a.fin.n_sets < 0 || a.fin.n_sets > 2 || (a.fin.n_sets > 0 && !a.fin.counter))
+      return fail(ctx, MP_ERR_ARG, "conv1x1: bad GroupNorm consumer request");
+    for (int q = 0; q < a.fin.n_sets; ++q)
+      if (!a.fin.set[q].gamma || !a.fin.set[q].beta || !a.fin.set[q].ss)
+        return fail(ctx, MP_ERR_ARG, "conv1x1: GroupNorm consumer %d lacks gamma / beta / ss", q);
+  }
+  // two 32-row blocks per wave (one workgroup = all 256 rows of 64 pixels) unless that leaves slots
+  // empty: then one block per wave and the row halves as separate workgroups (blockIdx.y)
+  int mrw = a.cout == 256 && (long long)tiles * a.n_img >= 512 ? 2 : 1;
+  if (g_conv1_mrw > 0 && a.cout == 256) mrw = g_conv1_mrw;
+  const int lds = a.y_hwc ? kC1Px * 512 * mrw : 2 * kC1Px * kC1Row;
+  void (*kern)(Conv1Args, const float *) =
+      mrw == 2 ? (f16 ? conv1x1_kernel<true, 2> : conv1x1_kernel<false, 2>)
+               : (f16 ? conv1x1_kernel<true, 1> : conv1x1_kernel<false, 1>);
+  int rc = raise_lds_limit(ctx, reinterpret_cast<const void *>(kern), kC1Px * 1024);
+  if (rc != MP_OK) return rc;
+  const dim3 grid((unsigned)(tiles * a.n_img), (unsigned)(a.cout / (128 * mrw)));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, wmax);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+// legacy form: optional partial sums (finalised by mp_gn_finalize)
 int launch_conv1x1_raw(mp_ctx *ctx, const float *x1, const float *ss1, int relu1, const float *x2, int n,
                        int c1, int c2, int cout, long long hw, const void *wp, int f16, const float *wmax,
                        const float *bias, const float *res, float *y, float *y_hwc, double *stats,
                        hipStream_t st) {
-  if (c1 <= 0 || c1 % kC1K || c2 < 0 || c2 % kC1K || hw % kC1Px || (c2 > 0) != (x2 != nullptr) ||
-      (cout != 256 && cout != 128))
-    return fail(ctx, MP_ERR_UNSUPPORTED,
-                "conv1x1: needs C1, C2 multiples of 64, H*W a multiple of 64 and 128 or 256 output channels "
-                "(got %d + %d -> %d, %lld)", c1, c2, cout, hw);
-  if (cout != 256 && (stats || y_hwc))
-    return fail(ctx, MP_ERR_UNSUPPORTED, "conv1x1: statistics / channels-last output are built for 256 channels");
   Conv1Args a;
   a.x1 = x1;
   a.ss1 = ss1;
@@ -1075,31 +1385,15 @@ int launch_conv1x1_raw(mp_ctx *ctx, const float *x1, const float *ss1, int relu1
   a.res = res;
   a.y = y;
   a.y_hwc = y_hwc;
-  a.stats = stats;
+  a.fin = gn_fin_none();
+  a.fin.partial = stats;
   a.n_img = n;
   a.c1 = c1;
   a.c2 = c2;
   a.hw = (int)hw;
   a.relu1 = relu1;
-  a.wp_floats = cout * (c1 + c2);
   a.cout = cout;
-  return launch_conv1x1(ctx, a, f16, wmax, st);
-}
-
-static int launch_conv1x1(mp_ctx *ctx, const Conv1Args &a, int f16, const float *wmax, hipStream_t st) {
-  const int lds = a.y_hwc ? kC1Px * 1024 : 2 * kC1Px * kC1Row;
-  void (*kern)(Conv1Args, const float *) =
-      a.cout == 256 ? (f16 ? conv1x1_kernel<true, 2> : conv1x1_kernel<false, 2>)
-                    : (f16 ? conv1x1_kernel<true, 1> : conv1x1_kernel<false, 1>);
-  const void *kern_id = reinterpret_cast<const void *>(kern);
-  if (!ctx->lds_attr_done.count(kern_id)) {
-    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, kC1Px * 1024));
-    ctx->lds_attr_done.insert(kern_id);
-  }
-  const dim3 grid((unsigned)((a.hw / kC1Px) * a.n_img));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, wmax);
-  MP_HIP(ctx, hipGetLastError());
-  return MP_OK;
+  return launch_conv1x1(ctx, a, f16, wmax, -1, st);
 }
 
 }  // namespace mp

@@ -9,6 +9,7 @@
 // Both are HBM-bound: bytes moved = 3x (GroupNorm: two reads + one write) resp. ~2.5x
 // (upsample-add) the tensor size; measured against the ~6.3 TB/s achievable HBM rate.
 #include "mp_internal.h"
+#include "gn_tail.h"
 
 namespace mp {
 
@@ -138,6 +139,30 @@ __device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4]) {
   w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
 }
 
+// one output pixel (oy, ox) of plane `src` [h, w]
+__device__ __forceinline__ float bicubic2x_at(const float *__restrict__ src, int h, int w, float sy, float sx,
+                                              int oy, int ox) {
+  const float ry = sy * oy, rx = sx * ox;
+  const float fy = floorf(ry), fx = floorf(rx);
+  const int iy = (int)fy, ix = (int)fx;
+  float wy[4], wx[4];
+  cubic_coeffs(ry - fy, wy);
+  cubic_coeffs(rx - fx, wx);
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int yy = min(max(iy - 1 + j, 0), h - 1);
+    float row = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int xx = min(max(ix - 1 + i, 0), w - 1);
+      row += src[yy * w + xx] * wx[i];
+    }
+    acc += row * wy[j];
+  }
+  return acc;
+}
+
 __global__ __launch_bounds__(256) void upsample_bicubic2x_kernel(const float *__restrict__ x, int c,
                                                                  int h, int w,
                                                                  const float *__restrict__ add,
@@ -149,25 +174,7 @@ __global__ __launch_bounds__(256) void upsample_bicubic2x_kernel(const float *__
        t += (long long)gridDim.x * blockDim.x) {
     const int ox = (int)(t % wo), oy = (int)((t / wo) % ho);
     const long long ch = t / ((long long)wo * ho);
-    const float ry = sy * oy, rx = sx * ox;
-    const float fy = floorf(ry), fx = floorf(rx);
-    const int iy = (int)fy, ix = (int)fx;
-    float wy[4], wx[4];
-    cubic_coeffs(ry - fy, wy);
-    cubic_coeffs(rx - fx, wx);
-    const float *src = x + ch * (long long)h * w;
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int yy = min(max(iy - 1 + j, 0), h - 1);
-      float row = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int xx = min(max(ix - 1 + i, 0), w - 1);
-        row += src[yy * w + xx] * wx[i];
-      }
-      acc += row * wy[j];
-    }
+    const float acc = bicubic2x_at(x + ch * (long long)h * w, h, w, sy, sx, oy, ox);
     y[t] = add ? add[t] + acc : acc;
   }
 }
@@ -179,6 +186,174 @@ int launch_upsample_bicubic2x(mp_ctx *ctx, const float *x, int c, int h, int w, 
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(upsample_bicubic2x_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, c, h, w,
                      add, y);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+// ---- elementwise producers that take the GroupNorm statistics of what they write ----------------
+// The tensors between the convolutions (2x2 average pool, HGFilters.py:93 / :171; bicubic x2 + skip
+// add, :108-111; the stem's GroupNorm + ReLU, :168) feed a GroupNorm(32, C) next.  One pass writes
+// the tensor AND publishes its statistics (gn_tail.h): workgroup = (image, group, slice) -- a group
+// is C / 32 adjacent planes, contiguous in NCHW -- and the last of a group's kGnSlices workgroups
+// turns the sums into (scale, shift) for the consumer(s): no statistics pass, no finalize launch.
+// Op::run(gi, i) computes and stores the 4 consecutive outputs at float4 index i of (image, group)
+// gi (hw % 4 == 0: they share a plane) and returns them.
+template <class Op>
+__global__ __launch_bounds__(kGnThreads) void ew_gn_kernel(Op op, long long group_elems, GnFin fin) {
+  __shared__ __attribute__((aligned(16))) unsigned char tail[kGnTailLdsBytes];
+  __shared__ double w1[kGnThreads / 64], w2[kGnThreads / 64];
+  const int gi = blockIdx.x / kGnSlices, s = blockIdx.x % kGnSlices;
+  const long long per = (group_elems / 4 + kGnSlices - 1) / kGnSlices;  // float4 per slice
+  const long long v0 = s * per, v1 = min(v0 + per, group_elems / 4);
+  float s1 = 0.f, s2 = 0.f;
+  double d1 = 0.0, d2 = 0.0;
+  int k = 0;
+  for (long long i = v0 + threadIdx.x; i < v1; i += kGnThreads) {
+    const f32x4 v = op.run(gi, i, group_elems);
+    s1 += (v[0] + v[1]) + (v[2] + v[3]);
+    s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    if (++k == 64) {
+      d1 += s1;
+      d2 += s2;
+      s1 = s2 = 0.f;
+      k = 0;
+    }
+  }
+  if (!fin.partial) return;
+  d1 += s1;
+  d2 += s2;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    d1 += __shfl_down(d1, o);
+    d2 += __shfl_down(d2, o);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+    w1[wv] = d1;
+    w2[wv] = d2;
+  }
+  __syncthreads();
+  double a = 0, b = 0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kGnThreads / 64; ++i) {
+      a += w1[i];
+      b += w2[i];
+    }
+  gn_publish<kGnThreads>(fin, gi / 32, gi % 32, 1, s, gi, kGnSlices, a, b, tail);
+}
+
+struct AvgPool2Op {  // y [N*C, H/2, W/2] = avg_pool2d(x [N*C, H, W], 2, stride 2)
+  const float *x;
+  float *y;
+  int ho, wo;  // output size; wo % 4 == 0
+  __device__ __forceinline__ f32x4 run(int gi, long long i, long long group_elems) const {
+    const long long e = gi * group_elems + 4 * i;  // first output element
+    const long long plane = e / ((long long)ho * wo);
+    const int rem = (int)(e - plane * ho * wo);
+    const int oy = rem / wo, ox = rem - oy * wo;
+    const float *r0 = x + (plane * 2 * ho + 2 * oy) * (2LL * wo) + 2 * ox;
+    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(r0), a1 = *reinterpret_cast<const f32x4 *>(r0 + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(r0 + 2 * wo), b1 = *reinterpret_cast<const f32x4 *>(r0 + 2 * wo + 4);
+    f32x4 v;  // torch's order: the window row by row, then the division
+    v[0] = (((a0[0] + a0[1]) + b0[0]) + b0[1]) * 0.25f;
+    v[1] = (((a0[2] + a0[3]) + b0[2]) + b0[3]) * 0.25f;
+    v[2] = (((a1[0] + a1[1]) + b1[0]) + b1[1]) * 0.25f;
+    v[3] = (((a1[2] + a1[3]) + b1[2]) + b1[3]) * 0.25f;
+    *reinterpret_cast<f32x4 *>(y + e) = v;
+    return v;
+  }
+};
+
+struct UpsampleAddOp {  // y [N*C, 2H, 2W] = add + bicubic_x2(x [N*C, H, W])
+  const float *x, *add;
+  float *y;
+  int h, w;  // input size
+  float sy, sx;
+  __device__ __forceinline__ f32x4 run(int gi, long long i, long long group_elems) const {
+    const int ho = 2 * h, wo = 2 * w;
+    const long long e = gi * group_elems + 4 * i;
+    const long long plane = e / ((long long)ho * wo);
+    const int rem = (int)(e - plane * ho * wo);
+    const int oy = rem / wo, ox = rem - oy * wo;
+    const float *src = x + plane * (long long)h * w;
+    f32x4 v = add ? *reinterpret_cast<const f32x4 *>(add + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float up = bicubic2x_at(src, h, w, sy, sx, oy, ox + q);
+      v[q] = add ? v[q] + up : up;
+    }
+    *reinterpret_cast<f32x4 *>(y + e) = v;
+    return v;
+  }
+};
+
+struct GnApplyOp {  // y = relu?(x * scale[n,c] + shift[n,c]), x / y [N*C, HW], ss [N*C, 2]
+  const float *x, *ss;
+  float *y;
+  long long hw;
+  int relu;
+  __device__ __forceinline__ f32x4 run(int gi, long long i, long long group_elems) const {
+    const long long e = gi * group_elems + 4 * i;
+    const long long plane = e / hw;
+    const float sc = ss[2 * plane], sh = ss[2 * plane + 1];
+    f32x4 v = *reinterpret_cast<const f32x4 *>(x + e);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float o = v[q] * sc + sh;
+      v[q] = (relu && o < 0.f) ? 0.f : o;
+    }
+    *reinterpret_cast<f32x4 *>(y + e) = v;
+    return v;
+  }
+};
+
+static int check_fin(mp_ctx *ctx, GnFin &f, int n, int c, long long hw_out, long long partial_cap, const char *who) {
+  if (!f.partial) return MP_OK;
+  f.c = c;
+  f.S = kGnSlices;
+  f.count = (double)(c / 32) * hw_out;
+  if (partial_cap >= 0 && partial_cap < (long long)n * 32 * kGnSlices * 2)
+    return fail(ctx, MP_ERR_ARG, "%s: statistics buffer holds %lld doubles, the launch writes %lld", who,
+                partial_cap, (long long)n * 32 * kGnSlices * 2);
+  if (f.n_sets < 0 || f.n_sets > 2 || (f.n_sets > 0 && !f.counter))
+    return fail(ctx, MP_ERR_ARG, "%s: bad GroupNorm consumer request", who);
+  for (int q = 0; q < f.n_sets; ++q)
+    if (!f.set[q].gamma || !f.set[q].beta || !f.set[q].ss)
+      return fail(ctx, MP_ERR_ARG, "%s: GroupNorm consumer %d lacks gamma / beta / ss", who, q);
+  return MP_OK;
+}
+
+int launch_avgpool2_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, float *y, GnFin fin,
+                       long long partial_cap, hipStream_t st) {
+  const long long hw_out = (long long)(h / 2) * (w / 2);
+  int rc = check_fin(ctx, fin, n, c, hw_out, partial_cap, "avgpool2_gn");
+  if (rc != MP_OK) return rc;
+  AvgPool2Op op{x, y, h / 2, w / 2};
+  hipLaunchKernelGGL(ew_gn_kernel<AvgPool2Op>, dim3(n * 32 * kGnSlices), dim3(kGnThreads), 0, st, op,
+                     (long long)(c / 32) * hw_out, fin);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+int launch_upsample_add_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, const float *add, float *y,
+                           GnFin fin, long long partial_cap, hipStream_t st) {
+  const long long hw_out = 4LL * h * w;
+  int rc = check_fin(ctx, fin, n, c, hw_out, partial_cap, "upsample_add_gn");
+  if (rc != MP_OK) return rc;
+  UpsampleAddOp op{x, add, y, h, w, (float)(h - 1) / (float)(2 * h - 1), (float)(w - 1) / (float)(2 * w - 1)};
+  hipLaunchKernelGGL(ew_gn_kernel<UpsampleAddOp>, dim3(n * 32 * kGnSlices), dim3(kGnThreads), 0, st, op,
+                     (long long)(c / 32) * hw_out, fin);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+int launch_gn_apply_gn(mp_ctx *ctx, const float *x, const float *ss, int relu, int n, int c, long long hw,
+                       float *y, GnFin fin, long long partial_cap, hipStream_t st) {
+  int rc = check_fin(ctx, fin, n, c, hw, partial_cap, "gn_apply_gn");
+  if (rc != MP_OK) return rc;
+  GnApplyOp op{x, ss, y, hw, relu};
+  hipLaunchKernelGGL(ew_gn_kernel<GnApplyOp>, dim3(n * 32 * kGnSlices), dim3(kGnThreads), 0, st, op,
+                     (long long)(c / 32) * hw, fin);
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
 }

@@ -30,6 +30,10 @@ ENCODER_CONV_MIN_H = int(os.environ.get("MONOPORT_ENCODER_CONV_MIN_H", "32"))
 # operand split into two halves, three MFMAs per product term, f32 accumulation -- the encoder-side
 # counterpart of SurfaceClassifier.set_precision("f16x3"))
 ENCODER_CONV_PRECISION = os.environ.get("MONOPORT_ENCODER_CONV_PRECISION", "f32")
+# "on" (default): the whole encoder runs as a chain of hand-written kernels with every GroupNorm handed
+# from the kernel that writes a tensor to the kernel that reads it (csrc/gn_tail.h); "off": round 2's
+# per-module fused kernels with stand-alone statistics / finalize launches and the MIOpen stem
+ENCODER_DATAFLOW = os.environ.get("MONOPORT_ENCODER_DATAFLOW", "on")
 
 
 def set_encoder_conv_precision(precision):
@@ -101,6 +105,50 @@ def _packed_conv(owner, conv):
     return hit[1]
 
 
+def _inference_only(*tensors_or_modules):
+    """The ctypes kernels return tensors without a grad_fn: take them only when nothing asks for
+    gradients (eval mode with autograd on -- saliency, fine-tuning with frozen statistics -- keeps the
+    differentiable PyTorch ops, as the reference modules would)."""
+    if not torch.is_grad_enabled():
+        return True
+    for t in tensors_or_modules:
+        if isinstance(t, nn.Module):
+            if any(p.requires_grad for p in t.parameters()):
+                return False
+        elif t is not None and t.requires_grad:
+            return False
+    return True
+
+
+def _pow2(v):
+    return v > 0 and (v & (v - 1)) == 0
+
+
+def _block_dataflow(blk, x, ss1, ss4=None, out_consumers=()):
+    """ConvBlock (HGFilters.py:40-62) as three launches of csrc/conv3x3.hip (+ one 1x1 launch for a
+    projection shortcut) and nothing else: every GroupNorm is handed from the kernel that writes a
+    tensor to the kernel that reads it (``ss1`` / ``ss4``: (scale, shift) of blk.bn1 / blk.bn4 over
+    x, published by x's producer), and torch.cat((out1, out2, out3), 1) + residual is written by the
+    three epilogues.  ``out_consumers``: GroupNorm modules that read the block's output.
+    Returns (out, [ss per consumer])."""
+    n, c_in, h, w = x.shape
+    ca, cb, cc = blk.conv1.out_channels, blk.conv2.out_channels, blk.conv3.out_channels
+    if blk.downsample is None:
+        shortcut = x
+    else:
+        shortcut, _ = ops.conv1x1_fused(x, ss4, True, None, blk._packed_projection())
+    out = torch.empty((n, ca + cb + cc, h, w), dtype=torch.float32, device=x.device)
+    oc = list(out_consumers)
+    out_ss = [torch.empty((n, ca + cb + cc, 2), dtype=torch.float32, device=x.device) for _ in oc]
+    a, ss_a, _ = ops.conv3x3_fused(x, ss1, blk._packed(blk.conv1), consumers=[blk.bn2], out=out, res=shortcut,
+                                   out_off=0, out_consumers=oc, out_ss=out_ss)
+    b, ss_b, _ = ops.conv3x3_fused(a, ss_a[0], blk._packed(blk.conv2), consumers=[blk.bn3], out=out, res=shortcut,
+                                   out_off=ca, out_consumers=oc, out_ss=out_ss)
+    ops.conv3x3_fused(b, ss_b[0], blk._packed(blk.conv3), want_y=False, out=out, res=shortcut, out_off=ca + cb,
+                      out_consumers=oc, out_ss=out_ss)
+    return out, out_ss
+
+
 class ConvBlock(nn.Module):
     """Pre-activation pyramid block: three GN-ReLU-3x3 convs of widths C/2, C/4, C/4 whose
     outputs are concatenated and added to a (projected) shortcut (HGFilters.py:12-62)."""
@@ -126,6 +174,8 @@ class ConvBlock(nn.Module):
 
     def _fused_ok(self, x):
         if self.training or ENCODER_CONV != "hip" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+            return False
+        if not _inference_only(x, self):
             return False
         h, w = x.shape[2], x.shape[3]
         min_h = ENCODER_CONV_MIN_H if ENCODER_CONV_PRECISION == "f32" else min(ENCODER_CONV_MIN_H, 32)
@@ -211,6 +261,27 @@ class HourGlass(nn.Module):
     def forward(self, x):
         return self._level(self.depth, x)
 
+    def first_norm(self):
+        """The GroupNorm that reads the hourglass input first (b1 of the outermost level)."""
+        return getattr(self, "b1_%d" % self.depth).bn1
+
+    def _level_dataflow(self, level, x, ss_b1, next_gn):
+        """_level on the hand-over kernels: ``ss_b1`` = (scale, shift) of b1_level.bn1 over x from x's
+        producer; the returned tensor carries the statistics for ``next_gn`` (b3 of the enclosing
+        level, or top_m).  Same evaluation order as HGFilters.py:87-111."""
+        b1, b2, b3 = (getattr(self, "b%d_%d" % (k, level)) for k in (1, 2, 3))
+        skip, _ = _block_dataflow(b1, x, ss_b1)
+        pooled, ss_p = ops.avgpool2_gn(x, [b2.bn1])
+        if level > 1:
+            inner = getattr(self, "b1_%d" % (level - 1))
+            y, ss_y = _block_dataflow(b2, pooled, ss_p[0], out_consumers=[inner.bn1])
+            y, ss_y = self._level_dataflow(level - 1, y, ss_y[0], b3.bn1)
+        else:
+            y, ss_y = _block_dataflow(b2, pooled, ss_p[0], out_consumers=[self.b2_plus_1.bn1])
+            y, ss_y = _block_dataflow(self.b2_plus_1, y, ss_y[0], out_consumers=[b3.bn1])
+        y, _ = _block_dataflow(b3, y, ss_y[0])
+        return ops.upsample_add_gn(y, skip, [next_gn])
+
 
 class HGFilter(nn.Module):
     """Stacked-hourglass encoder: [B,3,512,512] -> num_stack x ([B,256,128,128],)
@@ -271,12 +342,64 @@ class HGFilter(nn.Module):
             x, _ = ops.conv1x1(t, ss, True, out, packs[2], res=x)
         return out, x
 
+    def _dataflow_ok(self, x):
+        """The whole encoder on the hand-over kernels: inference, f32 images whose maps are powers of
+        two down to 32 x 32 at the bottom of the hourglass (512 x 512 and up)."""
+        if self.training or ENCODER_CONV != "hip" or ENCODER_DATAFLOW != "on" or not x.is_cuda:
+            return False
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3 or not _inference_only(x, self):
+            return False
+        h, w = x.shape[2], x.shape[3]
+        depth = self.m0.depth
+        return (_pow2(h) and _pow2(w) and (h >> (2 + depth)) >= 8 and (w >> (2 + depth)) >= 32
+                and ops.convk_supported(3, 64, 7, 2, h, w))
+
+    def _stem_packed(self):
+        cache = self.__dict__.setdefault("_tail_cache", {})
+        w, b = self.conv1.weight, self.conv1.bias
+        key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+        hit = cache.get("stem")
+        if hit is None or hit[0] != key:
+            hit = (key, ops.PackedConvK(w, b))
+            cache["stem"] = hit
+        return hit[1]
+
+    def _forward_dataflow(self, x, last_only, hwc_out, keep_nchw):
+        """HGFilters.py:167-204 as a chain of hand-written kernels only (no MIOpen / torch op): stem
+        7x7 (csrc/convim2col.hip) -> GroupNorm + ReLU -> pyramid blocks / hourglasses / 1x1 tails, with
+        every GroupNorm handed from producer to consumer (csrc/gn_tail.h)."""
+        c2, c3, c4 = self.conv2, self.conv3, self.conv4
+        t, ss = ops.convk(x, None, False, self._stem_packed(), 2, consumers=[self.bn1])
+        x, ss = ops.gn_apply(t, ss[0], True, consumers=[c2.bn1, c2.bn4])
+        y, _ = _block_dataflow(c2, x, ss[0], ss[1])
+        y, ss = ops.avgpool2_gn(y, [c3.bn1])
+        y, ss = _block_dataflow(c3, y, ss[0], out_consumers=[c4.bn1, c4.bn4])
+        x, ss_x = _block_dataflow(c4, y, ss[0], ss[1], out_consumers=[self.m0.first_norm()])
+        outputs = []
+        for i in range(self.num_stack):
+            hg, top = getattr(self, "m%d" % i), getattr(self, "top_m_%d" % i)
+            last = i == self.num_stack - 1
+            y, ss_y = hg._level_dataflow(hg.depth, x, ss_x[0], top.bn1)
+            y, _ = _block_dataflow(top, y, ss_y[0])
+            packs = self._tail_packed(i)
+            t, ss_t = ops.conv1x1_fused(y, None, False, None, packs[0], consumers=[getattr(self, "bn_end%d" % i)])
+            want_nchw = not last or keep_nchw or not (last_only and hwc_out is not None)
+            out, _ = ops.conv1x1_fused(t, ss_t[0], True, None, packs[1], want_nchw=want_nchw,
+                                       y_hwc=hwc_out if last else None)
+            outputs.append((out,))
+            if not last:
+                nxt = getattr(self, "m%d" % (i + 1)).first_norm()
+                x, ss_x = ops.conv1x1_fused(t, ss_t[0], True, out, packs[2], res=x, consumers=[nxt])
+        return outputs[-1:] if last_only else outputs
+
     def forward(self, x, last_only=False, hwc_out=None, keep_nchw=False):
         """``last_only=True`` skips materialising the per-stack outputs nobody reads in eval mode
         (MonoPortNet.py:63-64 keeps feats_stages[-1] only); the default matches the reference.
         ``hwc_out`` ([B,H,W,256], fused path only): the LAST stack's features are written there in
         channels-last layout by the producing kernel (no NCHW -> HWC pass); with ``last_only`` the
         NCHW copy is then skipped and the returned entry is None, unless ``keep_nchw``."""
+        if self._dataflow_ok(x):
+            return self._forward_dataflow(x.contiguous(), last_only, hwc_out, keep_nchw)
         x = self.bn1(self.conv1(x), relu=True)
         x = F.avg_pool2d(self.conv2(x), 2, stride=2)
         x = self.conv4(self.conv3(x))
@@ -319,6 +442,8 @@ class _ResBlock(nn.Module):
     def _fused_ok(self, x):
         if self.training or ENCODER_CONV != "hip" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
             return False
+        if not _inference_only(x, self):
+            return False
         c = self.conv_block[1]
         return (x.shape[2] * x.shape[3]) % 4 == 0 and ops.conv3x3_supported(c.in_channels, c.out_channels,
                                                                            x.shape[2], x.shape[3])
@@ -338,6 +463,17 @@ class _ResBlock(nn.Module):
             return x + u
         ss = ops.gn_finalize(st, n, c, _GROUPS, (c // _GROUPS) * h * w, blk[6].weight, blk[6].bias, blk[6].eps)
         return ops.scale_shift_add(u, ss, x)
+
+    def _forward_dataflow(self, x):
+        """_forward_fused with the GroupNorms handed over inside the convolution kernels (no
+        finalize launches)."""
+        blk = self.conv_block
+        last = len(blk) == 6
+        t, ss, _ = ops.conv3x3_fused(x, None, _packed_conv(self, blk[1]), relu=False, reflect=True,
+                                     consumers=[blk[2]])
+        u, ss_u, _ = ops.conv3x3_fused(t, ss[0], _packed_conv(self, blk[5]), relu=True, reflect=True,
+                                       consumers=[] if last else [blk[6]])
+        return x + u if last else ops.scale_shift_add(u, ss_u[0], x)
 
     def forward(self, x):
         if self._fused_ok(x):
@@ -360,7 +496,47 @@ class ResnetFilter(nn.Module):
             layers.append(_ResBlock(ch, last=(i == n_blocks - 1)))
         self.model = nn.Sequential(*layers)
 
+    def _dataflow_ok(self, x):
+        if self.training or ENCODER_CONV != "hip" or ENCODER_DATAFLOW != "on" or not x.is_cuda:
+            return False
+        if x.dtype != torch.float32 or x.dim() != 4 or not _inference_only(x, self):
+            return False
+        m = self.model
+        if not (len(m) >= 11 and isinstance(m[1], nn.Conv2d) and m[1].kernel_size == (7, 7)
+                and m[1].in_channels == 3 and m[1].bias is None):
+            return False
+        h, w = x.shape[2], x.shape[3]
+        return (_pow2(h) and _pow2(w) and h >= 32 and w >= 256
+                and ops.convk_supported(3, m[1].out_channels, 7, 1, h, w)
+                and ops.convk_supported(m[4].in_channels, m[4].out_channels, 3, 2, h, w)
+                and ops.convk_supported(m[7].in_channels, m[7].out_channels, 3, 2, h // 2, w // 2))
+
+    def _packed_k(self, conv):
+        cache = self.__dict__.setdefault("_packed_cache", {})
+        w = conv.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.PackedConvK(w, conv.bias))
+            cache[id(conv)] = hit
+        return hit[1]
+
+    def _forward_dataflow(self, x):
+        """ResBlkFilters.py:111-139 on hand-written kernels only: reflect-padded 7x7 and the two
+        stride-2 convolutions on csrc/convim2col.hip (each applies the previous GroupNorm + ReLU while
+        it gathers its input and hands its own statistics on), then the residual blocks."""
+        m = self.model
+        t, ss = ops.convk(x, None, False, self._packed_k(m[1]), 1, reflect=True, consumers=[m[2]])
+        t, ss = ops.convk(t, ss[0], True, self._packed_k(m[4]), 2, consumers=[m[5]])
+        t, ss = ops.convk(t, ss[0], True, self._packed_k(m[7]), 2, consumers=[m[8]])
+        x, _ = ops.gn_apply(t, ss[0], True)
+        for blk in list(m)[10:]:
+            x = blk._forward_dataflow(x)
+        return [(x,)]
+
     def forward(self, x):
+        if self._dataflow_ok(x):
+            return self._forward_dataflow(x.contiguous())
         return [(_run_sequential(self.model, x),)]
 
 

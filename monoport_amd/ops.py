@@ -439,6 +439,8 @@ def stream_release(stream):
     ctx = get_context(stream.device)
     ctx.check(ctx.lib.mp_stream_release(ctx.handle, ctypes.c_void_p(stream.cuda_stream)),
               "mp_stream_release")
+    with _counter_lock:
+        _counter_cache.pop((ctx.device_index, stream.cuda_stream), None)
 
 
 def forward_vertices_raw(volume, direction="front"):
@@ -715,7 +717,7 @@ def conv1x1(x1, ss1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=None, wa
     y = torch.empty((n, packed.cout, h, w), dtype=torch.float32, device=x1.device) if want_nchw else None
     stats = None
     if want_stats:
-        s = (hw // 64) * 8
+        s = ctx.lib.mp_conv1x1_stat_slices(hw)
         stats = (torch.empty((n, 32, s, 2), dtype=torch.float64, device=x1.device), s)
     if y_hwc is not None:
         assert y_hwc.is_contiguous() and y_hwc.numel() == n * hw * 256 and y_hwc.dtype == torch.float32
@@ -751,6 +753,220 @@ def gn_finalize(stats, n, c, groups, count, weight, bias, eps):
                                      int(count), _ptr(weight), _ptr(bias), float(eps), _ptr(ss),
                                      _stream(partial)), "mp_gn_finalize")
     return ss
+
+
+# ---- GroupNorm hand-over: statistics taken by the producing kernel (include/monoport_hip.h) ----
+_counter_cache = {}
+_counter_lock = threading.Lock()
+_COUNTER_ROWS = 2          # fin / fin2 of one launch need separate counters
+_COUNTER_IMAGES = 64
+
+
+def _counters(device, n):
+    """Zero-initialised arrival counters int32 [2, >= n * 32] for the caller's current stream; the
+    kernels leave them zero, so one buffer per (device, stream) serves every launch."""
+    stream = torch.cuda.current_stream(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream.cuda_stream)
+    need = max(n, _COUNTER_IMAGES) * 32
+    with _counter_lock:
+        buf = _counter_cache.get(key)
+        if buf is None or buf.shape[1] < need:
+            buf = torch.zeros((_COUNTER_ROWS, need), dtype=torch.int32, device=device)
+            _counter_cache[key] = buf
+    return buf
+
+
+def _gn_fin(fin, device, n, c, slices, consumers, ss_out=None, row=0, keep=None):
+    """Fill a _lib.GnFin for ``consumers`` (GroupNorm modules reading the tensor a kernel is about to
+    write; [] = no statistics).  Returns the list of ss tensors [N,C,2] (``ss_out`` when given:
+    several launches fill channel ranges of the same tensors)."""
+    if not consumers:
+        fin.partial = None
+        fin.n_sets = 0
+        return []
+    if len(consumers) > 2:
+        raise ValueError("at most two GroupNorm consumers per tensor")
+    partial = torch.empty((n * 32 * slices * 2,), dtype=torch.float64, device=device)
+    fin.partial = partial.data_ptr()
+    fin.partial_doubles = partial.numel()
+    fin.counters = _counters(device, n)[row].data_ptr()
+    fin.n_sets = len(consumers)
+    ss = ss_out if ss_out is not None else [torch.empty((n, c, 2), dtype=torch.float32, device=device)
+                                            for _ in consumers]
+    for k, gn in enumerate(consumers):
+        if gn.num_groups != 32 or gn.num_channels != c:
+            raise ValueError("consumer GroupNorm(%d, %d) does not match a %d-channel tensor"
+                             % (gn.num_groups, gn.num_channels, c))
+        fin.gamma[k] = gn.weight.data_ptr()
+        fin.beta[k] = gn.bias.data_ptr()
+        fin.eps[k] = float(gn.eps)
+        fin.ss[k] = ss[k].data_ptr()
+    if keep is not None:
+        keep.append(partial)
+    return ss
+
+
+def conv3x3_fused(x, ss, packed, relu=True, reflect=False, want_y=True, consumers=(), out=None, res=None,
+                  out_off=0, out_consumers=(), out_ss=None):
+    """mp_conv3x3_ex: y = conv3x3(relu?(x * scale + shift)) with the hand-over to the next GroupNorm(s)
+    and, optionally, the pyramid block's tail fused into the epilogue.
+      consumers      GroupNorm modules that read y           -> their ss (list)
+      out, res       [N,Ctot,H,W]: out[:, out_off:out_off+Cout] = y + res[:, same]  (cat + residual)
+      out_consumers  GroupNorm(32, Ctot) modules that read ``out``; out_ss: their ss tensors, shared
+                     by the launches that fill ``out``
+    Returns (y or None, ss list, out_ss list)."""
+    ctx = get_context(x.device)
+    n, cin, h, w = x.shape
+    if cin != packed.cin:
+        raise ValueError("conv3x3: input has %d channels, weights expect %d" % (cin, packed.cin))
+    a = _lib.Conv3x3Args()
+    keep = []
+    y = torch.empty((n, packed.cout, h, w), dtype=torch.float32, device=x.device) if want_y else None
+    f16 = packed.precision == "f16x3"
+    slices = ctx.lib.mp_conv3x3_stat_slices(packed.cout, n, h, w, int(f16))
+    ss_y = _gn_fin(a.fin, x.device, n, packed.cout, slices, list(consumers), row=0, keep=keep)
+    ss_o = []
+    if out is not None:
+        ss_o = _gn_fin(a.fin2, x.device, n, out.shape[1], slices, list(out_consumers), ss_out=out_ss, row=1,
+                       keep=keep)
+        a.y2, a.res = out.data_ptr(), res.data_ptr()
+        a.y2_channels, a.y2_offset = out.shape[1], int(out_off)
+        assert out.is_contiguous() and res.is_contiguous() and out.shape == res.shape
+    a.x, a.n, a.cin, a.h, a.w = x.data_ptr(), n, cin, h, w
+    a.ss = ss.data_ptr() if ss is not None else None
+    a.relu, a.reflect = int(bool(relu)), int(bool(reflect))
+    a.packed = packed.data.data_ptr()
+    a.wmax = packed.wmax.data_ptr() if f16 else None
+    a.cout = packed.cout
+    a.y = y.data_ptr() if y is not None else None
+    ctx.check(ctx.lib.mp_conv3x3_ex(ctx.handle, ctypes.byref(a), _stream(x)), "mp_conv3x3_ex")
+    return y, ss_y, ss_o
+
+
+def conv1x1_fused(x1, ss1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=None, consumers=()):
+    """mp_conv1x1_ex: ``conv1x1`` with the hand-over to the GroupNorm(s) that read the output.
+    Returns (y or None, ss list)."""
+    ctx = get_context(x1.device)
+    x1 = x1.contiguous()
+    n, c1, h, w = x1.shape
+    hw = h * w
+    if c1 != packed.c1 or (x2 is None) != (packed.c2 == 0) or (x2 is not None and x2.shape[1] != packed.c2):
+        raise ValueError("conv1x1: inputs do not match the packed weights")
+    a = _lib.Conv1x1Args()
+    keep = []
+    y = torch.empty((n, packed.cout, h, w), dtype=torch.float32, device=x1.device) if want_nchw else None
+    ss = _gn_fin(a.fin, x1.device, n, packed.cout, ctx.lib.mp_conv1x1_stat_slices(hw), list(consumers), keep=keep)
+    if y_hwc is not None:
+        assert y_hwc.is_contiguous() and y_hwc.numel() == n * hw * 256 and y_hwc.dtype == torch.float32
+    a.x1 = x1.data_ptr()
+    a.ss1 = ss1.data_ptr() if ss1 is not None else None
+    a.relu1 = int(bool(relu1))
+    if x2 is not None:
+        x2 = x2.contiguous()
+        a.x2 = x2.data_ptr()
+    if res is not None:
+        res = res.contiguous()
+        a.res = res.data_ptr()
+    a.n, a.c1, a.c2, a.cout, a.hw = n, c1, packed.c2, packed.cout, hw
+    a.packed = packed.data.data_ptr()
+    a.f16 = int(packed.precision == "f16x3")
+    a.wmax = packed.wmax.data_ptr()
+    a.bias = packed.bias.data_ptr() if packed.bias is not None else None
+    a.y = y.data_ptr() if y is not None else None
+    a.y_hwc = y_hwc.data_ptr() if y_hwc is not None else None
+    ctx.check(ctx.lib.mp_conv1x1_ex(ctx.handle, ctypes.byref(a), _stream(x1)), "mp_conv1x1_ex")
+    return y, ss
+
+
+class PackedConvK:
+    """Weights of a 7x7 (3 -> 64) or 3x3 stride-2 convolution in the fragment order of
+    csrc/convim2col.hip (mp_convk_pack); ``bias`` may be None."""
+
+    def __init__(self, weight, bias=None):
+        w = _f32c(weight.detach())
+        self.cout, self.cin, self.ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+        ctx = get_context(w.device)
+        n = ctx.lib.mp_convk_packed_floats(self.cin, self.cout, self.ks)
+        if n <= 0 or w.shape[2] != w.shape[3]:
+            raise ValueError("PackedConvK: unsupported weight %s" % (tuple(w.shape),))
+        self.data = torch.empty((n,), dtype=torch.float32, device=w.device)
+        self.bias = None if bias is None else _f32c(bias.detach())
+        ctx.check(ctx.lib.mp_convk_pack(ctx.handle, _ptr(w), self.cout, self.cin, self.ks, _ptr(self.data),
+                                        _stream(w)), "mp_convk_pack")
+        w.record_stream(torch.cuda.current_stream(w.device))
+
+
+def convk_supported(cin, cout, ks, stride, h, w):
+    return bool(_lib.load().mp_convk_supported(int(cin), int(cout), int(ks), int(stride), int(h), int(w)))
+
+
+def convk(x, ss, relu, packed, stride, reflect=False, consumers=()):
+    """mp_convk: y = conv_ks(relu?(x * scale + shift)) (+ bias), stride 1 / 2, padding ks // 2 (zero or
+    reflect) with the hand-over to the GroupNorm(s) reading y.  Returns (y, ss list)."""
+    ctx = get_context(x.device)
+    x = x.contiguous()
+    n, cin, h, w = x.shape
+    a = _lib.ConvKArgs()
+    keep = []
+    y = torch.empty((n, packed.cout, h // stride, w // stride), dtype=torch.float32, device=x.device)
+    sl = ctx.lib.mp_convk_stat_slices(packed.ks, stride, h, w)
+    ss_y = _gn_fin(a.fin, x.device, n, packed.cout, sl, list(consumers), keep=keep)
+    a.x, a.n, a.cin, a.h, a.w = x.data_ptr(), n, cin, h, w
+    a.ss = ss.data_ptr() if ss is not None else None
+    a.relu, a.reflect = int(bool(relu)), int(bool(reflect))
+    a.packed = packed.data.data_ptr()
+    a.bias = packed.bias.data_ptr() if packed.bias is not None else None
+    a.cout, a.ks, a.stride = packed.cout, packed.ks, int(stride)
+    a.y = y.data_ptr()
+    ctx.check(ctx.lib.mp_convk(ctx.handle, ctypes.byref(a), _stream(x)), "mp_convk")
+    return y, ss_y
+
+
+def _ew_fin(x, n, c, consumers):
+    fin = _lib.GnFin()
+    keep = []
+    ss = _gn_fin(fin, x.device, n, c, get_context(x.device).lib.mp_gn_stat_slices(), list(consumers), keep=keep)
+    return fin, ss, keep
+
+
+def avgpool2_gn(x, consumers=()):
+    """F.avg_pool2d(x, 2, stride=2) + the statistics for the GroupNorm(s) that read it -> (y, ss list)."""
+    ctx = get_context(x.device)
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    fin, ss, keep = _ew_fin(x, n, c, consumers)
+    ctx.check(ctx.lib.mp_avgpool2_gn(ctx.handle, _ptr(x), n, c, h, w, _ptr(y), ctypes.byref(fin), _stream(x)),
+              "mp_avgpool2_gn")
+    return y, ss
+
+
+def upsample_add_gn(x, add, consumers=()):
+    """add + bicubic x2 of x (HGFilters.py:108-111) + statistics hand-over -> (y, ss list)."""
+    ctx = get_context(x.device)
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    if add is not None:
+        add = add.contiguous()
+    fin, ss, keep = _ew_fin(x, n, c, consumers)
+    ctx.check(ctx.lib.mp_upsample_bicubic2x_gn(ctx.handle, _ptr(x), n, c, h, w,
+                                               _ptr(add) if add is not None else None, _ptr(y),
+                                               ctypes.byref(fin), _stream(x)), "mp_upsample_bicubic2x_gn")
+    return y, ss
+
+
+def gn_apply(x, ss, relu=True, consumers=()):
+    """relu?(x * scale + shift) materialised (+ statistics hand-over of the result) -> (y, ss list)."""
+    ctx = get_context(x.device)
+    x = x.contiguous()
+    n, c = x.shape[0], x.shape[1]
+    hw = x.shape[2] * x.shape[3]
+    y = torch.empty_like(x)
+    fin, ss_y, keep = _ew_fin(x, n, c, consumers)
+    ctx.check(ctx.lib.mp_gn_apply(ctx.handle, _ptr(x), _ptr(ss), int(bool(relu)), n, c, hw, _ptr(y),
+                                  ctypes.byref(fin), _stream(x)), "mp_gn_apply")
+    return y, ss_y
 
 
 def profile_begin(device, max_records=4096):

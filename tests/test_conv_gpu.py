@@ -152,7 +152,8 @@ def test_conv3x3_f16x3_is_f32_class(n, cin, cout, h, w):
     print("conv f16x3 %s: |f16x3 - f64| %.3g, |f32 - f64| %.3g, |f16x3 - f32| %.3g"
           % ((n, cin, cout, h, w), e16, e32, (y16 - y32).abs().max().item()))
     assert e16 <= 2e-5 * max(1.0, ref.abs().max().item())
-    assert (st16[0] - st32[0]).abs().max().item() <= 1e-2  # sums over 128 values of O(1) numbers
+    # the two kernels may tile the launch differently (different slot counts): compare the sums per group
+    assert (st16[0].sum(2) - st32[0].sum(2)).abs().max().item() <= 1e-2 * st32[1]
 
 
 def test_encoder_f16x3_convs_vs_reference_golden(monkeypatch):

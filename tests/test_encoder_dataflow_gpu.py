@@ -1,0 +1,315 @@
+"""Round 3: GroupNorm hand-over inside the producing kernels (csrc/gn_tail.h), the pyramid block's
+cat + residual written by the convolution epilogues, the split-K 3x3 kernel for small launches, the
+im2col kernel for the stems / stride-2 convolutions (csrc/convim2col.hip) and the encoders built from
+them -- against stock PyTorch ops in fp64 and the REFERENCE's encoder goldens.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from monoport_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+DEV = "cuda:0"
+
+
+def _gn(c, seed):
+    g = torch.Generator().manual_seed(seed)
+    gn = torch.nn.GroupNorm(32, c)
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        gn.bias.copy_(torch.rand(c, generator=g) - 0.5)
+    return gn.to(DEV)
+
+
+def _ss_ref(t, gn):
+    """(scale, shift) of GroupNorm gn over t [N,C,H,W], from the definition, in fp64."""
+    n, c = t.shape[0], t.shape[1]
+    tg = t.double().reshape(n, 32, -1)
+    mean, var = tg.mean(2), tg.var(2, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + gn.eps)
+    cpg = c // 32
+    sc = (rstd[:, :, None] * gn.weight.double().reshape(1, 32, cpg)).reshape(n, c)
+    sh = gn.bias.double()[None] - mean[:, :, None].expand(-1, -1, cpg).reshape(n, c) * sc
+    return torch.stack((sc, sh), 2)
+
+
+def _check_ss(ss, t, gn, what, tol=2e-5):
+    ref = _ss_ref(t, gn)
+    err = (ss.double() - ref).abs().max().item()
+    assert ss.shape == ref.shape and err <= tol * max(1.0, ref.abs().max().item()), "%s: ss off by %g" % (what, err)
+
+
+def _counters_clean():
+    from monoport_amd import ops
+    torch.cuda.synchronize()
+    return all(int(buf.abs().sum().item()) == 0 for buf in ops._counter_cache.values())
+
+
+# (N, Cin, Cout, H, W, Ctot, off): Ctot / off = the pyramid block this convolution fills
+CASES = [(1, 256, 128, 128, 128, 256, 0), (1, 128, 64, 128, 128, 256, 128), (1, 64, 64, 128, 128, 256, 192),
+         (1, 256, 128, 64, 64, 256, 0), (1, 128, 64, 32, 32, 256, 128), (2, 64, 64, 32, 32, 256, 192),
+         (1, 64, 32, 256, 256, 128, 64), (1, 32, 32, 256, 256, 128, 96), (3, 256, 128, 32, 32, 256, 0),
+         (10, 128, 64, 64, 64, 256, 128), (1, 16, 32, 32, 32, 128, 32)]
+
+
+@pytest.mark.parametrize("mode", ["auto", "large", "splitk"])
+@pytest.mark.parametrize("n,cin,cout,h,w,ctot,off", CASES)
+def test_conv3x3_fused_handover_and_tail(mode, n, cin, cout, h, w, ctot, off):
+    from monoport_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(cin * 7 + cout + h + n)
+    x = (torch.randn((n, cin, h, w), generator=g) * 2 + 0.3).to(DEV)
+    res = torch.randn((n, ctot, h, w), generator=g).to(DEV)
+    wt = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).to(DEV)
+    gn_in = _gn(cin, 1) if cin % 32 == 0 else None
+    gn_y, gn_o1, gn_o2 = _gn(cout, 2), _gn(ctot, 3), _gn(ctot, 4)
+    ss_in = _ss_ref(x, gn_in).float() if gn_in is not None else None
+    packed = ops.PackedConv3x3(wt)
+    out = torch.full((n, ctot, h, w), 7.0, device=DEV)
+    out_ss = [torch.full((n, ctot, 2), 9.0, device=DEV) for _ in range(2)]
+    lib.mp_conv3x3_tune({"auto": 0, "large": 0x100, "splitk": 0x200}[mode])
+    try:
+        y, ss_y, ss_o = ops.conv3x3_fused(x, ss_in, packed, relu=gn_in is not None, consumers=[gn_y], out=out,
+                                          res=res, out_off=off, out_consumers=[gn_o1, gn_o2], out_ss=out_ss)
+        y2, ss_y2, _ = ops.conv3x3_fused(x, ss_in, packed, relu=gn_in is not None, consumers=[gn_y], out=out.clone(),
+                                         res=res, out_off=off, out_consumers=[gn_o1, gn_o2],
+                                         out_ss=[t.clone() for t in out_ss])
+    finally:
+        lib.mp_conv3x3_tune(0)
+    with torch.no_grad():
+        v = x.double()
+        if gn_in is not None:
+            v = torch.relu(v * ss_in[..., 0, None, None].double() + ss_in[..., 1, None, None].double())
+        ref = torch.nn.functional.conv2d(v, wt.double(), padding=1)
+    err = (y.double() - ref).abs().max().item()
+    print("conv3x3_fused %s %s: max|d| %.3g" % (mode, (n, cin, cout, h, w), err))
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(y, y2) and torch.equal(ss_y[0], ss_y2[0])            # deterministic
+    _check_ss(ss_y[0], y, gn_y, "raw output")
+    # the block tail: this launch's channels of cat + residual, everything else untouched
+    assert torch.equal(out[:, off:off + cout], y + res[:, off:off + cout])
+    untouched = torch.ones(ctot, dtype=torch.bool)
+    untouched[off:off + cout] = False
+    assert (out[:, untouched] == 7.0).all()
+    full = out.clone()
+    full[:, untouched] = 0.0  # statistics are per group: only this launch's groups are defined
+    for k, gn in enumerate((gn_o1, gn_o2)):
+        ref_ss = _ss_ref(out, gn)
+        got = ss_o[k]
+        assert ss_o[k] is out_ss[k]
+        sl = slice(off, off + cout)
+        e = (got[:, sl].double() - ref_ss[:, sl]).abs().max().item()
+        assert e <= 2e-5 * max(1.0, ref_ss[:, sl].abs().max().item()), "tail consumer %d: %g" % (k, e)
+        assert (got[:, untouched] == 9.0).all()
+    assert _counters_clean()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_conv3x3_fused_f16x3_and_reflect(precision):
+    from monoport_amd import ops
+    n, c, h, w = 2, 256, 64, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((n, c, h, w), generator=g).to(DEV)
+    wt = (torch.randn((c, c, 3, 3), generator=g) * (2.0 / (9 * c)) ** 0.5).to(DEV)
+    gn = _gn(c, 8)
+    y, ss, _ = ops.conv3x3_fused(x, None, ops.PackedConv3x3(wt, precision), relu=False, reflect=True, consumers=[gn])
+    ref = torch.nn.functional.conv2d(torch.nn.ReflectionPad2d(1)(x).double(), wt.double())
+    assert (y.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    _check_ss(ss[0], y, gn, "reflect conv")
+    assert _counters_clean()
+
+
+@pytest.mark.parametrize("mrw", [0, 1, 2])
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_conv1x1_fused_handover(precision, mrw):
+    from monoport_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11 + mrw)
+    n, h, w = 2, 64, 64
+    y = (torch.randn((n, 256, h, w), generator=g) * 1.5).to(DEV)
+    x = torch.randn((n, 256, h, w), generator=g).to(DEV)
+    convs = [torch.nn.Conv2d(256, 256, 1).to(DEV) for _ in range(4)]  # conv_last, l, bl, al
+    gn_end, gn_next = _gn(256, 21), _gn(256, 22)
+    lib.mp_conv3x3_tune(mrw << 12)
+    try:
+        with torch.no_grad():
+            p_last = ops.PackedConv1x1(convs[0].weight, convs[0].bias, precision=precision)
+            p_l = ops.PackedConv1x1(convs[1].weight, convs[1].bias, precision=precision)
+            p_blal = ops.PackedConv1x1(convs[2].weight, convs[2].bias, convs[3].weight, convs[3].bias,
+                                       precision=precision)
+            t, ss_t = ops.conv1x1_fused(y, None, False, None, p_last, consumers=[gn_end])
+            t_ref = torch.nn.functional.conv2d(y.double(), convs[0].weight.double(), convs[0].bias.double())
+            assert (t.double() - t_ref).abs().max().item() <= 2e-5 * max(1.0, t_ref.abs().max().item())
+            _check_ss(ss_t[0], t, gn_end, "conv_last")
+            hwc = torch.empty((n, h, w, 256), device=DEV)
+            out, _ = ops.conv1x1_fused(t, ss_t[0], True, None, p_l, y_hwc=hwc)
+            v = torch.relu(t.double() * ss_t[0][..., 0, None, None].double() + ss_t[0][..., 1, None, None].double())
+            out_ref = torch.nn.functional.conv2d(v, convs[1].weight.double(), convs[1].bias.double())
+            assert (out.double() - out_ref).abs().max().item() <= 5e-5 * max(1.0, out_ref.abs().max().item())
+            assert torch.equal(hwc, out.permute(0, 2, 3, 1).contiguous())
+            xn, ss_x = ops.conv1x1_fused(t, ss_t[0], True, out, p_blal, res=x, consumers=[gn_next])
+            xn_ref = (x.double() + torch.nn.functional.conv2d(v, convs[2].weight.double(), convs[2].bias.double())
+                      + torch.nn.functional.conv2d(out.double(), convs[3].weight.double(), convs[3].bias.double()))
+            assert (xn.double() - xn_ref).abs().max().item() <= 5e-5 * max(1.0, xn_ref.abs().max().item())
+            _check_ss(ss_x[0], xn, gn_next, "x + bl + al")
+    finally:
+        lib.mp_conv3x3_tune(0)
+    assert _counters_clean()
+
+
+def test_convk_stem_and_downsampling():
+    from monoport_amd import ops
+    g = torch.Generator().manual_seed(3)
+    img = torch.from_numpy(np.stack([syn.synthetic_image(s) for s in (3, 4)])).to(DEV)
+    # hourglass stem: 7x7 stride 2, zero padding 3, bias
+    conv = torch.nn.Conv2d(3, 64, 7, 2, 3).to(DEV)
+    gn = _gn(64, 31)
+    with torch.no_grad():
+        y, ss = ops.convk(img, None, False, ops.PackedConvK(conv.weight, conv.bias), 2, consumers=[gn, gn])
+        ref = torch.nn.functional.conv2d(img.double(), conv.weight.double(), conv.bias.double(), stride=2, padding=3)
+    e = (y.double() - ref).abs().max().item()
+    print("stem 7x7 s2: %.3g" % e)
+    assert y.shape == (2, 64, 256, 256) and e <= 2e-5 * max(1.0, ref.abs().max().item())
+    _check_ss(ss[0], y, gn, "stem")
+    assert torch.equal(ss[0], ss[1])
+    # netC stem: ReflectionPad2d(3) + 7x7, no bias
+    conv7 = torch.nn.Conv2d(3, 64, 7, bias=False).to(DEV)
+    gn7 = _gn(64, 32)
+    with torch.no_grad():
+        t, ss7 = ops.convk(img, None, False, ops.PackedConvK(conv7.weight), 1, reflect=True, consumers=[gn7])
+        ref7 = torch.nn.functional.conv2d(torch.nn.ReflectionPad2d(3)(img).double(), conv7.weight.double())
+    e = (t.double() - ref7).abs().max().item()
+    print("netC stem 7x7 reflect: %.3g" % e)
+    assert t.shape == (2, 64, 512, 512) and e <= 2e-5 * max(1.0, ref7.abs().max().item())
+    _check_ss(ss7[0], t, gn7, "netC stem")
+    # stride-2 3x3 with the previous GroupNorm + ReLU applied while gathering
+    for cin, cout, src, gnp in ((64, 128, t, gn7), (128, 256, None, None)):
+        if src is None:
+            src = (torch.randn((2, cin, 256, 256), generator=g) * 1.3).to(DEV)
+            gnp = _gn(cin, 33)
+        ss_in = _ss_ref(src, gnp).float()
+        cv = torch.nn.Conv2d(cin, cout, 3, 2, 1, bias=False).to(DEV)
+        gno = _gn(cout, 34)
+        with torch.no_grad():
+            d, ssd = ops.convk(src, ss_in, True, ops.PackedConvK(cv.weight), 2, consumers=[gno])
+            v = torch.relu(src.double() * ss_in[..., 0, None, None].double() + ss_in[..., 1, None, None].double())
+            refd = torch.nn.functional.conv2d(v, cv.weight.double(), stride=2, padding=1)
+        e = (d.double() - refd).abs().max().item()
+        print("3x3 s2 %d -> %d: %.3g" % (cin, cout, e))
+        assert d.shape == refd.shape and e <= 2e-5 * max(1.0, refd.abs().max().item())
+        _check_ss(ssd[0], d, gno, "3x3 s2")
+    assert _counters_clean()
+
+
+def test_elementwise_producers_with_handover():
+    from monoport_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for n, c, h in ((1, 256, 128), (3, 128, 32), (2, 64, 256)):
+        x = (torch.randn((n, c, h, h), generator=g) * 1.7 + 0.2).to(DEV)
+        gn_a, gn_b = _gn(c, 41), _gn(c, 42)
+        y, ss = ops.avgpool2_gn(x, [gn_a])
+        ref = torch.nn.functional.avg_pool2d(x, 2, stride=2)
+        assert (y - ref).abs().max().item() <= 1e-6
+        _check_ss(ss[0], y, gn_a, "avgpool")
+        if h <= 128:
+            skip = torch.randn((n, c, 2 * h, 2 * h), generator=g).to(DEV)
+            u, ssu = ops.upsample_add_gn(x, skip, [gn_a, gn_b])
+            assert torch.equal(u, ops.upsample_bicubic2x(x, add=skip))
+            want = skip + torch.nn.functional.interpolate(x, scale_factor=2, mode="bicubic", align_corners=True)
+            assert (u - want).abs().max().item() <= 1e-4
+            _check_ss(ssu[0], u, gn_a, "upsample_add a")
+            _check_ss(ssu[1], u, gn_b, "upsample_add b")
+        ss_in = _ss_ref(x, gn_b).float()
+        z, ssz = ops.gn_apply(x, ss_in, True, [gn_a])
+        with torch.no_grad():
+            want = torch.relu(gn_b(x))
+        assert (z - want).abs().max().item() <= 5e-5
+        _check_ss(ssz[0], z, gn_a, "gn_apply")
+        z2, none = ops.gn_apply(x, ss_in, False)
+        assert none == [] and (z2 - gn_b(x)).abs().max().item() <= 5e-5
+    assert _counters_clean()
+
+
+def _netg(seed=71):
+    from monoport_amd.modeling import PIFuNetG
+    net = PIFuNetG().eval()
+    shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
+    net.image_filter.load_state_dict(
+        {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, seed).items()})
+    net.image_filter.to(DEV)
+    return net
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_hgfilter_dataflow_vs_reference_and_round2_path(monkeypatch, precision):
+    """The hourglass encoder as a chain of hand-written kernels only (stem included) against the
+    REFERENCE's CPU output (1e-4) and against round 2's per-module path; batch 1 and batch 3 (the
+    small maps take the split-K kernel at batch 1, large tiles at batch 3)."""
+    from monoport_amd.modeling import backbones
+    monkeypatch.setattr(backbones, "ENCODER_CONV_PRECISION", precision)
+    gold = load_golden("encoders")
+    net = _netg()
+    imgs = torch.stack([torch.from_numpy(syn.synthetic_image(s)) for s in (73, 74, 75)]).to(DEV)
+    with torch.no_grad():
+        assert net.image_filter._dataflow_ok(imgs)
+        one = net.image_filter(imgs[:1])
+        three = net.image_filter(imgs)
+        again = net.image_filter(imgs)
+        monkeypatch.setattr(backbones, "ENCODER_DATAFLOW", "off")
+        assert not net.image_filter._dataflow_ok(imgs)
+        old = net.image_filter(imgs)
+    for i in range(4):
+        err = float(np.abs(one[i][0][0, ::8, ::8, ::8].cpu().numpy() - gold["G%d" % i]).max())
+        e3 = float(np.abs(three[i][0][0, ::8, ::8, ::8].cpu().numpy() - gold["G%d" % i]).max())
+        d_old = (three[i][0] - old[i][0]).abs().max().item()
+        d_b = (three[i][0][:1] - one[i][0]).abs().max().item()
+        print("HGFilter dataflow %s stack %d: vs reference %.3g (batch 3: %.3g), vs round-2 path %.3g, "
+              "batch 1 vs 3 %.3g" % (precision, i, err, e3, d_old, d_b))
+        assert err <= 1e-4 and e3 <= 1e-4 and d_old <= 1e-4 and d_b <= 1e-4
+        assert torch.equal(three[i][0], again[i][0])  # deterministic
+    assert _counters_clean()
+
+
+def test_hgfilter_dataflow_hwc_and_last_only():
+    from monoport_amd import ops
+    net = _netg()
+    img = torch.stack([torch.from_numpy(syn.synthetic_image(s)) for s in (73, 74)]).to(DEV)
+    hwc = torch.empty((2, 128, 128, 256), device=DEV)
+    with torch.no_grad():
+        outs = net.image_filter(img, hwc_out=hwc)
+        assert len(outs) == 4
+        for b in range(2):
+            assert torch.equal(hwc[b], ops.pack_features(outs[-1][0][b:b + 1]))
+        only = net.image_filter(img, last_only=True, hwc_out=torch.empty_like(hwc))
+        assert len(only) == 1 and only[-1][0] is None
+
+
+def test_resnet_filter_dataflow(monkeypatch):
+    from monoport_amd.modeling import backbones
+    net = backbones.ResnetFilter().eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, 5).items()})
+    net.to(DEV)
+    img = torch.from_numpy(syn.synthetic_image(6))[None].to(DEV)
+    with torch.no_grad():
+        assert net._dataflow_ok(img)
+        got = net(img)[0][0]
+        monkeypatch.setattr(backbones, "ENCODER_CONV", "miopen")
+        ref = net(img)[0][0]
+    err = (got - ref).abs().max().item()
+    print("ResnetFilter dataflow vs stock ops: %.3g (max|ref| %.3g)" % (err, ref.abs().max().item()))
+    assert got.shape == (1, 256, 128, 128) and err <= 1e-4 * max(1.0, ref.abs().max().item())
+    assert _counters_clean()
+
+
+def test_fused_paths_stay_out_of_autograd():
+    """eval mode with gradients requested keeps the differentiable PyTorch ops."""
+    from monoport_amd.modeling import backbones
+    blk = backbones.ConvBlock(64, 64).to(DEV).eval()
+    x = torch.randn((1, 64, 32, 32), device=DEV, requires_grad=True)
+    assert not blk._fused_ok(x)
+    y = blk(x)
+    assert y.grad_fn is not None
+    with torch.no_grad():
+        assert blk._fused_ok(x.detach())
