@@ -330,37 +330,45 @@ int mp_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int groups,
                    int64_t count, const float *gamma, const float *beta, float eps, float *ss,
                    mp_stream stream);
 
-/* ---- GroupNorm statistics taken by the producing kernel (round 3) ------------------------------
+/* ---- GroupNorm handed from producer to consumer (round 3) --------------------------------------
  * Every GroupNorm(32, C) of the encoders (backbones/HGFilters.py:23-27, ResBlkFilters.py:19) needs
  * the statistics of a whole (image, group) before the first normalised value exists.  The kernels
- * below publish the partial sums of the tensor they WRITE and the last workgroup to finish turns
- * them -- in a fixed order, no floating-point atomics -- into ss [N,C,2] = (gamma rstd, beta - mean
- * gamma rstd) for the one or two GroupNorm modules that will read the tensor; the consumer applies
- * ss while it stages its input (ss arguments of the convolutions), so a normalised tensor never
- * exists in memory and a GroupNorm costs no launch.
- *   partial          scratch, `partial_doubles` doubles, at least N * 32 * slices * 2 with slices =
- *                    mp_conv3x3_stat_slices / mp_conv1x1_stat_slices / mp_convk_stat_slices /
- *                    mp_gn_stat_slices of the launch (checked); NULL = no statistics
- *   counters         int32 [N * 32], ALL ZERO before the first launch that uses it; every launch
- *                    leaves it zero, so one buffer serves all launches of a stream (two requests of
- *                    ONE launch -- fin and fin2 of mp_conv3x3_ex -- need separate buffers); unused
- *                    when n_sets == 0
- *   n_sets           0: partial sums only (finalise with mp_gn_finalize); 1 or 2 consumers
- *   gamma/beta/eps   affine parameters of consumer k; ss[k]: out [N,C,2] */
-typedef struct mp_gn_fin {
+ * below ADD the per-group sums of the tensor they WRITE into an accumulator (fire-and-forget 64-bit
+ * integer atomics on a fixed-point representation: order-independent, hence deterministic), and the
+ * kernel that READS the tensor turns the accumulator into (mean, rstd) in its prologue and applies
+ * scale = rstd * gamma[c], shift = beta[c] - mean * scale while it stages its input.  A normalised
+ * tensor never exists in memory and a GroupNorm costs neither a launch nor a wait (csrc/gn_tail.h
+ * records the variants that were measured and dropped).
+ *   accumulator  int64 [R,N,32,4] per normalised tensor, R = mp_gn_acc_replicas() copies that the
+ *                producers' workgroups spread over (same-address device atomics serialise) and the
+ *                consumer adds up; a group's 4 words = (sum hi, sum lo, sumsq hi, sumsq lo) with
+ *                value = hi * 2^-16 + lo * 2^-64; it must be ZERO before the producing launch
+ *                (hipMemsetAsync one arena per encoder pass) and is complete when that launch has
+ *                finished; several launches may fill disjoint groups of one accumulator (the three
+ *                convolutions of a pyramid block);
+ *   mp_gn_out    producer side: acc and / or the legacy partial-sum buffer (partial_doubles >=
+ *                N * 32 * slices * 2 with the launch's mp_*_stat_slices; finalise with
+ *                mp_gn_finalize); both NULL = no statistics;
+ *   mp_gn_in     consumer side: acc + the GroupNorm's gamma / beta / eps, or the legacy precomputed
+ *                ss [N,C,2] from mp_gn_finalize, or all NULL = plain input. */
+int mp_gn_acc_replicas(void);
+typedef struct mp_gn_out {
+  int64_t *acc;
   double *partial;
   int64_t partial_doubles;
-  int32_t *counters;
-  int n_sets;
-  const float *gamma[2];
-  const float *beta[2];
-  float eps[2];
-  float *ss[2];
-} mp_gn_fin;
+} mp_gn_out;
+typedef struct mp_gn_in {
+  const int64_t *acc;
+  const float *gamma;
+  const float *beta;
+  float eps;
+  const float *ss;
+} mp_gn_in;
 
 /* mp_conv3x3_gn / mp_conv3x3_gn16 with the pyramid block's tail and the GroupNorm hand-over fused in
- * (backbones/HGFilters.py:40-62).  wmax == NULL: packed by mp_conv3x3_pack (exact f32); else by
- * mp_conv3x3_pack16.  y may be NULL when y2 is given.  y2 / res [N, y2_channels, H, W]:
+ * (backbones/HGFilters.py:40-62).  gn: GroupNorm(32, Cin) of the input (+ ReLU with `relu`).  wmax ==
+ * NULL: packed by mp_conv3x3_pack (exact f32); else by mp_conv3x3_pack16.  y may be NULL when y2 is
+ * given.  y2 / res [N, y2_channels, H, W]:
  *     y2[n, y2_offset + c] = conv[n, c] + res[n, y2_offset + c]
  * -- torch.cat((out1, out2, out3), 1) + residual (HGFilters.py:57-60) written by the three
  * convolutions themselves.  fin: GroupNorm(32, Cout) over y (the next convolution of the block);
@@ -370,7 +378,7 @@ typedef struct mp_gn_fin {
 typedef struct mp_conv3x3_args {
   const float *x;
   int n, cin, h, w;
-  const float *ss;
+  mp_gn_in gn;
   int relu, reflect;
   const void *packed;
   const float *wmax;
@@ -379,16 +387,17 @@ typedef struct mp_conv3x3_args {
   float *y2;
   const float *res;
   int y2_channels, y2_offset;
-  mp_gn_fin fin, fin2;
+  mp_gn_out fin, fin2;
 } mp_conv3x3_args;
 int mp_conv3x3_ex(mp_ctx *ctx, const mp_conv3x3_args *args, mp_stream stream);
 
-/* mp_conv1x1 with the GroupNorm hand-over: fin = GroupNorm(32, 256) over the output (res included),
- * i.e. bn_end after conv_last and the first GroupNorm of the next stack after x + bl(.) + al(.)
- * (HGFilters.py:184-204).  Same tensors and restrictions as mp_conv1x1. */
+/* mp_conv1x1 with the GroupNorm hand-over: gn1 = GroupNorm(32, C1) of x1 (+ ReLU with relu1); fin =
+ * GroupNorm(32, 256) over the output (res included), i.e. bn_end after conv_last and the first
+ * GroupNorm of the next stack after x + bl(.) + al(.) (HGFilters.py:184-204).  Same tensors and
+ * restrictions as mp_conv1x1. */
 typedef struct mp_conv1x1_args {
   const float *x1;
-  const float *ss1;
+  mp_gn_in gn1;
   int relu1;
   const float *x2;
   int n, c1, c2, cout;
@@ -400,7 +409,7 @@ typedef struct mp_conv1x1_args {
   const float *res;
   float *y;
   float *y_hwc;
-  mp_gn_fin fin;
+  mp_gn_out fin;
 } mp_conv1x1_args;
 int mp_conv1x1_ex(mp_ctx *ctx, const mp_conv1x1_args *args, mp_stream stream);
 int mp_conv1x1_stat_slices(int64_t hw);
@@ -410,18 +419,18 @@ int mp_conv1x1_stat_slices(int64_t hw);
  * HGFilters.py:125, :168) or stride 1 + nn.ReflectionPad2d(3) (netC's stem, ResBlkFilters.py:111-113);
  * ks = 3, stride 2, zero padding 1, Cin % 16 == 0, Cout % 128 == 0 (netC's two down-sampling
  * convolutions, ResBlkFilters.py:115-121).  y [N, Cout, H/stride, W/stride], W/stride % 64 == 0.
- * ss / relu: GroupNorm (+ReLU) of the INPUT applied while gathering, as in mp_conv3x3_gn; bias may be
+ * gn / relu: GroupNorm (+ReLU) of the INPUT applied while gathering, as in mp_conv3x3_ex; bias may be
  * NULL; fin: GroupNorm(32, Cout) over y.  packed: mp_convk_packed_floats floats from mp_convk_pack. */
 typedef struct mp_convk_args {
   const float *x;
   int n, cin, h, w;
-  const float *ss;
+  mp_gn_in gn;
   int relu, reflect;
   const float *packed;
   const float *bias;
   int cout, ks, stride;
   float *y;
-  mp_gn_fin fin;
+  mp_gn_out fin;
 } mp_convk_args;
 int mp_convk_supported(int cin, int cout, int ks, int stride, int h, int w);
 int64_t mp_convk_packed_floats(int cin, int cout, int ks);
@@ -431,16 +440,17 @@ int mp_convk_pack(mp_ctx *ctx, const float *w /*[Cout,Cin,ks,ks]*/, int cout, in
 int mp_convk(mp_ctx *ctx, const mp_convk_args *args, mp_stream stream);
 
 /* The tensors between the convolutions, written together with their statistics (fin may be NULL;
- * slices = mp_gn_stat_slices(); C % 32 == 0):
+ * slices of a legacy partial buffer = mp_gn_stat_slices(); C % 32 == 0):
  *   mp_avgpool2_gn            y [N,C,H/2,W/2] = avg_pool2d(x, 2, stride 2)  (HGFilters.py:93, :171), W % 8 == 0
  *   mp_upsample_bicubic2x_gn  y [N,C,2H,2W] = add + bicubic_x2(x)           (HGFilters.py:108-111), add may be NULL
- *   mp_gn_apply               y = relu?(x * scale + shift), ss [N,C,2]      (the stem's GroupNorm + ReLU, :168) */
-int mp_avgpool2_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, float *y, const mp_gn_fin *fin,
+ *   mp_gn_apply               y = [res +] relu?(GroupNorm(x)), gn as above  (the stem's GroupNorm + ReLU, :168;
+ *                             x + GroupNorm(conv(.)) at the end of a residual block, ResBlkFilters.py:75-84) */
+int mp_avgpool2_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, float *y, const mp_gn_out *fin,
                    mp_stream stream);
 int mp_upsample_bicubic2x_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, const float *add, float *y,
-                             const mp_gn_fin *fin, mp_stream stream);
-int mp_gn_apply(mp_ctx *ctx, const float *x, const float *ss, int relu, int n, int c, int64_t hw, float *y,
-                const mp_gn_fin *fin, mp_stream stream);
+                             const mp_gn_out *fin, mp_stream stream);
+int mp_gn_apply(mp_ctx *ctx, const float *x, const mp_gn_in *gn, int relu, int n, int c, int64_t hw,
+                const float *res, float *y, const mp_gn_out *fin, mp_stream stream);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Brackets every fused-query kernel launch made through this context with a pair of HIP events

@@ -19,32 +19,36 @@ _pf32 = ctypes.POINTER(ctypes.c_float)
 
 
 
-class GnFin(ctypes.Structure):
-    """mp_gn_fin (include/monoport_hip.h): GroupNorm statistics request of a producing kernel."""
-    _fields_ = [("partial", c_vp), ("partial_doubles", c_i64), ("counters", c_vp), ("n_sets", c_int),
-                ("gamma", c_vp * 2), ("beta", c_vp * 2), ("eps", c_f32 * 2), ("ss", c_vp * 2)]
+class GnOut(ctypes.Structure):
+    """mp_gn_out (include/monoport_hip.h): where a producing kernel leaves GroupNorm statistics."""
+    _fields_ = [("acc", c_vp), ("partial", c_vp), ("partial_doubles", c_i64)]
+
+
+class GnIn(ctypes.Structure):
+    """mp_gn_in: the GroupNorm a consuming kernel applies to its input while staging it."""
+    _fields_ = [("acc", c_vp), ("gamma", c_vp), ("beta", c_vp), ("eps", c_f32), ("ss", c_vp)]
 
 
 class Conv3x3Args(ctypes.Structure):
     """mp_conv3x3_args"""
-    _fields_ = [("x", c_vp), ("n", c_int), ("cin", c_int), ("h", c_int), ("w", c_int), ("ss", c_vp),
+    _fields_ = [("x", c_vp), ("n", c_int), ("cin", c_int), ("h", c_int), ("w", c_int), ("gn", GnIn),
                 ("relu", c_int), ("reflect", c_int), ("packed", c_vp), ("wmax", c_vp), ("cout", c_int),
                 ("y", c_vp), ("y2", c_vp), ("res", c_vp), ("y2_channels", c_int), ("y2_offset", c_int),
-                ("fin", GnFin), ("fin2", GnFin)]
+                ("fin", GnOut), ("fin2", GnOut)]
 
 
 class Conv1x1Args(ctypes.Structure):
     """mp_conv1x1_args"""
-    _fields_ = [("x1", c_vp), ("ss1", c_vp), ("relu1", c_int), ("x2", c_vp), ("n", c_int), ("c1", c_int),
+    _fields_ = [("x1", c_vp), ("gn1", GnIn), ("relu1", c_int), ("x2", c_vp), ("n", c_int), ("c1", c_int),
                 ("c2", c_int), ("cout", c_int), ("hw", c_i64), ("packed", c_vp), ("f16", c_int),
-                ("wmax", c_vp), ("bias", c_vp), ("res", c_vp), ("y", c_vp), ("y_hwc", c_vp), ("fin", GnFin)]
+                ("wmax", c_vp), ("bias", c_vp), ("res", c_vp), ("y", c_vp), ("y_hwc", c_vp), ("fin", GnOut)]
 
 
 class ConvKArgs(ctypes.Structure):
     """mp_convk_args"""
-    _fields_ = [("x", c_vp), ("n", c_int), ("cin", c_int), ("h", c_int), ("w", c_int), ("ss", c_vp),
+    _fields_ = [("x", c_vp), ("n", c_int), ("cin", c_int), ("h", c_int), ("w", c_int), ("gn", GnIn),
                 ("relu", c_int), ("reflect", c_int), ("packed", c_vp), ("bias", c_vp), ("cout", c_int),
-                ("ks", c_int), ("stride", c_int), ("y", c_vp), ("fin", GnFin)]
+                ("ks", c_int), ("stride", c_int), ("y", c_vp), ("fin", GnOut)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check the exported surface against
@@ -113,15 +117,17 @@ SIGNATURES = {
     "mp_conv3x3_ex": (c_int, [c_vp, ctypes.POINTER(Conv3x3Args), c_vp]),
     "mp_conv1x1_ex": (c_int, [c_vp, ctypes.POINTER(Conv1x1Args), c_vp]),
     "mp_conv1x1_stat_slices": (c_int, [c_i64]),
+    "mp_gn_acc_replicas": (c_int, []),
     "mp_convk_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "mp_convk_packed_floats": (c_i64, [c_int, c_int, c_int]),
     "mp_convk_stat_slices": (c_int, [c_int, c_int, c_int, c_int]),
     "mp_convk_pack": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "mp_convk": (c_int, [c_vp, ctypes.POINTER(ConvKArgs), c_vp]),
-    "mp_avgpool2_gn": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, ctypes.POINTER(GnFin), c_vp]),
+    "mp_avgpool2_gn": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, ctypes.POINTER(GnOut), c_vp]),
     "mp_upsample_bicubic2x_gn": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp,
-                                         ctypes.POINTER(GnFin), c_vp]),
-    "mp_gn_apply": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_vp, ctypes.POINTER(GnFin), c_vp]),
+                                         ctypes.POINTER(GnOut), c_vp]),
+    "mp_gn_apply": (c_int, [c_vp, c_vp, ctypes.POINTER(GnIn), c_int, c_int, c_int, c_i64, c_vp, c_vp,
+                            ctypes.POINTER(GnOut), c_vp]),
     "mp_profile_begin": (c_int, [c_vp, c_int]),
     "mp_profile_end": (c_int, [c_vp, _pf32, c_int, _pint]),
 }

@@ -835,17 +835,25 @@ int mp_gn_finalize(mp_ctx *ctx, const double *partial, int n, int c, int groups,
                             (hipStream_t)stream);
 }
 
-// mp_gn_fin (C-ABI) -> GnFin (kernel argument); the launchers fill c / S / count
-static GnFin to_fin(const mp_gn_fin *f) {
-  GnFin g = gn_fin_none();
-  if (!f || !f->partial) return g;
+// mp_gn_out / mp_gn_in (C-ABI) -> GnOut / GnIn (kernel arguments); the launchers fill c / S / count
+static GnOut to_out(const mp_gn_out *f) {
+  GnOut g = gn_out_none();
+  if (!f) return g;
+  g.acc = reinterpret_cast<long long *>(f->acc);
   g.partial = f->partial;
-  g.counter = f->counters;
-  g.n_sets = f->n_sets;
-  for (int k = 0; k < 2; ++k) g.set[k] = GnSet{f->gamma[k], f->beta[k], f->ss[k], f->eps[k]};
   return g;
 }
-static long long fin_cap(const mp_gn_fin *f) { return f && f->partial ? (long long)f->partial_doubles : -1; }
+static long long out_cap(const mp_gn_out *f) { return f && f->partial ? (long long)f->partial_doubles : -1; }
+static GnIn to_in(const mp_gn_in *f) {
+  GnIn g = gn_in_none();
+  if (!f) return g;
+  g.acc = reinterpret_cast<const long long *>(f->acc);
+  g.gamma = f->gamma;
+  g.beta = f->beta;
+  g.eps = f->eps;
+  g.ss = f->acc ? nullptr : f->ss;
+  return g;
+}
 
 int mp_conv3x3_ex(mp_ctx *ctx, const mp_conv3x3_args *q, mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
@@ -857,15 +865,15 @@ int mp_conv3x3_ex(mp_ctx *ctx, const mp_conv3x3_args *q, mp_stream stream) {
   DeviceGuard g(ctx->device);
   ConvArgs a;
   a.x = q->x;
-  a.ss = q->ss;
+  a.gn = to_in(&q->gn);
   a.wp = static_cast<const float *>(q->packed);
   a.y = q->y;
   a.y2 = q->y2;
   a.res = q->res;
   a.y2_c = q->y2 ? q->y2_channels : 32;
   a.y2_off = q->y2 ? q->y2_offset : 0;
-  a.fin = to_fin(&q->fin);
-  a.fin2 = to_fin(&q->fin2);
+  a.fin = to_out(&q->fin);
+  a.fin2 = to_out(&q->fin2);
   a.n_img = q->n;
   a.cin = q->cin;
   a.cout = q->cout;
@@ -873,7 +881,7 @@ int mp_conv3x3_ex(mp_ctx *ctx, const mp_conv3x3_args *q, mp_stream stream) {
   a.w = q->w;
   a.relu = q->relu;
   a.reflect = q->reflect;
-  const long long cap[2] = {fin_cap(&q->fin), fin_cap(&q->fin2)};
+  const long long cap[2] = {out_cap(&q->fin), out_cap(&q->fin2)};
   return launch_conv3x3(ctx, a, q->wmax, cap, (hipStream_t)stream);
 }
 
@@ -887,22 +895,24 @@ int mp_conv1x1_ex(mp_ctx *ctx, const mp_conv1x1_args *q, mp_stream stream) {
   DeviceGuard g(ctx->device);
   Conv1Args a;
   a.x1 = q->x1;
-  a.ss1 = q->ss1;
+  a.gn1 = to_in(&q->gn1);
   a.x2 = q->x2;
   a.wp = static_cast<const float *>(q->packed);
   a.bias = q->bias;
   a.res = q->res;
   a.y = q->y;
   a.y_hwc = q->y_hwc;
-  a.fin = to_fin(&q->fin);
+  a.fin = to_out(&q->fin);
   a.n_img = q->n;
   a.c1 = q->c1;
   a.c2 = q->c2;
   a.hw = (int)q->hw;
   a.relu1 = q->relu1;
   a.cout = q->cout;
-  return launch_conv1x1(ctx, a, q->f16, q->wmax, fin_cap(&q->fin), (hipStream_t)stream);
+  return launch_conv1x1(ctx, a, q->f16, q->wmax, out_cap(&q->fin), (hipStream_t)stream);
 }
+
+int mp_gn_acc_replicas(void) { return kGnReplicas; }
 
 int mp_conv1x1_stat_slices(int64_t hw) { return hw > 0 ? conv1x1_stat_slices(hw) : 0; }
 
@@ -939,11 +949,11 @@ int mp_convk(mp_ctx *ctx, const mp_convk_args *q, mp_stream stream) {
   DeviceGuard g(ctx->device);
   ConvKArgs a;
   a.x = q->x;
-  a.ss = q->ss;
+  a.gn = to_in(&q->gn);
   a.wp = q->packed;
   a.bias = q->bias;
   a.y = q->y;
-  a.fin = to_fin(&q->fin);
+  a.fin = to_out(&q->fin);
   a.n_img = q->n;
   a.cin = q->cin;
   a.cout = q->cout;
@@ -956,7 +966,7 @@ int mp_convk(mp_ctx *ctx, const mp_convk_args *q, mp_stream stream) {
   a.reflect = q->reflect;
   a.relu = q->relu;
   a.wp_floats = 0;
-  return launch_convk(ctx, a, fin_cap(&q->fin), (hipStream_t)stream);
+  return launch_convk(ctx, a, out_cap(&q->fin), (hipStream_t)stream);
 }
 
 static int check_ew(mp_ctx *ctx, const char *who, const void *x, const void *y, int n, int c, long long hw_out) {
@@ -966,7 +976,7 @@ static int check_ew(mp_ctx *ctx, const char *who, const void *x, const void *y, 
   return MP_OK;
 }
 
-int mp_avgpool2_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, float *y, const mp_gn_fin *fin,
+int mp_avgpool2_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, float *y, const mp_gn_out *fin,
                    mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -974,11 +984,11 @@ int mp_avgpool2_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, floa
   int rc = check_ew(ctx, "mp_avgpool2_gn", x, y, n, c, (long long)(h / 2) * (w / 2));
   if (rc != MP_OK) return rc;
   DeviceGuard g(ctx->device);
-  return launch_avgpool2_gn(ctx, x, n, c, h, w, y, to_fin(fin), fin_cap(fin), (hipStream_t)stream);
+  return launch_avgpool2_gn(ctx, x, n, c, h, w, y, to_out(fin), out_cap(fin), (hipStream_t)stream);
 }
 
 int mp_upsample_bicubic2x_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, const float *add, float *y,
-                             const mp_gn_fin *fin, mp_stream stream) {
+                             const mp_gn_out *fin, mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (h < 2 || w < 2 || w % 2) return fail(ctx, MP_ERR_UNSUPPORTED, "mp_upsample_bicubic2x_gn: needs H, W >= 2, W %% 2 == 0");
@@ -986,18 +996,19 @@ int mp_upsample_bicubic2x_gn(mp_ctx *ctx, const float *x, int n, int c, int h, i
   if (rc != MP_OK) return rc;
   if (add && !aligned16(add)) return fail(ctx, MP_ERR_UNSUPPORTED, "mp_upsample_bicubic2x_gn: add must be 16-byte aligned");
   DeviceGuard g(ctx->device);
-  return launch_upsample_add_gn(ctx, x, n, c, h, w, add, y, to_fin(fin), fin_cap(fin), (hipStream_t)stream);
+  return launch_upsample_add_gn(ctx, x, n, c, h, w, add, y, to_out(fin), out_cap(fin), (hipStream_t)stream);
 }
 
-int mp_gn_apply(mp_ctx *ctx, const float *x, const float *ss, int relu, int n, int c, int64_t hw, float *y,
-                const mp_gn_fin *fin, mp_stream stream) {
+int mp_gn_apply(mp_ctx *ctx, const float *x, const mp_gn_in *gn, int relu, int n, int c, int64_t hw,
+                const float *res, float *y, const mp_gn_out *fin, mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  if (!ss) return fail(ctx, MP_ERR_ARG, "mp_gn_apply: bad argument");
+  if (!gn) return fail(ctx, MP_ERR_ARG, "mp_gn_apply: bad argument");
   int rc = check_ew(ctx, "mp_gn_apply", x, y, n, c, hw);
   if (rc != MP_OK) return rc;
+  if (res && !aligned16(res)) return fail(ctx, MP_ERR_UNSUPPORTED, "mp_gn_apply: res must be 16-byte aligned");
   DeviceGuard g(ctx->device);
-  return launch_gn_apply_gn(ctx, x, ss, relu, n, c, hw, y, to_fin(fin), fin_cap(fin), (hipStream_t)stream);
+  return launch_gn_apply_gn(ctx, x, to_in(gn), relu, n, c, hw, res, y, to_out(fin), out_cap(fin), (hipStream_t)stream);
 }
 
 int mp_profile_begin(mp_ctx *ctx, int max_records) {

@@ -71,35 +71,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, const float (&v
   const long long o1 = ((long long)img * p.cout + ch0) * hw;
   const long long o2 = ((long long)img * p.y2_c + p.y2_off + ch0) * hw;
   const bool cat = p.y2 != nullptr;
-  float s1[TN], s2[TN], q1[TN], q2[TN];
-#pragma unroll
-  for (int tt = 0; tt < TN; ++tt) s1[tt] = s2[tt] = q1[tt] = q2[tt] = 0.0f;
-#pragma unroll
-  for (int n = 0; n < NR; ++n) {
+  const bool st1 = gn_wanted(p.fin), st2 = cat && gn_wanted(p.fin2);
+  const int tid = threadIdx.x;
+  // offset of value (n, tt) inside this wave's 32-channel block of an image (recomputed where it is
+  // used: keeping 16 NR 64-bit offsets alive cost a whole occupancy step)
+  auto off = [&](int n, int tt) {
     const int cb = cwi * NR + n;
     const int ty = (32 * cb) / p.tw, tx = (32 * cb) - ty * p.tw;
-    const long long pix = (long long)(y0 + ty) * p.w + x0 + tx + j;
-#pragma unroll
-    for (int tt = 0; tt < TN; ++tt) {
-      const int t = t0 + tt;
-      const long long ro = (long long)((t & 3) + 8 * (t >> 2) + 4 * h) * hw + pix;
-      const float val = v[n][tt];
-      if (p.y) p.y[o1 + ro] = val;
-      s1[tt] += val;
-      s2[tt] = fmaf(val, val, s2[tt]);
-      if (cat) {
-        const float u = val + p.res[o2 + ro];
-        p.y2[o2 + ro] = u;
-        q1[tt] += u;
-        q2[tt] = fmaf(u, u, q2[tt]);
-      }
-    }
-  }
-  double *cs = reinterpret_cast<double *>(smem);  // [CW][NCH][2] per-channel (sum, sum of squares)
-  unsigned char *tail = smem + 4096;
-  const int tid = threadIdx.x;
-  const int cidx = img * gridDim.y + blockIdx.y;
-  auto publish = [&](const GnFin &f, float (&a1)[TN], float (&a2)[TN], int c_off) {
+    const int t = t0 + tt;
+    return ((t & 3) + 8 * (t >> 2) + 4 * h) * hw + (y0 + ty) * p.w + x0 + tx + j;
+  };
+  // ---- statistics: the per-channel sums of all waves meet in LDS, wave 0 folds them into the
+  // workgroup's per-group sums (fixed order) and hands them on (gn_tail.h: fire-and-forget) ----
+  double *cs1 = reinterpret_cast<double *>(smem);         // [CW][NCH][2] per-channel sums of y
+  double *cs2 = reinterpret_cast<double *>(smem + 2048);  // ... of y2
+  auto to_lds = [&](double *cs, float (&a1)[TN], float (&a2)[TN]) {
     // sum over the 32 lanes that share h (the pixels); lanes j == 0 then hold the row sums
 #pragma unroll
     for (int tt = 0; tt < TN; ++tt) {
@@ -118,26 +104,69 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, const float (&v
         cs[2 * idx + 1] = (double)a2[tt];
       }
     }
-    __syncthreads();
-    const int cpg = f.c / 32;  // channels per group of the normalised tensor
-    const int ng = NCH / cpg;  // groups this workgroup covers
-    const int g0 = (c_off + NCH * (int)blockIdx.y) / cpg;
-    double a = 0.0, b = 0.0;
-    if (tid < ng) {
-      for (int cw = 0; cw < CW; ++cw)
-        for (int ch = 0; ch < cpg; ++ch) {
-          const int idx = cw * NCH + tid * cpg + ch;
-          a += cs[2 * idx];
-          b += cs[2 * idx + 1];
-        }
-    }
-    gn_publish<256>(f, img, g0, ng, tile, cidx, tiles, a, b, tail);
   };
-  if (p.fin.partial) publish(p.fin, s1, s2, 0);
-  if (cat && p.fin2.partial) {
-    if (p.fin.partial) __syncthreads();  // cs is reused
-    publish(p.fin2, q1, q2, p.y2_off);
+  float u[NR][TN];  // the block tail: conv + res
+  if (cat) {
+#pragma unroll
+    for (int n = 0; n < NR; ++n)
+#pragma unroll
+      for (int tt = 0; tt < TN; ++tt) u[n][tt] = p.res[o2 + off(n, tt)];
   }
+  if (st1) {
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int tt = 0; tt < TN; ++tt) s1[tt] = s2[tt] = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NR; ++n)
+#pragma unroll
+      for (int tt = 0; tt < TN; ++tt) {
+        s1[tt] += v[n][tt];
+        s2[tt] = fmaf(v[n][tt], v[n][tt], s2[tt]);
+      }
+    to_lds(cs1, s1, s2);
+  }
+  if (cat) {
+    float q1[TN], q2[TN];
+#pragma unroll
+    for (int tt = 0; tt < TN; ++tt) q1[tt] = q2[tt] = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NR; ++n)
+#pragma unroll
+      for (int tt = 0; tt < TN; ++tt) {
+        u[n][tt] += v[n][tt];
+        q1[tt] += u[n][tt];
+        q2[tt] = fmaf(u[n][tt], u[n][tt], q2[tt]);
+      }
+    if (st2) to_lds(cs2, q1, q2);
+  }
+  if (st1 || st2) {
+    __syncthreads();
+    if (tid < 64) {
+      auto fold = [&](const GnOut &f, const double *cs, int c_off) {
+        const int cpg = f.c / 32;  // channels per group of the normalised tensor
+        const int ng = NCH / cpg;  // groups this workgroup covers
+        double a = 0.0, b = 0.0;
+        if (tid < ng)
+          for (int cw = 0; cw < CW; ++cw)
+            for (int ch = 0; ch < cpg; ++ch) {
+              const int idx = cw * NCH + tid * cpg + ch;
+              a += cs[2 * idx];
+              b += cs[2 * idx + 1];
+            }
+        gn_emit(f, img, (c_off + NCH * (int)blockIdx.y) / cpg, ng, tile, a, b);
+      };
+      if (st1) fold(p.fin, cs1, 0);
+      if (st2) fold(p.fin2, cs2, p.y2_off);
+    }
+  }
+  // ---- bulk stores ----
+#pragma unroll
+  for (int n = 0; n < NR; ++n)
+#pragma unroll
+    for (int tt = 0; tt < TN; ++tt) {
+      if (p.y) p.y[o1 + off(n, tt)] = v[n][tt];
+      if (cat) p.y2[o2 + off(n, tt)] = u[n][tt];
+    }
 }
 
 template <int RBW, int NR>
@@ -182,10 +211,10 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
     goff[it] = ok ? gy * p.w + gx : -1;
   }
   const float *xin = p.x + (long long)img * p.cin * hw;
-  const float *ssn = p.ss ? p.ss + (long long)img * p.cin * 2 : nullptr;
+  __shared__ float gn_stats[64];  // (mean, rstd) of the input's 32 groups (csrc/gn_tail.h)
 
   f32x4 stg[kStageIters];
-  float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};  // wave-uniform (SGPRs)
+  int ch_staged = 0;  // first channel of the chunk in stg (wave-uniform)
   auto stage_load = [&](int chunk) {
     const float *pl = xin + (long long)(chunk * kCK + 4 * wv) * hw;
 #pragma unroll
@@ -194,15 +223,12 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
 #pragma unroll
       for (int k = 0; k < 4; ++k) stg[it][k] = pl[(long long)k * hw + o];
     }
-    if (ssn) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        sc[k] = ssn[2 * (chunk * kCK + 4 * wv + k)];
-        sh[k] = ssn[2 * (chunk * kCK + 4 * wv + k) + 1];
-      }
-    }
+    ch_staged = chunk * kCK + 4 * wv;
   };
   auto stage_store = [&](unsigned char *buf) {
+    float sc[4], sh[4];  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gn_scale_shift(p.gn, img, ch_staged + k, gn_stats, sc[k], sh[k]);
 #pragma unroll
     for (int it = 0; it < kStageIters; ++it) {
       const int lp = lane + 64 * it;
@@ -250,6 +276,8 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
   for (int k = 0; k < 6; ++k) ring[k] = wload128(ws, a_base + min(k, kgt - 1) * 64);
 
   stage_load(0);
+  gn_load_stats(p.gn, img, gn_stats);
+  __syncthreads();
   stage_store(smem);
   __syncthreads();
 
@@ -356,16 +384,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_sk_kernel(ConvArgs p) {
     goff[it] = ok ? gy * p.w + gx : -1;
   }
   const float *xin = p.x + (long long)img * p.cin * hw;
-  const float *ssn = p.ss ? p.ss + (long long)img * p.cin * 2 : nullptr;
+  __shared__ float gn_stats[64];  // (mean, rstd) of the input's 32 groups (csrc/gn_tail.h)
 
   // lane = pixel, all 16 channels of the chunk
   f32x4 stg[kStageIters][4];
-  float sc[16], sh[16];  // wave-uniform
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    sc[k] = 1.0f;
-    sh[k] = 0.0f;
-  }
+  int ch_staged = 0;
   // activations through a buffer resource: lane part = the pixel's offset inside a plane (one VGPR
   // per pass), plane = wave-uniform scalar offset -- 64-bit flat addresses made hipcc hoist 16 plane
   // pointers per pass out of the loop and spill (the weight stream's story, query_common.h)
@@ -383,25 +406,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_sk_kernel(ConvArgs p) {
           stg[it][q][k] = __builtin_bit_cast(
               float, __builtin_amdgcn_raw_buffer_load_b32(xs, o, plane0 + (4 * q + k) * hw * 4, 0));
     }
-    if (ssn) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        sc[k] = ssn[2 * (chunk * kCK + k)];
-        sh[k] = ssn[2 * (chunk * kCK + k) + 1];
-      }
-    }
+    ch_staged = chunk * kCK;
   };
   auto stage_store = [&](unsigned char *buf) {
 #pragma unroll
-    for (int it = 0; it < kStageIters; ++it) {
-      const int lp = lane + 64 * it;
-      if (lp < NPH) {
+    for (int q = 0; q < 4; ++q) {
+      float sc[4], sh[4];  // wave-uniform
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+      for (int k = 0; k < 4; ++k) gn_scale_shift(p.gn, img, ch_staged + 4 * q + k, gn_stats, sc[k], sh[k]);
+#pragma unroll
+      for (int it = 0; it < kStageIters; ++it) {
+        const int lp = lane + 64 * it;
+        if (lp < NPH) {
           f32x4 v;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            float t = fmaf(stg[it][q][k], sc[4 * q + k], sh[4 * q + k]);
+            float t = fmaf(stg[it][q][k], sc[k], sh[k]);
             if (p.relu) t = fmaxf(t, 0.0f);
             v[k] = goff[it] < 0 ? 0.0f : t;
           }
@@ -429,12 +449,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_sk_kernel(ConvArgs p) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[n][t] = 0.0f;
 
+  if (wv < n_chunks) stage_load(wv);  // in flight while the input's GroupNorm statistics are read
+  gn_load_stats(p.gn, img, gn_stats);
+  __syncthreads();
   if (wv < n_chunks) {
     const int a_base = rb * kgt * 64;
     f32x4 ring[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) ring[k] = wload128(ws, a_base + (wv * 18 + k) * 64);
-    stage_load(wv);
     stage_store(mybuf);
     int it_n = 0;
     for (int chunk = wv; chunk < n_chunks; chunk += 4, ++it_n) {
@@ -592,10 +614,10 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
     goff[it] = ok ? gy * p.w + gx : -1;
   }
   const float *xin = p.x + (long long)img * p.cin * hw;
-  const float *ssn = p.ss ? p.ss + (long long)img * p.cin * 2 : nullptr;
+  __shared__ float gn_stats[64];  // (mean, rstd) of the input's 32 groups (csrc/gn_tail.h)
 
   f32x4 stg[kStageIters];
-  float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  int ch_staged = 0;  // first channel of the chunk in stg (wave-uniform)
   auto stage_load = [&](int chunk) {
     const float *pl = xin + (long long)(chunk * kCK + 4 * wv) * hw;
 #pragma unroll
@@ -604,17 +626,14 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
 #pragma unroll
       for (int k = 0; k < 4; ++k) stg[it][k] = pl[(long long)k * hw + o];
     }
-    if (ssn) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        sc[k] = ssn[2 * (chunk * kCK + 4 * wv + k)];
-        sh[k] = ssn[2 * (chunk * kCK + 4 * wv + k) + 1];
-      }
-    }
+    ch_staged = chunk * kCK + 4 * wv;
   };
   // channels 4 wv .. 4 wv + 3 of the chunk = 8 bytes at offset 8 (wv & 1) of hi slot (wv >> 1) and
   // of lo slot 2 + (wv >> 1)
   auto stage_store = [&](unsigned char *buf) {
+    float sc[4], sh[4];  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gn_scale_shift(p.gn, img, ch_staged + k, gn_stats, sc[k], sh[k]);
 #pragma unroll
     for (int it = 0; it < kStageIters; ++it) {
       const int lp = lane + 64 * it;
@@ -664,6 +683,8 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
   for (int k = 0; k < 6; ++k) ring[k] = hload16(ws, a_base + min(k >> 1, kst - 1) * 128 + (k & 1) * 64);
 
   stage_load(0);
+  gn_load_stats(p.gn, img, gn_stats);
+  __syncthreads();
   stage_store(smem);
   __syncthreads();
 
@@ -917,8 +938,8 @@ static int launch_conv_sk_t(mp_ctx *ctx, const ConvArgs &a, int tiles, hipStream
 }
 
 // Fills in what the launcher derives (tile shape, slots, group sizes) and checks the statistics
-// request against the launch: `a` arrives with x / ss / wp / y / y2 / res / fin / fin2 as the caller
-// gave them (fin.c, fin.S, fin.count unset).  partial_cap[k]: doubles the caller allocated for
+// request against the launch: `a` arrives with x / gn / wp / y / y2 / res / fin / fin2 as the caller
+// gave them (fin.c, fin.S, gn.c, gn.count unset).  partial_cap[k]: doubles the caller allocated for
 // fin / fin2 (-1 = unchecked legacy entry points).
 int launch_conv3x3(mp_ctx *ctx, ConvArgs a, const float *wmax16, const long long partial_cap[2], hipStream_t st) {
   const int n = a.n_img, cin = a.cin, cout = a.cout, h = a.h, w = a.w;
@@ -941,20 +962,23 @@ int launch_conv3x3(mp_ctx *ctx, ConvArgs a, const float *wmax16, const long long
     return fail(ctx, MP_ERR_ARG, "conv3x3: no output buffer");
   }
   for (int k = 0; k < 2; ++k) {
-    GnFin &f = k ? a.fin2 : a.fin;
-    if (!f.partial) continue;
+    GnOut &f = k ? a.fin2 : a.fin;
+    if (!gn_wanted(f)) continue;
     if (k && !a.y2) return fail(ctx, MP_ERR_ARG, "conv3x3: statistics of y2 requested without y2");
     f.c = k ? a.y2_c : cout;
     f.S = c.tiles;
-    f.count = (double)(f.c / 32) * h * w;
-    if (partial_cap[k] >= 0 && partial_cap[k] < (long long)n * 32 * f.S * 2)
+    f.n = n;
+    if (f.partial && partial_cap[k] >= 0 && partial_cap[k] < (long long)n * 32 * f.S * 2)
       return fail(ctx, MP_ERR_ARG, "conv3x3: statistics buffer holds %lld doubles, the launch writes %lld",
                   partial_cap[k], (long long)n * 32 * f.S * 2);
-    if (f.n_sets < 0 || f.n_sets > 2 || (f.n_sets > 0 && !f.counter))
-      return fail(ctx, MP_ERR_ARG, "conv3x3: bad GroupNorm consumer request");
-    for (int q = 0; q < f.n_sets; ++q)
-      if (!f.set[q].gamma || !f.set[q].beta || !f.set[q].ss)
-        return fail(ctx, MP_ERR_ARG, "conv3x3: GroupNorm consumer %d lacks gamma / beta / ss", q);
+  }
+  if (gn_active(a.gn)) {
+    if (cin % 32) return fail(ctx, MP_ERR_ARG, "conv3x3: a GroupNorm(32, Cin) input needs Cin %% 32 == 0");
+    if (a.gn.acc && (!a.gn.gamma || !a.gn.beta))
+      return fail(ctx, MP_ERR_ARG, "conv3x3: GroupNorm hand-over without gamma / beta");
+    a.gn.c = cin;
+    a.gn.n = n;
+    a.gn.count = (double)(cin / 32) * h * w;
   }
   if (c.sk) return c.nr == 2 ? launch_conv_sk_t<2>(ctx, a, c.tiles, st) : launch_conv_sk_t<1>(ctx, a, c.tiles, st);
   const int rbw = c.rbw, nr = c.nr, tiles = c.tiles;
@@ -981,15 +1005,16 @@ int launch_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w,
                       double *stats, hipStream_t st) {
   ConvArgs a;
   a.x = x;
-  a.ss = ss;
+  a.gn = gn_in_none();
+  a.gn.ss = ss;
   a.wp = wp;
   a.y = y;
   a.y2 = nullptr;
   a.res = nullptr;
   a.y2_c = 32;
   a.y2_off = 0;
-  a.fin = gn_fin_none();
-  a.fin2 = gn_fin_none();
+  a.fin = gn_out_none();
+  a.fin2 = gn_out_none();
   a.fin.partial = stats;
   a.n_img = n;
   a.cin = cin;
@@ -1080,7 +1105,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
 
   // staging: lane = pixel, wave wv = channels 16 wv .. 16 wv + 15 of the chunk
   f32x4 stg[4];
-  float sc[16], sh[16];
+  int c0_staged = -1;  // first channel (of segment 1) in stg, -1: segment 2 (plain)
+  __shared__ float gn_stats[64];  // (mean, rstd) of x1's 32 groups (csrc/gn_tail.h)
   auto stage_load = [&](int chunk) {
     const int c0 = chunk * kC1K + 16 * wv;  // first channel in the concatenated K
     const bool seg2 = c0 >= p.c1;
@@ -1090,17 +1116,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int k = 0; k < 4; ++k) stg[q][k] = pl[(long long)(4 * q + k) * p.hw + px0 + lane];
-    const bool norm = !seg2 && p.ss1 != nullptr;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      sc[k] = norm ? p.ss1[2 * ((long long)img * p.c1 + c0 + k)] : 1.0f;
-      sh[k] = norm ? p.ss1[2 * ((long long)img * p.c1 + c0 + k) + 1] : 0.0f;
-    }
+    c0_staged = seg2 ? -1 : c0;
   };
   auto stage_store = [&](int chunk, unsigned char *buf) {
     const bool act = chunk * kC1K < p.c1 && p.relu1;
     unsigned char *row = buf + lane * kC1Row;
     const int sw = lane & 15;
+    float sc[16], sh[16];  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (c0_staged >= 0) {
+        gn_scale_shift(p.gn1, img, c0_staged + k, gn_stats, sc[k], sh[k]);
+      } else {
+        sc[k] = 1.0f;
+        sh[k] = 0.0f;
+      }
+    }
     if constexpr (!F16) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1157,6 +1188,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
     for (int part = 0; part < FPS; ++part) ring[0][m][part] = a_load(m, 0, part);
 
   stage_load(0);
+  gn_load_stats(p.gn1, img, gn_stats);
+  __syncthreads();
   stage_store(0, smem);
   __syncthreads();
 
@@ -1215,68 +1248,77 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
     __syncthreads();
   }
 
-  // ---- epilogue ----
+  // ---- epilogue: values (+ bias, + residual) and their per-channel sums first ----
   const float inv_scale = F16 ? 1.0f / conv16_scale(*wmax) : 1.0f;
-  float s1[MRW][16], s2[MRW][16];
+  constexpr int NCH = 128 * MRW;  // output channels of this workgroup
+  double *cs = reinterpret_cast<double *>(smem);  // [NCH][2] per-channel (sum, sum of squares)
 #pragma unroll
   for (int m = 0; m < MRW; ++m) {
+    float s1[16], s2[16];  // one row block at a time: 64 live sums next to 128 accumulators spilled
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int co = 32 * (rb0 + m) + (t & 3) + 8 * (t >> 2) + 4 * h;
       const float b = p.bias ? p.bias[co] : 0.0f;
-      s1[m][t] = s2[m][t] = 0.0f;
+      s1[t] = s2[t] = 0.0f;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         const long long o = ((long long)img * p.cout + co) * p.hw + px0 + 32 * n + j;
         float v = acc[m][n][t] * inv_scale + b;
         if (p.res) v += p.res[o];
-        if (p.y) p.y[o] = v;
         acc[m][n][t] = v;
-        s1[m][t] += v;
-        s2[m][t] = fmaf(v, v, s2[m][t]);
+        s1[t] += v;
+        s2[t] = fmaf(v, v, s2[t]);
       }
     }
-  }
-  constexpr int NCH = 128 * MRW;  // output channels of this workgroup
-  if (p.fin.partial) {
-    // GroupNorm(32, Cout) statistics of the output (bn_end after conv_last; the first GroupNorm of the
-    // next stack after x + bl(.) + al(.)): per-channel sums meet in LDS, gn_tail.h does the rest
-#pragma unroll
-    for (int m = 0; m < MRW; ++m)
+    if (gn_wanted(p.fin)) {
+      // GroupNorm(32, Cout) statistics of the output (bn_end after conv_last; the first GroupNorm of
+      // the next stack after x + bl(.) + al(.)), handed on before the bulk stores (gn_tail.h)
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) {
-          s1[m][t] += __shfl_xor(s1[m][t], o);
-          s2[m][t] += __shfl_xor(s2[m][t], o);
+          s1[t] += __shfl_xor(s1[t], o);
+          s2[t] += __shfl_xor(s2[t], o);
         }
       }
-    double *cs = reinterpret_cast<double *>(smem);  // [NCH][2]
-    if (j == 0) {
-#pragma unroll
-      for (int m = 0; m < MRW; ++m)
+      if (j == 0) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
           const int lc = 32 * (MRW * wv + m) + (t & 3) + 8 * (t >> 2) + 4 * h;
-          cs[2 * lc] = (double)s1[m][t];
-          cs[2 * lc + 1] = (double)s2[m][t];
+          cs[2 * lc] = (double)s1[t];
+          cs[2 * lc + 1] = (double)s2[t];
         }
-    }
-    __syncthreads();
-    const int cpg = p.cout / 32, ng = NCH / cpg;
-    double a = 0.0, b = 0.0;
-    if (tid < ng)
-      for (int ch = 0; ch < cpg; ++ch) {
-        a += cs[2 * (tid * cpg + ch)];
-        b += cs[2 * (tid * cpg + ch) + 1];
       }
-    gn_publish<256>(p.fin, img, (NCH * (int)blockIdx.y) / cpg, ng, tile, img * gridDim.y + blockIdx.y, tiles, a, b,
-                    smem + 4096);
+    }
+  }
+  if (gn_wanted(p.fin)) {
+    __syncthreads();
+    if (tid < 64) {
+      const int cpg = p.cout / 32, ng = NCH / cpg;
+      double a = 0.0, b = 0.0;
+      if (tid < ng)
+        for (int ch = 0; ch < cpg; ++ch) {
+          a += cs[2 * (tid * cpg + ch)];
+          b += cs[2 * (tid * cpg + ch) + 1];
+        }
+      gn_emit(p.fin, img, (NCH * (int)blockIdx.y) / cpg, ng, tile, a, b);
+    }
+  }
+  if (p.y) {
+#pragma unroll
+    for (int m = 0; m < MRW; ++m)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int co = 32 * (rb0 + m) + (t & 3) + 8 * (t >> 2) + 4 * h;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          p.y[((long long)img * p.cout + co) * p.hw + px0 + 32 * n + j] = acc[m][n][t];
+      }
   }
   if (p.y_hwc) {
     // [64 px][NCH ch] f32 through LDS (16-byte slots swizzled with the pixel), then every pixel row
     // leaves as one burst of NCH * 4 bytes: wave wv writes pixels wv, wv + 4, ...
-    if (p.fin.partial) __syncthreads();
+    if (gn_wanted(p.fin)) __syncthreads();
     constexpr int kRow = NCH * 4, kSlots = NCH / 4;
     unsigned char *tr = smem;
 #pragma unroll
@@ -1338,22 +1380,24 @@ int launch_conv1x1(mp_ctx *ctx, Conv1Args a, int f16, const float *wmax, long lo
     return fail(ctx, MP_ERR_UNSUPPORTED,
                 "conv1x1: needs C1, C2 multiples of 64, H*W a multiple of 64 and 128 or 256 output channels "
                 "(got %d + %d -> %d, %d)", a.c1, a.c2, a.cout, a.hw);
-  if (a.cout != 256 && (a.fin.partial || a.y_hwc))
+  if (a.cout != 256 && (gn_wanted(a.fin) || a.y_hwc))
     return fail(ctx, MP_ERR_UNSUPPORTED, "conv1x1: statistics / channels-last output are built for 256 channels");
   a.wp_floats = a.cout * (a.c1 + a.c2);
   const int tiles = a.hw / kC1Px;
-  if (a.fin.partial) {
+  if (gn_wanted(a.fin)) {
     a.fin.c = a.cout;
     a.fin.S = tiles;
-    a.fin.count = (double)(a.cout / 32) * a.hw;
-    if (partial_cap >= 0 && partial_cap < (long long)a.n_img * 32 * tiles * 2)
+    a.fin.n = a.n_img;
+    if (a.fin.partial && partial_cap >= 0 && partial_cap < (long long)a.n_img * 32 * tiles * 2)
       return fail(ctx, MP_ERR_ARG, "conv1x1: statistics buffer holds %lld doubles, the launch writes %lld",
                   partial_cap, (long long)a.n_img * 32 * tiles * 2);
-    if (a.fin.n_sets < 0 || a.fin.n_sets > 2 || (a.fin.n_sets > 0 && !a.fin.counter))
-      return fail(ctx, MP_ERR_ARG, "conv1x1: bad GroupNorm consumer request");
-    for (int q = 0; q < a.fin.n_sets; ++q)
-      if (!a.fin.set[q].gamma || !a.fin.set[q].beta || !a.fin.set[q].ss)
-        return fail(ctx, MP_ERR_ARG, "conv1x1: GroupNorm consumer %d lacks gamma / beta / ss", q);
+  }
+  if (gn_active(a.gn1)) {
+    if (a.gn1.acc && (!a.gn1.gamma || !a.gn1.beta))
+      return fail(ctx, MP_ERR_ARG, "conv1x1: GroupNorm hand-over without gamma / beta");
+    a.gn1.c = a.c1;
+    a.gn1.n = a.n_img;
+    a.gn1.count = (double)(a.c1 / 32) * a.hw;
   }
   // two 32-row blocks per wave (one workgroup = all 256 rows of 64 pixels) unless that leaves slots
   // empty: then one block per wave and the row halves as separate workgroups (blockIdx.y)
@@ -1378,14 +1422,15 @@ int launch_conv1x1_raw(mp_ctx *ctx, const float *x1, const float *ss1, int relu1
                        hipStream_t st) {
   Conv1Args a;
   a.x1 = x1;
-  a.ss1 = ss1;
+  a.gn1 = gn_in_none();
+  a.gn1.ss = ss1;
   a.x2 = x2;
   a.wp = static_cast<const float *>(wp);
   a.bias = bias;
   a.res = res;
   a.y = y;
   a.y_hwc = y_hwc;
-  a.fin = gn_fin_none();
+  a.fin = gn_out_none();
   a.fin.partial = stats;
   a.n_img = n;
   a.c1 = c1;

@@ -11,8 +11,8 @@
 // (padded to a multiple of 8): the workgroup gathers [64 pixels][K chunk] into LDS -- strided /
 // mirrored / zero-padded reads, with the producer's GroupNorm + ReLU applied on the way like
 // conv3x3.hip does -- and the waves run v_mfma_f32_32x32x2_f32 over it with the weights streamed in
-// fragment order.  The epilogue adds the bias, writes NCHW and publishes the GroupNorm statistics of
-// the output (gn_tail.h).  Algorithmic work 2 KS^2 Cin Cout FLOP per output pixel; these layers are
+// fragment order.  The epilogue adds the bias, writes NCHW and hands the GroupNorm statistics of
+// the output on (gn_tail.h).  Algorithmic work 2 KS^2 Cin Cout FLOP per output pixel; these layers are
 // 12 % of netC's and 0.6 % of netG's encoder FLOPs, so the kernel is built for simplicity: the
 // gather is not overlapped with the MFMAs inside a workgroup (a second workgroup per CU fills in).
 #include "mp_internal.h"
@@ -67,8 +67,11 @@ __global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
   const int n_chunks = p.cin / CC;
   const long long hw_in = (long long)p.h * p.w;
   const float *xin = p.x + (long long)img * p.cin * hw_in;
-  const float *ssn = p.ss ? p.ss + (long long)img * p.cin * 2 : nullptr;
+  const bool norm = gn_active(p.gn);
+  __shared__ float gn_stats[64];  // (mean, rstd) of the input's 32 groups (csrc/gn_tail.h)
   const WStream ws = make_wstream(p.wp, p.wp_floats, lane);
+  gn_load_stats(p.gn, img, gn_stats);
+  __syncthreads();
 
   f32x16 acc[NR];
 #pragma unroll
@@ -102,8 +105,10 @@ __global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
         if (ok) {
           const int ci = chunk * CC + c;
           v = xin[ci * hw_in + (long long)iy * p.w + ix];
-          if (ssn) {
-            v = fmaf(v, ssn[2 * ci], ssn[2 * ci + 1]);
+          if (norm) {
+            float sc, sh;
+            gn_scale_shift(p.gn, img, ci, gn_stats, sc, sh);
+            v = fmaf(v, sc, sh);
             if (p.relu) v = fmaxf(v, 0.0f);
           }
         }
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
       s2[t] = fmaf(v, v, s2[t]);
     }
   }
-  if (p.fin.partial) {
+  if (gn_wanted(p.fin)) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
 #pragma unroll
@@ -185,8 +190,7 @@ __global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
           a += cs[2 * idx];
           b += cs[2 * idx + 1];
         }
-    gn_publish<256>(p.fin, img, (NCH * (int)blockIdx.y) / cpg, ng, tile, img * gridDim.y + blockIdx.y, tiles, a, b,
-                    smem + 4096);
+    gn_emit(p.fin, img, (NCH * (int)blockIdx.y) / cpg, ng, tile, a, b);
   }
 }
 
@@ -219,7 +223,7 @@ template <int RBW, int NR, int KS, int CC>
 static int launch_convk_t(mp_ctx *ctx, const ConvKArgs &a, hipStream_t st) {
   constexpr int PX = 32 * NR * (4 / RBW);
   constexpr int lds_tile = PX * (ceil8(CC * KS * KS) + 4) * 4;
-  constexpr int lds = lds_tile > 4096 + kGnTailLdsBytes ? lds_tile : 4096 + kGnTailLdsBytes;
+  constexpr int lds = lds_tile > 4096 ? lds_tile : 4096;
   auto kern = convk_kernel<RBW, NR, KS, CC>;
   const void *kern_id = reinterpret_cast<const void *>(kern);
   if (!ctx->lds_attr_done.count(kern_id)) {
@@ -232,7 +236,7 @@ static int launch_convk_t(mp_ctx *ctx, const ConvKArgs &a, hipStream_t st) {
   return MP_OK;
 }
 
-// `a` arrives with tensors, shapes, ks / stride / pad / reflect / relu and fin.{partial, counter, sets}
+// `a` arrives with tensors, shapes, ks / stride / pad / reflect / relu, gn and fin as the caller gave them
 int launch_convk(mp_ctx *ctx, ConvKArgs a, long long partial_cap, hipStream_t st) {
   if (!convk_supported(a.cin, a.cout, a.ks, a.stride, a.h, a.w))
     return fail(ctx, MP_ERR_UNSUPPORTED,
@@ -243,18 +247,21 @@ int launch_convk(mp_ctx *ctx, ConvKArgs a, long long partial_cap, hipStream_t st
   a.ho = a.h / a.stride;
   a.wo = a.w / a.stride;
   a.wp_floats = (int)convk_packed_floats(a.cin, a.cout, a.ks);
-  if (a.fin.partial) {
+  if (gn_wanted(a.fin)) {
     a.fin.c = a.cout;
     a.fin.S = a.ho * (a.wo / 64);
-    a.fin.count = (double)(a.cout / 32) * a.ho * a.wo;
-    if (partial_cap >= 0 && partial_cap < (long long)a.n_img * 32 * a.fin.S * 2)
+    a.fin.n = a.n_img;
+    if (a.fin.partial && partial_cap >= 0 && partial_cap < (long long)a.n_img * 32 * a.fin.S * 2)
       return fail(ctx, MP_ERR_ARG, "convk: statistics buffer holds %lld doubles, the launch writes %lld",
                   partial_cap, (long long)a.n_img * 32 * a.fin.S * 2);
-    if (a.fin.n_sets < 0 || a.fin.n_sets > 2 || (a.fin.n_sets > 0 && !a.fin.counter))
-      return fail(ctx, MP_ERR_ARG, "convk: bad GroupNorm consumer request");
-    for (int q = 0; q < a.fin.n_sets; ++q)
-      if (!a.fin.set[q].gamma || !a.fin.set[q].beta || !a.fin.set[q].ss)
-        return fail(ctx, MP_ERR_ARG, "convk: GroupNorm consumer %d lacks gamma / beta / ss", q);
+  }
+  if (gn_active(a.gn)) {
+    if (a.cin % 32) return fail(ctx, MP_ERR_ARG, "convk: a GroupNorm(32, Cin) input needs Cin %% 32 == 0");
+    if (a.gn.acc && (!a.gn.gamma || !a.gn.beta))
+      return fail(ctx, MP_ERR_ARG, "convk: GroupNorm hand-over without gamma / beta");
+    a.gn.c = a.cin;
+    a.gn.n = a.n_img;
+    a.gn.count = (double)(a.cin / 32) * a.h * a.w;
   }
   if (a.ks == 7) return launch_convk_t<2, 1, 7, 3>(ctx, a, st);
   return launch_convk_t<4, 2, 3, 16>(ctx, a, st);

@@ -5,37 +5,38 @@
 
 namespace mp {
 
-struct GnSet {
-  const float *gamma, *beta;  // [C] affine parameters of the consuming GroupNorm
-  float *ss;                  // out [N][C][2] = (gamma rstd, beta - mean gamma rstd)
-  float eps;
-};
+// Producer side of a GroupNorm hand-over (csrc/gn_tail.h): where the statistics of the tensor a
+// kernel writes go.  Both pointers may be set; both nullptr = no statistics.
+constexpr int kGnReplicas = 16;  // copies of an accumulator the producers' workgroups spread over (gn_tail.h)
 
-struct GnFin {
-  double *partial;  // [N][32][S][2] partial (sum, sum of squares); nullptr = no statistics
-  int *counter;     // arrival counters, zero before and after every launch (n_sets > 0)
-  GnSet set[2];
-  int n_sets;       // 0: partial sums only (mp_gn_finalize turns them into ss); 1-2: consumers
+struct GnOut {
+  long long *acc;   // [kGnReplicas][N][32][4] fixed-point accumulator, ZERO before the launch
+  double *partial;  // legacy: [N][32][S][2] plain partial sums, finalised by mp_gn_finalize
   int c;            // channels of the normalised tensor (groups of c / 32 adjacent channels)
-  int S;            // slots per (image, group)
-  double count;     // elements per group = (c / 32) * H * W
+  int S;            // slots per (image, group) of `partial`
+  int n;            // images (stride between replicas)
 };
 
-inline GnFin gn_fin_none() {
-  GnFin f;
-  f.partial = nullptr;
-  f.counter = nullptr;
-  f.n_sets = 0;
-  f.c = 32;
-  f.S = 0;
-  f.count = 1.0;
-  for (int k = 0; k < 2; ++k) f.set[k] = GnSet{nullptr, nullptr, nullptr, 1e-5f};
-  return f;
-}
+__host__ __device__ inline GnOut gn_out_none() { return GnOut{nullptr, nullptr, 32, 0, 1}; }
+__host__ __device__ inline bool gn_wanted(const GnOut &f) { return f.acc || f.partial; }
+
+// Consumer side: the GroupNorm applied to a kernel's INPUT while it is staged.
+struct GnIn {
+  const long long *acc;        // accumulator its producer filled, or nullptr
+  const float *gamma, *beta;   // [C] affine parameters (with acc)
+  const float *ss;             // legacy: precomputed [N][C][2] (scale, shift), or nullptr
+  float eps;
+  int c;                       // channels of the normalised tensor
+  int n;                       // images (stride between replicas)
+  double count;                // elements per group = (c / 32) * H * W
+};
+
+__host__ __device__ inline GnIn gn_in_none() { return GnIn{nullptr, nullptr, nullptr, nullptr, 1e-5f, 32, 1, 1.0}; }
+__host__ __device__ inline bool gn_active(const GnIn &g) { return g.acc || g.ss; }
 
 struct ConvArgs {
   const float *x;    // [N, Cin, H, W]
-  const float *ss;   // [N, Cin, 2] (scale, shift) of the fused GroupNorm, or nullptr: plain input
+  GnIn gn;           // GroupNorm(32, Cin) of the input, fused into the staging (gn_in_none(): plain input)
   const float *wp;   // packed weights [Cout/32][Cin/16 * 18][64][4]
   float *y;          // [N, Cout, H, W], or nullptr when only y2 is wanted
   // pyramid-block tail fused into the epilogue (HGFilters.py:57-60: cat((out1, out2, out3), 1) + residual):
@@ -43,8 +44,8 @@ struct ConvArgs {
   float *y2;
   const float *res;
   int y2_c, y2_off;
-  GnFin fin;         // GroupNorm(32, Cout) statistics of the raw output y (S = tiles per image)
-  GnFin fin2;        // GroupNorm(32, y2_c) statistics of this launch's channels of y2
+  GnOut fin;         // GroupNorm(32, Cout) statistics of the raw output y (S = tiles per image)
+  GnOut fin2;        // GroupNorm(32, y2_c) statistics of this launch's channels of y2
   int n_img, cin, cout, h, w;
   int tw, th;        // tile width / height in pixels (th * tw = 32 * NR * CW)
   int relu;          // apply ReLU to the (normalised) input
@@ -54,14 +55,15 @@ struct ConvArgs {
 };
 
 struct Conv1Args {
-  const float *x1, *ss1;  // [N,C1,HW], [N,C1,2] or nullptr
+  const float *x1;        // [N,C1,HW]
+  GnIn gn1;               // GroupNorm(32, C1) of x1, fused into the staging
   const float *x2;        // [N,C2,HW] or nullptr (plain second K segment)
   const float *wp;        // packed [8 row blocks][K/8 groups][64][4] f32, or [8][K/16][hi|lo][64] h8
   const float *bias;      // [256]
   const float *res;       // [N,256,HW] or nullptr
   float *y;               // [N,256,HW] or nullptr
   float *y_hwc;           // [N,HW,256] or nullptr
-  GnFin fin;              // GroupNorm(32, Cout) statistics of the output (S = HW / 64), Cout = 256 only
+  GnOut fin;              // GroupNorm(32, Cout) statistics of the output (S = HW / 64), Cout = 256 only
   int n_img, c1, c2, hw, relu1, wp_floats;
   int cout;  // 256 (each wave two 32-row blocks) or 128 (one): the 1x1 projection of a pyramid block
 };
@@ -70,11 +72,11 @@ struct Conv1Args {
 // convim2col.hip: 7x7 (3 -> 64, stride 1 / 2) and 3x3 stride-2 convolutions
 struct ConvKArgs {
   const float *x;     // [N, Cin, H, W]
-  const float *ss;    // [N, Cin, 2] fused GroupNorm of the input, or nullptr
+  GnIn gn;            // GroupNorm(32, Cin) of the input, applied while gathering
   const float *wp;    // packed by convk_pack_kernel
   const float *bias;  // [Cout] or nullptr
   float *y;           // [N, Cout, H / stride, W / stride]
-  GnFin fin;          // GroupNorm(32, Cout) statistics of y (S = output rows * output width / 64)
+  GnOut fin;          // GroupNorm(32, Cout) statistics of y (S = output rows * output width / 64)
   int n_img, cin, cout, h, w, ho, wo;
   int ks, stride, pad, reflect, relu;
   int wp_floats;
@@ -92,11 +94,11 @@ int convk_stat_slices(int ks, int stride, int h, int w);
 int launch_convk_pack(mp_ctx *ctx, const float *w, int cout, int cin, int ks, float *wp, hipStream_t st);
 int launch_convk(mp_ctx *ctx, ConvKArgs a, long long partial_cap, hipStream_t st);
 // encoder_ops.hip: elementwise producers that publish the GroupNorm statistics of their output
-int launch_avgpool2_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, float *y, GnFin fin,
+int launch_avgpool2_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, float *y, GnOut fin,
                        long long partial_cap, hipStream_t st);
 int launch_upsample_add_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, const float *add, float *y,
-                           GnFin fin, long long partial_cap, hipStream_t st);
-int launch_gn_apply_gn(mp_ctx *ctx, const float *x, const float *ss, int relu, int n, int c, long long hw,
-                       float *y, GnFin fin, long long partial_cap, hipStream_t st);
+                           GnOut fin, long long partial_cap, hipStream_t st);
+int launch_gn_apply_gn(mp_ctx *ctx, const float *x, GnIn gn, int relu, int n, int c, long long hw,
+                       const float *res, float *y, GnOut fin, long long partial_cap, hipStream_t st);
 
 }  // namespace mp

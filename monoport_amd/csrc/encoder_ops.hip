@@ -199,19 +199,26 @@ int launch_upsample_bicubic2x(mp_ctx *ctx, const float *x, int c, int h, int w, 
 // Op::run(gi, i) computes and stores the 4 consecutive outputs at float4 index i of (image, group)
 // gi (hw % 4 == 0: they share a plane) and returns them.
 template <class Op>
-__global__ __launch_bounds__(kGnThreads) void ew_gn_kernel(Op op, long long group_elems, GnFin fin) {
-  __shared__ __attribute__((aligned(16))) unsigned char tail[kGnTailLdsBytes];
+__global__ __launch_bounds__(kGnThreads) void ew_gn_kernel(Op op, long long group_elems, GnOut fin) {
   __shared__ double w1[kGnThreads / 64], w2[kGnThreads / 64];
+  constexpr int V = Op::kVec;  // outputs per thread and step: 4 (one float4) or 1
   const int gi = blockIdx.x / kGnSlices, s = blockIdx.x % kGnSlices;
-  const long long per = (group_elems / 4 + kGnSlices - 1) / kGnSlices;  // float4 per slice
-  const long long v0 = s * per, v1 = min(v0 + per, group_elems / 4);
+  const long long per = (group_elems / V + kGnSlices - 1) / kGnSlices;  // steps per slice
+  const long long v0 = s * per, v1 = min(v0 + per, group_elems / V);
+  op.begin(gi);
   float s1 = 0.f, s2 = 0.f;
   double d1 = 0.0, d2 = 0.0;
   int k = 0;
   for (long long i = v0 + threadIdx.x; i < v1; i += kGnThreads) {
-    const f32x4 v = op.run(gi, i, group_elems);
-    s1 += (v[0] + v[1]) + (v[2] + v[3]);
-    s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    if constexpr (V == 4) {
+      const f32x4 v = op.run(gi, i, group_elems);
+      s1 += (v[0] + v[1]) + (v[2] + v[3]);
+      s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    } else {
+      const float v = op.run(gi, i, group_elems);
+      s1 += v;
+      s2 += v * v;
+    }
     if (++k == 64) {
       d1 += s1;
       d2 += s2;
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(kGnThreads) void ew_gn_kernel(Op op, long long grou
       k = 0;
     }
   }
-  if (!fin.partial) return;
+  if (!gn_wanted(fin)) return;
   d1 += s1;
   d2 += s2;
 #pragma unroll
@@ -239,13 +246,15 @@ __global__ __launch_bounds__(kGnThreads) void ew_gn_kernel(Op op, long long grou
       a += w1[i];
       b += w2[i];
     }
-  gn_publish<kGnThreads>(fin, gi / 32, gi % 32, 1, s, gi, kGnSlices, a, b, tail);
+  gn_emit(fin, gi / 32, gi % 32, 1, s, a, b);
 }
 
 struct AvgPool2Op {  // y [N*C, H/2, W/2] = avg_pool2d(x [N*C, H, W], 2, stride 2)
+  static constexpr int kVec = 4;
   const float *x;
   float *y;
   int ho, wo;  // output size; wo % 4 == 0
+  __device__ __forceinline__ void begin(int) {}
   __device__ __forceinline__ f32x4 run(int gi, long long i, long long group_elems) const {
     const long long e = gi * group_elems + 4 * i;  // first output element
     const long long plane = e / ((long long)ho * wo);
@@ -265,68 +274,102 @@ struct AvgPool2Op {  // y [N*C, H/2, W/2] = avg_pool2d(x [N*C, H, W], 2, stride 
 };
 
 struct UpsampleAddOp {  // y [N*C, 2H, 2W] = add + bicubic_x2(x [N*C, H, W])
+  // one output per thread: 16 taps each, and four pixels per thread (64 loads in flight per thread,
+  // 126 VGPRs) measured 1.5x slower than upsample_bicubic2x_kernel's one
+  static constexpr int kVec = 1;
   const float *x, *add;
   float *y;
   int h, w;  // input size
   float sy, sx;
-  __device__ __forceinline__ f32x4 run(int gi, long long i, long long group_elems) const {
+  __device__ __forceinline__ void begin(int) {}
+  __device__ __forceinline__ float run(int gi, long long i, long long group_elems) const {
     const int ho = 2 * h, wo = 2 * w;
-    const long long e = gi * group_elems + 4 * i;
+    const long long e = gi * group_elems + i;
     const long long plane = e / ((long long)ho * wo);
     const int rem = (int)(e - plane * ho * wo);
     const int oy = rem / wo, ox = rem - oy * wo;
-    const float *src = x + plane * (long long)h * w;
-    f32x4 v = add ? *reinterpret_cast<const f32x4 *>(add + e) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float up = bicubic2x_at(src, h, w, sy, sx, oy, ox + q);
-      v[q] = add ? v[q] + up : up;
-    }
-    *reinterpret_cast<f32x4 *>(y + e) = v;
+    const float up = bicubic2x_at(x + plane * (long long)h * w, h, w, sy, sx, oy, ox);
+    const float v = add ? add[e] + up : up;
+    y[e] = v;
     return v;
   }
 };
 
-struct GnApplyOp {  // y = relu?(x * scale[n,c] + shift[n,c]), x / y [N*C, HW], ss [N*C, 2]
-  const float *x, *ss;
+struct GnApplyOp {  // y = [res +] relu?(GroupNorm(x)), x / y / res [N*C, HW]; the GroupNorm as GnIn
+  static constexpr int kVec = 4;
+  const float *x, *res;
   float *y;
   long long hw;
   int relu;
+  GnIn gn;
+  float mean, rstd;  // of this workgroup's group (hand-over mode)
+  __device__ __forceinline__ void begin(int gi) {
+    mean = 0.0f;
+    rstd = 1.0f;
+    if (gn.acc) {  // one group per workgroup: lanes 0..R-1 fetch one replica each, wave 0 adds them up
+      __shared__ float mr[2];
+      if (threadIdx.x < 64) {
+        unsigned long long w[4] = {0, 0, 0, 0};
+        if (threadIdx.x < kGnReplicas) {
+          const unsigned long long *a = reinterpret_cast<const unsigned long long *>(gn.acc) +
+                                        ((long long)threadIdx.x * gn.n * 32 + gi) * 4;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[k] = a[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int o = 1; o < kGnReplicas; o <<= 1) w[k] += __shfl_xor(w[k], o);
+        if (threadIdx.x == 0) gn_mean_rstd(gn, w, mr[0], mr[1]);
+      }
+      __syncthreads();
+      mean = mr[0];
+      rstd = mr[1];
+    }
+  }
   __device__ __forceinline__ f32x4 run(int gi, long long i, long long group_elems) const {
     const long long e = gi * group_elems + 4 * i;
     const long long plane = e / hw;
-    const float sc = ss[2 * plane], sh = ss[2 * plane + 1];
+    float sc, sh;
+    if (gn.acc) {
+      const int c = (int)(plane % gn.c);
+      sc = rstd * gn.gamma[c];
+      sh = gn.beta[c] - mean * sc;
+    } else {
+      sc = gn.ss[2 * plane];
+      sh = gn.ss[2 * plane + 1];
+    }
     f32x4 v = *reinterpret_cast<const f32x4 *>(x + e);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float o = v[q] * sc + sh;
       v[q] = (relu && o < 0.f) ? 0.f : o;
     }
+    if (res) {
+      const f32x4 r = *reinterpret_cast<const f32x4 *>(res + e);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = r[q] + v[q];
+    }
     *reinterpret_cast<f32x4 *>(y + e) = v;
     return v;
   }
 };
 
-static int check_fin(mp_ctx *ctx, GnFin &f, int n, int c, long long hw_out, long long partial_cap, const char *who) {
-  if (!f.partial) return MP_OK;
+static int check_fin(mp_ctx *ctx, GnOut &f, int n, int c, long long partial_cap, const char *who) {
+  if (!gn_wanted(f)) return MP_OK;
   f.c = c;
   f.S = kGnSlices;
-  f.count = (double)(c / 32) * hw_out;
-  if (partial_cap >= 0 && partial_cap < (long long)n * 32 * kGnSlices * 2)
+  f.n = n;
+  if (f.partial && partial_cap >= 0 && partial_cap < (long long)n * 32 * kGnSlices * 2)
     return fail(ctx, MP_ERR_ARG, "%s: statistics buffer holds %lld doubles, the launch writes %lld", who,
                 partial_cap, (long long)n * 32 * kGnSlices * 2);
-  if (f.n_sets < 0 || f.n_sets > 2 || (f.n_sets > 0 && !f.counter))
-    return fail(ctx, MP_ERR_ARG, "%s: bad GroupNorm consumer request", who);
-  for (int q = 0; q < f.n_sets; ++q)
-    if (!f.set[q].gamma || !f.set[q].beta || !f.set[q].ss)
-      return fail(ctx, MP_ERR_ARG, "%s: GroupNorm consumer %d lacks gamma / beta / ss", who, q);
   return MP_OK;
 }
 
-int launch_avgpool2_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, float *y, GnFin fin,
+int launch_avgpool2_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, float *y, GnOut fin,
                        long long partial_cap, hipStream_t st) {
   const long long hw_out = (long long)(h / 2) * (w / 2);
-  int rc = check_fin(ctx, fin, n, c, hw_out, partial_cap, "avgpool2_gn");
+  int rc = check_fin(ctx, fin, n, c, partial_cap, "avgpool2_gn");
   if (rc != MP_OK) return rc;
   AvgPool2Op op{x, y, h / 2, w / 2};
   hipLaunchKernelGGL(ew_gn_kernel<AvgPool2Op>, dim3(n * 32 * kGnSlices), dim3(kGnThreads), 0, st, op,
@@ -336,9 +379,9 @@ int launch_avgpool2_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, 
 }
 
 int launch_upsample_add_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int w, const float *add, float *y,
-                           GnFin fin, long long partial_cap, hipStream_t st) {
+                           GnOut fin, long long partial_cap, hipStream_t st) {
   const long long hw_out = 4LL * h * w;
-  int rc = check_fin(ctx, fin, n, c, hw_out, partial_cap, "upsample_add_gn");
+  int rc = check_fin(ctx, fin, n, c, partial_cap, "upsample_add_gn");
   if (rc != MP_OK) return rc;
   UpsampleAddOp op{x, add, y, h, w, (float)(h - 1) / (float)(2 * h - 1), (float)(w - 1) / (float)(2 * w - 1)};
   hipLaunchKernelGGL(ew_gn_kernel<UpsampleAddOp>, dim3(n * 32 * kGnSlices), dim3(kGnThreads), 0, st, op,
@@ -347,11 +390,16 @@ int launch_upsample_add_gn(mp_ctx *ctx, const float *x, int n, int c, int h, int
   return MP_OK;
 }
 
-int launch_gn_apply_gn(mp_ctx *ctx, const float *x, const float *ss, int relu, int n, int c, long long hw,
-                       float *y, GnFin fin, long long partial_cap, hipStream_t st) {
-  int rc = check_fin(ctx, fin, n, c, hw, partial_cap, "gn_apply_gn");
+int launch_gn_apply_gn(mp_ctx *ctx, const float *x, GnIn gn, int relu, int n, int c, long long hw,
+                       const float *res, float *y, GnOut fin, long long partial_cap, hipStream_t st) {
+  int rc = check_fin(ctx, fin, n, c, partial_cap, "gn_apply");
   if (rc != MP_OK) return rc;
-  GnApplyOp op{x, ss, y, hw, relu};
+  if (!gn_active(gn) || (gn.acc && (!gn.gamma || !gn.beta)))
+    return fail(ctx, MP_ERR_ARG, "gn_apply: needs the GroupNorm of the input (accumulator + gamma / beta, or ss)");
+  gn.c = c;
+  gn.n = n;
+  gn.count = (double)(c / 32) * hw;
+  GnApplyOp op{x, res, y, hw, relu, gn, 0.0f, 1.0f};
   hipLaunchKernelGGL(ew_gn_kernel<GnApplyOp>, dim3(n * 32 * kGnSlices), dim3(kGnThreads), 0, st, op,
                      (long long)(c / 32) * hw, fin);
   MP_HIP(ctx, hipGetLastError());

@@ -52,7 +52,7 @@ class _GroupNorm(nn.GroupNorm):
     take the stock PyTorch op."""
 
     def forward(self, x, relu=False):
-        if not self.training and ops.group_norm_supported(x):
+        if not self.training and ops.group_norm_supported(x) and _inference_only(x, self):
             return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, relu)
         y = super().forward(x)
         return F.relu(y) if relu else y
@@ -87,7 +87,7 @@ def _run_sequential(seq, x):
 
 def _upsample2x_add(low, skip):
     """skip + bicubic x2 (align_corners=True) of ``low`` (HGFilters.py:108-111)."""
-    if low.is_cuda and low.dtype == torch.float32:
+    if low.is_cuda and low.dtype == torch.float32 and _inference_only(low, skip):
         return ops.upsample_bicubic2x(low.contiguous(), add=skip.contiguous())
     return skip + F.interpolate(low, scale_factor=2, mode="bicubic", align_corners=True)
 
@@ -124,29 +124,29 @@ def _pow2(v):
     return v > 0 and (v & (v - 1)) == 0
 
 
-def _block_dataflow(blk, x, ss1, ss4=None, out_consumers=()):
+def _block_dataflow(blk, x, acc_x, arena, out_stats=False):
     """ConvBlock (HGFilters.py:40-62) as three launches of csrc/conv3x3.hip (+ one 1x1 launch for a
     projection shortcut) and nothing else: every GroupNorm is handed from the kernel that writes a
-    tensor to the kernel that reads it (``ss1`` / ``ss4``: (scale, shift) of blk.bn1 / blk.bn4 over
-    x, published by x's producer), and torch.cat((out1, out2, out3), 1) + residual is written by the
-    three epilogues.  ``out_consumers``: GroupNorm modules that read the block's output.
-    Returns (out, [ss per consumer])."""
+    tensor to the kernel that reads it (``acc_x``: the accumulator x's producer filled; bn1 and bn4
+    read the same statistics with their own affine parameters), and torch.cat((out1, out2, out3), 1)
+    + residual is written by the three epilogues.  ``out_stats``: also collect the statistics of the
+    block's output.  Returns (out, accumulator of out or None)."""
     n, c_in, h, w = x.shape
     ca, cb, cc = blk.conv1.out_channels, blk.conv2.out_channels, blk.conv3.out_channels
     if blk.downsample is None:
         shortcut = x
     else:
-        shortcut, _ = ops.conv1x1_fused(x, ss4, True, None, blk._packed_projection())
+        shortcut = ops.conv1x1_fused(x, (acc_x, blk.bn4), True, None, blk._packed_projection())
     out = torch.empty((n, ca + cb + cc, h, w), dtype=torch.float32, device=x.device)
-    oc = list(out_consumers)
-    out_ss = [torch.empty((n, ca + cb + cc, 2), dtype=torch.float32, device=x.device) for _ in oc]
-    a, ss_a, _ = ops.conv3x3_fused(x, ss1, blk._packed(blk.conv1), consumers=[blk.bn2], out=out, res=shortcut,
-                                   out_off=0, out_consumers=oc, out_ss=out_ss)
-    b, ss_b, _ = ops.conv3x3_fused(a, ss_a[0], blk._packed(blk.conv2), consumers=[blk.bn3], out=out, res=shortcut,
-                                   out_off=ca, out_consumers=oc, out_ss=out_ss)
-    ops.conv3x3_fused(b, ss_b[0], blk._packed(blk.conv3), want_y=False, out=out, res=shortcut, out_off=ca + cb,
-                      out_consumers=oc, out_ss=out_ss)
-    return out, out_ss
+    acc_out = arena.take() if out_stats else None
+    acc_a, acc_b = arena.take(), arena.take()
+    a = ops.conv3x3_fused(x, (acc_x, blk.bn1), blk._packed(blk.conv1), stats=acc_a, out=out, res=shortcut,
+                          out_off=0, out_stats=acc_out)
+    b = ops.conv3x3_fused(a, (acc_a, blk.bn2), blk._packed(blk.conv2), stats=acc_b, out=out, res=shortcut,
+                          out_off=ca, out_stats=acc_out)
+    ops.conv3x3_fused(b, (acc_b, blk.bn3), blk._packed(blk.conv3), want_y=False, out=out, res=shortcut,
+                      out_off=ca + cb, out_stats=acc_out)
+    return out, acc_out
 
 
 class ConvBlock(nn.Module):
@@ -231,7 +231,7 @@ class ConvBlock(nn.Module):
         b = self.conv2(self.bn2(a, relu=True))
         c = self.conv3(self.bn3(b, relu=True))
         shortcut = x if self.downsample is None else _run_sequential(self.downsample, x)
-        if not self.training and ops.concat3_add_supported(a, b, c, shortcut):
+        if not self.training and ops.concat3_add_supported(a, b, c, shortcut) and _inference_only(a, b, c, shortcut):
             return ops.concat3_add(a, b, c, shortcut)  # one pass instead of cat + add
         return torch.cat((a, b, c), 1) + shortcut
 
@@ -265,22 +265,22 @@ class HourGlass(nn.Module):
         """The GroupNorm that reads the hourglass input first (b1 of the outermost level)."""
         return getattr(self, "b1_%d" % self.depth).bn1
 
-    def _level_dataflow(self, level, x, ss_b1, next_gn):
-        """_level on the hand-over kernels: ``ss_b1`` = (scale, shift) of b1_level.bn1 over x from x's
-        producer; the returned tensor carries the statistics for ``next_gn`` (b3 of the enclosing
-        level, or top_m).  Same evaluation order as HGFilters.py:87-111."""
+    def _level_dataflow(self, level, x, acc_x, arena):
+        """_level on the hand-over kernels: ``acc_x`` = statistics of x from x's producer (read by
+        b1_level.bn1); the returned tensor comes with the statistics its reader needs (b3 of the
+        enclosing level, or top_m).  Same evaluation order as HGFilters.py:87-111."""
         b1, b2, b3 = (getattr(self, "b%d_%d" % (k, level)) for k in (1, 2, 3))
-        skip, _ = _block_dataflow(b1, x, ss_b1)
-        pooled, ss_p = ops.avgpool2_gn(x, [b2.bn1])
+        skip, _ = _block_dataflow(b1, x, acc_x, arena)
+        acc_p = arena.take()
+        pooled = ops.avgpool2_gn(x, acc_p)
+        y, acc_y = _block_dataflow(b2, pooled, acc_p, arena, out_stats=True)
         if level > 1:
-            inner = getattr(self, "b1_%d" % (level - 1))
-            y, ss_y = _block_dataflow(b2, pooled, ss_p[0], out_consumers=[inner.bn1])
-            y, ss_y = self._level_dataflow(level - 1, y, ss_y[0], b3.bn1)
+            y, acc_y = self._level_dataflow(level - 1, y, acc_y, arena)
         else:
-            y, ss_y = _block_dataflow(b2, pooled, ss_p[0], out_consumers=[self.b2_plus_1.bn1])
-            y, ss_y = _block_dataflow(self.b2_plus_1, y, ss_y[0], out_consumers=[b3.bn1])
-        y, _ = _block_dataflow(b3, y, ss_y[0])
-        return ops.upsample_add_gn(y, skip, [next_gn])
+            y, acc_y = _block_dataflow(self.b2_plus_1, y, acc_y, arena, out_stats=True)
+        y, _ = _block_dataflow(b3, y, acc_y, arena)
+        acc_u = arena.take()
+        return ops.upsample_add_gn(y, skip, acc_u), acc_u
 
 
 class HGFilter(nn.Module):
@@ -365,31 +365,40 @@ class HGFilter(nn.Module):
         return hit[1]
 
     def _forward_dataflow(self, x, last_only, hwc_out, keep_nchw):
-        """HGFilters.py:167-204 as a chain of hand-written kernels only (no MIOpen / torch op): stem
-        7x7 (csrc/convim2col.hip) -> GroupNorm + ReLU -> pyramid blocks / hourglasses / 1x1 tails, with
-        every GroupNorm handed from producer to consumer (csrc/gn_tail.h)."""
+        """HGFilters.py:167-204 as a chain of hand-written kernels only (no MIOpen / torch op but the
+        one fill that clears the GroupNorm accumulators): stem 7x7 (csrc/convim2col.hip) -> GroupNorm +
+        ReLU -> pyramid blocks / hourglasses / 1x1 tails, every GroupNorm handed from producer to
+        consumer (csrc/gn_tail.h)."""
+        depth = self.m0.depth
+        blocks = 3 + self.num_stack * (3 * depth + 2)
+        arena = ops.GnArena(x.device, x.shape[0], 3 * blocks + self.num_stack * (2 * depth + 2) + 8)
         c2, c3, c4 = self.conv2, self.conv3, self.conv4
-        t, ss = ops.convk(x, None, False, self._stem_packed(), 2, consumers=[self.bn1])
-        x, ss = ops.gn_apply(t, ss[0], True, consumers=[c2.bn1, c2.bn4])
-        y, _ = _block_dataflow(c2, x, ss[0], ss[1])
-        y, ss = ops.avgpool2_gn(y, [c3.bn1])
-        y, ss = _block_dataflow(c3, y, ss[0], out_consumers=[c4.bn1, c4.bn4])
-        x, ss_x = _block_dataflow(c4, y, ss[0], ss[1], out_consumers=[self.m0.first_norm()])
+        acc = arena.take()
+        t = ops.convk(x, None, False, self._stem_packed(), 2, stats=acc)
+        acc_x = arena.take()
+        x = ops.gn_apply(t, (acc, self.bn1), True, stats=acc_x)
+        y, _ = _block_dataflow(c2, x, acc_x, arena)
+        acc = arena.take()
+        y = ops.avgpool2_gn(y, acc)
+        y, acc = _block_dataflow(c3, y, acc, arena, out_stats=True)
+        x, acc_x = _block_dataflow(c4, y, acc, arena, out_stats=True)
         outputs = []
         for i in range(self.num_stack):
             hg, top = getattr(self, "m%d" % i), getattr(self, "top_m_%d" % i)
             last = i == self.num_stack - 1
-            y, ss_y = hg._level_dataflow(hg.depth, x, ss_x[0], top.bn1)
-            y, _ = _block_dataflow(top, y, ss_y[0])
+            y, acc_y = hg._level_dataflow(hg.depth, x, acc_x, arena)
+            y, _ = _block_dataflow(top, y, acc_y, arena)
             packs = self._tail_packed(i)
-            t, ss_t = ops.conv1x1_fused(y, None, False, None, packs[0], consumers=[getattr(self, "bn_end%d" % i)])
+            acc_t = arena.take()
+            t = ops.conv1x1_fused(y, None, False, None, packs[0], stats=acc_t)
+            bn_end = (acc_t, getattr(self, "bn_end%d" % i))
             want_nchw = not last or keep_nchw or not (last_only and hwc_out is not None)
-            out, _ = ops.conv1x1_fused(t, ss_t[0], True, None, packs[1], want_nchw=want_nchw,
-                                       y_hwc=hwc_out if last else None)
+            out = ops.conv1x1_fused(t, bn_end, True, None, packs[1], want_nchw=want_nchw,
+                                    y_hwc=hwc_out if last else None)
             outputs.append((out,))
             if not last:
-                nxt = getattr(self, "m%d" % (i + 1)).first_norm()
-                x, ss_x = ops.conv1x1_fused(t, ss_t[0], True, out, packs[2], res=x, consumers=[nxt])
+                acc_x = arena.take()
+                x = ops.conv1x1_fused(t, bn_end, True, out, packs[2], res=x, stats=acc_x)
         return outputs[-1:] if last_only else outputs
 
     def forward(self, x, last_only=False, hwc_out=None, keep_nchw=False):
@@ -464,16 +473,16 @@ class _ResBlock(nn.Module):
         ss = ops.gn_finalize(st, n, c, _GROUPS, (c // _GROUPS) * h * w, blk[6].weight, blk[6].bias, blk[6].eps)
         return ops.scale_shift_add(u, ss, x)
 
-    def _forward_dataflow(self, x):
-        """_forward_fused with the GroupNorms handed over inside the convolution kernels (no
-        finalize launches)."""
+    def _forward_dataflow(self, x, arena):
+        """_forward_fused with the GroupNorms handed from kernel to kernel (no statistics / finalize
+        launches): two reflect-padded convolutions + the x + GroupNorm(.) tail."""
         blk = self.conv_block
         last = len(blk) == 6
-        t, ss, _ = ops.conv3x3_fused(x, None, _packed_conv(self, blk[1]), relu=False, reflect=True,
-                                     consumers=[blk[2]])
-        u, ss_u, _ = ops.conv3x3_fused(t, ss[0], _packed_conv(self, blk[5]), relu=True, reflect=True,
-                                       consumers=[] if last else [blk[6]])
-        return x + u if last else ops.scale_shift_add(u, ss_u[0], x)
+        acc_t = arena.take()
+        t = ops.conv3x3_fused(x, None, _packed_conv(self, blk[1]), relu=False, reflect=True, stats=acc_t)
+        acc_u = None if last else arena.take()
+        u = ops.conv3x3_fused(t, (acc_t, blk[2]), _packed_conv(self, blk[5]), relu=True, reflect=True, stats=acc_u)
+        return x + u if last else ops.gn_apply(u, (acc_u, blk[6]), False, res=x)
 
     def forward(self, x):
         if self._fused_ok(x):
@@ -526,12 +535,15 @@ class ResnetFilter(nn.Module):
         stride-2 convolutions on csrc/convim2col.hip (each applies the previous GroupNorm + ReLU while
         it gathers its input and hands its own statistics on), then the residual blocks."""
         m = self.model
-        t, ss = ops.convk(x, None, False, self._packed_k(m[1]), 1, reflect=True, consumers=[m[2]])
-        t, ss = ops.convk(t, ss[0], True, self._packed_k(m[4]), 2, consumers=[m[5]])
-        t, ss = ops.convk(t, ss[0], True, self._packed_k(m[7]), 2, consumers=[m[8]])
-        x, _ = ops.gn_apply(t, ss[0], True)
-        for blk in list(m)[10:]:
-            x = blk._forward_dataflow(x)
+        blocks = list(m)[10:]
+        arena = ops.GnArena(x.device, x.shape[0], 3 + 2 * len(blocks))
+        a0, a1, a2 = arena.take(), arena.take(), arena.take()
+        t = ops.convk(x, None, False, self._packed_k(m[1]), 1, reflect=True, stats=a0)
+        t = ops.convk(t, (a0, m[2]), True, self._packed_k(m[4]), 2, stats=a1)
+        t = ops.convk(t, (a1, m[5]), True, self._packed_k(m[7]), 2, stats=a2)
+        x = ops.gn_apply(t, (a2, m[8]), True)
+        for blk in blocks:
+            x = blk._forward_dataflow(x, arena)
         return [(x,)]
 
     def forward(self, x):

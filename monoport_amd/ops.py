@@ -439,8 +439,6 @@ def stream_release(stream):
     ctx = get_context(stream.device)
     ctx.check(ctx.lib.mp_stream_release(ctx.handle, ctypes.c_void_p(stream.cuda_stream)),
               "mp_stream_release")
-    with _counter_lock:
-        _counter_cache.pop((ctx.device_index, stream.cuda_stream), None)
 
 
 def forward_vertices_raw(volume, direction="front"):
@@ -755,97 +753,108 @@ def gn_finalize(stats, n, c, groups, count, weight, bias, eps):
     return ss
 
 
-# ---- GroupNorm hand-over: statistics taken by the producing kernel (include/monoport_hip.h) ----
-_counter_cache = {}
-_counter_lock = threading.Lock()
-_COUNTER_ROWS = 2          # fin / fin2 of one launch need separate counters
-_COUNTER_IMAGES = 64
+# ---- GroupNorm hand-over from producer to consumer (include/monoport_hip.h, csrc/gn_tail.h) ----
+def gn_acc_zeros(device, n, slots=None):
+    """Zeroed GroupNorm accumulator(s): int64 [R,N,32,4] (or [slots,R,N,32,4]), R = mp_gn_acc_replicas()."""
+    r = _lib.load().mp_gn_acc_replicas()
+    shape = (r, n, 32, 4) if slots is None else (slots, r, n, 32, 4)
+    return torch.zeros(shape, dtype=torch.int64, device=device)
 
 
-def _counters(device, n):
-    """Zero-initialised arrival counters int32 [2, >= n * 32] for the caller's current stream; the
-    kernels leave them zero, so one buffer per (device, stream) serves every launch."""
-    stream = torch.cuda.current_stream(device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), stream.cuda_stream)
-    need = max(n, _COUNTER_IMAGES) * 32
-    with _counter_lock:
-        buf = _counter_cache.get(key)
-        if buf is None or buf.shape[1] < need:
-            buf = torch.zeros((_COUNTER_ROWS, need), dtype=torch.int32, device=device)
-            _counter_cache[key] = buf
-    return buf
+class GnArena:
+    """Accumulators [slots, R, N, 32, 4] int64 for the GroupNorms of one encoder pass, zeroed by ONE fill
+    kernel; ``take()`` hands out the next [R,N,32,4] slice.  A producing kernel adds the statistics of
+    the tensor it writes into its slice, the consuming kernel reads them (``gn=(acc, module)``)."""
+
+    def __init__(self, device, n, slots):
+        self.buf = gn_acc_zeros(device, n, slots)
+        self.used = 0
+
+    def take(self):
+        if self.used >= self.buf.shape[0]:
+            raise RuntimeError("GnArena: more GroupNorms than slots (%d)" % self.buf.shape[0])
+        acc = self.buf[self.used]
+        self.used += 1
+        return acc
 
 
-def _gn_fin(fin, device, n, c, slices, consumers, ss_out=None, row=0, keep=None):
-    """Fill a _lib.GnFin for ``consumers`` (GroupNorm modules reading the tensor a kernel is about to
-    write; [] = no statistics).  Returns the list of ss tensors [N,C,2] (``ss_out`` when given:
-    several launches fill channel ranges of the same tensors)."""
-    if not consumers:
-        fin.partial = None
-        fin.n_sets = 0
-        return []
-    if len(consumers) > 2:
-        raise ValueError("at most two GroupNorm consumers per tensor")
-    partial = torch.empty((n * 32 * slices * 2,), dtype=torch.float64, device=device)
-    fin.partial = partial.data_ptr()
-    fin.partial_doubles = partial.numel()
-    fin.counters = _counters(device, n)[row].data_ptr()
-    fin.n_sets = len(consumers)
-    ss = ss_out if ss_out is not None else [torch.empty((n, c, 2), dtype=torch.float32, device=device)
-                                            for _ in consumers]
-    for k, gn in enumerate(consumers):
-        if gn.num_groups != 32 or gn.num_channels != c:
-            raise ValueError("consumer GroupNorm(%d, %d) does not match a %d-channel tensor"
-                             % (gn.num_groups, gn.num_channels, c))
-        fin.gamma[k] = gn.weight.data_ptr()
-        fin.beta[k] = gn.bias.data_ptr()
-        fin.eps[k] = float(gn.eps)
-        fin.ss[k] = ss[k].data_ptr()
-    if keep is not None:
-        keep.append(partial)
-    return ss
+def gn_reference_ss(acc, gn, count):
+    """(scale, shift) [N,C,2] a consumer derives from an accumulator -- host-side restatement of
+    gn_load_stats / gn_scale_shift for tests and probes (not used by the product path)."""
+    a = acc.sum(0).to(torch.float64)  # the replicas add up as integers
+    lo_s = torch.where(a[..., 1] < 0, a[..., 1] + 2.0 ** 64, a[..., 1])
+    lo_q = torch.where(a[..., 3] < 0, a[..., 3] + 2.0 ** 64, a[..., 3])
+    s = a[..., 0] / 65536.0 + lo_s / 2.0 ** 64
+    q = a[..., 2] / 65536.0 + lo_q / 2.0 ** 64
+    mean = s / count
+    var = torch.clamp(q / count - mean * mean, min=0.0)
+    rstd = (1.0 / torch.sqrt(var + gn.eps)).float()
+    mean = mean.float()
+    cpg = gn.num_channels // 32
+    sc = rstd.repeat_interleave(cpg, 1) * gn.weight[None]
+    sh = gn.bias[None] - mean.repeat_interleave(cpg, 1) * sc
+    return torch.stack((sc, sh), 2)
 
 
-def conv3x3_fused(x, ss, packed, relu=True, reflect=False, want_y=True, consumers=(), out=None, res=None,
-                  out_off=0, out_consumers=(), out_ss=None):
-    """mp_conv3x3_ex: y = conv3x3(relu?(x * scale + shift)) with the hand-over to the next GroupNorm(s)
-    and, optionally, the pyramid block's tail fused into the epilogue.
-      consumers      GroupNorm modules that read y           -> their ss (list)
-      out, res       [N,Ctot,H,W]: out[:, out_off:out_off+Cout] = y + res[:, same]  (cat + residual)
-      out_consumers  GroupNorm(32, Ctot) modules that read ``out``; out_ss: their ss tensors, shared
-                     by the launches that fill ``out``
-    Returns (y or None, ss list, out_ss list)."""
+def _gn_in(dst, gn, c):
+    """Fill a _lib.GnIn: ``gn`` = None (plain input), (acc [N,32,4] int64, GroupNorm module) or a
+    precomputed ss [N,C,2] tensor (legacy, from gn_finalize)."""
+    if gn is None:
+        return
+    if torch.is_tensor(gn):
+        dst.ss = gn.data_ptr()
+        return
+    acc, mod = gn
+    if mod.num_groups != 32 or mod.num_channels != c:
+        raise ValueError("GroupNorm(%d, %d) does not match a %d-channel input" % (mod.num_groups, mod.num_channels, c))
+    dst.acc = acc.data_ptr()
+    dst.gamma = mod.weight.data_ptr()
+    dst.beta = mod.bias.data_ptr()
+    dst.eps = float(mod.eps)
+
+
+def _gn_out(dst, acc):
+    if acc is not None:
+        assert acc.dtype == torch.int64 and acc.is_contiguous()
+        dst.acc = acc.data_ptr()
+
+
+def conv3x3_fused(x, gn, packed, relu=True, reflect=False, want_y=True, stats=None, out=None, res=None,
+                  out_off=0, out_stats=None):
+    """mp_conv3x3_ex: y = conv3x3(relu?(GroupNorm(x))) with the GroupNorm hand-over and, optionally, the
+    pyramid block's tail fused into the epilogue.
+      gn         GroupNorm of the input: None, (acc, module) or a legacy ss tensor
+      stats      accumulator [R,N,32,4] that receives the statistics of y (for the GroupNorm reading y)
+      out, res   [N,Ctot,H,W]: out[:, out_off:out_off+Cout] = y + res[:, same]  (cat + residual)
+      out_stats  accumulator for GroupNorm(32, Ctot) over ``out`` (shared by the launches filling it)
+    Returns y (or None with want_y=False)."""
     ctx = get_context(x.device)
     n, cin, h, w = x.shape
     if cin != packed.cin:
         raise ValueError("conv3x3: input has %d channels, weights expect %d" % (cin, packed.cin))
     a = _lib.Conv3x3Args()
-    keep = []
     y = torch.empty((n, packed.cout, h, w), dtype=torch.float32, device=x.device) if want_y else None
     f16 = packed.precision == "f16x3"
-    slices = ctx.lib.mp_conv3x3_stat_slices(packed.cout, n, h, w, int(f16))
-    ss_y = _gn_fin(a.fin, x.device, n, packed.cout, slices, list(consumers), row=0, keep=keep)
-    ss_o = []
+    _gn_in(a.gn, gn, cin)
+    _gn_out(a.fin, stats)
     if out is not None:
-        ss_o = _gn_fin(a.fin2, x.device, n, out.shape[1], slices, list(out_consumers), ss_out=out_ss, row=1,
-                       keep=keep)
+        assert out.is_contiguous() and res.is_contiguous() and out.shape == res.shape
+        _gn_out(a.fin2, out_stats)
         a.y2, a.res = out.data_ptr(), res.data_ptr()
         a.y2_channels, a.y2_offset = out.shape[1], int(out_off)
-        assert out.is_contiguous() and res.is_contiguous() and out.shape == res.shape
     a.x, a.n, a.cin, a.h, a.w = x.data_ptr(), n, cin, h, w
-    a.ss = ss.data_ptr() if ss is not None else None
     a.relu, a.reflect = int(bool(relu)), int(bool(reflect))
     a.packed = packed.data.data_ptr()
     a.wmax = packed.wmax.data_ptr() if f16 else None
     a.cout = packed.cout
     a.y = y.data_ptr() if y is not None else None
     ctx.check(ctx.lib.mp_conv3x3_ex(ctx.handle, ctypes.byref(a), _stream(x)), "mp_conv3x3_ex")
-    return y, ss_y, ss_o
+    return y
 
 
-def conv1x1_fused(x1, ss1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=None, consumers=()):
-    """mp_conv1x1_ex: ``conv1x1`` with the hand-over to the GroupNorm(s) that read the output.
-    Returns (y or None, ss list)."""
+def conv1x1_fused(x1, gn1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=None, stats=None):
+    """mp_conv1x1_ex: ``conv1x1`` with the GroupNorm hand-over (gn1 / stats as in conv3x3_fused).
+    Returns y (or None)."""
     ctx = get_context(x1.device)
     x1 = x1.contiguous()
     n, c1, h, w = x1.shape
@@ -853,13 +862,12 @@ def conv1x1_fused(x1, ss1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=No
     if c1 != packed.c1 or (x2 is None) != (packed.c2 == 0) or (x2 is not None and x2.shape[1] != packed.c2):
         raise ValueError("conv1x1: inputs do not match the packed weights")
     a = _lib.Conv1x1Args()
-    keep = []
     y = torch.empty((n, packed.cout, h, w), dtype=torch.float32, device=x1.device) if want_nchw else None
-    ss = _gn_fin(a.fin, x1.device, n, packed.cout, ctx.lib.mp_conv1x1_stat_slices(hw), list(consumers), keep=keep)
+    _gn_in(a.gn1, gn1, c1)
+    _gn_out(a.fin, stats)
     if y_hwc is not None:
         assert y_hwc.is_contiguous() and y_hwc.numel() == n * hw * 256 and y_hwc.dtype == torch.float32
     a.x1 = x1.data_ptr()
-    a.ss1 = ss1.data_ptr() if ss1 is not None else None
     a.relu1 = int(bool(relu1))
     if x2 is not None:
         x2 = x2.contiguous()
@@ -875,7 +883,7 @@ def conv1x1_fused(x1, ss1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=No
     a.y = y.data_ptr() if y is not None else None
     a.y_hwc = y_hwc.data_ptr() if y_hwc is not None else None
     ctx.check(ctx.lib.mp_conv1x1_ex(ctx.handle, ctypes.byref(a), _stream(x1)), "mp_conv1x1_ex")
-    return y, ss
+    return y
 
 
 class PackedConvK:
@@ -900,73 +908,73 @@ def convk_supported(cin, cout, ks, stride, h, w):
     return bool(_lib.load().mp_convk_supported(int(cin), int(cout), int(ks), int(stride), int(h), int(w)))
 
 
-def convk(x, ss, relu, packed, stride, reflect=False, consumers=()):
-    """mp_convk: y = conv_ks(relu?(x * scale + shift)) (+ bias), stride 1 / 2, padding ks // 2 (zero or
-    reflect) with the hand-over to the GroupNorm(s) reading y.  Returns (y, ss list)."""
+def convk(x, gn, relu, packed, stride, reflect=False, stats=None):
+    """mp_convk: y = conv_ks(relu?(GroupNorm(x))) (+ bias), stride 1 / 2, padding ks // 2 (zero or
+    reflect); gn / stats as in conv3x3_fused.  Returns y."""
     ctx = get_context(x.device)
     x = x.contiguous()
     n, cin, h, w = x.shape
     a = _lib.ConvKArgs()
-    keep = []
     y = torch.empty((n, packed.cout, h // stride, w // stride), dtype=torch.float32, device=x.device)
-    sl = ctx.lib.mp_convk_stat_slices(packed.ks, stride, h, w)
-    ss_y = _gn_fin(a.fin, x.device, n, packed.cout, sl, list(consumers), keep=keep)
+    _gn_in(a.gn, gn, cin)
+    _gn_out(a.fin, stats)
     a.x, a.n, a.cin, a.h, a.w = x.data_ptr(), n, cin, h, w
-    a.ss = ss.data_ptr() if ss is not None else None
     a.relu, a.reflect = int(bool(relu)), int(bool(reflect))
     a.packed = packed.data.data_ptr()
     a.bias = packed.bias.data_ptr() if packed.bias is not None else None
     a.cout, a.ks, a.stride = packed.cout, packed.ks, int(stride)
     a.y = y.data_ptr()
     ctx.check(ctx.lib.mp_convk(ctx.handle, ctypes.byref(a), _stream(x)), "mp_convk")
-    return y, ss_y
+    return y
 
 
-def _ew_fin(x, n, c, consumers):
-    fin = _lib.GnFin()
-    keep = []
-    ss = _gn_fin(fin, x.device, n, c, get_context(x.device).lib.mp_gn_stat_slices(), list(consumers), keep=keep)
-    return fin, ss, keep
-
-
-def avgpool2_gn(x, consumers=()):
-    """F.avg_pool2d(x, 2, stride=2) + the statistics for the GroupNorm(s) that read it -> (y, ss list)."""
+def avgpool2_gn(x, stats=None):
+    """F.avg_pool2d(x, 2, stride=2), adding the statistics of the result into ``stats``."""
     ctx = get_context(x.device)
     x = x.contiguous()
     n, c, h, w = x.shape
     y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
-    fin, ss, keep = _ew_fin(x, n, c, consumers)
+    fin = _lib.GnOut()
+    _gn_out(fin, stats)
     ctx.check(ctx.lib.mp_avgpool2_gn(ctx.handle, _ptr(x), n, c, h, w, _ptr(y), ctypes.byref(fin), _stream(x)),
               "mp_avgpool2_gn")
-    return y, ss
+    return y
 
 
-def upsample_add_gn(x, add, consumers=()):
-    """add + bicubic x2 of x (HGFilters.py:108-111) + statistics hand-over -> (y, ss list)."""
+def upsample_add_gn(x, add, stats=None):
+    """add + bicubic x2 of x (HGFilters.py:108-111), adding the statistics of the result into ``stats``."""
     ctx = get_context(x.device)
     x = x.contiguous()
     n, c, h, w = x.shape
     y = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
     if add is not None:
         add = add.contiguous()
-    fin, ss, keep = _ew_fin(x, n, c, consumers)
+    fin = _lib.GnOut()
+    _gn_out(fin, stats)
     ctx.check(ctx.lib.mp_upsample_bicubic2x_gn(ctx.handle, _ptr(x), n, c, h, w,
                                                _ptr(add) if add is not None else None, _ptr(y),
                                                ctypes.byref(fin), _stream(x)), "mp_upsample_bicubic2x_gn")
-    return y, ss
+    return y
 
 
-def gn_apply(x, ss, relu=True, consumers=()):
-    """relu?(x * scale + shift) materialised (+ statistics hand-over of the result) -> (y, ss list)."""
+def gn_apply(x, gn, relu=True, res=None, stats=None):
+    """[res +] relu?(GroupNorm(x)) materialised (gn = (acc, module) or a legacy ss tensor), adding the
+    statistics of the result into ``stats``."""
     ctx = get_context(x.device)
     x = x.contiguous()
     n, c = x.shape[0], x.shape[1]
     hw = x.shape[2] * x.shape[3]
     y = torch.empty_like(x)
-    fin, ss_y, keep = _ew_fin(x, n, c, consumers)
-    ctx.check(ctx.lib.mp_gn_apply(ctx.handle, _ptr(x), _ptr(ss), int(bool(relu)), n, c, hw, _ptr(y),
-                                  ctypes.byref(fin), _stream(x)), "mp_gn_apply")
-    return y, ss_y
+    g = _lib.GnIn()
+    _gn_in(g, gn, c)
+    fin = _lib.GnOut()
+    _gn_out(fin, stats)
+    if res is not None:
+        res = res.contiguous()
+    ctx.check(ctx.lib.mp_gn_apply(ctx.handle, _ptr(x), ctypes.byref(g), int(bool(relu)), n, c, hw,
+                                  _ptr(res) if res is not None else None, _ptr(y), ctypes.byref(fin),
+                                  _stream(x)), "mp_gn_apply")
+    return y
 
 
 def profile_begin(device, max_records=4096):

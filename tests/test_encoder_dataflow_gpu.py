@@ -34,16 +34,34 @@ def _ss_ref(t, gn):
     return torch.stack((sc, sh), 2)
 
 
-def _check_ss(ss, t, gn, what, tol=2e-5):
-    ref = _ss_ref(t, gn)
-    err = (ss.double() - ref).abs().max().item()
-    assert ss.shape == ref.shape and err <= tol * max(1.0, ref.abs().max().item()), "%s: ss off by %g" % (what, err)
-
-
-def _counters_clean():
+def _check_acc(acc, t, gn, what, channels=None, tol=2e-5):
+    """The (scale, shift) a consumer derives from accumulator ``acc`` against GroupNorm's definition
+    over t (``channels``: only this slice was accumulated)."""
     from monoport_amd import ops
-    torch.cuda.synchronize()
-    return all(int(buf.abs().sum().item()) == 0 for buf in ops._counter_cache.values())
+    c = t.shape[1]
+    count = (c // 32) * t.shape[2] * t.shape[3]
+    got = ops.gn_reference_ss(acc, gn, count).double()
+    ref = _ss_ref(t, gn)
+    if channels is not None:
+        got, ref = got[:, channels], ref[:, channels]
+    err = (got - ref).abs().max().item()
+    assert got.shape == ref.shape and err <= tol * max(1.0, ref.abs().max().item()), "%s: ss off by %g" % (what, err)
+
+
+def _acc(n):
+    from monoport_amd import ops
+    return ops.gn_acc_zeros(DEV, n)
+
+
+def _acc_of(x):
+    """Accumulator holding the statistics of x (through mp_gn_apply with an identity scale / shift)."""
+    from monoport_amd import ops
+    ident = torch.zeros((x.shape[0], x.shape[1], 2), device=DEV)
+    ident[..., 0] = 1.0
+    acc = _acc(x.shape[0])
+    y = ops.gn_apply(x, ident, relu=False, stats=acc)
+    assert torch.equal(y, x)
+    return acc
 
 
 # (N, Cin, Cout, H, W, Ctot, off): Ctot / off = the pyramid block this convolution fills
@@ -63,46 +81,44 @@ def test_conv3x3_fused_handover_and_tail(mode, n, cin, cout, h, w, ctot, off):
     res = torch.randn((n, ctot, h, w), generator=g).to(DEV)
     wt = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).to(DEV)
     gn_in = _gn(cin, 1) if cin % 32 == 0 else None
-    gn_y, gn_o1, gn_o2 = _gn(cout, 2), _gn(ctot, 3), _gn(ctot, 4)
-    ss_in = _ss_ref(x, gn_in).float() if gn_in is not None else None
+    gn_y, gn_o = _gn(cout, 2), _gn(ctot, 3)
+    acc_x = _acc_of(x) if gn_in is not None else None
     packed = ops.PackedConv3x3(wt)
     out = torch.full((n, ctot, h, w), 7.0, device=DEV)
-    out_ss = [torch.full((n, ctot, 2), 9.0, device=DEV) for _ in range(2)]
+    acc_y, acc_o, acc_y2, acc_o2 = _acc(n), _acc(n), _acc(n), _acc(n)
+    gn_arg = (acc_x, gn_in) if gn_in is not None else None
     lib.mp_conv3x3_tune({"auto": 0, "large": 0x100, "splitk": 0x200}[mode])
     try:
-        y, ss_y, ss_o = ops.conv3x3_fused(x, ss_in, packed, relu=gn_in is not None, consumers=[gn_y], out=out,
-                                          res=res, out_off=off, out_consumers=[gn_o1, gn_o2], out_ss=out_ss)
-        y2, ss_y2, _ = ops.conv3x3_fused(x, ss_in, packed, relu=gn_in is not None, consumers=[gn_y], out=out.clone(),
-                                         res=res, out_off=off, out_consumers=[gn_o1, gn_o2],
-                                         out_ss=[t.clone() for t in out_ss])
+        y = ops.conv3x3_fused(x, gn_arg, packed, relu=gn_in is not None, stats=acc_y, out=out, res=res,
+                              out_off=off, out_stats=acc_o)
+        y2 = ops.conv3x3_fused(x, gn_arg, packed, relu=gn_in is not None, stats=acc_y2, out=out.clone(), res=res,
+                               out_off=off, out_stats=acc_o2)
+        if gn_in is not None:  # the legacy form of the same input GroupNorm: precomputed (scale, shift)
+            ss_in = ops.gn_reference_ss(acc_x, gn_in, (cin // 32) * h * w)
+            y3 = ops.conv3x3_fused(x, ss_in, packed, relu=True)
     finally:
         lib.mp_conv3x3_tune(0)
     with torch.no_grad():
         v = x.double()
         if gn_in is not None:
-            v = torch.relu(v * ss_in[..., 0, None, None].double() + ss_in[..., 1, None, None].double())
+            ss64 = _ss_ref(x, gn_in)
+            v = torch.relu(v * ss64[..., 0, None, None] + ss64[..., 1, None, None])
         ref = torch.nn.functional.conv2d(v, wt.double(), padding=1)
     err = (y.double() - ref).abs().max().item()
     print("conv3x3_fused %s %s: max|d| %.3g" % (mode, (n, cin, cout, h, w), err))
-    assert err <= 2e-5 * max(1.0, ref.abs().max().item())
-    assert torch.equal(y, y2) and torch.equal(ss_y[0], ss_y2[0])            # deterministic
-    _check_ss(ss_y[0], y, gn_y, "raw output")
+    assert err <= 3e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(y, y2) and torch.equal(acc_y, acc_y2) and torch.equal(acc_o, acc_o2)  # deterministic
+    if gn_in is not None:
+        assert torch.equal(y, y3)  # hand-over and precomputed (scale, shift) agree bit for bit
+    _check_acc(acc_y, y, gn_y, "raw output")
     # the block tail: this launch's channels of cat + residual, everything else untouched
     assert torch.equal(out[:, off:off + cout], y + res[:, off:off + cout])
     untouched = torch.ones(ctot, dtype=torch.bool)
     untouched[off:off + cout] = False
     assert (out[:, untouched] == 7.0).all()
-    full = out.clone()
-    full[:, untouched] = 0.0  # statistics are per group: only this launch's groups are defined
-    for k, gn in enumerate((gn_o1, gn_o2)):
-        ref_ss = _ss_ref(out, gn)
-        got = ss_o[k]
-        assert ss_o[k] is out_ss[k]
-        sl = slice(off, off + cout)
-        e = (got[:, sl].double() - ref_ss[:, sl]).abs().max().item()
-        assert e <= 2e-5 * max(1.0, ref_ss[:, sl].abs().max().item()), "tail consumer %d: %g" % (k, e)
-        assert (got[:, untouched] == 9.0).all()
-    assert _counters_clean()
+    _check_acc(acc_o, out, gn_o, "block output", channels=slice(off, off + cout))
+    cpg = ctot // 32
+    assert (acc_o[:, :, :off // cpg] == 0).all() and (acc_o[:, :, (off + cout) // cpg:] == 0).all()
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
@@ -113,11 +129,22 @@ def test_conv3x3_fused_f16x3_and_reflect(precision):
     x = torch.randn((n, c, h, w), generator=g).to(DEV)
     wt = (torch.randn((c, c, 3, 3), generator=g) * (2.0 / (9 * c)) ** 0.5).to(DEV)
     gn = _gn(c, 8)
-    y, ss, _ = ops.conv3x3_fused(x, None, ops.PackedConv3x3(wt, precision), relu=False, reflect=True, consumers=[gn])
+    acc = _acc(n)
+    y = ops.conv3x3_fused(x, None, ops.PackedConv3x3(wt, precision), relu=False, reflect=True, stats=acc)
     ref = torch.nn.functional.conv2d(torch.nn.ReflectionPad2d(1)(x).double(), wt.double())
     assert (y.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
-    _check_ss(ss[0], y, gn, "reflect conv")
-    assert _counters_clean()
+    _check_acc(acc, y, gn, "reflect conv")
+    # the block's second half: GroupNorm + ReLU handed over, then x + GroupNorm(.) (ResBlkFilters.py:75-84)
+    gn2 = _gn(c, 9)
+    acc2 = _acc(n)
+    u = ops.conv3x3_fused(y, (acc, gn), ops.PackedConv3x3(wt, precision), relu=True, reflect=True, stats=acc2)
+    out = ops.gn_apply(u, (acc2, gn2), False, res=x)
+    with torch.no_grad():
+        v = torch.relu(gn(y))
+        u_ref = torch.nn.functional.conv2d(torch.nn.ReflectionPad2d(1)(v).double(), wt.double())
+        want = x + gn2(u)
+    assert (u.double() - u_ref).abs().max().item() <= 5e-5 * max(1.0, u_ref.abs().max().item())
+    assert (out - want).abs().max().item() <= 5e-5
 
 
 @pytest.mark.parametrize("mrw", [0, 1, 2])
@@ -138,24 +165,24 @@ def test_conv1x1_fused_handover(precision, mrw):
             p_l = ops.PackedConv1x1(convs[1].weight, convs[1].bias, precision=precision)
             p_blal = ops.PackedConv1x1(convs[2].weight, convs[2].bias, convs[3].weight, convs[3].bias,
                                        precision=precision)
-            t, ss_t = ops.conv1x1_fused(y, None, False, None, p_last, consumers=[gn_end])
+            acc_t, acc_x = _acc(n), _acc(n)
+            t = ops.conv1x1_fused(y, None, False, None, p_last, stats=acc_t)
             t_ref = torch.nn.functional.conv2d(y.double(), convs[0].weight.double(), convs[0].bias.double())
             assert (t.double() - t_ref).abs().max().item() <= 2e-5 * max(1.0, t_ref.abs().max().item())
-            _check_ss(ss_t[0], t, gn_end, "conv_last")
+            _check_acc(acc_t, t, gn_end, "conv_last")
             hwc = torch.empty((n, h, w, 256), device=DEV)
-            out, _ = ops.conv1x1_fused(t, ss_t[0], True, None, p_l, y_hwc=hwc)
-            v = torch.relu(t.double() * ss_t[0][..., 0, None, None].double() + ss_t[0][..., 1, None, None].double())
+            out = ops.conv1x1_fused(t, (acc_t, gn_end), True, None, p_l, y_hwc=hwc)
+            v = torch.relu(gn_end(t)).double()
             out_ref = torch.nn.functional.conv2d(v, convs[1].weight.double(), convs[1].bias.double())
             assert (out.double() - out_ref).abs().max().item() <= 5e-5 * max(1.0, out_ref.abs().max().item())
             assert torch.equal(hwc, out.permute(0, 2, 3, 1).contiguous())
-            xn, ss_x = ops.conv1x1_fused(t, ss_t[0], True, out, p_blal, res=x, consumers=[gn_next])
+            xn = ops.conv1x1_fused(t, (acc_t, gn_end), True, out, p_blal, res=x, stats=acc_x)
             xn_ref = (x.double() + torch.nn.functional.conv2d(v, convs[2].weight.double(), convs[2].bias.double())
                       + torch.nn.functional.conv2d(out.double(), convs[3].weight.double(), convs[3].bias.double()))
             assert (xn.double() - xn_ref).abs().max().item() <= 5e-5 * max(1.0, xn_ref.abs().max().item())
-            _check_ss(ss_x[0], xn, gn_next, "x + bl + al")
+            _check_acc(acc_x, xn, gn_next, "x + bl + al")
     finally:
         lib.mp_conv3x3_tune(0)
-    assert _counters_clean()
 
 
 def test_convk_stem_and_downsampling():
@@ -165,41 +192,41 @@ def test_convk_stem_and_downsampling():
     # hourglass stem: 7x7 stride 2, zero padding 3, bias
     conv = torch.nn.Conv2d(3, 64, 7, 2, 3).to(DEV)
     gn = _gn(64, 31)
+    acc = _acc(2)
     with torch.no_grad():
-        y, ss = ops.convk(img, None, False, ops.PackedConvK(conv.weight, conv.bias), 2, consumers=[gn, gn])
+        y = ops.convk(img, None, False, ops.PackedConvK(conv.weight, conv.bias), 2, stats=acc)
         ref = torch.nn.functional.conv2d(img.double(), conv.weight.double(), conv.bias.double(), stride=2, padding=3)
     e = (y.double() - ref).abs().max().item()
     print("stem 7x7 s2: %.3g" % e)
     assert y.shape == (2, 64, 256, 256) and e <= 2e-5 * max(1.0, ref.abs().max().item())
-    _check_ss(ss[0], y, gn, "stem")
-    assert torch.equal(ss[0], ss[1])
+    _check_acc(acc, y, gn, "stem")
     # netC stem: ReflectionPad2d(3) + 7x7, no bias
     conv7 = torch.nn.Conv2d(3, 64, 7, bias=False).to(DEV)
     gn7 = _gn(64, 32)
+    acc7 = _acc(2)
     with torch.no_grad():
-        t, ss7 = ops.convk(img, None, False, ops.PackedConvK(conv7.weight), 1, reflect=True, consumers=[gn7])
+        t = ops.convk(img, None, False, ops.PackedConvK(conv7.weight), 1, reflect=True, stats=acc7)
         ref7 = torch.nn.functional.conv2d(torch.nn.ReflectionPad2d(3)(img).double(), conv7.weight.double())
     e = (t.double() - ref7).abs().max().item()
     print("netC stem 7x7 reflect: %.3g" % e)
     assert t.shape == (2, 64, 512, 512) and e <= 2e-5 * max(1.0, ref7.abs().max().item())
-    _check_ss(ss7[0], t, gn7, "netC stem")
+    _check_acc(acc7, t, gn7, "netC stem")
     # stride-2 3x3 with the previous GroupNorm + ReLU applied while gathering
-    for cin, cout, src, gnp in ((64, 128, t, gn7), (128, 256, None, None)):
+    for cin, cout, src, gnp, acc_in in ((64, 128, t, gn7, acc7), (128, 256, None, None, None)):
         if src is None:
             src = (torch.randn((2, cin, 256, 256), generator=g) * 1.3).to(DEV)
             gnp = _gn(cin, 33)
-        ss_in = _ss_ref(src, gnp).float()
+            acc_in = _acc_of(src)
         cv = torch.nn.Conv2d(cin, cout, 3, 2, 1, bias=False).to(DEV)
         gno = _gn(cout, 34)
+        accd = _acc(2)
         with torch.no_grad():
-            d, ssd = ops.convk(src, ss_in, True, ops.PackedConvK(cv.weight), 2, consumers=[gno])
-            v = torch.relu(src.double() * ss_in[..., 0, None, None].double() + ss_in[..., 1, None, None].double())
-            refd = torch.nn.functional.conv2d(v, cv.weight.double(), stride=2, padding=1)
+            d = ops.convk(src, (acc_in, gnp), True, ops.PackedConvK(cv.weight), 2, stats=accd)
+            refd = torch.nn.functional.conv2d(torch.relu(gnp(src)).double(), cv.weight.double(), stride=2, padding=1)
         e = (d.double() - refd).abs().max().item()
         print("3x3 s2 %d -> %d: %.3g" % (cin, cout, e))
-        assert d.shape == refd.shape and e <= 2e-5 * max(1.0, refd.abs().max().item())
-        _check_ss(ssd[0], d, gno, "3x3 s2")
-    assert _counters_clean()
+        assert d.shape == refd.shape and e <= 5e-5 * max(1.0, refd.abs().max().item())
+        _check_acc(accd, d, gno, "3x3 s2")
 
 
 def test_elementwise_producers_with_handover():
@@ -208,27 +235,29 @@ def test_elementwise_producers_with_handover():
     for n, c, h in ((1, 256, 128), (3, 128, 32), (2, 64, 256)):
         x = (torch.randn((n, c, h, h), generator=g) * 1.7 + 0.2).to(DEV)
         gn_a, gn_b = _gn(c, 41), _gn(c, 42)
-        y, ss = ops.avgpool2_gn(x, [gn_a])
+        acc = _acc(n)
+        y = ops.avgpool2_gn(x, acc)
         ref = torch.nn.functional.avg_pool2d(x, 2, stride=2)
         assert (y - ref).abs().max().item() <= 1e-6
-        _check_ss(ss[0], y, gn_a, "avgpool")
+        _check_acc(acc, y, gn_a, "avgpool")
         if h <= 128:
             skip = torch.randn((n, c, 2 * h, 2 * h), generator=g).to(DEV)
-            u, ssu = ops.upsample_add_gn(x, skip, [gn_a, gn_b])
+            acc_u = _acc(n)
+            u = ops.upsample_add_gn(x, skip, acc_u)
             assert torch.equal(u, ops.upsample_bicubic2x(x, add=skip))
             want = skip + torch.nn.functional.interpolate(x, scale_factor=2, mode="bicubic", align_corners=True)
             assert (u - want).abs().max().item() <= 1e-4
-            _check_ss(ssu[0], u, gn_a, "upsample_add a")
-            _check_ss(ssu[1], u, gn_b, "upsample_add b")
-        ss_in = _ss_ref(x, gn_b).float()
-        z, ssz = ops.gn_apply(x, ss_in, True, [gn_a])
+            _check_acc(acc_u, u, gn_a, "upsample_add a")
+            _check_acc(acc_u, u, gn_b, "upsample_add b")  # two readers, one accumulator
+        acc_x, acc_z = _acc_of(x), _acc(n)
+        z = ops.gn_apply(x, (acc_x, gn_b), True, stats=acc_z)
         with torch.no_grad():
             want = torch.relu(gn_b(x))
         assert (z - want).abs().max().item() <= 5e-5
-        _check_ss(ssz[0], z, gn_a, "gn_apply")
-        z2, none = ops.gn_apply(x, ss_in, False)
-        assert none == [] and (z2 - gn_b(x)).abs().max().item() <= 5e-5
-    assert _counters_clean()
+        _check_acc(acc_z, z, gn_a, "gn_apply")
+        z2 = ops.gn_apply(x, (acc_x, gn_b), False)
+        with torch.no_grad():
+            assert (z2 - gn_b(x)).abs().max().item() <= 5e-5
 
 
 def _netg(seed=71):
@@ -268,7 +297,6 @@ def test_hgfilter_dataflow_vs_reference_and_round2_path(monkeypatch, precision):
               "batch 1 vs 3 %.3g" % (precision, i, err, e3, d_old, d_b))
         assert err <= 1e-4 and e3 <= 1e-4 and d_old <= 1e-4 and d_b <= 1e-4
         assert torch.equal(three[i][0], again[i][0])  # deterministic
-    assert _counters_clean()
 
 
 def test_hgfilter_dataflow_hwc_and_last_only():
@@ -300,14 +328,13 @@ def test_resnet_filter_dataflow(monkeypatch):
     err = (got - ref).abs().max().item()
     print("ResnetFilter dataflow vs stock ops: %.3g (max|ref| %.3g)" % (err, ref.abs().max().item()))
     assert got.shape == (1, 256, 128, 128) and err <= 1e-4 * max(1.0, ref.abs().max().item())
-    assert _counters_clean()
 
 
 def test_fused_paths_stay_out_of_autograd():
     """eval mode with gradients requested keeps the differentiable PyTorch ops."""
     from monoport_amd.modeling import backbones
-    blk = backbones.ConvBlock(64, 64).to(DEV).eval()
-    x = torch.randn((1, 64, 32, 32), device=DEV, requires_grad=True)
+    blk = backbones.ConvBlock(128, 128).to(DEV).eval()
+    x = torch.randn((1, 128, 32, 32), device=DEV, requires_grad=True)
     assert not blk._fused_ok(x)
     y = blk(x)
     assert y.grad_fn is not None
