@@ -35,8 +35,13 @@ int ensure_scratch(mp_ctx *ctx, hipStream_t st, size_t bytes, void **out) {
     if (want < bytes) want = bytes;
     want = (want + 0xFFFF) & ~size_t(0xFFFF);
     void *p = nullptr;
-    if (hipMalloc(&p, want) != hipSuccess && (want == bytes || hipMalloc(&p, want = bytes) != hipSuccess))
-      return fail(ctx, MP_ERR_NOMEM, "scratch arena: hipMalloc(%zu) failed", want);
+    if (hipMalloc(&p, want) != hipSuccess) {
+      (void)hipGetLastError();  // the failed attempt must not surface as the next launch's error
+      if (want == bytes || hipMalloc(&p, want = bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, MP_ERR_NOMEM, "scratch arena: hipMalloc(%zu) failed", want);
+      }
+    }
     if (a.ptr) a.retired.push_back(a.ptr);
     a.ptr = p;
     a.bytes = want;
@@ -158,9 +163,15 @@ int mp_stream_release(mp_ctx *ctx, mp_stream stream) {
   DeviceGuard g(ctx->device);
   // the stream may already be destroyed (that is when this is called): drain the device instead
   MP_HIP(ctx, hipDeviceSynchronize());
-  if (it->second.ptr) MP_HIP(ctx, hipFree(it->second.ptr));
-  for (void *p : it->second.retired) MP_HIP(ctx, hipFree(p));
+  // free every block and forget the arena even if one hipFree fails (mp_destroy must not free twice)
+  hipError_t first = hipSuccess;
+  if (it->second.ptr) first = hipFree(it->second.ptr);
+  for (void *p : it->second.retired) {
+    const hipError_t e = hipFree(p);
+    if (first == hipSuccess) first = e;
+  }
   ctx->arenas.erase(it);
+  MP_HIP(ctx, first);
   return MP_OK;
 }
 

@@ -844,17 +844,21 @@ static ConvPlan conv_plan(int cout, int n, int h, int w, bool f16) {
   c.rbw = cout % 128 == 0 ? 4 : cout % 64 == 0 ? 2 : 1;
   const int cw = 4 / c.rbw;
   const long long pix = (long long)n * h * w;
-  // NR = 2 unless that leaves fewer than 2 workgroups per slot (512 slots); NR = 4 needs all 256
-  // VGPRs (spills) and measured slower at every shape, so it is not built
-  c.nr = 2;
-  if (g_conv_nr > 0)
-    c.nr = g_conv_nr;
-  else if (pix / (32 * c.nr * cw) * (cout / (32 * c.rbw)) < 1024)
-    c.nr = 1;
-  if (c.nr > 2 && (c.rbw == 1 || !f16)) c.nr = 2;  // NR = 4 is built for the split-f16 kernels only
+  // NR (32-pixel column blocks per wave).  Every workgroup of these launches is resident at once, so
+  // a launch lasts as long as the busiest CU: ceil(workgroups / 256) x NR units of MFMA work.  NR = 2
+  // halves the workgroups and the weight bytes streamed per FLOP and gives a wave two independent
+  // accumulator chains; it wins every tie (measured, profiles/r03d_conv_bench.txt: 256 -> 128 at
+  // 128^2, batch 1: 118 us as 256 workgroups of NR = 2, 130 us as 512 of NR = 1) and loses when the
+  // halved launch quantises badly (128 -> 64 at 64^2 x 10: 320 workgroups of NR = 2 = 2 x 2 units,
+  // 640 of NR = 1 = 3).  NR = 4 needs all 256 VGPRs (spills) and measured slower at every shape, so
+  // it is built for the split-f16 kernels only.
+  const long long wg1 = pix / (32 * cw) * (cout / (32 * c.rbw));  // workgroups at NR = 1
+  const long long wg2 = wg1 / 2;
+  c.nr = ((wg2 + 255) / 256) * 2 <= (wg1 + 255) / 256 ? 2 : 1;
+  if (g_conv_nr > 0) c.nr = g_conv_nr;
+  if (c.nr > 2 && (c.rbw == 1 || !f16)) c.nr = 2;
   // split-K when even the smallest large-tile launch does not give every slot a workgroup
-  const long long wg_large = pix / (32 * c.nr * cw) * (cout / (32 * c.rbw));
-  c.sk = !f16 && (g_conv_sk >= 0 ? g_conv_sk == 1 : wg_large < 512);
+  c.sk = !f16 && (g_conv_sk >= 0 ? g_conv_sk == 1 : wg1 < 512);
   if (c.sk) {
     c.rbw = 1;
     c.nr = g_conv_nr > 0 ? (g_conv_nr > 2 ? 2 : g_conv_nr) : (pix / 64 * (cout / 32) >= 512 ? 2 : 1);
@@ -1181,11 +1185,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
   auto a_load = [&](int m, int s, int part) {
     return wload128(ws, a_base + m * rb_stride + (min(s, steps - 1) * FPS + part) * 64);
   };
-  f32x4 ring[2][MRW][FPS];  // [slot][m][part], one step ahead
+  // A fragments kAhead steps ahead of their MFMAs: one step (16 MFMAs = 0.4 us at MRW = 2) does not
+  // cover an L2 hit under load, and unlike the 3x3 kernel there are no taps to spread the stream over
+  constexpr int kAhead = 3;
+  f32x4 ring[4][MRW][FPS];  // [step & 3][m][part]
 #pragma unroll
-  for (int m = 0; m < MRW; ++m)
+  for (int q = 0; q < kAhead; ++q)
 #pragma unroll
-    for (int part = 0; part < FPS; ++part) ring[0][m][part] = a_load(m, 0, part);
+    for (int m = 0; m < MRW; ++m)
+#pragma unroll
+      for (int part = 0; part < FPS; ++part) ring[q][m][part] = a_load(m, q, part);
 
   stage_load(0);
   gn_load_stats(p.gn1, img, gn_stats);
@@ -1201,11 +1210,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
 #pragma unroll
     for (int s = 0; s < SPC; ++s) {
       const int gs = chunk * SPC + s;
-      // next step's A fragments
+      // the A fragments of step gs + kAhead (SPC is a multiple of 4: gs & 3 == s & 3)
 #pragma unroll
       for (int m = 0; m < MRW; ++m)
 #pragma unroll
-        for (int part = 0; part < FPS; ++part) ring[(s + 1) & 1][m][part] = a_load(m, gs + 1, part);
+        for (int part = 0; part < FPS; ++part) ring[(s + kAhead) & 3][m][part] = a_load(m, gs + kAhead, part);
       if constexpr (!F16) {
         f32x4 b[2];
 #pragma unroll
@@ -1218,7 +1227,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
           for (int m = 0; m < MRW; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[s & 1][m][0][i], b[n][i], acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[s & 3][m][0][i], b[n][i], acc[m][n], 0, 0, 0);
       } else {
         h8 bh[2], bl[2];
 #pragma unroll
@@ -1230,8 +1239,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MRW; ++m) {
-          const h8 ah = __builtin_bit_cast(h8, ring[s & 1][m][0]);
-          const h8 al = __builtin_bit_cast(h8, ring[s & 1][m][FPS - 1]);
+          const h8 ah = __builtin_bit_cast(h8, ring[s & 3][m][0]);
+          const h8 al = __builtin_bit_cast(h8, ring[s & 3][m][FPS - 1]);
 #pragma unroll
           for (int n = 0; n < 2; ++n)
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[n], acc[m][n], 0, 0, 0);

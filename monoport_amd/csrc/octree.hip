@@ -244,7 +244,6 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
 }
 
 // 9^3, 7^3, 3^3 boxes at levels 1, 2, 3+ (the upstream engine's "faster" schedule)
-static int box_of_level(int level) { return level == 1 ? 9 : level == 2 ? 7 : 3; }
 
 static void launch_select(int box, unsigned blocks, hipStream_t st, const u64 *bnd,
                           const u64 *ev_prev, int rp, int w64p, u64 *ev, int r, int w64,
@@ -451,7 +450,7 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
       hipLaunchKernelGGL(upsample_classify_kernel,
                          dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp), dim3(256),
                          0, st, lv[f][l - 1].occ, rp, lv[f][l].occ, r, balance, lv[f][l].bnd, w64);
-      launch_select(box_of_level(l), (unsigned)((items + 255) / 256), st, lv[f][l].bnd, lv[f][l - 1].ev, rp,
+      launch_select(octree_box_of_level(l), (unsigned)((items + 255) / 256), st, lv[f][l].bnd, lv[f][l - 1].ev, rp,
                     words64(rp), lv[f][l].ev, r, w64, packed[f], status[f] + 1 + l);
       QueryItem &q = set.it[f];
       q.out = lv[f][l].occ;

@@ -38,8 +38,8 @@ class Seg3dLossless(nn.Module):
                  align_corners=False, visualize=False, debug=False, use_cuda_impl=False,
                  faster=False, use_shadow=False, **kwargs):
         super().__init__()
-        if kwargs:
-            raise TypeError("Seg3dLossless: unknown arguments %s" % sorted(kwargs))
+        if kwargs:  # the upstream constructor swallows **kwargs: stay drop-in, but say so
+            warnings.warn("Seg3dLossless: ignoring unknown arguments %s" % sorted(kwargs))
         self.query_func = query_func
         self.b_min = np.asarray(b_min, np.float32).reshape(-1, 3)
         self.b_max = np.asarray(b_max, np.float32).reshape(-1, 3)
@@ -73,6 +73,12 @@ class Seg3dLossless(nn.Module):
         self.debug = bool(debug)
         self.last_status = None
         self.last_path = None  # "fused" | "generic": which engine served the last call
+        # "first": the first VALIDATE_CALLS calls are validated against query_func (see forward); once
+        # that many in a row agreed with the fused kernel, later calls with the same network head are
+        # trusted and skip the validation query.  "always": validate every call (debugging).
+        self.validate = "first"
+        self._agreed = 0          # consecutive validated calls that agreed
+        self._trusted_key = None  # (id(packed head), precision, z scale) those calls were bound to
         # nn.Module.to(device) is called on the engine (RTL/main.py:195): carry a buffer so it
         # has a device like the upstream module does
         self.register_buffer("_device_tag", torch.zeros(1), persistent=False)
@@ -87,8 +93,17 @@ class Seg3dLossless(nn.Module):
         its coarsest level is compared with what ``query_func`` returned; only if they are
         identical is the fused volume returned.  Anything else -- another network, extra
         arithmetic around the call (1 - pred, scaled points, ...), several calls -- goes through
-        the level-at-a-time engine, which evaluates every level with ``query_func`` itself."""
+        the level-at-a-time engine, which evaluates every level with ``query_func`` itself.
+
+        Limits of the check: only the coarsest lattice is compared, so a ``query_func`` that equals
+        MonoPortNet.query there but post-processes finer levels differently (resolution-dependent
+        logic) would pass; and after VALIDATE_CALLS agreeing calls in a row the check is skipped
+        for later calls bound to the same head (``self.validate = "always"`` keeps it on)."""
         dev = self._device_tag.device
+        if self.faster and self.validate != "always" and self._agreed >= self.VALIDATE_CALLS:
+            out = self._forward_trusted(kwargs)
+            if out is not NotImplemented:
+                return out
         eng = ops.LevelEngine(dev, self.b_min[0], self.b_max[0], self.resolutions,
                               self.balance_value, self.faster)
         pts0 = eng.select()
@@ -106,7 +121,11 @@ class Seg3dLossless(nn.Module):
             st = torch.cat([status, differs]).cpu()
             if int(st[-1]) == 0:
                 self.last_status, self.last_path = st[:-1], "fused"
+                key = self._binding_key(binding)
+                self._agreed = self._agreed + 1 if key == self._trusted_key else 1
+                self._trusted_key = key
                 return None if int(st[0]) == 0 else volume[None, None]
+            self._agreed, self._trusted_key = 0, None
             warnings.warn("Seg3dLossless: query_func is not a plain MonoPortNet.query call (its "
                           "values differ from the fused kernel's); using the level-at-a-time engine")
             volume, counts = ops.recon_generic(self.query_func, kwargs, dev, self.b_min[0],
@@ -119,6 +138,30 @@ class Seg3dLossless(nn.Module):
         self.last_path = "generic"
         self.last_status = torch.tensor([int(volume is not None)] + counts, dtype=torch.int32)
         return None if volume is None else volume[None, None]
+
+    VALIDATE_CALLS = 3
+
+    @staticmethod
+    def _binding_key(binding):
+        return (id(binding.mlp), binding.mlp.precision, float(binding.z_scale))
+
+    def _forward_trusted(self, kwargs):
+        """A query_func whose last VALIDATE_CALLS calls were plain MonoPortNet.query calls agreeing
+        with the fused kernel: bind this frame's features / calibration through a one-point probe
+        (recorded, not launched) and run the fused engine without the 17^3 validation query (one
+        host sync instead of two).  NotImplemented = the binding changed: validate again."""
+        probe = torch.zeros((1, 1, 3), dtype=torch.float32, device=self._device_tag.device)
+        with record_query(capture_only=True) as rec:
+            self.query_func(points=probe, **kwargs)
+        b = rec.binding
+        if b is None or rec.calls != 1 or self._binding_key(b) != self._trusted_key:
+            self._agreed, self._trusted_key = 0, None
+            return NotImplemented
+        volume, status = ops.recon(b.mlp, b.feat_hwc, b.calib, b.z_scale, self.b_min[0], self.b_max[0],
+                                   self.resolutions, self.balance_value)
+        st = status.cpu()
+        self.last_status, self.last_path = st, "fused"
+        return None if int(st[0]) == 0 else volume[None, None]
 
     def forward_async(self, **kwargs):
         """Fused path only, no host sync and no validation of ``query_func`` (the caller vouches

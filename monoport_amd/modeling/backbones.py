@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from .. import ops
 
 import os
+import threading
 
 _GROUPS = 32  # GroupNorm(32, C) everywhere (HGFilters.py:23-27, ResBlkFilters.py:19)
 # "hip" (default): the pyramid blocks' GroupNorm -> ReLU -> conv3x3 chains run as the fused f32-MFMA
@@ -122,6 +123,68 @@ def _inference_only(*tensors_or_modules):
 
 def _pow2(v):
     return v > 0 and (v & (v - 1)) == 0
+
+
+# "on": a drop-in call of an encoder (netG.filter(image) from a stage thread, RTL/main.py:366-370) replays
+# its ~135 launches as ONE hipGraph captured on first use per (shape, flags); outputs are copied out of
+# the graph's buffers, so they are ordinary tensors that outlive the call (RTL/dataloader.py:1048-1054).
+# Default "off": measured on the MI355X box the chain is GPU-bound even launch by launch (batch 1: 4.03
+# ms eager, 3.99 ms replayed; single-frame latency 10.6 vs 10.9 ms with the extra copies), so the graph
+# only pays on a host too loaded to issue 135 C-ABI calls in 4 ms.  Batches above
+# ENCODER_GRAPH_MAX_BATCH always run eagerly (FramePipeline captures its own graph of the whole slot).
+ENCODER_GRAPH = os.environ.get("MONOPORT_ENCODER_GRAPH", "off")
+ENCODER_GRAPH_MAX_BATCH = int(os.environ.get("MONOPORT_ENCODER_GRAPH_MAX_BATCH", "4"))
+
+
+class _GraphedForward:
+    """Per-module cache of captured forwards: key -> (graph, static input, static outputs)."""
+
+    def __init__(self):
+        self.entries = {}
+        self.lock = threading.Lock()
+
+    @staticmethod
+    def fingerprint(module):
+        """Cheap identity of the parameters a captured graph baked in (packed copies keyed on data
+        pointer / version): changes after load_state_dict, .to(), in-place updates."""
+        ver = 0
+        first = last = None
+        for p in module.parameters():
+            ver += p._version
+            if first is None:
+                first = p
+            last = p
+        return (ver, first.data_ptr() if first is not None else 0, last.data_ptr() if last is not None else 0)
+
+    def run(self, key, x, fn):
+        """fn(x_static) -> flat tuple of tensors / None.  Returns fresh copies of the outputs."""
+        with self.lock:
+            entry = self.entries.get(key)
+            if entry is None:
+                cur = torch.cuda.current_stream(x.device)
+                side = torch.cuda.Stream(device=x.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    x_static = x.clone()
+                    fn(x_static)  # eager warm-up: weight packs, scratch arenas
+                    side.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                        outs = fn(x_static)
+                    side.synchronize()
+                if len(self.entries) >= 8:  # shapes keep changing: do not hoard graph pools
+                    self.entries.clear()
+                entry = self.entries[key] = (graph, x_static, outs)
+            graph, x_static, outs = entry
+            x_static.copy_(x)
+            graph.replay()
+            return tuple(None if o is None else o.clone() for o in outs)
+
+
+def _graph_wanted(x, graphed):
+    if graphed is None:
+        graphed = ENCODER_GRAPH == "on" and x.shape[0] <= ENCODER_GRAPH_MAX_BATCH
+    return bool(graphed) and not torch.cuda.is_current_stream_capturing()
 
 
 def _block_dataflow(blk, x, acc_x, arena, out_stats=False):
@@ -401,14 +464,31 @@ class HGFilter(nn.Module):
                 x = ops.conv1x1_fused(t, bn_end, True, out, packs[2], res=x, stats=acc_x)
         return outputs[-1:] if last_only else outputs
 
-    def forward(self, x, last_only=False, hwc_out=None, keep_nchw=False):
+    def forward(self, x, last_only=False, hwc_out=None, keep_nchw=False, graphed=None):
         """``last_only=True`` skips materialising the per-stack outputs nobody reads in eval mode
         (MonoPortNet.py:63-64 keeps feats_stages[-1] only); the default matches the reference.
         ``hwc_out`` ([B,H,W,256], fused path only): the LAST stack's features are written there in
         channels-last layout by the producing kernel (no NCHW -> HWC pass); with ``last_only`` the
-        NCHW copy is then skipped and the returned entry is None, unless ``keep_nchw``."""
+        NCHW copy is then skipped and the returned entry is None, unless ``keep_nchw``.
+        ``graphed``: replay the kernel chain as one hipGraph (None = the ENCODER_GRAPH policy)."""
         if self._dataflow_ok(x):
-            return self._forward_dataflow(x.contiguous(), last_only, hwc_out, keep_nchw)
+            x = x.contiguous()
+            if not _graph_wanted(x, graphed):
+                return self._forward_dataflow(x, last_only, hwc_out, keep_nchw)
+            cache = self.__dict__.setdefault("_graphs", _GraphedForward())
+            key = (tuple(x.shape), str(x.device), bool(last_only), hwc_out is not None, bool(keep_nchw),
+                   ENCODER_CONV_PRECISION, _GraphedForward.fingerprint(self))
+
+            def run(xs):
+                hwc = torch.empty((xs.shape[0], xs.shape[2] // 4, xs.shape[3] // 4, 256), dtype=torch.float32,
+                                  device=xs.device) if hwc_out is not None else None
+                outs = self._forward_dataflow(xs, last_only, hwc, keep_nchw)
+                return tuple(o[0] for o in outs) + (hwc,)
+
+            flat = cache.run(key, x, run)
+            if hwc_out is not None:
+                hwc_out.copy_(flat[-1].reshape(hwc_out.shape))
+            return [(o,) for o in flat[:-1]]
         x = self.bn1(self.conv1(x), relu=True)
         x = F.avg_pool2d(self.conv2(x), 2, stride=2)
         x = self.conv4(self.conv3(x))
@@ -546,9 +626,14 @@ class ResnetFilter(nn.Module):
             x = blk._forward_dataflow(x, arena)
         return [(x,)]
 
-    def forward(self, x):
+    def forward(self, x, graphed=None):
         if self._dataflow_ok(x):
-            return self._forward_dataflow(x.contiguous())
+            x = x.contiguous()
+            if not _graph_wanted(x, graphed):
+                return self._forward_dataflow(x)
+            cache = self.__dict__.setdefault("_graphs", _GraphedForward())
+            key = (tuple(x.shape), str(x.device), ENCODER_CONV_PRECISION, _GraphedForward.fingerprint(self))
+            return [cache.run(key, x, lambda xs: (self._forward_dataflow(xs)[0][0],))]
         return [(_run_sequential(self.model, x),)]
 
 

@@ -94,7 +94,7 @@ class FrameSlot:
         """Both encoders on the slot's image buffers: (featG [B,256,128,128], featC or None)."""
         if self.hwc_direct:
             feat = self.net.image_filter(self.image, last_only=True, hwc_out=self.feat_hwc_all,
-                                         keep_nchw=self.netC is not None)[-1][0]
+                                         keep_nchw=self.netC is not None, graphed=False)[-1][0]
             if self.feature_hook is not None:
                 self.feature_hook.hwc(self.feat_hwc_all)
                 if feat is not None:

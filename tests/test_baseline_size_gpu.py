@@ -9,8 +9,9 @@ import pytest
 
 from conftest import load_golden
 from monoport_amd import synthetic as syn
-from test_oracle_golden import (DENSE64_CASES, PIPE257, dense64_inputs, dense_lattice,
-                                pipeline257_golden)
+from test_oracle_golden import (DENSE64_CASES, PIPE257, PIPE257_RES, PIPE257_SCENES, dense64_inputs, dense_lattice,
+                                pipeline257_check, pipeline257_golden, pipeline257_inputs,
+                                pipeline257_vertex_agreement)
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -101,16 +102,21 @@ def test_dense64_all_f16x3_encoder_in_the_loop(monkeypatch):
     assert fe <= 1e-4 and err.max() <= TOL_REF
 
 
-def test_pipeline257_vs_reference():
+@pytest.mark.parametrize("name", sorted(PIPE257_SCENES))
+def test_pipeline257_vs_reference(name):
     """BASELINE configs[1] size through the drop-in surface (RTL/main.py:169-195, :389-406):
     Seg3dLossless(17..257) + forward_vertices vs the reference's netG.query / forward_vertices run
-    on the CPU.  Same nodes queried at every level, every queried value within 1e-4, X / Y equal."""
+    on the CPU, three scenes (two of them not picked for their margin, one with an unsaturated
+    field).  Same nodes queried at every level and every queried value within 1e-4 -- outside the
+    reach of nodes the REFERENCE evaluated within fp32 noise of the threshold (test_oracle_golden.
+    pipeline257_undecided) -- and the same visible vertices."""
     from monoport_amd.implicit_seg.functional import Seg3dLossless
     from monoport_amd.modeling import PIFuNetG
     from monoport_amd.recon import forward_vertices, pifu_calib
-    g, queried = pipeline257_golden()
+    g, _ = pipeline257_golden(name)
+    layers, fmap, step = pipeline257_inputs(name)
     netG = PIFuNetG().eval()
-    _load_mlp(netG, syn.body_mlp("G", noise=PIPE257["mlp"][2], seed=PIPE257["mlp"][1]))
+    _load_mlp(netG, layers)
     netG.surface_classifier.to(DEV)
 
     def query_func(points, im_feat_list, calib_tensor):  # RTL/main.py:169-183
@@ -120,27 +126,28 @@ def test_pipeline257_vs_reference():
         return netG.query(im_feat_list, points=samples, calibs=calib_tensor)[0]
 
     engine = Seg3dLossless(query_func=query_func, b_min=np.array([[-1., -1., -1.]]),
-                           b_max=np.array([[1., 1., 1.]]), resolutions=PIPE257["res"],
+                           b_max=np.array([[1., 1., 1.]]), resolutions=PIPE257_RES,
                            balance_value=0.5, use_cuda_impl=False, faster=True).to(DEV)
-    calib = pifu_calib(*syn.scene_camera(PIPE257["step"]), device=DEV)
+    calib = pifu_calib(*syn.scene_camera(step), device=DEV)
     assert np.array_equal(calib.cpu().numpy(), g["calib"])
-    f = torch.from_numpy(syn.body_feat(256, 128, 128, PIPE257["feat"]))[None].to(DEV)
+    f = torch.from_numpy(fmap)[None].to(DEV)
     feats = [[torch.zeros(1, 256, 2, 2, device=DEV)]] * 3 + [[f]]
     sdf = engine(im_feat_list=feats, calib_tensor=calib)
     assert sdf.shape == (1, 1, 257, 257, 257)
-    assert list(engine.last_status[1:].numpy()) == list(g["stats"])  # same counts at every level
     vol = sdf[0, 0].cpu().numpy()
-    err = float(np.abs(vol[queried] - g["values"]).max())
-    print("pipeline257: %d queried nodes, max|HIP - reference| = %.3g" % (queried.sum(), err))
-    assert err <= TOL_REF
-    assert err <= 5e-6  # measured 4.5e-7
+    _, undecided, n_amb = pipeline257_check(name, vol, None, engine.last_status[1:].numpy(), TOL_REF)
     X, Y, Z, norm = forward_vertices(sdf, direction="front")
-    assert np.array_equal(X.cpu().numpy(), g["X"].astype(np.int64))
-    assert np.array_equal(Y.cpu().numpy(), g["Y"].astype(np.int64))
-    zerr = float(np.abs(Z.cpu().numpy() - g["Z"]).max())
-    nerr = float(np.abs(norm.cpu().numpy() - g["norm"]).max())
-    print("pipeline257: %d vertices, max|dZ| = %.3g voxels, max|dnorm| = %.3g" % (X.shape[0], zerr, nerr))
-    assert zerr <= 1e-3 and nerr <= 1e-4  # measured 3.1e-5 voxels / 2.4e-6
+    if n_amb == 0:
+        assert np.array_equal(X.cpu().numpy(), g["X"].astype(np.int64))
+        assert np.array_equal(Y.cpu().numpy(), g["Y"].astype(np.int64))
+        zerr = float(np.abs(Z.cpu().numpy() - g["Z"]).max())
+        nerr = float(np.abs(norm.cpu().numpy() - g["norm"]).max())
+        print("%s: %d vertices, max|dZ| = %.3g voxels, max|dnorm| = %.3g" % (name, X.shape[0], zerr, nerr))
+        assert zerr <= 1e-3 and nerr <= 1e-4  # measured 3.1e-5 voxels / 2.4e-6
+    else:
+        same = pipeline257_vertex_agreement(g, X.cpu().numpy(), Y.cpu().numpy(), Z.cpu().numpy())
+        print("%s: %.4f of the reference's %d vertices reproduced" % (name, same, g["X"].shape[0]))
+        assert same >= 0.99
 
 
 def test_marching_cubes_257_identical_connectivity(oracle):

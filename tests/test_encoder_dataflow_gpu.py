@@ -5,7 +5,7 @@ them -- against stock PyTorch ops in fp64 and the REFERENCE's encoder goldens.  
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import check_full_coverage, load_golden
 from monoport_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -297,6 +297,8 @@ def test_hgfilter_dataflow_vs_reference_and_round2_path(monkeypatch, precision):
               "batch 1 vs 3 %.3g" % (precision, i, err, e3, d_old, d_b))
         assert err <= 1e-4 and e3 <= 1e-4 and d_old <= 1e-4 and d_b <= 1e-4
         assert torch.equal(three[i][0], again[i][0])  # deterministic
+    eb, ep = check_full_coverage(gold, "G3", one[3][0][0].cpu().numpy())
+    print("HGFilter dataflow %s: full-coverage G3 block-mean error %.3g, pixel-mean error %.3g" % (precision, eb, ep))
 
 
 def test_hgfilter_dataflow_hwc_and_last_only():
@@ -311,6 +313,29 @@ def test_hgfilter_dataflow_hwc_and_last_only():
             assert torch.equal(hwc[b], ops.pack_features(outs[-1][0][b:b + 1]))
         only = net.image_filter(img, last_only=True, hwc_out=torch.empty_like(hwc))
         assert len(only) == 1 and only[-1][0] is None
+
+
+def test_encoder_graph_replay_equals_eager():
+    """graphed=True: the kernel chain replayed as one hipGraph gives the eager results bit for bit,
+    returns tensors that survive the next call, and is re-captured when the weights change."""
+    net = _netg()
+    img = torch.stack([torch.from_numpy(syn.synthetic_image(s)) for s in (73, 74)]).to(DEV)
+    enc = net.image_filter
+    with torch.no_grad():
+        eager = enc(img[:1], graphed=False)
+        first = enc(img[:1], graphed=True)
+        keep = first[3][0].clone()
+        second = enc(img[1:], graphed=True)          # same graph, other image
+        assert all(torch.equal(a[0], b[0]) for a, b in zip(eager, first))
+        assert torch.equal(first[3][0], keep)         # not overwritten by the replay
+        assert not torch.equal(second[3][0], keep)
+        hwc = torch.empty((1, 128, 128, 256), device=DEV)
+        only = enc(img[:1], last_only=True, hwc_out=hwc, graphed=True)
+        assert only[-1][0] is None and torch.equal(hwc[0], eager[3][0][0].permute(1, 2, 0))
+        enc.conv1.bias.add_(0.25)                     # in-place update: the fingerprint changes
+        changed = enc(img[:1], graphed=True)
+        assert torch.equal(changed[3][0], enc(img[:1], graphed=False)[3][0])
+        assert not torch.equal(changed[3][0], keep)
 
 
 def test_resnet_filter_dataflow(monkeypatch):
@@ -328,6 +353,29 @@ def test_resnet_filter_dataflow(monkeypatch):
     err = (got - ref).abs().max().item()
     print("ResnetFilter dataflow vs stock ops: %.3g (max|ref| %.3g)" % (err, ref.abs().max().item()))
     assert got.shape == (1, 256, 128, 128) and err <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_netc_filter_dataflow_vs_reference_full_coverage():
+    """netC.filter(image, feat_prior = netG's last stack) with BOTH encoders on the hand-over kernels
+    against the reference's CPU output: the strided samples and every element through the 8 x 8 block /
+    pixel means of the fixture."""
+    from monoport_amd.modeling import PIFuNetC
+    gold = load_golden("encoders")
+    netg = _netg(71)
+    netc = PIFuNetC().eval()
+    shapes = {k: tuple(v.shape) for k, v in netc.image_filter.state_dict().items()}
+    netc.image_filter.load_state_dict(
+        {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, 72).items()})
+    netc.image_filter.to(DEV)
+    img = torch.from_numpy(syn.synthetic_image(73))[None].to(DEV)
+    with torch.no_grad():
+        fg = netg.filter(img)
+        fc = netc.filter(img, feat_prior=fg[-1][-1])
+    c0 = fc[0][0][0].cpu().numpy()
+    err = float(np.abs(c0[::8, ::8, ::8] - gold["C0"]).max())
+    eb, ep = check_full_coverage(gold, "C0", c0)
+    print("netC.filter dataflow vs reference: samples %.3g, block means %.3g, pixel means %.3g" % (err, eb, ep))
+    assert err <= 1e-4
 
 
 def test_fused_paths_stay_out_of_autograd():

@@ -42,6 +42,9 @@ def test_encoders_match_reference_goldens():
     for i in range(4):
         assert np.abs(fg[i][0][0, ::8, ::8, ::8].numpy() - g["G%d" % i]).max() <= 1e-4
     assert np.abs(fc[0][0][0, ::8, ::8, ::8].numpy() - g["C0"]).max() <= 1e-4
+    from conftest import check_full_coverage
+    check_full_coverage(g, "G3", fg[-1][0][0].numpy())
+    check_full_coverage(g, "C0", fc[0][0][0].numpy())
     # prior first (MonoPortNet.py:44)
     assert torch.equal(fc[0][0][:, :256], fg[-1][-1])
 

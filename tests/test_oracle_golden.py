@@ -154,33 +154,105 @@ def test_dense64_matches_reference(oracle, case):
     assert np.abs(out - ref).max() <= 5e-6
 
 
-PIPE257 = dict(mlp=("body", 95, 0.05), feat=96, step=170, res=[17, 33, 65, 129, 257])
+PIPE257_RES = [17, 33, 65, 129, 257]
+# name -> (body_mlp arguments, body_feat seed, camera step): oracle/gen_golden.py PIPE257_SCENES.
+# "pipeline257" is round 2's scene (camera picked for a 6e-6 margin to the threshold: identical
+# decisions under any fp32-class evaluation); "_b" and "_soft" were NOT picked -- each holds queried
+# values within one ulp of 0.5 -- and "_soft" is an unsaturated field in which every head weight and
+# feature channel matters (72 % of its queried values lie in (0.01, 0.99)).
+PIPE257_SCENES = {
+    "pipeline257": (dict(k=40.0, c=2.0, noise=0.05, seed=95), 96, 170),
+    "pipeline257_b": (dict(k=40.0, c=2.0, noise=0.05, seed=195), 196, 40),
+    "pipeline257_soft": (dict(k=6.0, c=2.0, noise=1.0, seed=295), 296, 250),
+}
+PIPE257 = dict(mlp=("body", 95, 0.05), feat=96, step=170, res=PIPE257_RES)  # round-2 name of the first scene
+AMBIGUOUS = 2e-6  # |value - 0.5| below this is fp32 evaluation noise: the decision may go either way
 
 
-def pipeline257_golden():
-    g = load_golden("pipeline257")
-    rf = PIPE257["res"][-1]
+def pipeline257_golden(name="pipeline257"):
+    g = load_golden(name)
+    rf = PIPE257_RES[-1]
     queried = np.unpackbits(g["queried"])[:rf ** 3].astype(bool).reshape(rf, rf, rf)
     return g, queried
 
 
-def test_pipeline257_matches_reference(oracle):
+def pipeline257_inputs(name):
+    head, feat_seed, step = PIPE257_SCENES[name]
+    return syn.body_mlp("G", **head), syn.body_feat(256, 128, 128, feat_seed), step
+
+
+def pipeline257_undecided(g, queried):
+    """Mask of the 257^3 lattice where two fp32-class evaluations of the same field may legitimately
+    take different octree decisions: the reach of every reference-queried node whose value is within
+    AMBIGUOUS of the threshold.  A flip at level l (node spacing s_l) moves the boundary flags of the
+    adjacent cells and, through the dilation boxes 9 / 7 / 3 / 3 of the finer levels, the selection
+    within s_l + sum_{m>l} (box_m - 1) / 2 * s_m voxels (+ 2 for the interpolation footprint)."""
+    rf = PIPE257_RES[-1]
+    spacing = [(rf - 1) // (r - 1) for r in PIPE257_RES]  # 16, 8, 4, 2, 1
+    box = [0, 9, 7, 3, 3]
+    reach = [spacing[l] + sum((box[m] - 1) // 2 * spacing[m] for m in range(l + 1, 5)) + 2 for l in range(5)]
+    vals = np.zeros(queried.shape, np.float32)
+    vals[queried] = g["values"]
+    amb = np.argwhere(queried & (np.abs(vals - 0.5) <= AMBIGUOUS))
+    mask = np.zeros(queried.shape, bool)
+    for z, y, x in amb:
+        level = next(l for l in range(5) if z % spacing[l] == 0 and y % spacing[l] == 0 and x % spacing[l] == 0)
+        r = reach[level]
+        mask[max(z - r, 0):z + r + 1, max(y - r, 0):y + r + 1, max(x - r, 0):x + r + 1] = True
+    return mask, len(amb)
+
+
+def pipeline257_check(name, vol, queried, stats, tol):
+    """Octree result (volume, queried-node mask or None, per-level counts) against the reference-driven
+    fixture: outside the undecided regions the same nodes are queried and every queried value agrees
+    within ``tol``; with no undecided node the per-level counts are equal too."""
+    g, queried_ref = pipeline257_golden(name)
+    undecided, n_amb = pipeline257_undecided(g, queried_ref)
+    firm = queried_ref & ~undecided
+    ref_vol = np.zeros(queried_ref.shape, np.float32)
+    ref_vol[queried_ref] = g["values"]
+    err = float(np.abs(vol[firm] - ref_vol[firm]).max())
+    frac = float(undecided.mean())
+    print("%s: %d queried nodes, %d within %.0e of the threshold -> %.2f %% of the lattice undecided; "
+          "max|value - reference| over the %d firm nodes = %.3g; margin %.3g"
+          % (name, queried_ref.sum(), n_amb, AMBIGUOUS, 100 * frac, firm.sum(), err, float(g["margin"]) if "margin" in g else -1))
+    assert frac <= 0.25 and err <= tol
+    if queried is not None:
+        assert np.array_equal(queried & ~undecided, firm)
+    if n_amb == 0:
+        assert list(stats) == list(g["stats"])
+    else:  # the counts may differ by at most the nodes inside the undecided regions
+        assert abs(sum(stats) - int(g["stats"].sum())) <= int(undecided.sum())
+    return g, undecided, n_amb
+
+
+@pytest.mark.parametrize("name", sorted(PIPE257_SCENES))
+def test_pipeline257_matches_reference(oracle, name):
     """BASELINE configs[1] size: the 17..257 octree driven by the fp32 C oracle takes the same
     decisions as when driven by the reference's netG.query (same queried node set, same per-level
-    counts), the values agree to fp32 noise and forward_vertices gives the same columns."""
-    g, queried_ref = pipeline257_golden()
-    layers = syn.body_mlp("G", noise=PIPE257["mlp"][2], seed=PIPE257["mlp"][1])
-    f = syn.body_feat(256, 128, 128, PIPE257["feat"])
-    calib = oracle.pifu_calib(*syn.scene_camera(PIPE257["step"]))
+    counts -- up to nodes the reference itself evaluated within fp32 noise of the threshold), the
+    values agree to fp32 noise and forward_vertices gives the same columns."""
+    g, queried_ref = pipeline257_golden(name)
+    layers, f, step = pipeline257_inputs(name)
+    calib = oracle.pifu_calib(*syn.scene_camera(step))
     assert np.array_equal(calib, g["calib"])
     stats = []
     queried = np.zeros_like(queried_ref)
     vol = oracle.seg3d_lossless(
         lambda p: oracle.query(f, p, calib[0], layers, 1, syn.Z_SCALE, precision="f32")[0],
-        [-1, -1, -1], [1, 1, 1], PIPE257["res"], stats=stats, evaluated_out=queried)
-    assert stats == list(g["stats"]) and sum(stats) == g["values"].shape[0]
-    assert np.array_equal(queried, queried_ref)
-    assert np.abs(vol[queried] - g["values"]).max() <= 5e-6
+        [-1, -1, -1], [1, 1, 1], PIPE257_RES, stats=stats, evaluated_out=queried)
+    _, undecided, n_amb = pipeline257_check(name, vol, queried, stats, 5e-6)
     x, y, z, n = oracle.forward_vertices(vol, "front")
-    assert np.array_equal(x, g["X"].astype(np.int64)) and np.array_equal(y, g["Y"].astype(np.int64))
-    assert np.abs(z - g["Z"]).max() <= 2e-3  # voxel units
+    if n_amb == 0:
+        assert np.array_equal(x, g["X"].astype(np.int64)) and np.array_equal(y, g["Y"].astype(np.int64))
+        assert np.abs(z - g["Z"]).max() <= 2e-3  # voxel units
+    else:
+        same = pipeline257_vertex_agreement(g, x, y, z)
+        assert same >= 0.99
+
+
+def pipeline257_vertex_agreement(g, x, y, z):
+    """Fraction of the reference's visible vertices (X, Y) found at the same column with |dZ| <= 2e-3."""
+    ref = {(int(a), int(b)): float(c) for a, b, c in zip(g["X"], g["Y"], g["Z"])}
+    hit = sum(1 for a, b, c in zip(x, y, z) if abs(ref.get((int(a), int(b)), 1e9) - float(c)) <= 2e-3)
+    return hit / max(len(ref), 1)

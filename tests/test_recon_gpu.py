@@ -290,8 +290,46 @@ def test_non_faster_mode_equals_oracle_and_flags(ops, oracle, body):
     for bad in (dict(align_corners=True), dict(visualize=True), dict(use_shadow=True), dict(channels=2)):
         with pytest.raises(NotImplementedError):
             Seg3dLossless(query_func=query_func, **box, **bad)
-    with pytest.raises(TypeError):
+    with pytest.warns(UserWarning, match="ignoring unknown arguments"):  # upstream swallows **kwargs
         Seg3dLossless(query_func=query_func, no_such_flag=1, **box)
+
+
+def test_engine_trusts_a_query_func_after_validated_calls(ops, oracle, body):
+    """The 17^3 validation query runs for the first VALIDATE_CALLS frames; after that many agreeing
+    calls the fused engine is bound through a one-point probe (no validation query, one host sync).
+    Results are identical either way; validate="always" keeps the check; a changed head re-validates."""
+    from monoport_amd.implicit_seg.functional import Seg3dLossless
+    from monoport_amd.modeling import PIFuNetG
+    import torch
+    netG = PIFuNetG().eval()
+    netG.surface_classifier.load_state_dict(
+        {**{"filters.%d.weight" % i: torch.from_numpy(w)[:, :, None] for i, (w, _) in enumerate(body["layers"])},
+         **{"filters.%d.bias" % i: torch.from_numpy(b) for i, (_, b) in enumerate(body["layers"])}})
+    netG.surface_classifier.to(DEV)
+    feats = [[torch.from_numpy(body["f"])[None].to(DEV)]]
+    calls = []
+
+    def query_func(points, feats, calib):
+        calls.append(points.shape[1])
+        return netG.query(feats, points.permute(0, 2, 1), calib)[0]
+
+    res = [9, 17, 33, 65]
+    eng = Seg3dLossless(query_func=query_func, faster=True, b_min=np.array([[-1., -1., -1.]]),
+                        b_max=np.array([[1., 1., 1.]]), resolutions=res).to(DEV)
+    vols = []
+    for frame in range(eng.VALIDATE_CALLS + 2):
+        vols.append(eng(feats=feats, calib=body["cal"]))
+        assert eng.last_path == "fused"
+    # validated frames evaluate the 9^3 lattice through query_func, trusted ones only probe one point
+    assert calls == [729] * eng.VALIDATE_CALLS + [1, 1]
+    assert all(torch.equal(v, vols[0]) for v in vols[1:])
+    eng.validate = "always"
+    eng(feats=feats, calib=body["cal"])
+    assert calls[-1] == 729
+    eng.validate = "first"
+    netG.surface_classifier.set_precision("f16x3")  # another packed head: trust is dropped
+    eng(feats=feats, calib=body["cal"])
+    assert calls[-1] == 729 and eng.last_path == "fused"
 
 
 def test_wrapped_query_func_is_not_short_circuited(ops, oracle, body):

@@ -57,14 +57,14 @@ stages = [
 ]
 acc = {n: [] for n, _ in stages}
 with torch.no_grad():
-    for it in range(8):
+    for it in range(10):
         d = frame
         for name, fn in stages:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             d = fn(d)
             torch.cuda.synchronize()
-            if it >= 3:
+            if it >= 5:
                 acc[name].append((time.perf_counter() - t0) * 1e3)
 tot = 0.0
 for name, _ in stages:

@@ -6,12 +6,19 @@ output directory into the two small files committed under profiles/:
                               mean duration per octree level over the single-stream roofline leg
                               (the launches bench.py brackets with HIP events)
 
-    python tools/profile_summary.py DIR profiles/r01f_bench "command line that was profiled"
+    python tools/profile_summary.py DIR profiles/r01f_bench "command line that was profiled" [N_LEG [LAUNCH_LOG]]
+
+N_LEG = launches of the roofline leg (levels x batches); LAUNCH_LOG = the JSON bench.py writes when
+MONOPORT_BENCH_LAUNCH_LOG is set: per launch of that leg the HIP-event duration and the POINT COUNT,
+so that the per-launch TFLOP/s can be recomputed from the file alone.
 """
 import csv
 import glob
+import json
 import os
 import sys
+
+FLOP_PER_POINT = 2363906  # SURVEY.md section 8d
 
 
 def main(directory, prefix, command):
@@ -42,10 +49,24 @@ def main(directory, prefix, command):
         if single and len(sys.argv) > 4:
             n_leg = int(sys.argv[4])
             leg = durs[single[0] - n_leg:single[0]]
-            f.write("\nroofline leg = launches %d..%d: mean %.1f us (bench.py roofline.avg_launch_ms "
-                    "is the HIP-event mean of the same launches)\n"
-                    % (single[0] - n_leg, single[0] - 1, sum(leg) / len(leg)))
+            f.write("\nroofline leg = launches %d..%d (1-based, of the list above): mean %.1f us (bench.py "
+                    "roofline.avg_launch_ms is the HIP-event mean of the same launches)\n"
+                    % (single[0] - n_leg + 1, single[0], sum(leg) / len(leg)))
             print("roofline leg mean us:", sum(leg) / len(leg))
+            if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
+                log = json.load(open(sys.argv[5]))
+                f.write("per launch of the roofline leg: level, points (all frames of the launch), rocprofv3 "
+                        "duration, HIP-event duration, TFLOP/s = points x %d FLOP / rocprofv3 duration\n"
+                        % FLOP_PER_POINT)
+                tot_f = tot_t = 0.0
+                for i, (d, ms, pts) in enumerate(zip(leg, log["launch_ms"], log["launch_points"])):
+                    tf = pts * FLOP_PER_POINT / (d * 1e-6) / 1e12
+                    tot_f += pts * FLOP_PER_POINT
+                    tot_t += d * 1e-6
+                    f.write("  level %d  %9d points  %9.1f us  (events %9.1f us)  %6.1f TFLOP/s  frac %.3f\n"
+                            % (i % log["levels"], pts, d, ms * 1e3, tf, tf / 157.3))
+                f.write("  leg total: %.1f TFLOP/s = %.3f of the 157.3 TFLOP/s f32 MFMA peak\n"
+                        % (tot_f / tot_t / 1e12, tot_f / tot_t / 1e12 / 157.3))
     print("launches:", len(rows), "mean us:", sum(durs) / max(1, len(durs)))
 
 
