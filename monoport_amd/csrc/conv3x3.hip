@@ -160,6 +160,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, const float (&v
     }
   }
   // ---- bulk stores ----
+#ifdef MPC_NOSTORE
+  if (p.y && v[0][0] == 123.456f) p.y[0] = v[NR - 1][TN - 1] + (cat ? u[0][0] : 0.0f);
+#else
 #pragma unroll
   for (int n = 0; n < NR; ++n)
 #pragma unroll
@@ -167,6 +170,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, const float (&v
       if (p.y) p.y[o1 + off(n, tt)] = v[n][tt];
       if (cat) p.y2[o2 + off(n, tt)] = u[n][tt];
     }
+#endif
 }
 
 template <int RBW, int NR>
@@ -221,7 +225,12 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
     for (int it = 0; it < kStageIters; ++it) {
       const int o = goff[it] < 0 ? 0 : goff[it];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) stg[it][k] = pl[(long long)k * hw + o];
+      for (int k = 0; k < 4; ++k)
+#ifdef MPC_NOLOAD
+        stg[it][k] = (float)(o + k);
+#else
+        stg[it][k] = pl[(long long)k * hw + o];
+#endif
     }
     ch_staged = chunk * kCK + 4 * wv;
   };
@@ -305,7 +314,11 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
             bnxt[n] = *reinterpret_cast<const f32x4 *>(buf + (boff[n][3 * ky + (sn >> 1)] ^ (32 * (sn & 1))));
         }
         const f32x4 a = ring[s];
+#ifdef MPC_AHOT  // timing experiment: the weight stream always hits the same fragment
+        ring[s] = wload128(ws, a_base + s * 64);
+#else
         ring[s] = wload128(ws, a_base + min(kg0 + 6 + s, kgt - 1) * 64);
+#endif
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above the MFMAs (see query.hip)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1119,7 +1132,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) stg[q][k] = pl[(long long)(4 * q + k) * p.hw + px0 + lane];
+      for (int k = 0; k < 4; ++k)
+#ifdef MPC_NOLOAD  // timing experiment (tools/conv_ablate.sh): no activation reads
+        stg[q][k] = (float)(lane + q + k);
+#else
+        stg[q][k] = pl[(long long)(4 * q + k) * p.hw + px0 + lane];
+#endif
     c0_staged = seg2 ? -1 : c0;
   };
   auto stage_store = [&](int chunk, unsigned char *buf) {
@@ -1313,7 +1331,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
       gn_emit(p.fin, img, (NCH * (int)blockIdx.y) / cpg, ng, tile, a, b);
     }
   }
+#ifdef MPC_NOSTORE  // timing experiment: no output writes (one lane keeps the values alive)
+  if (p.y && acc[0][0][0] == 123.456f) p.y[0] = acc[0][1][3];
+  if (false) {
+#else
   if (p.y) {
+#endif
 #pragma unroll
     for (int m = 0; m < MRW; ++m)
 #pragma unroll

@@ -41,32 +41,34 @@ def main(directory, prefix, command):
         f.write("%d fused-query launches; duration (us), grid, kernel -- in start order\n" % len(rows))
         for (s, e, name, grid, wg), d in zip(rows, durs):
             f.write("%10.1f  grid %-8s %s\n" % (d, grid, name))
-        # bench.py's legs in launch order: slot warm-ups, timed pass (slots overlap on 3 streams),
-        # roofline leg (ONE stream, the launches bracketed by HIP events), breakdown leg (single
-        # frames: level 0 is 77 workgroups).  The roofline leg = the last `levels * batches`
-        # multi-frame launches before the first single-frame one.
-        single = [i for i, r in enumerate(rows) if int(r[3]) == 77 * 256]
-        if single and len(sys.argv) > 4:
-            n_leg = int(sys.argv[4])
-            leg = durs[single[0] - n_leg:single[0]]
-            f.write("\nroofline leg = launches %d..%d (1-based, of the list above): mean %.1f us (bench.py "
-                    "roofline.avg_launch_ms is the HIP-event mean of the same launches)\n"
-                    % (single[0] - n_leg + 1, single[0], sum(leg) / len(leg)))
+        # the roofline leg (ONE stream, every launch bracketed by HIP events) is found by its
+        # durations: the window of N_LEG consecutive launches that matches bench.py's HIP-event
+        # log best (the timed passes overlap three streams, so their launches run longer)
+        if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
+            log = json.load(open(sys.argv[5]))
+            ev = [ms * 1e3 for ms in log["launch_ms"]]
+            n_leg = len(ev)
+            best, at = None, 0
+            for i in range(0, len(durs) - n_leg + 1):
+                err = sum(abs(durs[i + k] - ev[k]) / ev[k] for k in range(n_leg))
+                if best is None or err < best:
+                    best, at = err, i
+            leg = durs[at:at + n_leg]
+            f.write("\nroofline leg = launches %d..%d (1-based, of the list above; mean relative difference to "
+                    "bench.py's HIP-event durations %.2f %%): mean %.1f us\n"
+                    % (at + 1, at + n_leg, 100 * best / n_leg, sum(leg) / len(leg)))
+            f.write("per launch: level, points (all frames of the launch), rocprofv3 duration, HIP-event "
+                    "duration, TFLOP/s = points x %d FLOP / rocprofv3 duration\n" % FLOP_PER_POINT)
+            tot_f = tot_t = 0.0
+            for i, (d, ms, pts) in enumerate(zip(leg, log["launch_ms"], log["launch_points"])):
+                tf = pts * FLOP_PER_POINT / (d * 1e-6) / 1e12
+                tot_f += pts * FLOP_PER_POINT
+                tot_t += d * 1e-6
+                f.write("  level %d  %9d points  %9.1f us  (events %9.1f us)  %6.1f TFLOP/s  frac %.3f\n"
+                        % (i % log["levels"], pts, d, ms * 1e3, tf, tf / 157.3))
+            f.write("  leg total: %.1f TFLOP/s = %.3f of the 157.3 TFLOP/s f32 MFMA peak\n"
+                    % (tot_f / tot_t / 1e12, tot_f / tot_t / 1e12 / 157.3))
             print("roofline leg mean us:", sum(leg) / len(leg))
-            if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
-                log = json.load(open(sys.argv[5]))
-                f.write("per launch of the roofline leg: level, points (all frames of the launch), rocprofv3 "
-                        "duration, HIP-event duration, TFLOP/s = points x %d FLOP / rocprofv3 duration\n"
-                        % FLOP_PER_POINT)
-                tot_f = tot_t = 0.0
-                for i, (d, ms, pts) in enumerate(zip(leg, log["launch_ms"], log["launch_points"])):
-                    tf = pts * FLOP_PER_POINT / (d * 1e-6) / 1e12
-                    tot_f += pts * FLOP_PER_POINT
-                    tot_t += d * 1e-6
-                    f.write("  level %d  %9d points  %9.1f us  (events %9.1f us)  %6.1f TFLOP/s  frac %.3f\n"
-                            % (i % log["levels"], pts, d, ms * 1e3, tf, tf / 157.3))
-                f.write("  leg total: %.1f TFLOP/s = %.3f of the 157.3 TFLOP/s f32 MFMA peak\n"
-                        % (tot_f / tot_t / 1e12, tot_f / tot_t / 1e12 / 157.3))
     print("launches:", len(rows), "mean us:", sum(durs) / max(1, len(durs)))
 
 
