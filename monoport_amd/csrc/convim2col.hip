@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
   const float *xin = p.x + (long long)img * p.cin * hw_in;
   const bool norm = gn_active(p.gn);
   __shared__ float gn_stats[64];  // (mean, rstd) of the input's 32 groups (csrc/gn_tail.h)
+  __shared__ float ss_tab[2 * (CC > 16 ? CC : 16)];
   const WStream ws = make_wstream(p.wp, p.wp_floats, lane);
   gn_load_stats(p.gn, img, gn_stats);
   __syncthreads();
@@ -84,7 +85,9 @@ __global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
     f32x4 ring[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) ring[k] = wload128(ws, a_base + (k < NG ? k : NG - 1) * 64);
-    if (chunk) __syncthreads();  // the previous chunk's tile has been consumed
+    // (scale, shift) of the chunk's input channels, once per chunk instead of once per gathered element
+    if (norm && tid < CC) gn_scale_shift(p.gn, img, chunk * CC + tid, gn_stats, ss_tab[2 * tid], ss_tab[2 * tid + 1]);
+    __syncthreads();  // the previous chunk's tile has been consumed; ss_tab is visible
     // ---- gather: element e = (pixel, k), k fastest (conflict-free LDS writes) ----
 #pragma unroll 2
     for (int it = 0; it < NE; ++it) {
@@ -106,9 +109,7 @@ __global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
           const int ci = chunk * CC + c;
           v = xin[ci * hw_in + (long long)iy * p.w + ix];
           if (norm) {
-            float sc, sh;
-            gn_scale_shift(p.gn, img, ci, gn_stats, sc, sh);
-            v = fmaf(v, sc, sh);
+            v = fmaf(v, ss_tab[2 * c], ss_tab[2 * c + 1]);
             if (p.relu) v = fmaxf(v, 0.0f);
           }
         }
