@@ -494,14 +494,13 @@ class HGFilter(nn.Module):
         x = self.conv4(self.conv3(x))
         fused = (not self.training and ENCODER_CONV == "hip" and ops.conv1x1_supported(x)
                  and x.shape[1] == 256)
-        if hwc_out is not None and not fused:
-            raise RuntimeError("HGFilter.forward(hwc_out=...) needs the fused convolution path")
+        pack_after = hwc_out is not None and not fused  # no producing kernel to write it: pack the NCHW result
         outputs = []
         for i in range(self.num_stack):
             y = getattr(self, "top_m_%d" % i)(getattr(self, "m%d" % i)(x))
             if fused:
-                out, x = self._tail_fused(i, y, x, hwc_out,
-                                          want_nchw=keep_nchw or not (last_only and hwc_out is not None))
+                out, x = self._tail_fused(i, y, x, None if pack_after else hwc_out,
+                                          want_nchw=keep_nchw or pack_after or not (last_only and hwc_out is not None))
                 outputs.append((out,))
                 continue
             y = getattr(self, "bn_end%d" % i)(getattr(self, "conv_last%d" % i)(y), relu=True)
@@ -509,6 +508,10 @@ class HGFilter(nn.Module):
             outputs.append((out,))
             if i < self.num_stack - 1:
                 x = x + getattr(self, "bl%d" % i)(y) + getattr(self, "al%d" % i)(out)
+        if pack_after:  # train mode / MONOPORT_ENCODER_CONV=miopen / odd shapes: same contract, one more pass
+            last = outputs[-1][0]
+            for b in range(last.shape[0]):
+                ops.pack_features(last[b:b + 1].detach(), out=hwc_out[b])
         return outputs[-1:] if last_only else outputs
 
 

@@ -338,6 +338,20 @@ def test_encoder_graph_replay_equals_eager():
         assert not torch.equal(changed[3][0], keep)
 
 
+def test_hwc_out_without_a_producing_kernel(monkeypatch):
+    """hwc_out on a path that has no kernel to write it (stock convolutions): packed from the NCHW
+    result instead of raising."""
+    from monoport_amd import ops
+    from monoport_amd.modeling import backbones
+    net = _netg()
+    img = torch.from_numpy(syn.synthetic_image(73))[None].to(DEV)
+    monkeypatch.setattr(backbones, "ENCODER_CONV", "miopen")
+    hwc = torch.empty((1, 128, 128, 256), device=DEV)
+    with torch.no_grad():
+        outs = net.image_filter(img, last_only=True, hwc_out=hwc)
+    assert torch.equal(hwc[0], ops.pack_features(outs[-1][0]))
+
+
 def test_resnet_filter_dataflow(monkeypatch):
     from monoport_amd.modeling import backbones
     net = backbones.ResnetFilter().eval()
