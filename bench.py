@@ -124,7 +124,7 @@ def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, 
     return pipe
 
 
-TRAFFIC_PROFILE = "r02_query_traffic.json"
+TRAFFIC_PROFILE = "r03_query_traffic.json"  # 16 frames per launch (r02_query_traffic.json: 10)
 
 
 def traffic_from_profile(precision, levels, with_color, frames_per_launch):
@@ -680,10 +680,12 @@ def measure_config(job, depth, batch, use_graph, resolutions, with_color, precis
 def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=48,
+                    help="frames in the timed region (default 48 = one submission of each of the 3 slots at 16 "
+                         "frames per slot; round 2 timed 20 = two submissions of 10)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--depth", type=int, default=3, help="pipeline slots (streams) per GPU")
-    ap.add_argument("--batch", type=int, default=10,
+    ap.add_argument("--batch", type=int, default=16,
                     help="frames per slot (upper bound): their encoder passes run as one batch and "
                          "their octree levels as one fused-query launch; depth x batch frames are in "
                          "flight.  The largest divisor of --steps not above this is used, so no slot "

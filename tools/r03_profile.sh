@@ -5,8 +5,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=${1:-r03p}
 out=$R/gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-CMD="python bench.py --steps 20 --warmup 5 --no-alt --no-dropin --no-cpu-baseline"
-MONOPORT_BENCH_LAUNCH_LOG=$out/launch_log.json rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/bench.py --steps 20 --warmup 5 --no-alt --no-dropin --no-cpu-baseline > $out/bench_prof.log 2>&1
+CMD="python bench.py --warmup 5 --no-alt --no-dropin --no-cpu-baseline"
+MONOPORT_BENCH_LAUNCH_LOG=$out/launch_log.json rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/bench.py --warmup 5 --no-alt --no-dropin --no-cpu-baseline > $out/bench_prof.log 2>&1
 cd $R
 python tools/profile_summary.py $out/trace $out/r03_bench "$CMD" 10 $out/launch_log.json > $out/summary.log 2>&1
 tail -1 $out/bench_prof.log | cut -c1-400; cat $out/summary.log

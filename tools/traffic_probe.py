@@ -1,12 +1,12 @@
 """Workload for the rocprofv3 --pmc passes behind bench.py's roofline.traffic.
 
-    run   : one pipeline slot, 10 frames per batch, 2 timed-style batches (after warm-up) --
+    run   : one pipeline slot, BATCH frames per batch, 2 timed-style batches (after warm-up) --
             the LAST 10 pifu_query_kernel dispatches are 2 batches x 5 octree levels
     parse : counter_collection.csv of the FETCH_SIZE and WRITE_SIZE passes -> profiles/*.json
 
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python tools/traffic_probe.py run
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python tools/traffic_probe.py run
-  python tools/traffic_probe.py parse gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_query_traffic.json
+  python tools/traffic_probe.py parse gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r03_query_traffic.json
 """
 import csv
 import glob
@@ -16,7 +16,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-BATCH, LEVELS = 10, 5  # bench.py default: --steps 20 -> 10 frames per slot submission / launch
+# frames per slot submission / launch: bench.py's default (16; round 2: 10) or MONOPORT_TRAFFIC_BATCH
+BATCH, LEVELS = int(os.environ.get("MONOPORT_TRAFFIC_BATCH", "16")), 5
 
 
 def run():
