@@ -9,8 +9,12 @@
 //   * GroupNorm + ReLU are applied to the INPUT while it is staged into LDS:
 //     v = max(x * scale[n,c] + shift[n,c], 0), zero outside the image (the convolution pads the
 //     normalised tensor, HGFilters.py:15-19 padding=1);
-//   * the epilogue writes NCHW and, on request, the per-channel sum / sum of squares of the tile
-//     (f32 over <= 128 values, then double): the NEXT GroupNorm's statistics without another pass;
+//   * the epilogue writes NCHW and hands the statistics the NEXT GroupNorm needs on (round 3,
+//     csrc/gn_tail.h): per-channel sums (f32 over <= 128 values, then double) meet in LDS, are folded
+//     to per-group sums in a fixed order and ADDED to the consumer's accumulator with integer
+//     atomics -- no statistics pass, no finalize launch, deterministic; it can also write the pyramid
+//     block's tail  y2 = cat(out1, out2, out3) + residual  (HGFilters.py:57-60) for its channels;
+//   * a consumer turns its input's accumulator into (mean, rstd) in its prologue (gn_load_stats);
 //   * weights stream from L2 in MFMA fragment order through a buffer resource (conv3x3_pack_kernel),
 //     the activation tile is staged pixel-major, XOR-swizzled, double-buffered over 16-channel chunks.
 //
