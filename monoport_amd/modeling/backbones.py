@@ -133,6 +133,11 @@ def _pow2(v):
 # only pays on a host too loaded to issue 135 C-ABI calls in 4 ms.  Batches above
 # ENCODER_GRAPH_MAX_BATCH always run eagerly (FramePipeline captures its own graph of the whole slot).
 ENCODER_GRAPH = os.environ.get("MONOPORT_ENCODER_GRAPH", "off")
+# "on" (default): at small batches (latency mode: a drop-in netG.filter(image) call) the skip branch of
+# every hourglass level runs on a side stream next to the low-resolution chain; larger batches and
+# hipGraph captures stay on one stream (the chip is full, and parallel graph branches measured slower)
+ENCODER_BRANCHES = os.environ.get("MONOPORT_ENCODER_BRANCHES", "on")
+ENCODER_BRANCH_MAX_BATCH = int(os.environ.get("MONOPORT_ENCODER_BRANCH_MAX_BATCH", "2"))
 ENCODER_GRAPH_MAX_BATCH = int(os.environ.get("MONOPORT_ENCODER_GRAPH_MAX_BATCH", "4"))
 
 
@@ -328,22 +333,46 @@ class HourGlass(nn.Module):
         """The GroupNorm that reads the hourglass input first (b1 of the outermost level)."""
         return getattr(self, "b1_%d" % self.depth).bn1
 
-    def _level_dataflow(self, level, x, acc_x, arena):
+    def _level_dataflow(self, level, x, acc_x, arena, sides=None):
         """_level on the hand-over kernels: ``acc_x`` = statistics of x from x's producer (read by
         b1_level.bn1); the returned tensor comes with the statistics its reader needs (b3 of the
-        enclosing level, or top_m).  Same evaluation order as HGFilters.py:87-111."""
+        enclosing level, or top_m).  Same evaluation order as HGFilters.py:87-111.
+        ``sides``: one side stream per level -- the skip branch b1(x) (three convolutions on the large
+        map) then runs next to the low-resolution chain, whose ~20 small launches leave most of the
+        chip idle at batch 1; joined before the upsample-add (latency mode, see HGFilter)."""
         b1, b2, b3 = (getattr(self, "b%d_%d" % (k, level)) for k in (1, 2, 3))
-        skip, _ = _block_dataflow(b1, x, acc_x, arena)
+        side = sides[level - 1] if sides else None
+        if side is None:
+            skip, _ = _block_dataflow(b1, x, acc_x, arena)
+            y, acc_u = self._low_chain(level, x, arena, sides)
+        else:
+            # skip branch first (three launches, enqueued at once) on the side stream, then the long
+            # low-resolution chain on the caller's stream.  The other way round -- chain on a
+            # high-priority side stream, skip filling in -- measured no gain (3.97 vs 3.84 ms at batch
+            # 1): the host needs ~1 ms to enqueue the chain before the skip branch would even start
+            cur = torch.cuda.current_stream(x.device)
+            side.wait_stream(cur)  # x and its statistics are complete on cur's timeline
+            with torch.cuda.stream(side):
+                skip, _ = _block_dataflow(b1, x, acc_x, arena)
+            x.record_stream(side)
+            y, acc_u = self._low_chain(level, x, arena, sides)
+            cur.wait_stream(side)
+            skip.record_stream(cur)
+        return ops.upsample_add_gn(y, skip, acc_u), acc_u
+
+    def _low_chain(self, level, x, arena, sides):
+        """avg-pool -> b2 -> (inner level | b2_plus_1) -> b3 of one hourglass level; returns the tensor
+        to upsample and the accumulator the upsample-add will fill."""
+        b2, b3 = getattr(self, "b2_%d" % level), getattr(self, "b3_%d" % level)
         acc_p = arena.take()
         pooled = ops.avgpool2_gn(x, acc_p)
         y, acc_y = _block_dataflow(b2, pooled, acc_p, arena, out_stats=True)
         if level > 1:
-            y, acc_y = self._level_dataflow(level - 1, y, acc_y, arena)
+            y, acc_y = self._level_dataflow(level - 1, y, acc_y, arena, sides)
         else:
             y, acc_y = _block_dataflow(self.b2_plus_1, y, acc_y, arena, out_stats=True)
         y, _ = _block_dataflow(b3, y, acc_y, arena)
-        acc_u = arena.take()
-        return ops.upsample_add_gn(y, skip, acc_u), acc_u
+        return y, arena.take()
 
 
 class HGFilter(nn.Module):
@@ -435,6 +464,16 @@ class HGFilter(nn.Module):
         depth = self.m0.depth
         blocks = 3 + self.num_stack * (3 * depth + 2)
         arena = ops.GnArena(x.device, x.shape[0], 3 * blocks + self.num_stack * (2 * depth + 2) + 8)
+        sides = None
+        if (ENCODER_BRANCHES == "on" and x.shape[0] <= ENCODER_BRANCH_MAX_BATCH
+                and not torch.cuda.is_current_stream_capturing()):
+            cache = self.__dict__.setdefault("_side_streams", {})
+            sides = cache.get(str(x.device))
+            if sides is None:
+                sides = cache[str(x.device)] = [torch.cuda.Stream(device=x.device) for _ in range(depth)]
+            arena.buf.record_stream(sides[0])
+            for st in sides[1:]:
+                arena.buf.record_stream(st)
         c2, c3, c4 = self.conv2, self.conv3, self.conv4
         acc = arena.take()
         t = ops.convk(x, None, False, self._stem_packed(), 2, stats=acc)
@@ -449,7 +488,7 @@ class HGFilter(nn.Module):
         for i in range(self.num_stack):
             hg, top = getattr(self, "m%d" % i), getattr(self, "top_m_%d" % i)
             last = i == self.num_stack - 1
-            y, acc_y = hg._level_dataflow(hg.depth, x, acc_x, arena)
+            y, acc_y = hg._level_dataflow(hg.depth, x, acc_x, arena, sides)
             y, _ = _block_dataflow(top, y, acc_y, arena)
             packs = self._tail_packed(i)
             acc_t = arena.take()

@@ -35,8 +35,9 @@ with torch.no_grad():
     for b in batches:
         img = torch.stack([torch.from_numpy(syn.synthetic_image(i)) for i in range(b)]).to(dev)
         hwc = torch.empty((b, 128, 128, 256), device=dev)
-        for flow in ("on", "off"):
-            backbones.ENCODER_DATAFLOW = flow
+        for flow in ("on", "on-1stream", "off"):
+            backbones.ENCODER_DATAFLOW = "off" if flow == "off" else "on"
+            backbones.ENCODER_BRANCHES = "off" if flow == "on-1stream" else "on"
             run = lambda: enc(img, last_only=True, hwc_out=hwc)
             t_eager = timed(run, 10)
             side = torch.cuda.Stream()
@@ -48,6 +49,6 @@ with torch.no_grad():
                     run()
                 side.synchronize()
                 t_graph = timed(graph.replay, 20)
-            print("encoder %s batch %2d dataflow %-3s: eager %.3f ms/frame, graph %.3f ms/frame (%.3f ms per launch)"
+            print("encoder %s batch %2d dataflow %-10s: eager %.3f ms/frame, graph %.3f ms/frame (%.3f ms per launch)"
                   % (prec, b, flow, t_eager / b, t_graph / b, t_graph), flush=True)
             del graph
