@@ -1408,7 +1408,7 @@ void conv1x1_set_mrw(int mrw) { g_conv1_mrw = mrw; }
 // slots per (image, group) of the statistics a 1x1 launch publishes
 int conv1x1_stat_slices(long long hw) { return (int)(hw / kC1Px); }
 
-// `a` arrives with the tensors, cout, fin.{partial, counter, sets} as the caller gave them;
+// `a` arrives with the tensors, cout, gn1 and fin.{acc, partial} as the caller gave them;
 // partial_cap: doubles allocated for fin.partial (-1 = unchecked legacy entry point)
 int launch_conv1x1(mp_ctx *ctx, Conv1Args a, int f16, const float *wmax, long long partial_cap, hipStream_t st) {
   if (a.c1 <= 0 || a.c1 % kC1K || a.c2 < 0 || a.c2 % kC1K || a.hw % kC1Px || (a.c2 > 0) != (a.x2 != nullptr) ||

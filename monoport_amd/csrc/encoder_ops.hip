@@ -1,6 +1,7 @@
-// Memory-bound helper kernels for the image encoders.  The encoders stay
-// under PyTorch-ROCm (MIOpen convolutions); what PyTorch does badly at batch 1 on a 256-CU part
-// is everything between the convolutions:
+// Memory-bound helper kernels for the image encoders: everything between
+// the convolutions.  Round 1 (the encoders still on MIOpen convolutions) replaced what PyTorch does
+// badly at batch 1 on a 256-CU part; round 3 added the producers that hand their statistics on
+// (ew_gn_kernel below), with which the encoders no longer call MIOpen or torch ops at all:
 //   * GroupNorm(32, C) (+ReLU): torch launches RowwiseMoments on 32 workgroups (one per group,
 //     12 % of the CUs), a parameter kernel, an affine kernel and a ReLU kernel -- 4.6 ms / frame.
 //     Here: a split reduction over (group, slice) workgroups + one fused normalise/affine/ReLU pass.
@@ -193,9 +194,9 @@ int launch_upsample_bicubic2x(mp_ctx *ctx, const float *x, int c, int h, int w, 
 // ---- elementwise producers that take the GroupNorm statistics of what they write ----------------
 // The tensors between the convolutions (2x2 average pool, HGFilters.py:93 / :171; bicubic x2 + skip
 // add, :108-111; the stem's GroupNorm + ReLU, :168) feed a GroupNorm(32, C) next.  One pass writes
-// the tensor AND publishes its statistics (gn_tail.h): workgroup = (image, group, slice) -- a group
-// is C / 32 adjacent planes, contiguous in NCHW -- and the last of a group's kGnSlices workgroups
-// turns the sums into (scale, shift) for the consumer(s): no statistics pass, no finalize launch.
+// the tensor AND adds its statistics to the consumer's accumulator (gn_tail.h): workgroup = (image,
+// group, slice) -- a group is C / 32 adjacent planes, contiguous in NCHW -- with one set of integer
+// atomics per workgroup: no statistics pass, no finalize launch.
 // Op::run(gi, i) computes and stores the 4 consecutive outputs at float4 index i of (image, group)
 // gi (hw % 4 == 0: they share a plane) and returns them.
 template <class Op>

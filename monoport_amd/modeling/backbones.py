@@ -1,4 +1,8 @@
-"""Image encoders of the PIFu networks, run once per frame under PyTorch-ROCm (MIOpen convs).
+"""Image encoders of the PIFu networks, run once per frame.  On an MI355X (eval mode, fp32, 512 x 512
+and up) both run as chains of hand-written kernels only (``_forward_dataflow``, csrc/conv3x3.hip /
+convim2col.hip / encoder_ops.hip / gn_tail.h); anything else -- CPU tensors, training, odd shapes,
+``MONOPORT_ENCODER_DATAFLOW=off`` -- takes the per-module paths below (MIOpen convolutions and / or
+round 2's fused kernels).
 
 Only the two encoders the reference's configs select are provided:
 
