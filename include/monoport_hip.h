@@ -282,6 +282,11 @@ int mp_conv3x3_pack(mp_ctx *ctx, const float *w /*[Cout,Cin,3,3]*/, int cout, in
 int mp_conv3x3_supported(int cin, int cout, int h, int w); /* 1 if the shape is built, else 0 */
 int mp_conv3x3_stat_slices(int cout, int n, int h, int w, int f16);
 void mp_conv3x3_tune(int nr);
+/* mp_query_tune(small_tiles): measurement hook for the fused f32 query of the netG heads on
+ * sampled features -- launches of fewer than small_tiles 64-point tiles run on the 32-point-tile
+ * kernel (query_small.hip), the others on the 64-point kernel (query.hip).  0: never, 1: always,
+ * negative: the default (2048).  The two kernels return identical bits. */
+void mp_query_tune(int small_tiles);
 int mp_conv3x3_gn(mp_ctx *ctx, const float *x, int n, int cin, int h, int w, const float *ss, int relu,
                   int reflect, const float *packed, int cout, float *y, double *stats, mp_stream stream);
 /* reflect != 0: nn.ReflectionPad2d(1) + an unpadded 3x3 convolution (the residual blocks of the

@@ -100,6 +100,7 @@ SIGNATURES = {
     "mp_conv3x3_pack": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "mp_conv3x3_stat_slices": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mp_conv3x3_tune": (None, [c_int]),
+    "mp_query_tune": (None, [c_int]),
     "mp_conv3x3_gn": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp,
                               c_vp, c_vp]),
     "mp_scale_shift_add": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_vp, c_vp]),
@@ -152,6 +153,10 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        # measurement hook (tools/): MONOPORT_QUERY_SMALL_TILES moves the gate
+        # between the 32- and 64-point query kernels; the results do not depend on it
+        if os.environ.get("MONOPORT_QUERY_SMALL_TILES"):
+            lib.mp_query_tune(int(os.environ["MONOPORT_QUERY_SMALL_TILES"]))
         _lib = lib
     return _lib
 

@@ -804,6 +804,8 @@ int mp_conv3x3_stat_slices(int cout, int n, int h, int w, int f16) {
   return conv3x3_stat_slices(cout, n, h, w, f16 != 0);
 }
 
+void mp_query_tune(int small_tiles) { mp::query_small_set_gate(small_tiles); }
+
 void mp_conv3x3_tune(int nr) {
   conv3x3_set_nr(nr & 0xfff);
   conv1x1_set_mrw((nr >> 12) & 3);

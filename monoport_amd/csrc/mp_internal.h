@@ -155,6 +155,13 @@ int launch_copy(mp_ctx *ctx, const float *src, float *dst, long long n, hipStrea
 int launch_absmax(mp_ctx *ctx, const float *src, long long n, unsigned int *out_bits, hipStream_t st);
 int launch_absmax_accumulate(mp_ctx *ctx, const float *src, long long n, unsigned int *out_bits,
                              hipStream_t st);
+// query_small.hip: the netG f32 query on 32-point tiles, for launches of fewer than
+// kSmallGateTiles 64-point tiles
+constexpr int kSmallGateTiles = 2048;
+int launch_query32(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
+                   long long max_points, bool device_counts, int gate_tiles64, hipStream_t st);
+void query_small_set_gate(int gate);  // 0 never, 1 always, n > 1 gate in 64-point tiles, < 0 default
+int query_small_gate();
 // query16.hip
 int launch_query16(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
                    long long max_points, bool device_counts, hipStream_t st);

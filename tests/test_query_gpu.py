@@ -283,3 +283,78 @@ def test_f16x3_no_noisier_than_f32_kernel_on_random_heads(ops, oracle, seed):
     e32, e16 = np.abs(out32 - ref).max(), np.abs(out16 - ref).max()
     print("seed %d: |f32 kernel - f64| %.3g, |f16x3 - f64| %.3g" % (seed, e32, e16))
     assert e32 <= 1e-4 and e16 <= 1e-4 and e16 <= 1.5 * e32 + 1e-7
+
+
+def _tuned(mode):
+    """Context manager around mp_query_tune (0 = 64-point tiles, 1 = 32-point tiles, -1 = default gate at 2048 tiles)."""
+    import contextlib
+    from monoport_amd import _lib
+
+    @contextlib.contextmanager
+    def cm():
+        lib = _lib.load()
+        lib.mp_query_tune(mode)
+        try:
+            yield
+        finally:
+            lib.mp_query_tune(-1)
+    return cm()
+
+
+@pytest.mark.parametrize("cout", [1, 3])
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 95, 1000, 40000])
+def test_small_tile_kernel_is_bit_identical(ops, n, cout):
+    """query_small.hip (32-point tiles, for launches with few tiles) returns the bits of
+    the 64-point kernel of query.hip: same K order, same FMA chains, bias first -- the parity
+    statements of this file hold for both."""
+    layers = syn.rand_mlp("G", 31 + cout, 2.0)
+    if cout == 3:  # a 3-channel head on a 256-channel map (the C = 256, Cout = 3 instantiation)
+        rs = np.random.RandomState(5)
+        w4, b4 = layers[-1]
+        layers[-1] = (rs.uniform(-0.1, 0.1, (3, w4.shape[1])).astype(np.float32),
+                      rs.uniform(-0.1, 0.1, (3,)).astype(np.float32))
+    dev = "cuda:0"
+    mlp = ops.PackedMLP.from_layers(dev, layers, 1 if cout == 1 else 2)
+    f = ops.pack_features(torch.from_numpy(syn.rand_feat(256, 128, 128, 6))[None].to(dev))
+    p = torch.from_numpy(syn.rand_points(n, 100 + n, 1.1))[None].to(dev)
+    cal = torch.from_numpy(np.eye(4, dtype=np.float32)[None]).to(dev)
+    cal[0, 0, 0] = 0.93
+    outs = {}
+    for mode in (0, 1, -1):
+        with _tuned(mode):
+            outs[mode] = ops.query(mlp, f, p, cal, syn.Z_SCALE)
+    assert outs[0].shape == (1, cout, n)
+    assert float(outs[0].abs().max()) > 0
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[-1])
+
+
+def test_small_tile_kernel_device_counts(ops):
+    """With the counts on the device both kernels are launched and each reads the counts: exactly
+    one of them produces the frame set, on either side of the 2048-tile gate (ragged, empty and full
+    frames), and the results equal the forced single-kernel runs."""
+    dev = "cuda:0"
+    mlp = ops.PackedMLP.from_layers(dev, syn.rand_mlp("G", 61, 2.0), 1)
+    cap = 40000  # 625 tiles of capacity per frame: 4-5 frames are above the gate, so the choice is made on the device
+    for counts_host in ([4097, 0, 64, 5000, 1], [40000, 13, 0, 977, 64], [40000] * 5,
+                        [40000, 40000, 40000, 172 * 64], [40000, 40000, 40000, 172 * 64 + 1],
+                        [40000, 40000, 40000, 171 * 64 + 1, 1]):
+        feats, pts, cnts, cals = [], [], [], []
+        for i, c in enumerate(counts_host):
+            feats.append(ops.pack_features(torch.from_numpy(syn.rand_feat(256, 64, 64, 70 + i))[None].to(dev)))
+            pts.append(torch.from_numpy(syn.rand_points(cap, 80 + i, 1.0)).to(dev).contiguous())
+            cnts.append(torch.tensor([c], dtype=torch.int32, device=dev))
+            cal = np.eye(4, dtype=np.float32)[None]
+            cal[0, 1, 1] = 1.0 - 0.04 * i
+            cals.append(torch.from_numpy(cal).to(dev))
+        outs = {}
+        for mode in (0, 1, -1):
+            with _tuned(mode):
+                outs[mode] = ops.query_counted_batch(mlp, feats, pts, cnts, cals, syn.Z_SCALE)
+        for i, c in enumerate(counts_host):
+            assert torch.equal(outs[0][i], outs[1][i]), (counts_host, i)
+            assert torch.equal(outs[0][i], outs[-1][i]), (counts_host, i)
+            if c:
+                assert float(outs[-1][i][:, :c].abs().max()) > 0.0
+            if c < cap:
+                assert float(outs[-1][i][:, c:].abs().max()) == 0.0

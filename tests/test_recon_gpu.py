@@ -541,3 +541,31 @@ def test_octree_lossless_against_full_dense_evaluation(ops, body, res):
           % (r, inter / union, union - inter, exact, n_queried))
     assert inter / union >= 0.99999
     assert exact >= n_queried  # every queried node holds its exact value (plus coincidences)
+
+
+def test_recon_same_bits_with_either_query_tile(ops, oracle):
+    """The coarse octree levels run on the 32-point-tile query kernel, the fine ones on the
+    64-point kernel (device-side gate at 2048 tiles): volumes and statuses equal the ones with the
+    small kernel switched off / always on, single frames and batches."""
+    from monoport_amd import _lib
+    lib = _lib.load()
+    mlp = ops.PackedMLP.from_layers(DEV, syn.body_mlp("G", noise=0.05, seed=1), 1)
+    res = [17, 33, 65, 129, 257]
+    feats = [ops.pack_features(torch.from_numpy(syn.body_feat(256, 128, 128, 2 + i))[None].to(DEV))
+             for i in range(3)]
+    cals = [torch.from_numpy(oracle.pifu_calib(*syn.scene_camera(40 * i))).to(DEV) for i in range(3)]
+    got = {}
+    for mode in (0, -1, 1):
+        lib.mp_query_tune(mode)
+        try:
+            v1, s1 = ops.recon(mlp, feats[0], cals[0], syn.Z_SCALE, BMIN, BMAX, res)
+            vb, sb = ops.recon_batch(mlp, feats, cals, syn.Z_SCALE, BMIN, BMAX, res)
+            got[mode] = (v1.clone(), s1.clone(), [v.clone() for v in vb], sb.clone())
+        finally:
+            lib.mp_query_tune(-1)
+    for mode in (-1, 1):
+        assert torch.equal(got[0][0], got[mode][0]) and torch.equal(got[0][1], got[mode][1])
+        assert torch.equal(got[0][3], got[mode][3])
+        for a, b in zip(got[0][2], got[mode][2]):
+            assert torch.equal(a, b)
+    assert int(got[0][1][0]) == 1

@@ -31,14 +31,21 @@ def main(directory, prefix, command):
     rows = []
     with open(trace) as f:
         for r in csv.DictReader(f):
-            if "pifu_query_kernel" in r["Kernel_Name"]:  # the f32 kernel (not pifu_query16_kernel)
+            # the f32 kernels: 32-point tiles (netG) / 64-point tiles -- not pifu_query16_kernel
+            if "pifu_query_t32_kernel<1>" in r["Kernel_Name"] or "pifu_query_kernel<256, 1" in r["Kernel_Name"]:
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:40],
                              r["Grid_Size_X"], r["Workgroup_Size_X"]))
     rows.sort()
+    # An octree level whose point counts live on the device is launched on BOTH tile sizes; the
+    # kernel the 2048-tile gate excludes leaves at its first instruction (a few us).  Those empty
+    # dispatches are not query launches: drop them from the list (counted in the header).
+    n_all = len(rows)
+    rows = [r for r in rows if (r[1] - r[0]) / 1e3 >= 25.0]
     durs = [(e - s) / 1e3 for s, e, *_ in rows]
     with open(prefix + "_query_launches.txt", "w") as f:
         f.write("rocprofv3 --kernel-trace --stats --output-format csv -- %s\n" % command)
-        f.write("%d fused-query launches; duration (us), grid, kernel -- in start order\n" % len(rows))
+        f.write("%d fused-query launches (+ %d gate-excluded empty dispatches of < 25 us, not listed); "
+                "duration (us), grid, kernel -- in start order\n" % (len(rows), n_all - len(rows)))
         for (s, e, name, grid, wg), d in zip(rows, durs):
             f.write("%10.1f  grid %-8s %s\n" % (d, grid, name))
         # the roofline leg (ONE stream, every launch bracketed by HIP events) is found by its

@@ -1,7 +1,9 @@
 """Workload for the rocprofv3 --pmc passes behind bench.py's roofline.traffic.
 
-    run   : one pipeline slot, BATCH frames per batch, 2 timed-style batches (after warm-up) --
-            the LAST 10 pifu_query_kernel dispatches are 2 batches x 5 octree levels
+    run   : one pipeline slot, BATCH frames per batch, 2 timed-style batches (after warm-up).
+            A batch is 9 fused-query dispatches: level 0 (host-side counts) on the kernel the launcher
+            picked, levels 1-4 (device-side counts) on BOTH tile sizes, of which the one the gate
+            excludes leaves at once and moves no bytes -- a level's traffic is the sum of its pair
     parse : counter_collection.csv of the FETCH_SIZE and WRITE_SIZE passes -> profiles/*.json
 
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python tools/traffic_probe.py run
@@ -36,20 +38,32 @@ def run():
 
 
 def counter_rows(directory, counter):
+    """Per-level counter values of the last 2 batches: [level 0, ..., level 4] x 2."""
     rows = []
     for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for r in csv.DictReader(f):
-                if r["Counter_Name"] == counter and "pifu_query_kernel" in r["Kernel_Name"]:
-                    rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+                name = r["Kernel_Name"]
+                if r["Counter_Name"] == counter and ("pifu_query_t32_kernel" in name or "pifu_query_kernel" in name):
+                    rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), "t32" in name))
     rows.sort()
-    return [v for _, v in rows]
+    per_batch = 1 + 2 * (LEVELS - 1)
+    rows = rows[-2 * per_batch:]
+    assert len(rows) == 2 * per_batch, len(rows)
+    out = []
+    for b in range(2):
+        r = rows[b * per_batch:(b + 1) * per_batch]
+        out.append(r[0][1])
+        for l in range(1, LEVELS):
+            pair = r[1 + 2 * (l - 1):3 + 2 * (l - 1)]
+            assert pair[0][2] != pair[1][2], "a device-count level is one dispatch of each kernel"
+            out.append(pair[0][1] + pair[1][1])
+    return out
 
 
 def parse(fetch_dir, write_dir, out_path):
-    fetch = counter_rows(fetch_dir, "FETCH_SIZE")[-2 * LEVELS:]
-    write = counter_rows(write_dir, "WRITE_SIZE")[-2 * LEVELS:]
-    assert len(fetch) == 2 * LEVELS and len(write) == 2 * LEVELS, (len(fetch), len(write))
+    fetch = counter_rows(fetch_dir, "FETCH_SIZE")
+    write = counter_rows(write_dir, "WRITE_SIZE")
     per_level_fetch = [(fetch[l] + fetch[LEVELS + l]) / 2 for l in range(LEVELS)]
     per_level_write = [(write[l] + write[LEVELS + l]) / 2 for l in range(LEVELS)]
     # rocprofv3 reports both in KB; FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: wide
@@ -58,7 +72,8 @@ def parse(fetch_dir, write_dir, out_path):
     out = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of "
                   "tools/traffic_probe.py run: one slot, %d frames per mp_recon_batch, mean of the "
-                  "last 2 batches, one pifu_query_kernel launch per octree level" % BATCH,
+                  "last 2 batches, one fused-query launch per octree level (32-point tiles below 2048 "
+                  "64-point tiles per launch, 64-point tiles above; the gate-excluded dispatch of a pair moves no bytes)" % BATCH,
         "unit": "KB (rocprofv3 counter units, x1024 bytes)",
         "FETCH_SIZE_per_level": per_level_fetch,
         "WRITE_SIZE_per_level": per_level_write,
