@@ -945,7 +945,7 @@ def main(argv=None):
             "mpts_per_s": main_res["points"] / main_res["elapsed"] / 1e6,
             "breakdown": breakdown,
             "roofline": {
-                "kernel": ("pifu_query_t32_kernel<1> (fused gather + MLP, 32-point tiles)" if args.precision == "f32"
+                "kernel": ("pifu_query_kernel<256,1> (fused gather + MLP; launches of < 2048 tiles run on its 32-point-tile twin pifu_query_t32_kernel<1>)" if args.precision == "f32"
                            else "pifu_query16_kernel<1,%d> (fused gather + MLP, %s)" % (terms, args.precision)),
                 "bound": "mfma",
                 "achieved": roof["achieved"],
