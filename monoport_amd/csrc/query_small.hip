@@ -36,10 +36,13 @@
 namespace mp {
 
 constexpr int kSmallPts = 32;
+#ifndef MP32_T32_WPS
+#define MP32_T32_WPS 3  // workgroups per CU the register allocator is held to (tools/ablate.py A/B)
+#endif
 constexpr int kSmallHbRow = 128 * 4;  // bytes per point of a 128-row hidden chunk
 
 template <int COUT>
-__global__ __launch_bounds__(kQueryThreads, 3) void pifu_query_t32_kernel(
+__global__ __launch_bounds__(kQueryThreads, MP32_T32_WPS) void pifu_query_t32_kernel(
     MlpPack mlp, int fh, int fw, float z_scale, int act, QuerySet set, int gate_tiles64) {
   constexpr int C = 256;
   constexpr int P = kSmallPts;
@@ -324,7 +327,7 @@ int launch_query32_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int 
   }
   if (max_points <= 0) return MP_OK;
   const long long tiles = (max_points + kSmallPts - 1) / kSmallPts + (set.n - 1);
-  const long long resident = (long long)ctx->n_cu * 3;
+  const long long resident = (long long)ctx->n_cu * MP32_T32_WPS;
   // device-side counts: launch the resident grid and let it stride; host-side counts: one
   // workgroup per tile up to a few waves of the machine
   long long grid = device_counts ? (tiles < resident ? tiles : resident)
