@@ -46,6 +46,10 @@ from monoport_amd.recon import pifu_calib  # noqa: E402
 RESOLUTIONS = [17, 33, 65, 129, 257]  # RTL/main.py:187
 B_MIN, B_MAX = [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]  # RTL/main.py:185-186
 FLOP_PER_POINT = 2363906  # netG MLP, SURVEY.md section 8d / BASELINE.md section 2
+# with the layer-0 tables (mp_l0_table, default): layer 0's 1024 x 256 product leaves the per-point
+# work (it is taken once per texel and frame: 8.6 GFLOP per frame in l0_table_kernel)
+FLOP_PER_POINT_L0_TABLE = FLOP_PER_POINT - 2 * 1024 * 256
+FLOP_L0_TABLE_PER_FRAME = 2 * 1024 * 256 * 128 * 128
 FLOP_PER_POINT_C = 3350022  # netC MLP (per-vertex colour query)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak
@@ -716,6 +720,9 @@ def parse_args(argv):
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip the drop-in-surface pass a default N=1 run appends")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-l0-table", action="store_true",
+                    help="plain query path: layer 0 on the MFMAs for every point instead of the per-frame "
+                         "layer-0 tables (mp_l0_table)")
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the informational f16x3 pass that a default N=1 run appends")
     ap.add_argument("--no-configs", action="store_true",
@@ -739,6 +746,10 @@ def main(argv=None):
         return rendezvous_only(args)
     if args.no_extras:
         args.no_dropin = args.no_cpu_baseline = args.no_alt = args.no_configs = True
+    from monoport_amd import pipeline as pipeline_mod
+    if args.no_l0_table:
+        pipeline_mod.L0_TABLE = False
+    l0_on = pipeline_mod.L0_TABLE and args.precision == "f32"
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # test hook (tests/test_dropin_gpu.py): exercise the N > 1 code path on a ONE-GPU box -- every
@@ -945,7 +956,10 @@ def main(argv=None):
             "mpts_per_s": main_res["points"] / main_res["elapsed"] / 1e6,
             "breakdown": breakdown,
             "roofline": {
-                "kernel": ("pifu_query_kernel<256,1> (fused gather + MLP; launches of < 2048 tiles run on its 32-point-tile twin pifu_query_t32_kernel<1>)" if args.precision == "f32"
+                "kernel": ("pifu_query_t32_kernel<1,true> (fused gather + MLP on 32-point tiles, layer 0 blended from "
+                           "the frame's layer-0 table, l0_table_kernel)" if l0_on else
+                           "pifu_query_kernel<256,1> (fused gather + MLP; launches of < 2048 tiles run on its "
+                           "32-point-tile twin pifu_query_t32_kernel<1,false>)" if args.precision == "f32"
                            else "pifu_query16_kernel<1,%d> (fused gather + MLP, %s)" % (terms, args.precision)),
                 "bound": "mfma",
                 "achieved": roof["achieved"],
@@ -960,6 +974,17 @@ def main(argv=None):
                 "frames_per_launch": min(batch, MAX_RECON_BATCH),
                 "avg_launch_ms": float(roof["launch_ms"].mean()) if roof["launches"] else None,
                 "flop_per_point": FLOP_PER_POINT,
+                # `achieved` / `frac` count the ALGORITHMIC FLOPs of the reference's MLP.  With
+                # the layer-0 tables the kernel EXECUTES fewer: W0 is applied once per texel and frame
+                # (l0_table_kernel, outside these launches, inside `value`) and blended per point.
+                "executed": ({"flop_per_point": FLOP_PER_POINT_L0_TABLE,
+                              "achieved": roof["achieved"] * FLOP_PER_POINT_L0_TABLE / FLOP_PER_POINT,
+                              "frac": roof["achieved"] * FLOP_PER_POINT_L0_TABLE / FLOP_PER_POINT / peak_tflops,
+                              "l0_table_flop_per_frame": FLOP_L0_TABLE_PER_FRAME,
+                              "note": "layer 0's 1024 x 256 product is hoisted out of the per-point work "
+                                      "(a linear map commutes with the bilinear interpolation); "
+                                      "--no-l0-table runs every FLOP per point"}
+                             if l0_on else None),
             },
         }
         out.update(extras)

@@ -356,6 +356,54 @@ int mp_feat_pack_hwc(mp_ctx *ctx, const float *src_chw, int c_src, int h, int w,
   return launch_pack_hwc(ctx, src_chw, c_src, h, w, dst_hwc, c_dst, c_offset, (hipStream_t)stream);
 }
 
+int mp_l0_table(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, float *table,
+                mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const Mlp *m = get_mlp(ctx, mlp);
+  int rc = check_ready(ctx, m, c);
+  if (rc != MP_OK) return rc;
+  if (!feat_hwc || !table || h <= 0 || w <= 0) return fail(ctx, MP_ERR_ARG, "mp_l0_table: bad argument");
+  if (!aligned16(feat_hwc) || !aligned16(table))
+    return fail(ctx, MP_ERR_ARG, "mp_l0_table: feat_hwc and table must be 16-byte aligned");
+  DeviceGuard g(ctx->device);
+  rc = launch_l0_table(ctx, *m, feat_hwc, h, w, table, (hipStream_t)stream);
+  if (rc != MP_OK) return rc;
+  ctx->l0_tables[feat_hwc] = mp_ctx::L0Entry{table, m->buf, h, w};
+  return MP_OK;
+}
+
+int mp_l0_table_batch(mp_ctx *ctx, int mlp, int n_maps, const float *feat_hwc, int c, int h, int w,
+                      float *table, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const Mlp *m = get_mlp(ctx, mlp);
+  int rc = check_ready(ctx, m, c);
+  if (rc != MP_OK) return rc;
+  if (!feat_hwc || !table || h <= 0 || w <= 0 || n_maps <= 0 || (long long)n_maps * h > (1 << 20))
+    return fail(ctx, MP_ERR_ARG, "mp_l0_table_batch: bad argument");
+  if (!aligned16(feat_hwc) || !aligned16(table))
+    return fail(ctx, MP_ERR_ARG, "mp_l0_table_batch: feat_hwc and table must be 16-byte aligned");
+  DeviceGuard g(ctx->device);
+  // the maps are contiguous: one launch over n_maps * H rows of texels
+  rc = launch_l0_table(ctx, *m, feat_hwc, n_maps * h, w, table, (hipStream_t)stream);
+  if (rc != MP_OK) return rc;
+  for (int i = 0; i < n_maps; ++i)
+    ctx->l0_tables[feat_hwc + (size_t)i * h * w * c] =
+        mp_ctx::L0Entry{table + (size_t)i * h * w * kHidden[0], m->buf, h, w};
+  return MP_OK;
+}
+
+int mp_l0_table_release(mp_ctx *ctx, const float *feat_hwc) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (feat_hwc)
+    ctx->l0_tables.erase(feat_hwc);
+  else
+    ctx->l0_tables.clear();
+  return MP_OK;
+}
+
 int mp_index(mp_ctx *ctx, const float *feat_hwc, int c, int h, int w, const float *uv, int64_t n,
              float *out, mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;

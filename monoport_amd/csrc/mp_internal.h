@@ -69,6 +69,7 @@ struct QueryItem {
   const float *calib;  // [3,4] rows of the 4x4
   float *out;
   PointSrc src;
+  const float *l0;     // optional layer-0 table of `feat` [H,W,1024] (mp_l0_table; filled in by the launcher)
 };
 struct QuerySet {
   int n;
@@ -117,6 +118,14 @@ struct mp_ctx {
   std::unordered_map<void *, Arena> arenas;
   // kernels whose dynamic-LDS limit has been raised on this context's device (guarded by mu)
   std::unordered_set<const void *> lds_attr_done;
+  // layer-0 tables registered for feature maps (mp_l0_table): feat pointer -> table + the packed
+  // head it was computed with
+  struct L0Entry {
+    const float *table;
+    const float *mlp_buf;
+    int h, w;
+  };
+  std::unordered_map<const float *, L0Entry> l0_tables;
   // optional event bracketing of query launches (mp_profile_begin / mp_profile_end)
   std::vector<hipEvent_t> prof_events;  // start/stop pairs
   int prof_used = 0;                    // pairs recorded
@@ -159,7 +168,9 @@ int launch_absmax_accumulate(mp_ctx *ctx, const float *src, long long n, unsigne
 // kSmallGateTiles 64-point tiles
 constexpr int kSmallGateTiles = 2048;
 int launch_query32(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
-                   long long max_points, bool device_counts, int gate_tiles64, hipStream_t st);
+                   long long max_points, bool device_counts, int gate_tiles64, bool table, hipStream_t st);
+int launch_l0_table(mp_ctx *ctx, const Mlp &m, const float *feat_hwc, int h, int w, float *table,
+                    hipStream_t st);
 void query_small_set_gate(int gate);  // 0 never, 1 always, n > 1 gate in 64-point tiles, < 0 default
 int query_small_gate();
 // query16.hip

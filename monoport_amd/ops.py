@@ -180,6 +180,49 @@ def orthogonal(points, calib):
     return out
 
 
+L0_ROWS = 1024  # rows of SurfaceClassifier's first layer
+
+
+def l0_table(mlp, feat_hwc, out=None):
+    """mp_l0_table: the layer-0 table of a channels-last feature map [H,W,256] for a netG head --
+    table[y,x,r] = W0[r,:256] . feat[y,x,:] -- computed once per map and REGISTERED for it: every
+    later fused query (query / recon / recon_batch ...) on maps that all have a table blends four
+    table rows per point instead of running layer 0's 1024 x 256 product on the MFMAs.  The result
+    differs from the plain path by f32 rounding only.  Returns the table [H,W,1024]; keep it alive
+    (and call l0_release) for as long as the feature map is queried."""
+    ctx = mlp.ctx
+    h, w, c = feat_hwc.shape
+    if out is None:
+        out = torch.empty((h, w, L0_ROWS), dtype=torch.float32, device=feat_hwc.device)
+    elif tuple(out.shape) != (h, w, L0_ROWS) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("l0_table: out must be a contiguous float32 [%d,%d,%d]" % (h, w, L0_ROWS))
+    ctx.check(ctx.lib.mp_l0_table(ctx.handle, mlp.id, _ptr(feat_hwc), c, h, w, _ptr(out), _stream(out)),
+              "mp_l0_table")
+    return out
+
+
+def l0_table_batch(mlp, feat_hwc_all, out=None):
+    """mp_l0_table_batch: the tables of B maps stored back to back [B,H,W,256] -> [B,H,W,1024] in one
+    launch; each map feat_hwc_all[i] is registered with its table out[i]."""
+    ctx = mlp.ctx
+    b, h, w, c = feat_hwc_all.shape
+    if not feat_hwc_all.is_contiguous():
+        raise ValueError("l0_table_batch: the maps must be contiguous")
+    if out is None:
+        out = torch.empty((b, h, w, L0_ROWS), dtype=torch.float32, device=feat_hwc_all.device)
+    elif tuple(out.shape) != (b, h, w, L0_ROWS) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("l0_table_batch: out must be a contiguous float32 [%d,%d,%d,%d]" % (b, h, w, L0_ROWS))
+    ctx.check(ctx.lib.mp_l0_table_batch(ctx.handle, mlp.id, b, _ptr(feat_hwc_all), c, h, w, _ptr(out),
+                                        _stream(out)), "mp_l0_table_batch")
+    return out
+
+
+def l0_release(ctx, feat_hwc=None):
+    """Forget the table registered for feat_hwc (None: every table of the context)."""
+    ctx.check(ctx.lib.mp_l0_table_release(ctx.handle, _ptr(feat_hwc) if feat_hwc is not None else None),
+              "mp_l0_table_release")
+
+
 def query(mlp, feat_hwc, points, calib, z_scale):
     """MonoPortNet.query (eval, one stage).  points [1,3,N] with ANY strides (the permuted view
     query_func builds at RTL/main.py:176-177 is consumed in place) -> [1,Cout,N]."""

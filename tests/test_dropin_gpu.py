@@ -302,9 +302,11 @@ def test_obj_export_and_vertex_colors(tmp_path):
     assert f0[0] == "f" and [int(a) for a in f0[1:]] == [int(a) + 1 for a in faces[0].tolist()]
 
 
-def test_frame_pipeline_matches_direct_calls():
+@pytest.mark.parametrize("l0_table", [False, True])
+def test_frame_pipeline_matches_direct_calls(l0_table):
     """FramePipeline (slots x batched encoder x hipGraph) must give, frame by frame, what the
-    plain call sequence gives: identical octree decisions and renders."""
+    plain call sequence gives: identical octree decisions and renders -- on the plain query path
+    and with the layer-0 tables (mp_l0_table) on both sides."""
     from monoport_amd import ops
     from monoport_amd.modeling import PIFuNetG
     from monoport_amd.pipeline import FramePipeline
@@ -331,13 +333,18 @@ def test_frame_pipeline_matches_direct_calls():
         for img, cal in zip(images, calibs):
             feat = netG.image_filter(img, last_only=True)[-1][0]
             hook(feat)
-            vol, st = ops.recon(mlp, ops.pack_features(feat), cal, syn.Z_SCALE, [-1] * 3, [1] * 3, res)
+            fh = ops.pack_features(feat)
+            table = ops.l0_table(mlp, fh) if l0_table else None
+            vol, st = ops.recon(mlp, fh, cal, syn.Z_SCALE, [-1] * 3, [1] * 3, res)
             x, y, z, n, c = ops.forward_vertices_raw(vol, "front")
             direct.append((st.cpu(), ops.paint(x, y, n, 0, c, res[-1], 0.5, 0.5, 0.0, 1.0).cpu()))
+            if l0_table:
+                ops.l0_release(mlp.ctx, fh)
+            del table
 
     for batch, use_graph in ((1, False), (3, True), (4, True)):  # 4: the last batch is short (6 = 4 + 2)
         pipe = FramePipeline(netG, DEV, depth=2, batch=batch, resolutions=res, feature_hook=hook,
-                             use_graph=use_graph)
+                             use_graph=use_graph, l0_table=l0_table)
         pipe.prepare()
         got = []
         for s0 in range(0, 6, batch):

@@ -358,3 +358,86 @@ def test_small_tile_kernel_device_counts(ops):
                 assert float(outs[-1][i][:, :c].abs().max()) > 0.0
             if c < cap:
                 assert float(outs[-1][i][:, c:].abs().max()) == 0.0
+
+
+def test_l0_table_matches_layer0_product(ops, oracle):
+    """mp_l0_table: table[y,x,r] = W0[r,:256] . feat[y,x,:], against a float64 product."""
+    layers = syn.rand_mlp("G", 77, 2.0)
+    f = syn.rand_feat(256, 40, 24, 8)  # 960 texels = 15 tiles of 64
+    dev = "cuda:0"
+    mlp = ops.PackedMLP.from_layers(dev, layers, 1)
+    fh = ops.pack_features(torch.from_numpy(f)[None].to(dev))
+    try:
+        table = ops.l0_table(mlp, fh)
+        torch.cuda.synchronize()
+        ref = np.einsum("rc,chw->hwr", layers[0][0][:, :256].astype(np.float64), f.astype(np.float64))
+        got = table.cpu().numpy()
+        assert got.shape == (40, 24, 1024)
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 2e-6 * scale
+    finally:
+        ops.l0_release(mlp.ctx)
+
+
+@pytest.mark.parametrize("name", ["query_G_rand", "query_G_body"])
+def test_l0_table_query_vs_reference_golden_and_plain_path(ops, oracle, name):
+    """The query through the layer-0 table (W0 applied per texel, four rows blended per point)
+    against the reference's golden output, the fp32 / fp64 oracle and the plain fused kernel: the
+    same field up to f32 rounding, exact zeros outside the image, no noisier than the reference."""
+    g = load_golden(name)
+    kind, layers, f, p = query_inputs(name)
+    dev = "cuda:0"
+    mlp = ops.PackedMLP.from_layers(dev, layers, syn.LAST_OP[kind])
+    fh = ops.pack_features(torch.from_numpy(f)[None].to(dev))
+    pts = torch.from_numpy(p)[None].to(dev)
+    cal = torch.from_numpy(g["calib"]).to(dev)
+    plain = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
+    try:
+        table = ops.l0_table(mlp, fh)
+        out = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
+        # an unrelated map without a table in the same context still runs the plain path
+        fh2 = fh.clone()
+        assert torch.equal(ops.query(mlp, fh2, pts, cal, syn.Z_SCALE)[0].cpu(), torch.from_numpy(plain))
+    finally:
+        ops.l0_release(mlp.ctx)
+    again = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
+    assert np.array_equal(again, plain)  # released: back on the plain path
+    assert not np.array_equal(out, plain)  # ... and the table path really ran
+    assert np.abs(out - g["out"]).max() <= TOL_REF
+    ref32 = oracle.query(f, p, g["calib"][0], layers, syn.LAST_OP[kind], syn.Z_SCALE, precision="f32")
+    assert np.abs(out - ref32).max() <= 3 * TOL_ORACLE
+    ref64 = oracle.query(f, p, g["calib"][0], layers, syn.LAST_OP[kind], syn.Z_SCALE, precision="f64")
+    err_tab, err_plain, err_ref = (np.abs(v - ref64).max() for v in (out, plain, g["out"]))
+    print("%s: |table-f64| %.3g  |plain-f64| %.3g  |reference-f64| %.3g  |table-plain| %.3g"
+          % (name, err_tab, err_plain, err_ref, np.abs(out - plain).max()))
+    assert err_tab <= max(2 * err_ref, 1e-5)
+    xyz = oracle.orthogonal(p, g["calib"][0])
+    outside = np.minimum(1 - np.abs(xyz[0]), 1 - np.abs(xyz[1])) < -1e-6
+    assert (out[:, outside] == 0).all()
+    del table
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 1000, 40000])
+def test_l0_table_ragged_sizes_and_device_counts(ops, oracle, n):
+    layers = syn.rand_mlp("G", 5, 2.0)
+    f = syn.rand_feat(256, 64, 64, 6)
+    p = syn.rand_points(n, 100 + n, 1.1)
+    calib = oracle.pifu_calib(*syn.scene_camera(40))
+    dev = "cuda:0"
+    mlp = ops.PackedMLP.from_layers(dev, layers, 1)
+    fh = ops.pack_features(torch.from_numpy(f)[None].to(dev))
+    try:
+        table = ops.l0_table(mlp, fh)
+        out = ops.query(mlp, fh, torch.from_numpy(p)[None].to(dev), torch.from_numpy(calib).to(dev), syn.Z_SCALE)
+        cap = n + 7
+        pts = torch.zeros((3, cap), device=dev)
+        pts[:, :n] = torch.from_numpy(p).to(dev)
+        cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+        counted = ops.query_counted(mlp, fh, pts.contiguous(), cnt, torch.from_numpy(calib).to(dev), syn.Z_SCALE)
+    finally:
+        ops.l0_release(mlp.ctx)
+    ref = oracle.query(f, p, calib[0], layers, 1, syn.Z_SCALE, precision="f32")
+    assert out.shape == (1, 1, n)
+    assert np.abs(out[0].cpu().numpy() - ref).max() <= TOL_ORACLE
+    assert torch.equal(counted[:, :n], out[0]) and float(counted[:, n:].abs().max()) == 0.0
+    del table

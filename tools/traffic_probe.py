@@ -47,6 +47,12 @@ def counter_rows(directory, counter):
                 if r["Counter_Name"] == counter and ("pifu_query_t32_kernel" in name or "pifu_query_kernel" in name):
                     rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), "t32" in name))
     rows.sort()
+    # with the layer-0 tables (default) every level is ONE dispatch of the table variant; on the plain
+    # path (MONOPORT_L0_TABLE=off) levels 1-4 are a gated pair
+    if not any(not t32 for _, _, t32 in rows[-2 * LEVELS:]):
+        rows = rows[-2 * LEVELS:]
+        assert len(rows) == 2 * LEVELS, len(rows)
+        return [v for _, v, _ in rows]
     per_batch = 1 + 2 * (LEVELS - 1)
     rows = rows[-2 * per_batch:]
     assert len(rows) == 2 * per_batch, len(rows)
