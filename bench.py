@@ -46,10 +46,11 @@ from monoport_amd.recon import pifu_calib  # noqa: E402
 RESOLUTIONS = [17, 33, 65, 129, 257]  # RTL/main.py:187
 B_MIN, B_MAX = [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]  # RTL/main.py:185-186
 FLOP_PER_POINT = 2363906  # netG MLP, SURVEY.md section 8d / BASELINE.md section 2
-# with the layer-0 tables (mp_l0_table, default): layer 0's 1024 x 256 product leaves the per-point
-# work (it is taken once per texel and frame: 8.6 GFLOP per frame in l0_table_kernel)
-FLOP_PER_POINT_L0_TABLE = FLOP_PER_POINT - 2 * 1024 * 256
-FLOP_L0_TABLE_PER_FRAME = 2 * 1024 * 256 * 128 * 128
+# with the skip tables (mp_skip_table, default): the products of weights with the sampled feature
+# (layer 0 and the skip connections: 1921 x 256 multiply-adds) leave the per-point work -- they are
+# taken once per texel and frame in skip_table_kernel (16 GFLOP per frame)
+FLOP_PER_POINT_SKIP_TABLE = FLOP_PER_POINT - 2 * 1921 * 256
+FLOP_SKIP_TABLE_PER_FRAME = 2 * 1921 * 256 * 128 * 128
 FLOP_PER_POINT_C = 3350022  # netC MLP (per-vertex colour query)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak
@@ -720,9 +721,9 @@ def parse_args(argv):
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip the drop-in-surface pass a default N=1 run appends")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-l0-table", action="store_true",
+    ap.add_argument("--no-skip-table", action="store_true",
                     help="plain query path: layer 0 on the MFMAs for every point instead of the per-frame "
-                         "layer-0 tables (mp_l0_table)")
+                         "layer-0 tables (mp_skip_table)")
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the informational f16x3 pass that a default N=1 run appends")
     ap.add_argument("--no-configs", action="store_true",
@@ -746,10 +747,9 @@ def main(argv=None):
         return rendezvous_only(args)
     if args.no_extras:
         args.no_dropin = args.no_cpu_baseline = args.no_alt = args.no_configs = True
-    from monoport_amd import pipeline as pipeline_mod
-    if args.no_l0_table:
-        pipeline_mod.L0_TABLE = False
-    l0_on = pipeline_mod.L0_TABLE and args.precision == "f32"
+    if args.no_skip_table:
+        ops.SKIP_TABLE = False
+    skip_on = ops.SKIP_TABLE and args.precision == "f32"
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # test hook (tests/test_dropin_gpu.py): exercise the N > 1 code path on a ONE-GPU box -- every
@@ -879,7 +879,8 @@ def main(argv=None):
             "config": "BASELINE configs[2]: netG + netC (ResNet encoder + per-vertex colour MLP)",
             "value": rc["value"], "unit": "recon/s", "ms_per_step": rc["ms_per_step"],
             "passes": rc["passes"],
-            "roofline_frac_netG_query": rc["roof"]["achieved"] / F32_MFMA_PEAK_TFLOPS,
+            "roofline_frac_netG_query": (rc["roof"]["achieved"] / F32_MFMA_PEAK_TFLOPS
+                                         * (FLOP_PER_POINT_SKIP_TABLE / FLOP_PER_POINT if skip_on else 1.0)),
             "roofline_frac_netC_query": (rc["roof"].get("color_achieved", 0.0) / F32_MFMA_PEAK_TFLOPS),
             "colour_points_per_frame": rc["roof"].get("color_points_per_frame")}
         # BASELINE configs[4]: 513^3, fp16 weights; parity deltas against the exact-f32 kernel on
@@ -956,16 +957,19 @@ def main(argv=None):
             "mpts_per_s": main_res["points"] / main_res["elapsed"] / 1e6,
             "breakdown": breakdown,
             "roofline": {
-                "kernel": ("pifu_query_t32_kernel<1,true> (fused gather + MLP on 32-point tiles, layer 0 blended from "
-                           "the frame's layer-0 table, l0_table_kernel)" if l0_on else
+                "kernel": ("pifu_query_tab_kernel<1> (fused MLP on 32-point tiles; the products with the sampled feature "
+                           "blended from the frame's skip table, skip_table_kernel)" if skip_on else
                            "pifu_query_kernel<256,1> (fused gather + MLP; launches of < 2048 tiles run on its "
                            "32-point-tile twin pifu_query_t32_kernel<1,false>)" if args.precision == "f32"
                            else "pifu_query16_kernel<1,%d> (fused gather + MLP, %s)" % (terms, args.precision)),
                 "bound": "mfma",
-                "achieved": roof["achieved"],
+                # with the skip tables the kernel EXECUTES fewer FLOPs than the reference's MLP has
+                # (`algorithmic` below): `achieved` / `frac` price the executed ones, so that
+                # frac stays a statement about the kernel against the MFMA peak
+                "achieved": roof["achieved"] * (FLOP_PER_POINT_SKIP_TABLE / FLOP_PER_POINT if skip_on else 1.0),
                 "peak": peak_tflops,
                 "unit": "TFLOP/s",
-                "frac": roof["achieved"] / peak_tflops,
+                "frac": roof["achieved"] * (FLOP_PER_POINT_SKIP_TABLE / FLOP_PER_POINT if skip_on else 1.0) / peak_tflops,
                 "traffic": traffic_from_profile(args.precision, args.levels, args.with_color,
                                                 min(batch, MAX_RECON_BATCH)),
                 "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
@@ -973,18 +977,17 @@ def main(argv=None):
                 "launches": roof["launches"],
                 "frames_per_launch": min(batch, MAX_RECON_BATCH),
                 "avg_launch_ms": float(roof["launch_ms"].mean()) if roof["launches"] else None,
-                "flop_per_point": FLOP_PER_POINT,
-                # `achieved` / `frac` count the ALGORITHMIC FLOPs of the reference's MLP.  With
-                # the layer-0 tables the kernel EXECUTES fewer: W0 is applied once per texel and frame
-                # (l0_table_kernel, outside these launches, inside `value`) and blended per point.
-                "executed": ({"flop_per_point": FLOP_PER_POINT_L0_TABLE,
-                              "achieved": roof["achieved"] * FLOP_PER_POINT_L0_TABLE / FLOP_PER_POINT,
-                              "frac": roof["achieved"] * FLOP_PER_POINT_L0_TABLE / FLOP_PER_POINT / peak_tflops,
-                              "l0_table_flop_per_frame": FLOP_L0_TABLE_PER_FRAME,
-                              "note": "layer 0's 1024 x 256 product is hoisted out of the per-point work "
-                                      "(a linear map commutes with the bilinear interpolation); "
-                                      "--no-l0-table runs every FLOP per point"}
-                             if l0_on else None),
+                "flop_per_point": FLOP_PER_POINT_SKIP_TABLE if skip_on else FLOP_PER_POINT,
+                "algorithmic": {"flop_per_point": FLOP_PER_POINT, "achieved": roof["achieved"],
+                                "frac": roof["achieved"] / peak_tflops,
+                                "note": ("the reference's MLP per point (SURVEY 8d) over the same launch times; above 1 "
+                                         "because 2 x 1921 x 256 FLOP per point -- every product of weights with the "
+                                         "sampled feature -- are hoisted out of the per-point work: a linear map "
+                                         "commutes with the bilinear interpolation, so skip_table_kernel takes them "
+                                         "once per texel and frame (%d FLOP per frame, outside these launches, inside "
+                                         "`value`) and the query blends four table rows per point; --no-skip-table "
+                                         "runs every FLOP per point" % FLOP_SKIP_TABLE_PER_FRAME)
+                                if skip_on else "equal to the executed FLOPs"},
             },
         }
         out.update(extras)
@@ -1002,7 +1005,8 @@ def main(argv=None):
             with open(launch_log, "w") as f:
                 json.dump({"launch_ms": [float(v) for v in roof["launch_ms"]],
                            "launch_points": [int(v) for v in roof["launch_pts"]],
-                           "levels": len(resolutions), "frames_per_launch": min(batch, MAX_RECON_BATCH)}, f)
+                           "levels": len(resolutions), "frames_per_launch": min(batch, MAX_RECON_BATCH),
+                           "flop_per_point": FLOP_PER_POINT_SKIP_TABLE if skip_on else FLOP_PER_POINT}, f)
         print(json.dumps(out), flush=True)
     pipe.close()
     if dist is not None:

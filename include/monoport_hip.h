@@ -103,27 +103,32 @@ int mp_mlp_set_precision(mp_ctx *ctx, int mlp, int precision);
 int mp_feat_pack_hwc(mp_ctx *ctx, const float *src_chw, int c_src, int h, int w, float *dst_hwc,
                      int c_dst, int c_offset, mp_stream stream);
 
-/* Optional accelerator of the exact-f32 query of a netG head (C = 256): the layer-0 table of a
- * feature map.  SurfaceClassifier's first layer (heads/SurfaceClassifier.py:39-71) applies W0 to the
- * SAMPLED feature, i.e. to a bilinear blend of four texels (geometry.py:4-16); a linear map commutes
- * with that blend, so  table[y][x][r] = sum_c W0[r][c] feat[y][x][c]  (r < 1024; no bias, no z
- * column) is computed ONCE per feature map here -- 8.6 GFLOP for a 128 x 128 map -- and the query of a
- * point blends four 1024-float rows of it instead of multiplying 1024 x 256 weights: 22 % of the
- * per-point MFMA work gone (the result differs from the plain path by f32 rounding only: a few
- * 1e-7 on the field, far inside the 1e-4 bar; tests/test_query_gpu.py::test_l0_table_*).
+/* Optional accelerator of the exact-f32 query of a netG head (C = 256): the SKIP TABLE of a feature
+ * map.  SurfaceClassifier (heads/SurfaceClassifier.py:39-71) multiplies weights with the SAMPLED
+ * feature in every layer -- layer 0's 1024 x 256 block and the skip connections of layers 1-4 (:55)
+ * -- and the sampled feature is a bilinear blend of four texels (geometry.py:4-16).  A linear map
+ * commutes with that blend, so  table[y][x][r] = sum_c W[r][c] feat[y][x][c]  for those 1921 weight
+ * rows (no bias, no z column; row layout: layers 0-3 at 0 / 1024 / 1536 / 1792, layer 4 at 1920,
+ * padded to MP_SKIP_TABLE_ROWS) is computed ONCE per feature map here -- 16 GFLOP for a 128 x 128
+ * map -- and the query of a point blends four rows of it instead of multiplying 492 k weights: 42 %
+ * of the per-point MFMA work gone.  The result differs from the plain path by f32 rounding only
+ * (1-3e-7 on the field, far inside the 1e-4 bar; tests/test_query_gpu.py::test_skip_table_*).
  * The call also REGISTERS the table for feat_hwc in the context: every later fused query launch
  * (mp_query*, mp_recon*) whose feature maps ALL have a registered table made with the same head
  * and map size uses it; others run the plain path.  The caller owns `table`
- * ([H, W, 1024] f32, 16-byte aligned; H * W a multiple of 64), must call mp_l0_table again after it
- * rewrites the feature map (stream-ordered with the queries, like any producer), and
- * mp_l0_table_release(ctx, feat_hwc) (NULL: all) before freeing either buffer. */
-int mp_l0_table(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, float *table,
+ * ([H, W, MP_SKIP_TABLE_ROWS] f32, 16-byte aligned; H * W a multiple of 64), must call mp_skip_table
+ * again after it rewrites the feature map (stream-ordered with the queries, like any producer), and
+ * mp_skip_table_release(ctx, feat_hwc, table) before freeing either buffer (table NULL: whatever is
+ * registered for feat_hwc; otherwise only if it still is that table; feat_hwc NULL: everything).
+ * mp_mlp_destroy drops the tables made with that head. */
+#define MP_SKIP_TABLE_ROWS 1924
+int mp_skip_table(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, float *table,
                 mp_stream stream);
-/* The same for n_maps maps stored back to back ([n_maps, H, W, C] -> table [n_maps, H, W, 1024]):
+/* The same for n_maps maps stored back to back ([n_maps, H, W, C] -> table [n_maps, H, W, MP_SKIP_TABLE_ROWS]):
  * one launch, one registration per map. */
-int mp_l0_table_batch(mp_ctx *ctx, int mlp, int n_maps, const float *feat_hwc, int c, int h, int w,
+int mp_skip_table_batch(mp_ctx *ctx, int mlp, int n_maps, const float *feat_hwc, int c, int h, int w,
                       float *table, mp_stream stream);
-int mp_l0_table_release(mp_ctx *ctx, const float *feat_hwc);
+int mp_skip_table_release(mp_ctx *ctx, const float *feat_hwc, const float *table);
 
 /* ---- per-point ops ------------------------------------------------------------------------- */
 /* index(feat, uv) (geometry.py:4-16): bilinear grid_sample, align_corners=True, zero padding.

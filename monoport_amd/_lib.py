@@ -64,9 +64,9 @@ SIGNATURES = {
     "mp_mlp_destroy": (c_int, [c_vp, c_int]),
     "mp_mlp_set_precision": (c_int, [c_vp, c_int, c_int]),
     "mp_feat_pack_hwc": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
-    "mp_l0_table": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
-    "mp_l0_table_batch": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
-    "mp_l0_table_release": (c_int, [c_vp, c_vp]),
+    "mp_skip_table": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "mp_skip_table_batch": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "mp_skip_table_release": (c_int, [c_vp, c_vp, c_vp]),
     "mp_index": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     "mp_orthogonal": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "mp_query": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_i64, c_vp,

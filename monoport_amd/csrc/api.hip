@@ -338,6 +338,9 @@ int mp_mlp_destroy(mp_ctx *ctx, int mlp) {
   if (!m) return fail(ctx, MP_ERR_ARG, "mp_mlp_destroy: unknown mlp id %d", mlp);
   DeviceGuard g(ctx->device);
   MP_HIP(ctx, hipDeviceSynchronize());
+  // skip tables made with this head die with it (a later head may get the same buffer address)
+  for (auto it = ctx->skip_tables.begin(); it != ctx->skip_tables.end();)
+    it = it->second.mlp_buf == m->buf ? ctx->skip_tables.erase(it) : std::next(it);
   if (m->buf) MP_HIP(ctx, hipFree(m->buf));
   if (m->buf16) MP_HIP(ctx, hipFree(m->buf16));
   if (m->raw) MP_HIP(ctx, hipFree(m->raw));
@@ -356,24 +359,26 @@ int mp_feat_pack_hwc(mp_ctx *ctx, const float *src_chw, int c_src, int h, int w,
   return launch_pack_hwc(ctx, src_chw, c_src, h, w, dst_hwc, c_dst, c_offset, (hipStream_t)stream);
 }
 
-int mp_l0_table(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, float *table,
+static_assert(MP_SKIP_TABLE_ROWS == mp::kTableRows, "header and kernels disagree on the table row length");
+
+int mp_skip_table(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, float *table,
                 mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   const Mlp *m = get_mlp(ctx, mlp);
   int rc = check_ready(ctx, m, c);
   if (rc != MP_OK) return rc;
-  if (!feat_hwc || !table || h <= 0 || w <= 0) return fail(ctx, MP_ERR_ARG, "mp_l0_table: bad argument");
+  if (!feat_hwc || !table || h <= 0 || w <= 0) return fail(ctx, MP_ERR_ARG, "mp_skip_table: bad argument");
   if (!aligned16(feat_hwc) || !aligned16(table))
-    return fail(ctx, MP_ERR_ARG, "mp_l0_table: feat_hwc and table must be 16-byte aligned");
+    return fail(ctx, MP_ERR_ARG, "mp_skip_table: feat_hwc and table must be 16-byte aligned");
   DeviceGuard g(ctx->device);
-  rc = launch_l0_table(ctx, *m, feat_hwc, h, w, table, (hipStream_t)stream);
+  rc = launch_skip_table(ctx, *m, feat_hwc, h, w, table, (hipStream_t)stream);
   if (rc != MP_OK) return rc;
-  ctx->l0_tables[feat_hwc] = mp_ctx::L0Entry{table, m->buf, h, w};
+  ctx->skip_tables[feat_hwc] = mp_ctx::SkipTable{table, m->buf, h, w};
   return MP_OK;
 }
 
-int mp_l0_table_batch(mp_ctx *ctx, int mlp, int n_maps, const float *feat_hwc, int c, int h, int w,
+int mp_skip_table_batch(mp_ctx *ctx, int mlp, int n_maps, const float *feat_hwc, int c, int h, int w,
                       float *table, mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -381,26 +386,28 @@ int mp_l0_table_batch(mp_ctx *ctx, int mlp, int n_maps, const float *feat_hwc, i
   int rc = check_ready(ctx, m, c);
   if (rc != MP_OK) return rc;
   if (!feat_hwc || !table || h <= 0 || w <= 0 || n_maps <= 0 || (long long)n_maps * h > (1 << 20))
-    return fail(ctx, MP_ERR_ARG, "mp_l0_table_batch: bad argument");
+    return fail(ctx, MP_ERR_ARG, "mp_skip_table_batch: bad argument");
   if (!aligned16(feat_hwc) || !aligned16(table))
-    return fail(ctx, MP_ERR_ARG, "mp_l0_table_batch: feat_hwc and table must be 16-byte aligned");
+    return fail(ctx, MP_ERR_ARG, "mp_skip_table_batch: feat_hwc and table must be 16-byte aligned");
   DeviceGuard g(ctx->device);
   // the maps are contiguous: one launch over n_maps * H rows of texels
-  rc = launch_l0_table(ctx, *m, feat_hwc, n_maps * h, w, table, (hipStream_t)stream);
+  rc = launch_skip_table(ctx, *m, feat_hwc, n_maps * h, w, table, (hipStream_t)stream);
   if (rc != MP_OK) return rc;
   for (int i = 0; i < n_maps; ++i)
-    ctx->l0_tables[feat_hwc + (size_t)i * h * w * c] =
-        mp_ctx::L0Entry{table + (size_t)i * h * w * kHidden[0], m->buf, h, w};
+    ctx->skip_tables[feat_hwc + (size_t)i * h * w * c] =
+        mp_ctx::SkipTable{table + (size_t)i * h * w * kTableRows, m->buf, h, w};
   return MP_OK;
 }
 
-int mp_l0_table_release(mp_ctx *ctx, const float *feat_hwc) {
+int mp_skip_table_release(mp_ctx *ctx, const float *feat_hwc, const float *table) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  if (feat_hwc)
-    ctx->l0_tables.erase(feat_hwc);
-  else
-    ctx->l0_tables.clear();
+  if (!feat_hwc) {
+    ctx->skip_tables.clear();
+    return MP_OK;
+  }
+  auto it = ctx->skip_tables.find(feat_hwc);
+  if (it != ctx->skip_tables.end() && (!table || it->second.table == table)) ctx->skip_tables.erase(it);
   return MP_OK;
 }
 

@@ -17,6 +17,10 @@ namespace mp {
 constexpr int kTilePts = 64;     // query points per workgroup tile
 constexpr int kQueryThreads = 256;
 constexpr int kHidden[4] = {1024, 512, 256, 128};  // SurfaceClassifier.py:76 / :84
+// rows of a feature map's skip table (mp_skip_table): the feature segments of layers 0-3 back to back
+// (1024 + 512 + 256 + 128), then the last layer's (<= 3 outputs, padded to one 16-byte slot)
+constexpr int kTableL[5] = {0, 1024, 1536, 1792, 1920};
+constexpr int kTableRows = 1924;
 
 // Device-side view of one packed SurfaceClassifier (see pack.hip for the fragment order).
 // One base pointer + float offsets keeps the kernel's SGPR footprint small.
@@ -69,7 +73,7 @@ struct QueryItem {
   const float *calib;  // [3,4] rows of the 4x4
   float *out;
   PointSrc src;
-  const float *l0;     // optional layer-0 table of `feat` [H,W,1024] (mp_l0_table; filled in by the launcher)
+  const float *l0;     // optional skip table of `feat` [H,W,kTableRows] (mp_skip_table; filled in by the launcher)
 };
 struct QuerySet {
   int n;
@@ -118,14 +122,14 @@ struct mp_ctx {
   std::unordered_map<void *, Arena> arenas;
   // kernels whose dynamic-LDS limit has been raised on this context's device (guarded by mu)
   std::unordered_set<const void *> lds_attr_done;
-  // layer-0 tables registered for feature maps (mp_l0_table): feat pointer -> table + the packed
+  // skip tables registered for feature maps (mp_skip_table): feat pointer -> table + the packed
   // head it was computed with
-  struct L0Entry {
+  struct SkipTable {
     const float *table;
     const float *mlp_buf;
     int h, w;
   };
-  std::unordered_map<const float *, L0Entry> l0_tables;
+  std::unordered_map<const float *, SkipTable> skip_tables;
   // optional event bracketing of query launches (mp_profile_begin / mp_profile_end)
   std::vector<hipEvent_t> prof_events;  // start/stop pairs
   int prof_used = 0;                    // pairs recorded
@@ -168,9 +172,12 @@ int launch_absmax_accumulate(mp_ctx *ctx, const float *src, long long n, unsigne
 // kSmallGateTiles 64-point tiles
 constexpr int kSmallGateTiles = 2048;
 int launch_query32(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
-                   long long max_points, bool device_counts, int gate_tiles64, bool table, hipStream_t st);
-int launch_l0_table(mp_ctx *ctx, const Mlp &m, const float *feat_hwc, int h, int w, float *table,
+                   long long max_points, bool device_counts, int gate_tiles64, hipStream_t st);
+// query_table.hip: the skip table of a feature map and the query kernel that blends its rows
+int launch_skip_table(mp_ctx *ctx, const Mlp &m, const float *feat_hwc, int h, int w, float *table,
                     hipStream_t st);
+int launch_query_tab(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
+                     long long max_points, bool device_counts, hipStream_t st);
 void query_small_set_gate(int gate);  // 0 never, 1 always, n > 1 gate in 64-point tiles, < 0 default
 int query_small_gate();
 // query16.hip

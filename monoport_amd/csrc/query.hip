@@ -451,14 +451,14 @@ static int launch_query_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h,
   int small = 0;  // 0 = this kernel only, 1 = the 32-point kernel only, 2 = both, gated
   int gate = 0;
   bool table = false;
-  QuerySet tset;  // the set with the layer-0 tables filled in (mp_l0_table), if every frame has one
+  QuerySet tset;  // the set with the layer-0 tables filled in (mp_skip_table), if every frame has one
   if constexpr (C == 256 && !DIRECT) {
-    if (!ctx->l0_tables.empty()) {
+    if (!ctx->skip_tables.empty()) {
       tset = set;
       table = true;
       for (int f = 0; f < set.n && table; ++f) {
-        auto it = ctx->l0_tables.find(set.it[f].feat);
-        table = it != ctx->l0_tables.end() && it->second.mlp_buf == m.buf && it->second.h == h && it->second.w == w;
+        auto it = ctx->skip_tables.find(set.it[f].feat);
+        table = it != ctx->skip_tables.end() && it->second.mlp_buf == m.buf && it->second.h == h && it->second.w == w;
         if (table) tset.it[f].l0 = it->second.table;
       }
     }
@@ -477,13 +477,13 @@ static int launch_query_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h,
   }
   const bool prof = 2 * (ctx->prof_used + 1) <= (int)ctx->prof_events.size();
   if (prof) MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], st));
-  if (table) {  // the table variant exists on 32-point tiles only: every launch size goes there
+  if (table) {  // query_table.hip: 32-point tiles at every launch size
     small = 1;
-    const int rc = launch_query32(ctx, m, tset, h, w, z_scale, max_points, device_counts, 0, true, st);
+    const int rc = launch_query_tab(ctx, m, tset, h, w, z_scale, max_points, device_counts, st);
     if (rc != MP_OK) return rc;
   } else if (small) {
     const int rc = launch_query32(ctx, m, set, h, w, z_scale, max_points, device_counts,
-                                  small == 2 ? gate : 0, false, st);
+                                  small == 2 ? gate : 0, st);
     if (rc != MP_OK) return rc;
   }
   if (small != 1)

@@ -41,15 +41,8 @@ constexpr int kSmallPts = 32;
 #endif
 constexpr int kSmallHbRow = 128 * 4;  // bytes per point of a 128-row hidden chunk
 
-// TABLE = true: layer 0's feature product comes from the per-texel table of mp_l0_table (see
-// l0_table_kernel below) instead of 1024 x 256 MFMA work per point: a linear map commutes with the
-// bilinear interpolation,  W0x . sum_k w_k F[texel_k] = sum_k w_k (W0x . F[texel_k]),  so the
-// 1024 x 256 product is taken ONCE per texel and frame (8.6 GFLOP) and a point blends four
-// 1024-float rows of it -- 22 % fewer MFMA FLOPs per point for 16 KB more gather (L2-served: the
-// lattice points of a tile share texels).  The rows of chunk ck + 1 are in flight under layer 1's
-// MFMAs of chunk ck (64 registers, so this variant is built for two workgroups per CU).
-template <int COUT, bool TABLE>
-__global__ __launch_bounds__(kQueryThreads, TABLE ? 2 : MP32_T32_WPS) void pifu_query_t32_kernel(
+template <int COUT>
+__global__ __launch_bounds__(kQueryThreads, MP32_T32_WPS) void pifu_query_t32_kernel(
     MlpPack mlp, int fh, int fw, float z_scale, int act, QuerySet set, int gate_tiles64) {
   constexpr int C = 256;
   constexpr int P = kSmallPts;
@@ -65,13 +58,6 @@ __global__ __launch_bounds__(kQueryThreads, TABLE ? 2 : MP32_T32_WPS) void pifu_
   const int j = lane & 31, h = lane >> 5;
   const int swz = h ^ (j & 15);
   const WStream ws = make_wstream(mlp.base, mlp.n_floats, lane);
-  // TABLE: layer 0's bias lives in LDS for the whole launch (4 KB behind the chunk buffer) -- read
-  // where it is added instead of riding in 16 registers across layer 1's MFMAs
-  float *bias0 = reinterpret_cast<float *>(smem + P * ROWB + P * kSmallHbRow);
-  if constexpr (TABLE) {
-    for (int i = tid; i < kHidden[0]; i += kQueryThreads) bias0[i] = (mlp.base + mlp.bias[0])[i];
-    __syncthreads();
-  }
 
   for (long long gtile = blockIdx.x;; gtile += gridDim.x) {
     int fi = -1;
@@ -105,8 +91,6 @@ __global__ __launch_bounds__(kQueryThreads, TABLE ? 2 : MP32_T32_WPS) void pifu_
 
     // ---------------- gather: 8 points per wave ----------------
     float zb[1];
-    int p0o[4] = {0, 0, 0, 0};  // TABLE: byte offsets of this lane's point's four table rows (+ its half)
-    float p0w[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     {
       float cal[12];
 #pragma unroll
@@ -145,14 +129,6 @@ __global__ __launch_bounds__(kQueryThreads, TABLE ? 2 : MP32_T32_WPS) void pifu_
         if (n < n_pts) load_point(src, n, px, py, pz, code);
         project(cal, px, py, pz, x, y, z);
         zb[0] = (h == 0 && n < n_pts) ? __fmul_rn(z, z_scale) : 0.0f;
-        if constexpr (TABLE) {
-          const Taps t = make_taps(x, y, fh, fw, kHidden[0], n < n_pts && in_image(x, y));
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            p0o[k] = (int)t.o[k] * 4 + 16 * h;
-            p0w[k] = t.w[k];
-          }
-        }
       }
     }
     __syncthreads();
@@ -169,52 +145,9 @@ __global__ __launch_bounds__(kQueryThreads, TABLE ? 2 : MP32_T32_WPS) void pifu_
       const int a0 = mlp.ax[0] / 4;
       const int rs1 = (kHidden[0] / 8) * 64;
       const int a1 = mlp.ah[1] / 4 + (4 * wv) * rs1;
+      f32x4 ring0[MP32_PF0 + 1][1];
       f32x16 acc0[1][1];
       float az0[1];
-      if constexpr (TABLE) {
-        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(item.l0), 0, fh * fw * kHidden[0] * 4, 0x00020000);
-        // [q][tap]: rows 32 rb + 8 q + 4 h .. + 3 of the point's four texels -- exactly the rows this
-        // lane's accumulator registers 4 q .. 4 q + 3 stand for (C layout), so everything after the
-        // blend (z column, leaky ReLU, store_hidden) is the MFMA path's
-        f32x4 tp[4][4];
-        auto table_issue = [&](int rb) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              tp[q][k] = __builtin_bit_cast(
-                  f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, p0o[k], (32 * rb + 8 * q) * 4, 0));
-        };
-        table_issue(wv);
-        az0[0] = wload32(ws, mlp.az[0] + wv * 64);
-#pragma unroll 1
-        for (int ck = 0; ck < kHidden[0] / 128; ++ck) {
-          const int rb = 4 * ck + wv;
-          // bias + grid_sample's FMA chain (query_common.h: blend) on the table rows
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 bq = *reinterpret_cast<const f32x4 *>(bias0 + 32 * rb + 8 * q + 4 * h);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              acc0[0][0][4 * q + i] =
-                  bq[i] + fmaf(tp[q][3][i], p0w[3],
-                               fmaf(tp[q][2][i], p0w[2], fmaf(tp[q][1][i], p0w[1], __fmul_rn(tp[q][0][i], p0w[0]))));
-          }
-          f32x4 ring1[MP32_PF1 + 1][4];
-          seg_prefetch<4, MP32_PF1>(ring1, ws, a1 + ck * 16 * 64, rs1, 16);
-          gemm_z<1, 1>(acc0, az0, zb);
-          lrelu(acc0[0][0]);
-          store_hidden<kSmallHbRow>(hb, acc0[0][0], wv, 0, j, h);
-          const int rbn = min(rb + 4, kHidden[0] / 32 - 4 + wv);
-          table_issue(rbn);
-          az0[0] = wload32(ws, mlp.az[0] + rbn * 64);
-          __syncthreads();
-          seg_main<4, 1, MP32_PF1, kSmallHbRow>(acc1, ring1, ws, a1 + ck * 16 * 64, rs1, 16, hrow1, swz);
-          __syncthreads();
-        }
-      } else {
-      f32x4 ring0[MP32_PF0 + 1][1];
       seg_prefetch<1, MP32_PF0>(ring0, ws, a0 + wv * NGX * 64, 0, NGX);
       init_from_bias(acc0[0][0], ws, mlp.bias[0] + 32 * wv);
       az0[0] = wload32(ws, mlp.az[0] + wv * 64);
@@ -235,7 +168,6 @@ __global__ __launch_bounds__(kQueryThreads, TABLE ? 2 : MP32_T32_WPS) void pifu_
         // layer-1 rows [128 wv, +128) += W1[:, 128 ck .. +128) * chunk
         seg_main<4, 1, MP32_PF1, kSmallHbRow>(acc1, ring1, ws, a1 + ck * 16 * 64, rs1, 16, hrow1, swz);
         __syncthreads();
-      }
       }
       const int a1x = mlp.ax[1] / 4 + (4 * wv) * NGX * 64;
       f32x4 ring1[MP32_PF1 + 1][4];
@@ -383,11 +315,11 @@ static int g_small_gate = kSmallGateTiles;
 void query_small_set_gate(int gate) { g_small_gate = gate < 0 ? kSmallGateTiles : gate; }
 int query_small_gate() { return g_small_gate; }
 
-template <int COUT, bool TABLE>
+template <int COUT>
 int launch_query32_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
                      long long max_points, bool device_counts, int gate_tiles64, hipStream_t st) {
-  constexpr int lds = kSmallPts * 256 * 4 + kSmallPts * kSmallHbRow + (TABLE ? kHidden[0] * 4 : 0);
-  auto kern = pifu_query_t32_kernel<COUT, TABLE>;
+  constexpr int lds = kSmallPts * 256 * 4 + kSmallPts * kSmallHbRow;
+  auto kern = pifu_query_t32_kernel<COUT>;
   const void *kern_id = reinterpret_cast<const void *>(kern);
   if (!ctx->lds_attr_done.count(kern_id)) {
     MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -395,7 +327,7 @@ int launch_query32_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int 
   }
   if (max_points <= 0) return MP_OK;
   const long long tiles = (max_points + kSmallPts - 1) / kSmallPts + (set.n - 1);
-  const long long resident = (long long)ctx->n_cu * (TABLE ? 2 : MP32_T32_WPS);
+  const long long resident = (long long)ctx->n_cu * MP32_T32_WPS;
   // device-side counts: launch the resident grid and let it stride; host-side counts: one
   // workgroup per tile up to a few waves of the machine
   long long grid = device_counts ? (tiles < resident ? tiles : resident)
@@ -409,90 +341,12 @@ int launch_query32_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int 
 }
 
 int launch_query32(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
-                   long long max_points, bool device_counts, int gate_tiles64, bool table, hipStream_t st) {
-#define MP_Q32(CO)                                                                                      \
-  if (m.cout == CO)                                                                                     \
-    return table ? launch_query32_t<CO, true>(ctx, m, set, h, w, z_scale, max_points, device_counts,    \
-                                              gate_tiles64, st)                                         \
-                 : launch_query32_t<CO, false>(ctx, m, set, h, w, z_scale, max_points, device_counts,   \
-                                               gate_tiles64, st);
-  MP_Q32(1)
-  MP_Q32(3)
-#undef MP_Q32
+                   long long max_points, bool device_counts, int gate_tiles64, hipStream_t st) {
+  if (m.cout == 1)
+    return launch_query32_t<1>(ctx, m, set, h, w, z_scale, max_points, device_counts, gate_tiles64, st);
+  if (m.cout == 3)
+    return launch_query32_t<3>(ctx, m, set, h, w, z_scale, max_points, device_counts, gate_tiles64, st);
   return fail(ctx, MP_ERR_UNSUPPORTED, "query32: Cout in {1,3}");
-}
-
-// ---- the layer-0 table ---------------------------------------------------------------------------
-// table[texel][r] = sum_c W0[r][c] F[texel][c]  (r < 1024, c < 256; no bias, no z column): layer 0's
-// feature segment evaluated AT the texels, in the K order of the MFMA path.  One workgroup = 64
-// texels staged into LDS exactly like a tile of sampled points; a wave takes 8 of the 32 row blocks,
-// two at a time against both column blocks.  8.6 GFLOP and 67 MB per 128^2 map.
-__global__ __launch_bounds__(kQueryThreads, 2) void l0_table_kernel(MlpPack mlp, const float *__restrict__ feat,
-                                                                    long long texels, float *__restrict__ table) {
-  constexpr int C = 256, ROWB = C * 4, NGX = C / 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *xs = smem;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  const int swz = h ^ (j & 15);
-  const WStream ws = make_wstream(mlp.base, mlp.n_floats, lane);
-  const long long n_tiles = texels / 64;
-  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const long long t0 = tile * 64;
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-      const int p = 16 * wv + i;
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(feat + (t0 + p) * C + 4 * lane);
-      *reinterpret_cast<f32x4 *>(xs + p * ROWB + ((lane ^ (p & 15)) << 4)) = v;
-    }
-    __syncthreads();
-    const unsigned char *xrow = xs + j * ROWB;
-#pragma unroll 1
-    for (int pair = 0; pair < 4; ++pair) {
-      const int rb = 8 * wv + 2 * pair;
-      f32x16 acc[2][2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int t = 0; t < 16; ++t) acc[m][n][t] = 0.0f;
-      const int a = mlp.ax[0] / 4 + rb * NGX * 64;
-      f32x4 ring[2][2];
-      seg_prefetch<2, 1>(ring, ws, a, NGX * 64, NGX);
-      seg_main<2, 2, 1, ROWB>(acc, ring, ws, a, NGX * 64, NGX, xrow, swz);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 o = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
-            *reinterpret_cast<f32x4 *>(table + (t0 + 32 * n + j) * kHidden[0] + 32 * (rb + m) + 8 * q + 4 * h) = o;
-          }
-    }
-    __syncthreads();  // xs is restaged by the next tile
-  }
-}
-
-int launch_l0_table(mp_ctx *ctx, const Mlp &m, const float *feat_hwc, int h, int w, float *table,
-                    hipStream_t st) {
-  const long long texels = (long long)h * w;
-  if (m.c != 256 || texels % 64)
-    return fail(ctx, MP_ERR_UNSUPPORTED, "l0 table: C = 256 heads and H * W a multiple of 64; got C=%d %dx%d", m.c, h, w);
-  constexpr int lds = 64 * 256 * 4;
-  const void *kern_id = reinterpret_cast<const void *>(l0_table_kernel);
-  if (!ctx->lds_attr_done.count(kern_id)) {
-    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    ctx->lds_attr_done.insert(kern_id);
-  }
-  const long long tiles = texels / 64, resident = (long long)ctx->n_cu * 2;
-  hipLaunchKernelGGL(l0_table_kernel, dim3((unsigned)(tiles < resident ? tiles : resident)), dim3(kQueryThreads), lds,
-                     st, m.pack(), feat_hwc, texels, table);
-  MP_HIP(ctx, hipGetLastError());
-  return MP_OK;
 }
 
 }  // namespace mp

@@ -1,0 +1,434 @@
+// The fused f32 query of a netG head through the SKIP TABLE of its feature map (round 3).
+//
+// SurfaceClassifier (heads/SurfaceClassifier.py:39-71) multiplies weights with the SAMPLED FEATURE
+// in every layer: layer 0's 1024 x 256 block and the skip connections of layers 1-4 (:55,
+// 512 + 256 + 128 + Cout rows) -- 42 % of a point's 2,363,906 FLOP.  The sampled feature is a
+// bilinear blend of four texels (geometry.py:4-16), and a linear map commutes with that blend:
+//     W . sum_k w_k F[texel_k]  =  sum_k w_k (W . F[texel_k]).
+// So skip_table_kernel takes those 1921 x 256 products ONCE per texel and frame
+// (table[y][x][r], 16 GFLOP and 126 MB for a 128 x 128 map) and pifu_query_tab_kernel gives a point
+// four rows of the table to blend -- with grid_sample's own FMA chain and zero padding -- instead of
+// 492 k multiply-adds on the MFMAs.  What is left per point is the hidden-to-hidden work
+// (1024 -> 512 -> 256 -> 128 -> Cout: 1,377,026 FLOP) and the z column.  The feature tile and its
+// gather disappear with the products (LDS: 20 KB instead of 48 KB); the price is 31 KB of gathered
+// table rows per point, L2-served because the lattice points of a tile share texels.
+//
+// The field differs from the plain kernels' (query.hip / query_small.hip) by f32 rounding only --
+// the same products summed in another order: measured 1-3e-7 on the goldens, the same distance
+// to the fp64 oracle as the plain path and as the reference itself (tests/test_query_gpu.py::
+// test_skip_table_*); the bar is 1e-4.  The plain kernels stay the default of the C-ABI: a launch
+// comes here only if every one of its feature maps has a registered table (mp_skip_table).
+//
+// Decomposition (32-point tiles, as query_small.hip; two workgroups per CU):
+//   * a lane owns ONE point (p = lane & 31) and the rows its MFMA accumulator registers stand for
+//     (C layout: rows 8 q + 4 h + i of a 32-row block), so a blend lands exactly where the MFMA
+//     path would have left the product and everything downstream (z column, leaky ReLU, the
+//     point-major hidden chunk) is shared with the plain kernels (query_mfma.h);
+//   * layer 0 in 128-row chunks: the 16 table loads of chunk ck + 1 are in flight under layer 1's
+//     MFMAs of chunk ck (64 registers);  layer 0's bias sits in LDS;
+//   * the skip rows of layers 1-3 are blended into the accumulators when those are initialised,
+//     layer 4's in the final reduction.
+#include <cstring>
+
+#include "mp_internal.h"
+#include "query_common.h"
+#include "query_mfma.h"
+
+#pragma clang fp contract(off)
+
+namespace mp {
+
+constexpr int kTabPts = 32;
+constexpr int kTabHbRow = 128 * 4;  // bytes per point of a 128-row hidden chunk
+
+typedef f32x4 TabRows[4][4];  // [q][tap]: rows 8 q + 4 h .. + 3 of a 32-row block, four texels
+
+// grid_sample's chain (query_common.h: blend) on table rows, added to an accumulator tile
+__device__ __forceinline__ void blend_add(f32x16 &acc, const TabRows &tp, const float (&w)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[4 * q + i] = acc[4 * q + i] + fmaf(tp[q][3][i], w[3],
+                                             fmaf(tp[q][2][i], w[2], fmaf(tp[q][1][i], w[1], __fmul_rn(tp[q][0][i], w[0]))));
+}
+
+template <int COUT>
+__global__ __launch_bounds__(kQueryThreads, 2) void pifu_query_tab_kernel(MlpPack mlp, int fh, int fw, float z_scale,
+                                                                          int act, QuerySet set) {
+  constexpr int P = kTabPts;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *hb = smem;  // hidden chunk: [32][128 rows] (layer 0 -> 1) or [32][64 rows]; `red` at the end
+  float *bias0 = reinterpret_cast<float *>(smem + P * kTabHbRow);  // layer 0's bias, for the whole launch
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int swz = h ^ (j & 15);
+  const WStream ws = make_wstream(mlp.base, mlp.n_floats, lane);
+  for (int i = tid; i < kHidden[0]; i += kQueryThreads) bias0[i] = (mlp.base + mlp.bias[0])[i];
+  __syncthreads();
+
+  for (long long gtile = blockIdx.x;; gtile += gridDim.x) {
+    int fi = -1;
+    long long tile0 = 0;
+    {
+      long long acc = 0;
+#pragma unroll
+      for (int f = 0; f < kMaxFrames; ++f) {
+        if (f < set.n) {
+          const PointSrc &s = set.it[f].src;
+          const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
+          const long long t = (nf + P - 1) / P;
+          if (fi < 0 && gtile < acc + t) {
+            fi = f;
+            tile0 = acc;
+          }
+          acc += t;
+        }
+      }
+    }
+    if (fi < 0) break;
+    const QueryItem &item = set.it[fi];
+    const float *__restrict__ calib = item.calib;
+    float *__restrict__ out = item.out;
+    const PointSrc &src = item.src;
+    const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
+    const long long n0 = (gtile - tile0) * P;
+    const __amdgpu_buffer_rsrc_t prs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(item.l0), 0, fh * fw * kTableRows * 4, 0x00020000);
+
+    // ---------------- this lane's point: projection, the four texels, z ----------------
+    float zb[1];
+    int to[4];    // byte offsets of the point's four table rows, + this lane's half of a row group
+    float tw[4];  // grid_sample weights (0 for taps outside the map and for dead points)
+    {
+      float cal[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) cal[i] = calib[i];
+      const long long n = n0 + j;
+      float px = 0, py = 0, pz = 0, x, y, z;
+      uint32_t code;
+      if (n < n_pts) load_point(src, n, px, py, pz, code);
+      project(cal, px, py, pz, x, y, z);
+      zb[0] = (h == 0 && n < n_pts) ? __fmul_rn(z, z_scale) : 0.0f;
+      const Taps t = make_taps(x, y, fh, fw, kTableRows, n < n_pts && in_image(x, y));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        to[k] = (int)t.o[k] * 4 + 16 * h;
+        tw[k] = t.w[k];
+      }
+    }
+    // rows row0 + 8 q + 4 h .. + 3 of the point's four texels
+    auto rows_issue = [&](TabRows &tp, int row0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          tp[q][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, to[k], (row0 + 8 * q) * 4, 0));
+    };
+
+    const unsigned char *hrow = hb + j * kHbRowBytes;  // 64-row chunks (layers 2, 3)
+    const unsigned char *hrow1 = hb + j * kTabHbRow;   // 128-row chunks (layer 0 -> 1)
+
+    // ---------------- layer 1 accumulators: bias + skip rows ----------------
+    // two row buffers, software-pipelined by hand: round m + 1 is in flight while round m is blended
+    // (sched_barriers pin that order -- left alone hipcc hoists all four rounds' loads to the top and
+    // spills), and layer 0's first chunk is requested under the last round
+    TabRows ta, tb;
+    f32x16 acc1[4][1];
+    rows_issue(ta, kTableL[1] + 32 * (4 * wv));
+    rows_issue(tb, kTableL[1] + 32 * (4 * wv + 1));
+#pragma unroll
+    for (int m = 0; m < 4; ++m) init_from_bias(acc1[m][0], ws, mlp.bias[1] + 32 * (4 * wv + m));
+    __builtin_amdgcn_sched_barrier(0);
+    blend_add(acc1[0][0], ta, tw);
+    __builtin_amdgcn_sched_barrier(0);
+    rows_issue(ta, kTableL[1] + 32 * (4 * wv + 2));
+    __builtin_amdgcn_sched_barrier(0);
+    blend_add(acc1[1][0], tb, tw);
+    __builtin_amdgcn_sched_barrier(0);
+    rows_issue(tb, kTableL[1] + 32 * (4 * wv + 3));
+    __builtin_amdgcn_sched_barrier(0);
+    blend_add(acc1[2][0], ta, tw);
+    __builtin_amdgcn_sched_barrier(0);
+    rows_issue(ta, kTableL[0] + 32 * wv);  // layer 0, chunk 0
+    __builtin_amdgcn_sched_barrier(0);
+    blend_add(acc1[3][0], tb, tw);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---------------- layers 0 + 1, fused over 128-row chunks of layer 0 ----------------
+    {
+      const int rs1 = (kHidden[0] / 8) * 64;
+      const int a1 = mlp.ah[1] / 4 + (4 * wv) * rs1;
+      f32x16 acc0[1][1];
+      float az0[1];
+      az0[0] = wload32(ws, mlp.az[0] + wv * 64);
+#pragma unroll 1
+      for (int ck = 0; ck < kHidden[0] / 128; ++ck) {
+        const int rb = 4 * ck + wv;  // layer-0 rows [32 rb, +32) x the 32 points
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 bq = *reinterpret_cast<const f32x4 *>(bias0 + 32 * rb + 8 * q + 4 * h);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc0[0][0][4 * q + i] = bq[i];
+        }
+        blend_add(acc0[0][0], ta, tw);
+        f32x4 ring1[MP32_PF1 + 1][4];
+        seg_prefetch<4, MP32_PF1>(ring1, ws, a1 + ck * 16 * 64, rs1, 16);
+        gemm_z<1, 1>(acc0, az0, zb);
+        lrelu(acc0[0][0]);
+        store_hidden<kTabHbRow>(hb, acc0[0][0], wv, 0, j, h);
+        // the next chunk's rows -- after the last chunk: the first half of layer 2's skip rows
+        const bool last = ck + 1 == kHidden[0] / 128;
+        const int rbn = last ? rb : rb + 4;
+        rows_issue(ta, last ? kTableL[2] + 32 * (2 * wv) : kTableL[0] + 32 * rbn);
+        az0[0] = wload32(ws, mlp.az[0] + rbn * 64);
+        __syncthreads();
+        // layer-1 rows [128 wv, +128) += W1[:, 128 ck .. +128) * chunk
+        seg_main<4, 1, MP32_PF1, kTabHbRow>(acc1, ring1, ws, a1 + ck * 16 * 64, rs1, 16, hrow1, swz);
+        __syncthreads();
+      }
+      rows_issue(tb, kTableL[2] + 32 * (2 * wv + 1));  // second half of layer 2's skip rows
+      float az1[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) az1[m] = wload32(ws, mlp.az[1] + (4 * wv + m) * 64);
+      gemm_z<4, 1>(acc1, az1, zb);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) lrelu(acc1[m][0]);
+    }
+
+    // ---------------- layer 2: rows [64 wv, +64): bias + skip rows, K = 512 hidden (8 chunks of 64) ----------------
+    f32x16 acc2[2][1];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) init_from_bias(acc2[m][0], ws, mlp.bias[2] + 32 * (2 * wv + m));
+    blend_add(acc2[0][0], ta, tw);
+    __builtin_amdgcn_sched_barrier(0);
+    rows_issue(ta, kTableL[3] + 32 * wv);  // layer 3's skip rows land under layer 2's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    blend_add(acc2[1][0], tb, tw);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int rs2 = (kHidden[1] / 8) * 64;
+      const int a2 = mlp.ah[2] / 4 + (2 * wv) * rs2;
+      f32x4 ring2[2][2];
+      seg_prefetch<2, 1>(ring2, ws, a2, rs2, 8);
+#pragma unroll
+      for (int ck = 0; ck < 8; ++ck) {
+        if (wv == (ck >> 1)) {  // owner of hidden rows [64 ck, +64): row blocks 2 (ck & 1), + 1
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) store_hidden(hb, acc1[2 * (ck & 1) + mm][0], mm, 0, j, h);
+        }
+        __syncthreads();
+        seg_main<2, 1, 1, kHbRowBytes>(acc2, ring2, ws, a2 + ck * 8 * 64, rs2, 8, hrow, swz);
+        if (ck < 7) seg_prefetch<2, 1>(ring2, ws, a2 + (ck + 1) * 8 * 64, rs2, 8);
+        __syncthreads();
+      }
+      float az2[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) az2[m] = wload32(ws, mlp.az[2] + (2 * wv + m) * 64);
+      gemm_z<2, 1>(acc2, az2, zb);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) lrelu(acc2[m][0]);
+    }
+
+    // ---------------- layer 3: rows [32 wv, +32): bias + skip rows, K = 256 hidden (4 chunks) ----------------
+    f32x16 acc3[1][1];
+    init_from_bias(acc3[0][0], ws, mlp.bias[3] + 32 * wv);
+    blend_add(acc3[0][0], ta, tw);
+    {
+      const int a3 = mlp.ah[3] / 4 + wv * (kHidden[2] / 8) * 64;
+      f32x4 ring3[4][1];
+      seg_prefetch<1, 3>(ring3, ws, a3, 0, 8);
+#pragma unroll
+      for (int ck = 0; ck < 4; ++ck) {
+        if (wv == ck) {
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) store_hidden(hb, acc2[mm][0], mm, 0, j, h);
+        }
+        __syncthreads();
+        seg_main<1, 1, 3, kHbRowBytes>(acc3, ring3, ws, a3 + ck * 8 * 64, 0, 8, hrow, swz);
+        if (ck < 3) seg_prefetch<1, 3>(ring3, ws, a3 + (ck + 1) * 8 * 64, 0, 8);
+        __syncthreads();
+      }
+      float az3[1];
+      az3[0] = wload32(ws, mlp.az[3] + wv * 64);
+      gemm_z<1, 1>(acc3, az3, zb);
+      lrelu(acc3[0][0]);
+    }
+
+    // ---------------- layer 4 on the VALU: hidden part per wave, skip rows + z in the reduction ----------------
+    float *red = reinterpret_cast<float *>(hb);  // red[wave][o][p]
+    constexpr int K4 = (kHidden[3] + 256 + 1 + 3) & ~3;
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+      const float *w4 = (mlp.base + mlp.w4) + o * K4 + 32 * wv + 4 * h;
+      float s0 = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 wq = *reinterpret_cast<const f32x4 *>(w4 + 8 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s0 = fmaf(wq[i], acc3[0][0][4 * q + i], s0);
+      }
+      s0 += __shfl_xor(s0, 32);
+      if (h == 0) red[(wv * COUT + o) * P + j] = s0;
+    }
+    __syncthreads();
+    if (tid < COUT * P) {
+      const int o = tid / P, p = tid % P;
+      const long long n = n0 + p;
+      if (n < n_pts) {
+        float v = (mlp.base + mlp.bias[4])[o];
+#pragma unroll
+        for (int part = 0; part < 4; ++part) v += red[(part * COUT + o) * P + p];
+        const float wz = (mlp.base + mlp.w4)[o * K4 + kHidden[3] + 256];
+        float cal[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cal[i] = calib[i];
+        float px, py, pz, x, y, z;
+        uint32_t code;
+        load_point(src, n, px, py, pz, code);
+        project(cal, px, py, pz, x, y, z);
+        const bool inside = in_image(x, y);
+        const Taps t = make_taps(x, y, fh, fw, kTableRows, inside);
+        const float *row = item.l0 + kTableL[4] + o;
+        v += fmaf(row[t.o[3]], t.w[3], fmaf(row[t.o[2]], t.w[2], fmaf(row[t.o[1]], t.w[1], __fmul_rn(row[t.o[0]], t.w[0]))));
+        v = fmaf(wz, __fmul_rn(z, z_scale), v);
+        v = inside ? activate(v, act) : 0.0f;  // MonoPortNet.py:89
+        if (src.packed) {
+          const int ix = code & 1023u, iy = (code >> 10) & 1023u, iz = code >> 20;
+          out[((long long)iz * src.level_res + iy) * src.level_res + ix] = v;
+        } else {
+          out[o * src.out_stride + n] = v;
+        }
+      }
+    }
+    __syncthreads();  // red / hb are rewritten by the next tile
+  }
+}
+
+template <int COUT>
+static int launch_query_tab_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
+                              long long max_points, bool device_counts, hipStream_t st) {
+  constexpr int lds = kTabPts * kTabHbRow + kHidden[0] * 4;
+  if (max_points <= 0) return MP_OK;
+  const long long tiles = (max_points + kTabPts - 1) / kTabPts + (set.n - 1);
+  const long long resident = (long long)ctx->n_cu * 2;
+  // device-side counts: launch the resident grid and let it stride; host-side counts: one
+  // workgroup per tile up to a few waves of the machine
+  const long long grid = device_counts ? (tiles < resident ? tiles : resident)
+                                       : (tiles < 8 * resident ? tiles : 8 * resident);
+  hipLaunchKernelGGL(pifu_query_tab_kernel<COUT>, dim3((unsigned)grid), dim3(kQueryThreads), lds, st, m.pack(), h, w,
+                     z_scale, m.act, set);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+int launch_query_tab(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
+                     long long max_points, bool device_counts, hipStream_t st) {
+  if ((long long)h * w * kTableRows * 4 >= (1LL << 31))
+    return fail(ctx, MP_ERR_UNSUPPORTED, "table query: %dx%d map is too large for 32-bit table offsets", h, w);
+  if (m.cout == 1) return launch_query_tab_t<1>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
+  if (m.cout == 3) return launch_query_tab_t<3>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
+  return fail(ctx, MP_ERR_UNSUPPORTED, "table query: Cout in {1,3}");
+}
+
+// ---- the skip table -------------------------------------------------------------------------------
+// table[texel][kTableL[l] + r] = sum_c W_l[r][hidden_l + c] F[texel][c]  for the feature segment of
+// every layer l = 0..4 (no bias, no z column), layers 0-3 on the MFMAs in the K order of the plain
+// kernels (the packed fragment streams mlp.ax[l]), layer 4 on the VALU.  One workgroup = 64 texels
+// staged into LDS exactly like a tile of sampled points; the 60 row blocks of layers 0-3 go to the
+// waves in pairs, each against both column blocks.  16 GFLOP and 126 MB per 128^2 map.
+template <int COUT>
+__global__ __launch_bounds__(kQueryThreads, 2) void skip_table_kernel(MlpPack mlp, const float *__restrict__ feat,
+                                                                    long long texels, float *__restrict__ table) {
+  constexpr int C = 256, ROWB = C * 4, NGX = C / 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *xs = smem;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int swz = h ^ (j & 15);
+  const WStream ws = make_wstream(mlp.base, mlp.n_floats, lane);
+  const long long n_tiles = texels / 64;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long t0 = tile * 64;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int p = 16 * wv + i;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(feat + (t0 + p) * C + 4 * lane);
+      *reinterpret_cast<f32x4 *>(xs + p * ROWB + ((lane ^ (p & 15)) << 4)) = v;
+    }
+    __syncthreads();
+    const unsigned char *xrow = xs + j * ROWB;
+#pragma unroll 1
+    for (int pair = wv; pair < 30; pair += 4) {
+      const int rb = 2 * pair;  // row block among the 32 + 16 + 8 + 4 of layers 0-3 (pairs never straddle)
+      const int l = rb < 32 ? 0 : rb < 48 ? 1 : rb < 56 ? 2 : 3;
+      const int rl = rb - (l == 0 ? 0 : l == 1 ? 32 : l == 2 ? 48 : 56);
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int t = 0; t < 16; ++t) acc[m][n][t] = 0.0f;
+      const int a = mlp.ax[l] / 4 + rl * NGX * 64;
+      f32x4 ring[2][2];
+      seg_prefetch<2, 1>(ring, ws, a, NGX * 64, NGX);
+      seg_main<2, 2, 1, ROWB>(acc, ring, ws, a, NGX * 64, NGX, xrow, swz);
+      const int row0 = kTableL[l] + 32 * rl;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 o = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+            *reinterpret_cast<f32x4 *>(table + (t0 + 32 * n + j) * kTableRows + row0 + 32 * m + 8 * q + 4 * h) = o;
+          }
+    }
+    // layer 4's feature segment: thread = (output o, texel p)
+    constexpr int K4 = (kHidden[3] + C + 1 + 3) & ~3;
+    if (tid < 64 * COUT) {
+      const int o = tid / 64, p = tid % 64;
+      float s = 0.0f;
+#pragma unroll 4
+      for (int slot = 0; slot < C / 4; ++slot) {
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xs + p * ROWB + ((slot ^ (p & 15)) << 4));
+        const f32x4 wq = *reinterpret_cast<const f32x4 *>((mlp.base + mlp.w4) + o * K4 + kHidden[3] + 4 * slot);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s = fmaf(wq[i], xv[i], s);
+      }
+      table[(t0 + p) * kTableRows + kTableL[4] + o] = s;
+    }
+    __syncthreads();  // xs is restaged by the next tile
+  }
+}
+
+int launch_skip_table(mp_ctx *ctx, const Mlp &m, const float *feat_hwc, int h, int w, float *table,
+                    hipStream_t st) {
+  const long long texels = (long long)h * w;
+  if (m.c != 256 || texels % 64 || (m.cout != 1 && m.cout != 3))
+    return fail(ctx, MP_ERR_UNSUPPORTED, "skip table: C = 256 heads with Cout in {1,3} and H * W a multiple of 64; got C=%d Cout=%d %dx%d",
+                m.c, m.cout, h, w);
+  constexpr int lds = 64 * 256 * 4;
+  const void *kern_id = m.cout == 1 ? reinterpret_cast<const void *>(skip_table_kernel<1>)
+                                    : reinterpret_cast<const void *>(skip_table_kernel<3>);
+  if (!ctx->lds_attr_done.count(kern_id)) {
+    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    ctx->lds_attr_done.insert(kern_id);
+  }
+  const long long tiles = texels / 64, resident = (long long)ctx->n_cu * 2;
+  const dim3 grid((unsigned)(tiles < resident ? tiles : resident));
+  if (m.cout == 1)
+    hipLaunchKernelGGL(skip_table_kernel<1>, grid, dim3(kQueryThreads), lds, st, m.pack(), feat_hwc, texels, table);
+  else
+    hipLaunchKernelGGL(skip_table_kernel<3>, grid, dim3(kQueryThreads), lds, st, m.pack(), feat_hwc, texels, table);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+}  // namespace mp

@@ -83,6 +83,7 @@ class MonoPortNet(nn.Module):
         self.projection = _REGISTRY[opt_net.projection]
         self.normalizer = _REGISTRY[opt_net.normalizer.IMF](opt_net.normalizer)
         self._hwc_cache = None  # (weakrefs of source maps, versions, packed map)
+        self._table_cache = None  # (packed map, its version, mlp, skip table) of the last bind
 
     # ---- encoder ---------------------------------------------------------------------------------
     def filter(self, images, feat_prior=None):
@@ -122,7 +123,27 @@ class MonoPortNet(nn.Module):
         if mlp.ctx.device_index != (dev.index if dev.index is not None else torch.cuda.current_device()):
             raise RuntimeError("surface_classifier and the feature maps must be on one GPU "
                                "(RTL/main.py:382-387 moves the features first)")
-        return QueryBinding(self, mlp, self._packed_features(feats), calibs, self.normalizer.scale)
+        packed = self._packed_features(feats)
+        self._skip_table(mlp, packed)
+        return QueryBinding(self, mlp, packed, calibs, self.normalizer.scale)
+
+    def _skip_table(self, mlp, packed):
+        """The skip table of the bound feature map (ops.skip_table: the MLP's products with the
+        sampled feature, taken once per texel instead of once per query point), computed when a new
+        map is bound and registered for it, so that every query of the frame -- this module's and
+        the octree engine's -- blends table rows.  netG heads in exact f32 only; switched off with
+        MONOPORT_SKIP_TABLE=off (ops.SKIP_TABLE)."""
+        c = self._table_cache
+        if c is not None and c[0] is packed and c[1] == packed._version and c[2] is mlp:
+            return
+        if c is not None:
+            c[3].release()
+            self._table_cache = None
+        h, w, ch = packed.shape
+        if not ops.SKIP_TABLE or ch != 256 or mlp.precision != "f32" or (h * w) % 64:
+            return
+        # the handle keeps map and table alive and unregisters them when it is dropped
+        self._table_cache = (packed, packed._version, mlp, ops.skip_table(mlp, packed))
 
     def query(self, feats_stages, points, calibs=None, transforms=None):
         """points [B,3,N] world coords -> [ [B,Cout,N] ] (MonoPortNet.py:48-91, eval mode).

@@ -5,6 +5,7 @@ current HIP stream and returns ordinary ``torch.Tensor`` objects that outlive th
 ownership rule of the reference's stage pipeline (RTL/dataloader.py:1048-1054).
 """
 import ctypes
+import os
 import threading
 
 import numpy as np
@@ -180,47 +181,96 @@ def orthogonal(points, calib):
     return out
 
 
-L0_ROWS = 1024  # rows of SurfaceClassifier's first layer
+# Skip tables (mp_skip_table): the products of the MLP's weights with the sampled feature (layer 0
+# and the skip connections, 42 % of a point's FLOPs) are taken once per texel of a frame's feature
+# map instead of once per query point -- 16 GFLOP + 126 MB per frame; the field differs from the
+# plain path by f32 rounding only (1-3e-7).  This flag is the default of the callers that make tables
+# on their own (pipeline.FrameSlot, MonoPortNet.bind); MONOPORT_SKIP_TABLE=off keeps the plain path.
+SKIP_TABLE = os.environ.get("MONOPORT_SKIP_TABLE", "on") != "off"
+SKIP_TABLE_ROWS = 1924  # kTableRows: the feature segments of layers 0-3 (1024 + 512 + 256 + 128) + the last layer's, padded
 
 
-def l0_table(mlp, feat_hwc, out=None):
-    """mp_l0_table: the layer-0 table of a channels-last feature map [H,W,256] for a netG head --
-    table[y,x,r] = W0[r,:256] . feat[y,x,:] -- computed once per map and REGISTERED for it: every
-    later fused query (query / recon / recon_batch ...) on maps that all have a table blends four
-    table rows per point instead of running layer 0's 1024 x 256 product on the MFMAs.  The result
-    differs from the plain path by f32 rounding only.  Returns the table [H,W,1024]; keep it alive
-    (and call l0_release) for as long as the feature map is queried."""
+class SkipTable:
+    """A registered skip table: holds the feature map(s) and the table alive and unregisters them
+    when released or garbage-collected -- a freed map's address may be handed to the next map, and a
+    stale registration would then route that map's queries through this table.  A handle only
+    unregisters what is still ITS registration: making a new table for the same map (same buffers,
+    next frame) supersedes the old handle."""
+
+    _latest = {}  # (context handle, feature-map address) -> id of the handle that registered it last
+    _lock = threading.Lock()
+
+    def __init__(self, ctx, feats, table):
+        self.ctx, self.feats, self.table = ctx, list(feats), table
+        self._tables = [table[i] for i in range(len(self.feats))] if table.dim() == 4 else [table]
+        with SkipTable._lock:
+            for f in self.feats:
+                SkipTable._latest[(ctx.handle.value if hasattr(ctx.handle, "value") else ctx.handle, f.data_ptr())] = id(self)
+
+    def release(self):
+        with SkipTable._lock:
+            for f, t in zip(self.feats, self._tables):
+                key = (self.ctx.handle.value if hasattr(self.ctx.handle, "value") else self.ctx.handle, f.data_ptr())
+                if SkipTable._latest.get(key) == id(self):
+                    del SkipTable._latest[key]
+                    self.ctx.lib.mp_skip_table_release(self.ctx.handle, _ptr(f), _ptr(t))
+            self.feats, self._tables = [], []
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:  # interpreter shutdown
+            pass
+
+
+def skip_table(mlp, feat_hwc, out=None):
+    """mp_skip_table: the skip table of a channels-last feature map [H,W,256] for a netG head --
+    table[y,x,:] = the products of every layer's feature-segment weights with feat[y,x,:]
+    (SurfaceClassifier's layer 0 and the skip connections of layers 1-4: 1921 rows) -- computed
+    once per map and REGISTERED for it: every later fused query (query / recon / recon_batch ...)
+    on maps that all have a table blends four table rows per point instead of multiplying those
+    weights with the sampled feature on the MFMAs (42 % of a point's FLOPs).  The result differs
+    from the plain path by f32 rounding only.  Returns a SkipTable handle (``.table`` is the
+    [H,W,1924] tensor); the registration lasts until ``.release()`` or the handle's collection.
+    Call again after rewriting the feature map."""
     ctx = mlp.ctx
     h, w, c = feat_hwc.shape
     if out is None:
-        out = torch.empty((h, w, L0_ROWS), dtype=torch.float32, device=feat_hwc.device)
-    elif tuple(out.shape) != (h, w, L0_ROWS) or out.dtype != torch.float32 or not out.is_contiguous():
-        raise ValueError("l0_table: out must be a contiguous float32 [%d,%d,%d]" % (h, w, L0_ROWS))
-    ctx.check(ctx.lib.mp_l0_table(ctx.handle, mlp.id, _ptr(feat_hwc), c, h, w, _ptr(out), _stream(out)),
-              "mp_l0_table")
-    return out
+        out = torch.empty((h, w, SKIP_TABLE_ROWS), dtype=torch.float32, device=feat_hwc.device)
+    elif tuple(out.shape) != (h, w, SKIP_TABLE_ROWS) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("skip_table: out must be a contiguous float32 [%d,%d,%d]" % (h, w, SKIP_TABLE_ROWS))
+    ctx.check(ctx.lib.mp_skip_table(ctx.handle, mlp.id, _ptr(feat_hwc), c, h, w, _ptr(out), _stream(out)),
+              "mp_skip_table")
+    return SkipTable(ctx, [feat_hwc], out)
 
 
-def l0_table_batch(mlp, feat_hwc_all, out=None):
-    """mp_l0_table_batch: the tables of B maps stored back to back [B,H,W,256] -> [B,H,W,1024] in one
-    launch; each map feat_hwc_all[i] is registered with its table out[i]."""
+def skip_table_batch(mlp, feat_hwc_all, out=None):
+    """mp_skip_table_batch: the tables of B maps stored back to back [B,H,W,256] -> [B,H,W,1924] in
+    one launch; each map feat_hwc_all[i] is registered with its table out[i].  Returns a SkipTable
+    handle for all of them."""
     ctx = mlp.ctx
     b, h, w, c = feat_hwc_all.shape
     if not feat_hwc_all.is_contiguous():
-        raise ValueError("l0_table_batch: the maps must be contiguous")
+        raise ValueError("skip_table_batch: the maps must be contiguous")
     if out is None:
-        out = torch.empty((b, h, w, L0_ROWS), dtype=torch.float32, device=feat_hwc_all.device)
-    elif tuple(out.shape) != (b, h, w, L0_ROWS) or out.dtype != torch.float32 or not out.is_contiguous():
-        raise ValueError("l0_table_batch: out must be a contiguous float32 [%d,%d,%d,%d]" % (b, h, w, L0_ROWS))
-    ctx.check(ctx.lib.mp_l0_table_batch(ctx.handle, mlp.id, b, _ptr(feat_hwc_all), c, h, w, _ptr(out),
-                                        _stream(out)), "mp_l0_table_batch")
-    return out
+        out = torch.empty((b, h, w, SKIP_TABLE_ROWS), dtype=torch.float32, device=feat_hwc_all.device)
+    elif tuple(out.shape) != (b, h, w, SKIP_TABLE_ROWS) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("skip_table_batch: out must be a contiguous float32 [%d,%d,%d,%d]"
+                         % (b, h, w, SKIP_TABLE_ROWS))
+    ctx.check(ctx.lib.mp_skip_table_batch(ctx.handle, mlp.id, b, _ptr(feat_hwc_all), c, h, w, _ptr(out),
+                                          _stream(out)), "mp_skip_table_batch")
+    return SkipTable(ctx, [feat_hwc_all[i] for i in range(b)], out)
 
 
-def l0_release(ctx, feat_hwc=None):
-    """Forget the table registered for feat_hwc (None: every table of the context)."""
-    ctx.check(ctx.lib.mp_l0_table_release(ctx.handle, _ptr(feat_hwc) if feat_hwc is not None else None),
-              "mp_l0_table_release")
+def skip_table_release(ctx, feat_hwc=None):
+    """Forget the table registered for feat_hwc (None: every table of the context), whichever handle
+    made it."""
+    with SkipTable._lock:
+        h = ctx.handle.value if hasattr(ctx.handle, "value") else ctx.handle
+        for key in [k for k in SkipTable._latest if k[0] == h and (feat_hwc is None or k[1] == feat_hwc.data_ptr())]:
+            del SkipTable._latest[key]
+    ctx.check(ctx.lib.mp_skip_table_release(ctx.handle, _ptr(feat_hwc) if feat_hwc is not None else None, None),
+              "mp_skip_table_release")
 
 
 def query(mlp, feat_hwc, points, calib, z_scale):

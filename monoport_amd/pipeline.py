@@ -18,8 +18,6 @@ that host-side launch latency and GPU fill, not thread parallelism, are what mat
   streams fill the CUs that the coarse octree levels and the small encoder kernels leave idle
   (``depth`` x ``batch`` frames in flight; BASELINE configs[3] asks for 8).
 """
-import os
-
 import numpy as np
 import torch
 
@@ -28,11 +26,6 @@ from .synthetic import Z_SCALE
 
 RESOLUTIONS = (17, 33, 65, 129, 257)  # RTL/main.py:187
 MAX_RECON_BATCH = 16  # kMaxFrames of the C-ABI (include/monoport_hip.h, mp_recon_batch)
-# Layer-0 tables (mp_l0_table): the first layer's 1024 x 256 product is taken once per texel of a
-# frame's feature map instead of once per query point -- 22 % of the per-point MFMA work for 8.6
-# GFLOP + 67 MB per frame; the field differs from the plain path by f32 rounding only (a few 1e-7).
-# MONOPORT_L0_TABLE=off keeps the plain path (bit-identical to the per-frame C-ABI calls).
-L0_TABLE = os.environ.get("MONOPORT_L0_TABLE", "on") != "off"
 
 
 class FrameSlot:
@@ -40,7 +33,7 @@ class FrameSlot:
     the netC texture stages :373-441 when ``netC`` is given)."""
 
     def __init__(self, netG, device, resolutions=RESOLUTIONS, b_min=(-1, -1, -1), b_max=(1, 1, 1),
-                 balance=0.5, feature_hook=None, use_graph=False, netC=None, batch=1, l0_table=None):
+                 balance=0.5, feature_hook=None, use_graph=False, netC=None, batch=1, skip_table=None):
         self.net = netG
         self.netC = netC
         self.device = torch.device(device)
@@ -57,10 +50,10 @@ class FrameSlot:
         # one [B,128,128,256] channels-last map; feats_hwc[b] are its per-frame views
         self.feat_hwc_all = torch.empty((b, 128, 128, 256), dtype=torch.float32, device=dev)
         self.feats_hwc = [self.feat_hwc_all[i] for i in range(b)]
-        # layer-0 tables of the slot's maps (module flag L0_TABLE unless the caller says otherwise)
-        self.l0_table = L0_TABLE if l0_table is None else bool(l0_table)
-        self.l0 = (torch.empty((b, 128, 128, ops.L0_ROWS), dtype=torch.float32, device=dev)
-                   if self.l0_table else None)
+        # skip tables of the slot's maps (ops.SKIP_TABLE unless the caller says otherwise)
+        self.skip_table = ops.SKIP_TABLE if skip_table is None else bool(skip_table)
+        self.tables = (torch.empty((b, 128, 128, ops.SKIP_TABLE_ROWS), dtype=torch.float32, device=dev)
+                   if self.skip_table else None)
         # the hourglass encoder can write its last stack's features straight into that map
         # (HGFilter.forward(hwc_out=...), csrc/conv3x3.hip: conv1x1_kernel); a feature_hook must
         # then come with a channels-last twin, ``feature_hook.hwc(feat_hwc_all)``
@@ -134,8 +127,10 @@ class FrameSlot:
         if not self.hwc_direct:
             for b in range(n):
                 ops.pack_features(feat[b:b + 1], out=self.feats_hwc[b])
-        if self.l0 is not None and mlp.precision == "f32":
-            ops.l0_table_batch(mlp, self.feat_hwc_all[:n], out=self.l0[:n])
+        if self.tables is not None and mlp.precision == "f32":
+            # (re)made after every encoder pass; the handle of the previous pass unregisters the same
+            # pointers only if they still point at its table views, so dropping it here is harmless
+            self._table_handle = ops.skip_table_batch(mlp, self.feat_hwc_all[:n], out=self.tables[:n])
         # the octree of all frames of the slot level by level: one fused-query launch per level
         # covers every frame (mp_recon_batch takes up to MAX_RECON_BATCH frames per call)
         for b0 in range(0, n, MAX_RECON_BATCH):
@@ -238,11 +233,11 @@ class FrameSlot:
         """Release the C-ABI scratch arena keyed by this slot's stream (mp_stream_release)."""
         self.wait()
         self.graph = None
-        if self.l0 is not None:
-            ctx = self.net.surface_classifier.packed().ctx
-            for f in self.feats_hwc:
-                ops.l0_release(ctx, f)
-            self.l0 = None
+        if self.tables is not None:
+            if self._table_handle is not None:
+                self._table_handle.release()
+            self._table_handle = None
+            self.tables = None
         ops.stream_release(self.stream)
 
 

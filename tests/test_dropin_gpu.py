@@ -302,11 +302,11 @@ def test_obj_export_and_vertex_colors(tmp_path):
     assert f0[0] == "f" and [int(a) for a in f0[1:]] == [int(a) + 1 for a in faces[0].tolist()]
 
 
-@pytest.mark.parametrize("l0_table", [False, True])
-def test_frame_pipeline_matches_direct_calls(l0_table):
+@pytest.mark.parametrize("skip_table", [False, True])
+def test_frame_pipeline_matches_direct_calls(skip_table):
     """FramePipeline (slots x batched encoder x hipGraph) must give, frame by frame, what the
     plain call sequence gives: identical octree decisions and renders -- on the plain query path
-    and with the layer-0 tables (mp_l0_table) on both sides."""
+    and with the layer-0 tables (mp_skip_table) on both sides."""
     from monoport_amd import ops
     from monoport_amd.modeling import PIFuNetG
     from monoport_amd.pipeline import FramePipeline
@@ -334,17 +334,16 @@ def test_frame_pipeline_matches_direct_calls(l0_table):
             feat = netG.image_filter(img, last_only=True)[-1][0]
             hook(feat)
             fh = ops.pack_features(feat)
-            table = ops.l0_table(mlp, fh) if l0_table else None
+            table = ops.skip_table(mlp, fh) if skip_table else None
             vol, st = ops.recon(mlp, fh, cal, syn.Z_SCALE, [-1] * 3, [1] * 3, res)
             x, y, z, n, c = ops.forward_vertices_raw(vol, "front")
             direct.append((st.cpu(), ops.paint(x, y, n, 0, c, res[-1], 0.5, 0.5, 0.0, 1.0).cpu()))
-            if l0_table:
-                ops.l0_release(mlp.ctx, fh)
-            del table
+            if skip_table:
+                table.release()
 
     for batch, use_graph in ((1, False), (3, True), (4, True)):  # 4: the last batch is short (6 = 4 + 2)
         pipe = FramePipeline(netG, DEV, depth=2, batch=batch, resolutions=res, feature_hook=hook,
-                             use_graph=use_graph, l0_table=l0_table)
+                             use_graph=use_graph, skip_table=skip_table)
         pipe.prepare()
         got = []
         for s0 in range(0, 6, batch):
@@ -433,3 +432,41 @@ def test_bench_two_ranks_on_one_gpu():
     assert 0 < out["scaling_vs_single_rank"]["efficiency"]
     # configs[3] at N = 2: 8 frames in flight = 2 slots x 2 frames per rank
     assert out["in_flight_8"]["value"] > 0 and "2 slot(s) x 2 frame(s)" in out["in_flight_8"]["config"]
+
+
+def test_netg_query_uses_the_skip_table_by_default(monkeypatch):
+    """MonoPortNet.bind makes and registers the skip table of a newly bound feature map
+    (ops.SKIP_TABLE, default on): netG.query and the fused octree engine then blend table rows.  The
+    field equals the plain path's up to f32 rounding; Seg3dLossless validates and fuses as before."""
+    from monoport_amd import ops
+    from monoport_amd.implicit_seg.functional import Seg3dLossless
+    from monoport_amd.modeling import PIFuNetG
+    from monoport_amd.recon import pifu_calib
+    netG = PIFuNetG()
+    _load_mlp(netG, syn.body_mlp("G", noise=0.05, seed=81))
+    netG.to(DEV).eval()
+    feats = [[torch.from_numpy(syn.body_feat(256, 128, 128, 4))[None].to(DEV)]]
+    calib = pifu_calib(*syn.scene_camera(35), device=DEV)
+    pts = torch.from_numpy(syn.rand_points(30000, 3, 1.0))[None].to(DEV)
+
+    def query_func(points, feats, calib):
+        return netG.query(feats, points.permute(0, 2, 1), calib)[0]
+
+    res = [17, 33, 65, 129]
+    box = dict(b_min=np.array([[-1., -1., -1.]]), b_max=np.array([[1., 1., 1.]]), resolutions=res)
+    got = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "SKIP_TABLE", flag)
+        netG._hwc_cache = None  # a fresh bind (the cache key is the source tensors)
+        out = netG.query(feats, pts, calib)[0]
+        eng = Seg3dLossless(query_func=query_func, faster=True, **box).to(DEV)
+        sdf = eng(feats=feats, calib=calib)
+        assert eng.last_path == "fused"
+        got[flag] = (out.clone(), sdf.clone(), eng.last_status.clone())
+        assert (netG._table_cache is not None) == flag
+    d = (got[True][0] - got[False][0]).abs().max().item()
+    print("netG.query: |skip table - plain| = %.3g" % d)
+    assert 0 < d <= 2e-6
+    assert (got[True][1] - got[False][1]).abs().max().item() <= 2e-6
+    # a voxel whose value sits within rounding of the threshold may land on either side
+    assert int(((got[True][1] > 0.5) != (got[False][1] > 0.5)).sum()) <= 4

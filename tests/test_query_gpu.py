@@ -360,28 +360,41 @@ def test_small_tile_kernel_device_counts(ops):
                 assert float(outs[-1][i][:, c:].abs().max()) == 0.0
 
 
-def test_l0_table_matches_layer0_product(ops, oracle):
-    """mp_l0_table: table[y,x,r] = W0[r,:256] . feat[y,x,:], against a float64 product."""
+@pytest.mark.parametrize("cout", [1, 3])
+def test_skip_table_matches_float64_products(ops, oracle, cout):
+    """mp_skip_table: table[y,x,:] = the feature-segment weights of layers 0-4 times feat[y,x,:],
+    against float64 products (rows 0 / 1024 / 1536 / 1792 / 1920)."""
     layers = syn.rand_mlp("G", 77, 2.0)
+    if cout == 3:
+        rs = np.random.RandomState(5)
+        w4 = layers[-1][0]
+        layers[-1] = (rs.uniform(-0.1, 0.1, (3, w4.shape[1])).astype(np.float32),
+                      rs.uniform(-0.1, 0.1, (3,)).astype(np.float32))
     f = syn.rand_feat(256, 40, 24, 8)  # 960 texels = 15 tiles of 64
     dev = "cuda:0"
-    mlp = ops.PackedMLP.from_layers(dev, layers, 1)
+    mlp = ops.PackedMLP.from_layers(dev, layers, 1 if cout == 1 else 2)
     fh = ops.pack_features(torch.from_numpy(f)[None].to(dev))
     try:
-        table = ops.l0_table(mlp, fh)
+        table = ops.skip_table(mlp, fh)
         torch.cuda.synchronize()
-        ref = np.einsum("rc,chw->hwr", layers[0][0][:, :256].astype(np.float64), f.astype(np.float64))
-        got = table.cpu().numpy()
-        assert got.shape == (40, 24, 1024)
-        scale = np.abs(ref).max()
-        assert np.abs(got - ref).max() <= 2e-6 * scale
+        got = table.table.cpu().numpy()
+        assert got.shape == (40, 24, ops.SKIP_TABLE_ROWS)
+        row0 = 0
+        for l, (w, _) in enumerate(layers):
+            hidden = w.shape[1] - 257  # input = [hidden | 256 features | z]
+            wx = w[:, hidden:hidden + 256].astype(np.float64)
+            ref = np.einsum("rc,chw->hwr", wx, f.astype(np.float64))
+            part = got[:, :, row0:row0 + w.shape[0]]
+            assert np.abs(part - ref).max() <= 2e-6 * np.abs(ref).max(), l
+            row0 += w.shape[0]
+        assert row0 == 1920 + cout
     finally:
-        ops.l0_release(mlp.ctx)
+        ops.skip_table_release(mlp.ctx)
 
 
 @pytest.mark.parametrize("name", ["query_G_rand", "query_G_body"])
-def test_l0_table_query_vs_reference_golden_and_plain_path(ops, oracle, name):
-    """The query through the layer-0 table (W0 applied per texel, four rows blended per point)
+def test_skip_table_query_vs_reference_golden_and_plain_path(ops, oracle, name):
+    """The query through the skip table (feature-segment weights applied per texel, four rows blended per point)
     against the reference's golden output, the fp32 / fp64 oracle and the plain fused kernel: the
     same field up to f32 rounding, exact zeros outside the image, no noisier than the reference."""
     g = load_golden(name)
@@ -393,13 +406,13 @@ def test_l0_table_query_vs_reference_golden_and_plain_path(ops, oracle, name):
     cal = torch.from_numpy(g["calib"]).to(dev)
     plain = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
     try:
-        table = ops.l0_table(mlp, fh)
+        table = ops.skip_table(mlp, fh)
         out = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
         # an unrelated map without a table in the same context still runs the plain path
         fh2 = fh.clone()
         assert torch.equal(ops.query(mlp, fh2, pts, cal, syn.Z_SCALE)[0].cpu(), torch.from_numpy(plain))
     finally:
-        ops.l0_release(mlp.ctx)
+        ops.skip_table_release(mlp.ctx)
     again = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
     assert np.array_equal(again, plain)  # released: back on the plain path
     assert not np.array_equal(out, plain)  # ... and the table path really ran
@@ -418,7 +431,7 @@ def test_l0_table_query_vs_reference_golden_and_plain_path(ops, oracle, name):
 
 
 @pytest.mark.parametrize("n", [1, 31, 33, 1000, 40000])
-def test_l0_table_ragged_sizes_and_device_counts(ops, oracle, n):
+def test_skip_table_ragged_sizes_and_device_counts(ops, oracle, n):
     layers = syn.rand_mlp("G", 5, 2.0)
     f = syn.rand_feat(256, 64, 64, 6)
     p = syn.rand_points(n, 100 + n, 1.1)
@@ -427,7 +440,7 @@ def test_l0_table_ragged_sizes_and_device_counts(ops, oracle, n):
     mlp = ops.PackedMLP.from_layers(dev, layers, 1)
     fh = ops.pack_features(torch.from_numpy(f)[None].to(dev))
     try:
-        table = ops.l0_table(mlp, fh)
+        table = ops.skip_table(mlp, fh)
         out = ops.query(mlp, fh, torch.from_numpy(p)[None].to(dev), torch.from_numpy(calib).to(dev), syn.Z_SCALE)
         cap = n + 7
         pts = torch.zeros((3, cap), device=dev)
@@ -435,7 +448,7 @@ def test_l0_table_ragged_sizes_and_device_counts(ops, oracle, n):
         cnt = torch.tensor([n], dtype=torch.int32, device=dev)
         counted = ops.query_counted(mlp, fh, pts.contiguous(), cnt, torch.from_numpy(calib).to(dev), syn.Z_SCALE)
     finally:
-        ops.l0_release(mlp.ctx)
+        ops.skip_table_release(mlp.ctx)
     ref = oracle.query(f, p, calib[0], layers, 1, syn.Z_SCALE, precision="f32")
     assert out.shape == (1, 1, n)
     assert np.abs(out[0].cpu().numpy() - ref).max() <= TOL_ORACLE

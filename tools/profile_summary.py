@@ -32,7 +32,8 @@ def main(directory, prefix, command):
     with open(trace) as f:
         for r in csv.DictReader(f):
             # the f32 kernels: 32-point tiles (netG) / 64-point tiles -- not pifu_query16_kernel
-            if "pifu_query_t32_kernel<1," in r["Kernel_Name"] or "pifu_query_kernel<256, 1" in r["Kernel_Name"]:
+            if ("pifu_query_tab_kernel<1>" in r["Kernel_Name"] or "pifu_query_t32_kernel<1>" in r["Kernel_Name"]
+                    or "pifu_query_kernel<256, 1" in r["Kernel_Name"]):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:40],
                              r["Grid_Size_X"], r["Workgroup_Size_X"]))
     rows.sort()
@@ -64,12 +65,16 @@ def main(directory, prefix, command):
             f.write("\nroofline leg = launches %d..%d (1-based, of the list above; mean relative difference to "
                     "bench.py's HIP-event durations %.2f %%): mean %.1f us\n"
                     % (at + 1, at + n_leg, 100 * best / n_leg, sum(leg) / len(leg)))
+            fpp = int(log.get("flop_per_point", FLOP_PER_POINT))  # executed per point (skip tables: fewer)
             f.write("per launch: level, points (all frames of the launch), rocprofv3 duration, HIP-event "
-                    "duration, TFLOP/s = points x %d FLOP / rocprofv3 duration\n" % FLOP_PER_POINT)
+                    "duration, TFLOP/s = points x %d EXECUTED FLOP / rocprofv3 duration%s\n"
+                    % (fpp, "" if fpp == FLOP_PER_POINT else
+                       " (the reference's MLP has %d per point: x %.3f for the algorithmic rate)"
+                       % (FLOP_PER_POINT, FLOP_PER_POINT / fpp)))
             tot_f = tot_t = 0.0
             for i, (d, ms, pts) in enumerate(zip(leg, log["launch_ms"], log["launch_points"])):
-                tf = pts * FLOP_PER_POINT / (d * 1e-6) / 1e12
-                tot_f += pts * FLOP_PER_POINT
+                tf = pts * fpp / (d * 1e-6) / 1e12
+                tot_f += pts * fpp
                 tot_t += d * 1e-6
                 f.write("  level %d  %9d points  %9.1f us  (events %9.1f us)  %6.1f TFLOP/s  frac %.3f\n"
                         % (i % log["levels"], pts, d, ms * 1e3, tf, tf / 157.3))

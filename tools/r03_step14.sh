@@ -6,7 +6,7 @@ cd $R
 timeout 1500 python -m pytest tests -q -m gpu -x > $out/tests.log 2>&1
 echo "pytest rc=$?" >> $out/tests.log
 grep -E "passed|failed|^FAILED|^ERROR|rc=|Error" $out/tests.log | tail -8
-for flag in "" "--no-l0-table" ""; do
+for flag in "" "--no-skip-table" ""; do
 timeout 600 python bench.py --no-extras --no-cpu-baseline $flag > $out/bench_ab.json 2> $out/bench.err
 python - $out/bench_ab.json "$flag" <<'PY'
 import json,sys

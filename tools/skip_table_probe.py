@@ -1,7 +1,7 @@
-"""The layer-0 table path (mp_l0_table + the TABLE variant of the 32-point query kernel) against the
+"""The skip-table path (mp_skip_table + pifu_query_tab_kernel, csrc/query_table.hip) against the
 plain fused kernels: a fixed set of lattice points, then mp_recon_batch of 16 frames.
 
-    python tools/l0_table_probe.py
+    python tools/skip_table_probe.py
 """
 import os
 import sys
@@ -61,17 +61,23 @@ def main():
     lib.mp_query_tune(-1)
     rows["default gate"] = (timed(lambda: ops.query(mlp, feats[0], p, cal, syn.Z_SCALE)),
                             timed(lambda: ops.recon_batch(mlp, feats, [cal] * frames, syn.Z_SCALE, [-1] * 3, [1] * 3, res), reps=5))
-    tables = torch.empty((frames, 128, 128, ops.L0_ROWS), device=dev)
-    t_tab = timed(lambda: [ops.l0_table(mlp, feats[i], out=tables[i]) for i in range(frames)])
-    rows["layer-0 table"] = (timed(lambda: ops.query(mlp, feats[0], p, cal, syn.Z_SCALE)),
+    tables = torch.empty((frames, 128, 128, ops.SKIP_TABLE_ROWS), device=dev)
+    handles = [None] * frames  # the registrations live as long as these handles do
+
+    def make_tables():
+        for i in range(frames):
+            handles[i] = ops.skip_table(mlp, feats[i], out=tables[i])
+
+    t_tab = timed(make_tables)
+    rows["skip table"] = (timed(lambda: ops.query(mlp, feats[0], p, cal, syn.Z_SCALE)),
                              timed(lambda: ops.recon_batch(mlp, feats, [cal] * frames, syn.Z_SCALE, [-1] * 3, [1] * 3, res), reps=5))
-    ops.l0_release(mlp.ctx)
+    ops.skip_table_release(mlp.ctx)
     print("%d lattice points (one launch) / mp_recon_batch of %d frames at 257^3" % (n, frames))
     for name, (tq, tr) in rows.items():
         print("  %-16s %8.3f ms  %6.1f TFLOP/s-equivalent   |  %8.3f ms = %.3f ms per frame"
               % (name, tq, n * 2363906 / tq / 1e9, tr, tr / frames))
-    print("  mp_l0_table of %d maps: %.3f ms = %.3f ms per frame (%.1f TFLOP/s)"
-          % (frames, t_tab, t_tab / frames, frames * 128 * 128 * 1024 * 256 * 2 / t_tab / 1e9))
+    print("  mp_skip_table of %d maps: %.3f ms = %.3f ms per frame (%.1f TFLOP/s)"
+          % (frames, t_tab, t_tab / frames, frames * 128 * 128 * 1921 * 256 * 2 / t_tab / 1e9))
 
 
 if __name__ == "__main__":

@@ -48,7 +48,7 @@ def counter_rows(directory, counter):
                     rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), "t32" in name))
     rows.sort()
     # with the layer-0 tables (default) every level is ONE dispatch of the table variant; on the plain
-    # path (MONOPORT_L0_TABLE=off) levels 1-4 are a gated pair
+    # path (MONOPORT_SKIP_TABLE=off) levels 1-4 are a gated pair
     if not any(not t32 for _, _, t32 in rows[-2 * LEVELS:]):
         rows = rows[-2 * LEVELS:]
         assert len(rows) == 2 * LEVELS, len(rows)
