@@ -39,22 +39,34 @@
 namespace mp {
 
 constexpr int kTabPts = 32;
+// A/B hooks (tools/ablate.py): workgroups per CU the register allocator is held to, and how many
+// of a 32-row block's four row groups one round of table loads fetches (4: 16 loads = 64 registers
+// per lane; 2: 8 loads = 32 registers)
+#ifndef MPT_WPS
+#define MPT_WPS 2
+#endif
+#ifndef MPT_QROUND
+#define MPT_QROUND 4
+#endif
+constexpr int kTabQ = MPT_QROUND;
 constexpr int kTabHbRow = 128 * 4;  // bytes per point of a 128-row hidden chunk
 
-typedef f32x4 TabRows[4][4];  // [q][tap]: rows 8 q + 4 h .. + 3 of a 32-row block, four texels
+typedef f32x4 TabRows[kTabQ][4];  // [q][tap]: rows 8 (q0 + q) + 4 h .. + 3 of a 32-row block, four texels
 
-// grid_sample's chain (query_common.h: blend) on table rows, added to an accumulator tile
-__device__ __forceinline__ void blend_add(f32x16 &acc, const TabRows &tp, const float (&w)[4]) {
+// grid_sample's chain (query_common.h: blend) on table rows, added to row groups q0 .. q0 + kTabQ - 1
+// of an accumulator tile
+__device__ __forceinline__ void blend_add(f32x16 &acc, const TabRows &tp, const float (&w)[4], int q0) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < kTabQ; ++q)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      acc[4 * q + i] = acc[4 * q + i] + fmaf(tp[q][3][i], w[3],
-                                             fmaf(tp[q][2][i], w[2], fmaf(tp[q][1][i], w[1], __fmul_rn(tp[q][0][i], w[0]))));
+      acc[4 * (q0 + q) + i] =
+          acc[4 * (q0 + q) + i] +
+          fmaf(tp[q][3][i], w[3], fmaf(tp[q][2][i], w[2], fmaf(tp[q][1][i], w[1], __fmul_rn(tp[q][0][i], w[0]))));
 }
 
 template <int COUT>
-__global__ __launch_bounds__(kQueryThreads, 2) void pifu_query_tab_kernel(MlpPack mlp, int fh, int fw, float z_scale,
+__global__ __launch_bounds__(kQueryThreads, MPT_WPS) void pifu_query_tab_kernel(MlpPack mlp, int fh, int fw, float z_scale,
                                                                           int act, QuerySet set) {
   constexpr int P = kTabPts;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -120,43 +132,36 @@ __global__ __launch_bounds__(kQueryThreads, 2) void pifu_query_tab_kernel(MlpPac
         tw[k] = t.w[k];
       }
     }
-    // rows row0 + 8 q + 4 h .. + 3 of the point's four texels
-    auto rows_issue = [&](TabRows &tp, int row0) {
+    // acc += blend of rows row0 .. row0 + 31 (this lane: 8 q + 4 h .. + 3) of the point's four texels,
+    // kTabQ row groups per round of loads.  The loads are requested where they are used: the
+    // second workgroup of the CU covers their latency, and a lane keeps 64 (32) registers less
+    // alive across the MFMA phases than with a one-phase-ahead prefetch (measured: 9.72 against
+    // 10.17 ms per 885 k lattice points, profiles/r03af_skip_table_variants.txt)
+    auto rows_blend = [&](f32x16 &acc, int row0) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q0 = 0; q0 < 4; q0 += kTabQ) {
+        TabRows tp;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          tp[q][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, to[k], (row0 + 8 * q) * 4, 0));
+        for (int q = 0; q < kTabQ; ++q)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            tp[q][k] = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, to[k], (row0 + 8 * (q0 + q)) * 4, 0));
+        blend_add(acc, tp, tw, q0);
+        __builtin_amdgcn_sched_barrier(0);  // one round at a time (hipcc would hoist them all and spill)
+      }
     };
 
     const unsigned char *hrow = hb + j * kHbRowBytes;  // 64-row chunks (layers 2, 3)
     const unsigned char *hrow1 = hb + j * kTabHbRow;   // 128-row chunks (layer 0 -> 1)
 
     // ---------------- layer 1 accumulators: bias + skip rows ----------------
-    // two row buffers, software-pipelined by hand: round m + 1 is in flight while round m is blended
-    // (sched_barriers pin that order -- left alone hipcc hoists all four rounds' loads to the top and
-    // spills), and layer 0's first chunk is requested under the last round
-    TabRows ta, tb;
     f32x16 acc1[4][1];
-    rows_issue(ta, kTableL[1] + 32 * (4 * wv));
-    rows_issue(tb, kTableL[1] + 32 * (4 * wv + 1));
 #pragma unroll
-    for (int m = 0; m < 4; ++m) init_from_bias(acc1[m][0], ws, mlp.bias[1] + 32 * (4 * wv + m));
-    __builtin_amdgcn_sched_barrier(0);
-    blend_add(acc1[0][0], ta, tw);
-    __builtin_amdgcn_sched_barrier(0);
-    rows_issue(ta, kTableL[1] + 32 * (4 * wv + 2));
-    __builtin_amdgcn_sched_barrier(0);
-    blend_add(acc1[1][0], tb, tw);
-    __builtin_amdgcn_sched_barrier(0);
-    rows_issue(tb, kTableL[1] + 32 * (4 * wv + 3));
-    __builtin_amdgcn_sched_barrier(0);
-    blend_add(acc1[2][0], ta, tw);
-    __builtin_amdgcn_sched_barrier(0);
-    rows_issue(ta, kTableL[0] + 32 * wv);  // layer 0, chunk 0
-    __builtin_amdgcn_sched_barrier(0);
-    blend_add(acc1[3][0], tb, tw);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int m = 0; m < 4; ++m) {
+      init_from_bias(acc1[m][0], ws, mlp.bias[1] + 32 * (4 * wv + m));
+      rows_blend(acc1[m][0], kTableL[1] + 32 * (4 * wv + m));
+    }
 
     // ---------------- layers 0 + 1, fused over 128-row chunks of layer 0 ----------------
     {
@@ -174,23 +179,19 @@ __global__ __launch_bounds__(kQueryThreads, 2) void pifu_query_tab_kernel(MlpPac
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc0[0][0][4 * q + i] = bq[i];
         }
-        blend_add(acc0[0][0], ta, tw);
+        rows_blend(acc0[0][0], kTableL[0] + 32 * rb);
         f32x4 ring1[MP32_PF1 + 1][4];
         seg_prefetch<4, MP32_PF1>(ring1, ws, a1 + ck * 16 * 64, rs1, 16);
         gemm_z<1, 1>(acc0, az0, zb);
         lrelu(acc0[0][0]);
         store_hidden<kTabHbRow>(hb, acc0[0][0], wv, 0, j, h);
-        // the next chunk's rows -- after the last chunk: the first half of layer 2's skip rows
-        const bool last = ck + 1 == kHidden[0] / 128;
-        const int rbn = last ? rb : rb + 4;
-        rows_issue(ta, last ? kTableL[2] + 32 * (2 * wv) : kTableL[0] + 32 * rbn);
+        const int rbn = min(rb + 4, kHidden[0] / 32 - 4 + wv);
         az0[0] = wload32(ws, mlp.az[0] + rbn * 64);
         __syncthreads();
         // layer-1 rows [128 wv, +128) += W1[:, 128 ck .. +128) * chunk
         seg_main<4, 1, MP32_PF1, kTabHbRow>(acc1, ring1, ws, a1 + ck * 16 * 64, rs1, 16, hrow1, swz);
         __syncthreads();
       }
-      rows_issue(tb, kTableL[2] + 32 * (2 * wv + 1));  // second half of layer 2's skip rows
       float az1[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) az1[m] = wload32(ws, mlp.az[1] + (4 * wv + m) * 64);
@@ -203,12 +204,8 @@ __global__ __launch_bounds__(kQueryThreads, 2) void pifu_query_tab_kernel(MlpPac
     f32x16 acc2[2][1];
 #pragma unroll
     for (int m = 0; m < 2; ++m) init_from_bias(acc2[m][0], ws, mlp.bias[2] + 32 * (2 * wv + m));
-    blend_add(acc2[0][0], ta, tw);
-    __builtin_amdgcn_sched_barrier(0);
-    rows_issue(ta, kTableL[3] + 32 * wv);  // layer 3's skip rows land under layer 2's MFMAs
-    __builtin_amdgcn_sched_barrier(0);
-    blend_add(acc2[1][0], tb, tw);
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) rows_blend(acc2[m][0], kTableL[2] + 32 * (2 * wv + m));
     {
       const int rs2 = (kHidden[1] / 8) * 64;
       const int a2 = mlp.ah[2] / 4 + (2 * wv) * rs2;
@@ -236,7 +233,7 @@ __global__ __launch_bounds__(kQueryThreads, 2) void pifu_query_tab_kernel(MlpPac
     // ---------------- layer 3: rows [32 wv, +32): bias + skip rows, K = 256 hidden (4 chunks) ----------------
     f32x16 acc3[1][1];
     init_from_bias(acc3[0][0], ws, mlp.bias[3] + 32 * wv);
-    blend_add(acc3[0][0], ta, tw);
+    rows_blend(acc3[0][0], kTableL[3] + 32 * wv);
     {
       const int a3 = mlp.ah[3] / 4 + wv * (kHidden[2] / 8) * 64;
       f32x4 ring3[4][1];
@@ -314,7 +311,7 @@ static int launch_query_tab_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, in
   constexpr int lds = kTabPts * kTabHbRow + kHidden[0] * 4;
   if (max_points <= 0) return MP_OK;
   const long long tiles = (max_points + kTabPts - 1) / kTabPts + (set.n - 1);
-  const long long resident = (long long)ctx->n_cu * 2;
+  const long long resident = (long long)ctx->n_cu * MPT_WPS;
   // device-side counts: launch the resident grid and let it stride; host-side counts: one
   // workgroup per tile up to a few waves of the machine
   const long long grid = device_counts ? (tiles < resident ? tiles : resident)
