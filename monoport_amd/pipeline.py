@@ -53,7 +53,8 @@ class FrameSlot:
         # skip tables of the slot's maps (ops.SKIP_TABLE unless the caller says otherwise)
         self.skip_table = ops.SKIP_TABLE if skip_table is None else bool(skip_table)
         self.tables = (torch.empty((b, 128, 128, ops.SKIP_TABLE_ROWS), dtype=torch.float32, device=dev)
-                   if self.skip_table else None)
+                       if self.skip_table else None)
+        self._table_handle = None  # registration of the tables of the last encoder pass
         # the hourglass encoder can write its last stack's features straight into that map
         # (HGFilter.forward(hwc_out=...), csrc/conv3x3.hip: conv1x1_kernel); a feature_hook must
         # then come with a channels-last twin, ``feature_hook.hwc(feat_hwc_all)``

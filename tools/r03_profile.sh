@@ -2,7 +2,7 @@
 # Round-3 profile collection on the GPU box (through gpurun): kernel trace + stats of the default
 # bench with the per-launch point counts of the roofline leg; kernel stats of the mesh leg.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-tag=${1:-r04b}
+tag=${1:-r04q}
 out=$R/gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 CMD="python bench.py --warmup 5 --no-alt --no-dropin --no-cpu-baseline"

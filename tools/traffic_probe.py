@@ -44,10 +44,11 @@ def counter_rows(directory, counter):
         with open(path) as f:
             for r in csv.DictReader(f):
                 name = r["Kernel_Name"]
-                if r["Counter_Name"] == counter and ("pifu_query_t32_kernel" in name or "pifu_query_kernel" in name):
-                    rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), "t32" in name))
+                if r["Counter_Name"] == counter and ("pifu_query_tab_kernel" in name or "pifu_query_t32_kernel" in name
+                                                     or "pifu_query_kernel" in name):
+                    rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), "t32" in name or "tab" in name))
     rows.sort()
-    # with the layer-0 tables (default) every level is ONE dispatch of the table variant; on the plain
+    # with the skip tables (default) every level is ONE dispatch of pifu_query_tab_kernel; on the plain
     # path (MONOPORT_SKIP_TABLE=off) levels 1-4 are a gated pair
     if not any(not t32 for _, _, t32 in rows[-2 * LEVELS:]):
         rows = rows[-2 * LEVELS:]
@@ -78,8 +79,8 @@ def parse(fetch_dir, write_dir, out_path):
     out = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of "
                   "tools/traffic_probe.py run: one slot, %d frames per mp_recon_batch, mean of the "
-                  "last 2 batches, one fused-query launch per octree level (32-point tiles below 2048 "
-                  "64-point tiles per launch, 64-point tiles above; the gate-excluded dispatch of a pair moves no bytes)" % BATCH,
+                  "last 2 batches, one fused-query launch per octree level (skip-table kernel by default; on "
+                  "the plain path 32-point tiles below 2048 64-point tiles per launch, 64-point tiles above)" % BATCH,
         "unit": "KB (rocprofv3 counter units, x1024 bytes)",
         "FETCH_SIZE_per_level": per_level_fetch,
         "WRITE_SIZE_per_level": per_level_write,
