@@ -128,7 +128,11 @@ __global__ __launch_bounds__(kQueryThreads, MPT_WPS) void pifu_query_tab_kernel(
       const Taps t = make_taps(x, y, fh, fw, kTableRows, n < n_pts && in_image(x, y));
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
+#ifdef MPT_FAKE_GATHER  // timing experiment (wrong results): every point reads texel k -> the gather's cost
+        to[k] = k * kTableRows * 4 + 16 * h;
+#else
         to[k] = (int)t.o[k] * 4 + 16 * h;
+#endif
         tw[k] = t.w[k];
       }
     }

@@ -454,3 +454,45 @@ def test_skip_table_ragged_sizes_and_device_counts(ops, oracle, n):
     assert np.abs(out[0].cpu().numpy() - ref).max() <= TOL_ORACLE
     assert torch.equal(counted[:, :n], out[0]) and float(counted[:, n:].abs().max()) == 0.0
     del table
+
+
+def test_skip_table_registry_semantics(ops, oracle):
+    """Registration follows the feature map: a handle unregisters only what is still its own, a
+    rewritten map needs a new table (the old one would be stale), netC heads (C = 512) and
+    odd-sized maps are refused, and destroying a head drops its tables."""
+    dev = "cuda:0"
+    layers = syn.rand_mlp("G", 9, 2.0)
+    mlp = ops.PackedMLP.from_layers(dev, layers, 1)
+    f1, f2 = syn.rand_feat(256, 64, 64, 1), syn.rand_feat(256, 64, 64, 2)
+    fh = ops.pack_features(torch.from_numpy(f1)[None].to(dev))
+    p = syn.rand_points(5000, 4, 1.0)
+    pts = torch.from_numpy(p)[None].to(dev)
+    cal = torch.from_numpy(np.eye(4, dtype=np.float32)[None]).to(dev)
+    plain1 = ops.query(mlp, fh, pts, cal, syn.Z_SCALE).clone()
+    buf = torch.empty((64, 64, ops.SKIP_TABLE_ROWS), device=dev)
+    h1 = ops.skip_table(mlp, fh, out=buf)
+    tab1 = ops.query(mlp, fh, pts, cal, syn.Z_SCALE).clone()
+    assert not torch.equal(tab1, plain1) and float((tab1 - plain1).abs().max()) <= 2e-6
+    # the map is rewritten in place: a new table into the same buffer supersedes the old handle
+    fh.copy_(ops.pack_features(torch.from_numpy(f2)[None].to(dev)))
+    h2 = ops.skip_table(mlp, fh, out=buf)
+    h1.release()  # must NOT unregister h2's registration of the same (map, table) pair
+    tab2 = ops.query(mlp, fh, pts, cal, syn.Z_SCALE).clone()
+    ref2 = oracle.query(f2, p, np.eye(4, dtype=np.float32), layers, 1, syn.Z_SCALE, precision="f32")
+    assert np.abs(tab2[0].cpu().numpy() - ref2).max() <= TOL_ORACLE
+    h2.release()
+    plain2 = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)
+    assert not torch.equal(plain2, tab2) and float((tab2 - plain2).abs().max()) <= 2e-6
+    # a second head on the same map: its launches do not pick up the first head's table
+    mlp_b = ops.PackedMLP.from_layers(dev, syn.rand_mlp("G", 10, 2.0), 1)
+    h3 = ops.skip_table(mlp, fh)
+    out_b = ops.query(mlp_b, fh, pts, cal, syn.Z_SCALE)
+    h3.release()
+    assert torch.equal(out_b, ops.query(mlp_b, fh, pts, cal, syn.Z_SCALE))
+    # refused: netC head (C = 512), texel count not a multiple of 64
+    from monoport_amd._lib import MonoportError
+    mlp_c = ops.PackedMLP.from_layers(dev, syn.rand_mlp("C", 3, 1.0), 2)
+    with pytest.raises(MonoportError, match="skip table"):
+        ops.skip_table(mlp_c, ops.pack_features(torch.zeros(1, 512, 64, 64, device=dev)))
+    with pytest.raises(MonoportError, match="skip table"):
+        ops.skip_table(mlp, ops.pack_features(torch.zeros(1, 256, 10, 10, device=dev)))
