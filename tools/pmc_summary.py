@@ -6,7 +6,7 @@ grid = {}
 for path in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     with open(path) as f:
         for r in csv.DictReader(f):
-            if "pifu_query" in r["Kernel_Name"]:
+            if "pifu_query" in r["Kernel_Name"] or "skip_table_kernel" in r["Kernel_Name"]:
                 d = int(r["Dispatch_Id"])
                 rows[d][r["Counter_Name"]] = rows[d].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                 grid[d] = r["Grid_Size"]
