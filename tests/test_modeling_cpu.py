@@ -115,3 +115,43 @@ def test_query_on_cpu_fails_loudly():
     feats = [[torch.zeros(1, 256, 128, 128)]]
     with pytest.raises(MonoportError):
         net.query(feats, torch.zeros(1, 3, 8), torch.eye(4)[None])
+
+
+def test_skip_table_handle_supersession_cpu():
+    """ops.SkipTable (host logic only, fake context): a handle unregisters a map only while it is the
+    LAST registration of that map -- re-making the table of the same buffers (next frame) must not be
+    undone when the older handle is dropped -- and release is idempotent."""
+    import ctypes
+    import torch
+    from monoport_amd import ops
+
+    calls = []
+
+    class FakeLib:
+        def mp_skip_table_release(self, handle, feat, table):
+            calls.append((feat.value, table.value))
+            return 0
+
+    class FakeCtx:
+        lib = FakeLib()
+        handle = ctypes.c_void_p(1234)
+
+    ctx = FakeCtx()
+    feat = torch.zeros((4, 4, 256))
+    table = torch.zeros((4, 4, ops.SKIP_TABLE_ROWS))
+    h1 = ops.SkipTable(ctx, [feat], table)
+    h2 = ops.SkipTable(ctx, [feat], table)  # same buffers, next frame
+    h1.release()
+    assert calls == []  # superseded: nothing to undo
+    h1.release()
+    h2.release()
+    assert calls == [(feat.data_ptr(), table.data_ptr())]
+    h2.release()
+    assert len(calls) == 1
+    # a batch handle: one registration per map, table views per map
+    feats = torch.zeros((3, 4, 4, 256))
+    tables = torch.zeros((3, 4, 4, ops.SKIP_TABLE_ROWS))
+    hb = ops.SkipTable(ctx, [feats[i] for i in range(3)], tables)
+    del hb  # collection releases
+    assert [c[0] for c in calls[1:]] == [feats[i].data_ptr() for i in range(3)]
+    assert [c[1] for c in calls[1:]] == [tables[i].data_ptr() for i in range(3)]
