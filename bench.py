@@ -818,6 +818,24 @@ def main(argv=None):
                         "driver computes its own efficiency from separate --gpus 1 runs"}
         job.barrier()
 
+    # the same configuration on the PLAIN query kernels (every FLOP of the reference's MLP per point):
+    # what the skip tables buy, on the driver's own record
+    if world == 1 and skip_on and not args.no_configs and not args.with_color and args.levels == 5 \
+            and args.in_flight == 0:
+        ops.SKIP_TABLE = False
+        try:
+            rp, pp = measure_config(job, depth, batch, use_graph, resolutions, False, "f32", args.passes)
+        finally:
+            ops.SKIP_TABLE = True
+        pp.close()
+        del pp
+        extras["plain_query_path"] = {
+            "config": "the headline configuration with --no-skip-table: layer 0 and the skip connections on the MFMAs "
+                      "for every point (pifu_query_kernel / pifu_query_t32_kernel)",
+            "value": rp["value"], "unit": "recon/s", "ms_per_step": rp["ms_per_step"], "passes": rp["passes"],
+            "roofline_frac": rp["roof"]["achieved"] / F32_MFMA_PEAK_TFLOPS,
+            "roofline_achieved_tflops": rp["roof"]["achieved"], "flop_per_point": FLOP_PER_POINT}
+
     # BASELINE configs[3]: 8 frames in flight across the node, at every N that divides 8
     if not args.no_configs and args.in_flight == 0 and 8 % world == 0 and not args.with_color \
             and args.precision == "f32" and args.levels == 5:
