@@ -3,6 +3,7 @@
 
 One "step" = one full geometry reconstruction of one synthetic frame on one MI355X
 (BASELINE.json configs[1]): netG.filter (hourglass encoder) -> channels-last features ->
+the frame's skip table (the MLP's products with the sampled feature, once per texel) ->
 coarse-to-fine octree 17..257 driving the fused HIP query kernel -> forward_vertices -> normal
 render.  Inputs are resident in HBM before the timed region.  With --gpus N every rank
 reconstructs its own frames (frame-parallel, weak scaling) and the renders are gathered to rank 0
@@ -16,7 +17,10 @@ fewer than N GPUs are visible; under ``python -m torch.distributed.run --nproc-p
 bench.py --gpus N ...`` it joins the ranks the launcher made.  Either way rank 0 prints ONE JSON
 line with the driver's contract fields plus
 
-  "roofline"      the fused query kernel against the f32 MFMA peak (HIP-event timed, live)
+  "roofline"      the fused query kernel against the f32 MFMA peak (HIP-event timed, live): priced
+                  on the FLOPs it executes, with the reference's per-point FLOPs beside it
+                  (`algorithmic`) -- the skip tables hoist 42 % of them out of the per-point work
+  "plain_query_path"  (N=1 only) the headline configuration without skip tables (--no-skip-table)
   "cpu_baseline"  the CPU oracle path timed on this box's host cores (rank 0, N=1 only)
   "passes"        the timed region is run 3 times (each EXACTLY --steps frames between barrier +
                   synchronize pairs); `value` is the median pass, min / max are listed
