@@ -85,7 +85,8 @@ int mp_mlp_create(mp_ctx *ctx, int n_layers, const int *channels /*host, n_layer
 /* Loads filters.{layer}.{weight,bias} (state-dict layout, weight [out,in(,1)] row-major with the
  * K order [hidden | feature | z] of SurfaceClassifier.py:55) and re-packs it into MFMA fragment
  * order.  W and b are DEVICE pointers.  Replaces load_state_dict / load_legacy_pifu
- * (MonoPortNet.py:153-160). */
+ * (MonoPortNet.py:153-160).  Loading a layer FORGETS every skip table made with this head
+ * (mp_skip_table below: a table holds products of the old weights); make them again afterwards. */
 int mp_mlp_load(mp_ctx *ctx, int mlp, int layer, const float *W, const float *b, int out_ch,
                 int in_ch, mp_stream stream);
 int mp_mlp_destroy(mp_ctx *ctx, int mlp); /* synchronises the device before freeing */
@@ -120,7 +121,7 @@ int mp_feat_pack_hwc(mp_ctx *ctx, const float *src_chw, int c_src, int h, int w,
  * again after it rewrites the feature map (stream-ordered with the queries, like any producer), and
  * mp_skip_table_release(ctx, feat_hwc, table) before freeing either buffer (table NULL: whatever is
  * registered for feat_hwc; otherwise only if it still is that table; feat_hwc NULL: everything).
- * mp_mlp_destroy drops the tables made with that head. */
+ * mp_mlp_destroy and mp_mlp_load (new weights) drop the tables made with that head. */
 #define MP_SKIP_TABLE_ROWS 1924
 int mp_skip_table(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, float *table,
                 mp_stream stream);

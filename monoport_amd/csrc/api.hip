@@ -250,6 +250,10 @@ int mp_mlp_load(mp_ctx *ctx, int mlp, int layer, const float *W, const float *b,
     return fail(ctx, MP_ERR_ARG, "mp_mlp_load: layer %d expects weight [%d,%d], got [%d,%d]", layer,
                 want_out, want_in, out_ch, in_ch);
   DeviceGuard g(ctx->device);
+  // skip tables hold products of THESE weights (layer 0 + the skip segments): a table made before
+  // the reload would blend the old head into the new one's hidden layers -- forget them
+  for (auto it = ctx->skip_tables.begin(); it != ctx->skip_tables.end();)
+    it = it->second.mlp_buf == m->buf ? ctx->skip_tables.erase(it) : std::next(it);
   int rc = launch_pack_layer(ctx, *m, layer, W, b, (hipStream_t)stream);
   if (rc == MP_OK && layer < 4)
     rc = launch_copy(ctx, W, m->raw + m->off_raw[layer], (long long)out_ch * in_ch,

@@ -75,9 +75,13 @@ class Seg3dLossless(nn.Module):
         self.last_path = None  # "fused" | "generic": which engine served the last call
         # "first": the first VALIDATE_CALLS calls are validated against query_func (see forward); once
         # that many in a row agreed with the fused kernel, later calls with the same network head are
-        # trusted and skip the validation query.  "always": validate every call (debugging).
+        # trusted and skip the validation query -- except every REVALIDATE_EVERY-th one, which is
+        # validated again, so a query_func whose wrapper arithmetic changes later (a closure flag, a
+        # `1 - pred` from some frame on) is caught within that many frames instead of never.
+        # "always": validate every call (a query_func with per-call state).
         self.validate = "first"
         self._agreed = 0          # consecutive validated calls that agreed
+        self._since_check = 0     # trusted calls since the last validated one
         self._trusted_key = None  # (id(packed head), precision, z scale) those calls were bound to
         # nn.Module.to(device) is called on the engine (RTL/main.py:195): carry a buffer so it
         # has a device like the upstream module does
@@ -98,12 +102,16 @@ class Seg3dLossless(nn.Module):
         Limits of the check: only the coarsest lattice is compared, so a ``query_func`` that equals
         MonoPortNet.query there but post-processes finer levels differently (resolution-dependent
         logic) would pass; and after VALIDATE_CALLS agreeing calls in a row the check is skipped
-        for later calls bound to the same head (``self.validate = "always"`` keeps it on)."""
+        for later calls bound to the same head, except every REVALIDATE_EVERY-th one
+        (``self.validate = "always"`` keeps it on for every call)."""
         dev = self._device_tag.device
-        if self.faster and self.validate != "always" and self._agreed >= self.VALIDATE_CALLS:
+        if (self.faster and self.validate != "always" and self._agreed >= self.VALIDATE_CALLS
+                and self._since_check + 1 < self.REVALIDATE_EVERY):
             out = self._forward_trusted(kwargs)
             if out is not NotImplemented:
+                self._since_check += 1
                 return out
+        self._since_check = 0
         eng = ops.LevelEngine(dev, self.b_min[0], self.b_max[0], self.resolutions,
                               self.balance_value, self.faster)
         pts0 = eng.select()
@@ -140,6 +148,7 @@ class Seg3dLossless(nn.Module):
         return None if volume is None else volume[None, None]
 
     VALIDATE_CALLS = 3
+    REVALIDATE_EVERY = 32  # a trusted query_func is validated again on every 32nd call
 
     @staticmethod
     def _binding_key(binding):

@@ -83,7 +83,8 @@ class MonoPortNet(nn.Module):
         self.projection = _REGISTRY[opt_net.projection]
         self.normalizer = _REGISTRY[opt_net.normalizer.IMF](opt_net.normalizer)
         self._hwc_cache = None  # (weakrefs of source maps, versions, packed map)
-        self._table_cache = None  # (packed map, its version, mlp, skip table) of the last bind
+        self._table_cache = None  # (packed map, its version, mlp, skip table, mlp generation) of the last bind
+        self._served = (None, 0)  # (packed map, query points it has served so far)
 
     # ---- encoder ---------------------------------------------------------------------------------
     def filter(self, images, feat_prior=None):
@@ -109,8 +110,11 @@ class MonoPortNet(nn.Module):
         self._hwc_cache = (key, [weakref.ref(f) for f in feats], packed)
         return packed
 
-    def bind(self, feats_stages, calibs):
-        """QueryBinding for eval-mode queries against ``feats_stages`` / ``calibs``."""
+    def bind(self, feats_stages, calibs, n_points=0, for_engine=False):
+        """QueryBinding for eval-mode queries against ``feats_stages`` / ``calibs``.
+        ``n_points``: how many points the caller is about to query; ``for_engine``: the caller is
+        the octree engine (a whole reconstruction follows) -- both feed the decision whether the
+        map gets a skip table (``_skip_table``)."""
         if self.training:
             raise NotImplementedError("monoport_amd implements the inference path (net.eval())")
         if self.projection is not orthogonal:
@@ -124,34 +128,46 @@ class MonoPortNet(nn.Module):
             raise RuntimeError("surface_classifier and the feature maps must be on one GPU "
                                "(RTL/main.py:382-387 moves the features first)")
         packed = self._packed_features(feats)
-        self._skip_table(mlp, packed)
+        served = (self._served[1] if self._served[0] is packed else 0) + int(n_points)
+        self._served = (packed, served)
+        self._skip_table(mlp, packed, for_engine or served >= ops.SKIP_TABLE_MIN_POINTS)
         return QueryBinding(self, mlp, packed, calibs, self.normalizer.scale)
 
-    def _skip_table(self, mlp, packed):
+    def _skip_table(self, mlp, packed, worth_it=True):
         """The skip table of the bound feature map (ops.skip_table: the MLP's products with the
-        sampled feature, taken once per texel instead of once per query point), computed when a new
-        map is bound and registered for it, so that every query of the frame -- this module's and
-        the octree engine's -- blends table rows.  netG heads in exact f32 only; switched off with
-        MONOPORT_SKIP_TABLE=off (ops.SKIP_TABLE)."""
+        sampled feature, taken once per texel instead of once per query point), registered for the
+        map so that every query of the frame -- this module's and the octree engine's -- blends
+        table rows.  A table costs 16 GFLOP / 126 MB whatever follows, the work of ~16 k plain-path
+        points: it is made when the octree engine binds the map (``worth_it``: a reconstruction of
+        ~3e5 points follows) or once the map has served ops.SKIP_TABLE_MIN_POINTS query points;
+        a few small ``query`` calls stay on the plain kernels (the two paths differ by f32
+        rounding, 1-5e-7).  netG heads in exact f32 only; MONOPORT_SKIP_TABLE=off (ops.SKIP_TABLE)
+        switches it off."""
         c = self._table_cache
-        if c is not None and c[0] is packed and c[1] == packed._version and c[2] is mlp:
+        h, w, ch = packed.shape
+        wanted = ops.SKIP_TABLE and ch == 256 and mlp.precision == "f32" and (h * w) % 64 == 0
+        if wanted and not worth_it and not (c is not None and c[0] is packed):
+            wanted = False  # not yet: keep whatever state there is for OTHER maps out of the way below
+        # mlp.generation: SurfaceClassifier.packed() re-packs new weights (load_state_dict,
+        # load_legacy_pifu, in-place updates) into the SAME PackedMLP -- the table is stale then
+        if (wanted and c is not None and c[0] is packed and c[1] == packed._version and c[2] is mlp
+                and c[4] == mlp.generation):
             return
         if c is not None:
             c[3].release()
             self._table_cache = None
-        h, w, ch = packed.shape
-        if not ops.SKIP_TABLE or ch != 256 or mlp.precision != "f32" or (h * w) % 64:
+        if not wanted:
             return
         # the handle keeps map and table alive and unregisters them when it is dropped
-        self._table_cache = (packed, packed._version, mlp, ops.skip_table(mlp, packed))
+        self._table_cache = (packed, packed._version, mlp, ops.skip_table(mlp, packed), mlp.generation)
 
     def query(self, feats_stages, points, calibs=None, transforms=None):
         """points [B,3,N] world coords -> [ [B,Cout,N] ] (MonoPortNet.py:48-91, eval mode).
         Out-of-image points come back as exactly 0 (:89)."""
         if transforms is not None:
             raise NotImplementedError("query(transforms=...) is a training-time option")
-        binding = self.bind(feats_stages, calibs)
         cap = getattr(_tls, "capture", None)
+        binding = self.bind(feats_stages, calibs, n_points=points.shape[2], for_engine=cap is not None)
         if cap is not None:
             cap.calls += 1
             if cap.binding is None:

@@ -86,11 +86,14 @@ class PackedMLP:
         self.c = self.channels[0] - 1
         self.cout = self.channels[-1]
         self.precision = "f32"
+        self.generation = 0  # bumped by every load_layer: skip tables made before it are stale
 
     def load_layer(self, layer, weight, bias):
-        """weight [out,in] or [out,in,1] (Conv1d k=1), bias [out]; device tensors."""
+        """weight [out,in] or [out,in,1] (Conv1d k=1), bias [out]; device tensors.  The C side
+        forgets the skip tables made with this head (they hold products of the old weights)."""
         w = _f32c(weight.reshape(weight.shape[0], -1))
         b = _f32c(bias)
+        self.generation += 1
         self.ctx.check(self.ctx.lib.mp_mlp_load(self.ctx.handle, self.id, layer, _ptr(w), _ptr(b),
                                                 w.shape[0], w.shape[1], _stream(w)), "mp_mlp_load")
         # the pack kernels read w/b asynchronously: keep them alive until the stream drains
@@ -187,6 +190,9 @@ def orthogonal(points, calib):
 # plain path by f32 rounding only (1-3e-7).  This flag is the default of the callers that make tables
 # on their own (pipeline.FrameSlot, MonoPortNet.bind); MONOPORT_SKIP_TABLE=off keeps the plain path.
 SKIP_TABLE = os.environ.get("MONOPORT_SKIP_TABLE", "on") != "off"
+# MonoPortNet.bind makes a table for a map once it has served this many query points (or at once for
+# the octree engine): the table costs what ~16 k points cost on the plain kernels
+SKIP_TABLE_MIN_POINTS = int(os.environ.get("MONOPORT_SKIP_TABLE_MIN_POINTS", "16384"))
 SKIP_TABLE_ROWS = 1924  # kTableRows: the feature segments of layers 0-3 (1024 + 512 + 256 + 128) + the last layer's, padded
 
 
@@ -198,7 +204,8 @@ class SkipTable:
     next frame) supersedes the old handle."""
 
     _latest = {}  # (context handle, feature-map address) -> id of the handle that registered it last
-    _lock = threading.Lock()
+    # re-entrant: __del__ -> release() may run from the cyclic GC while this thread holds the lock
+    _lock = threading.RLock()
 
     def __init__(self, ctx, feats, table):
         self.ctx, self.feats, self.table = ctx, list(feats), table

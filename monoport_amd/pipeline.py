@@ -5,9 +5,11 @@ The reference overlaps frames with one Python thread per stage (RTL/dataloader.p
 that host-side launch latency and GPU fill, not thread parallelism, are what matter:
 
 * a ``FrameSlot`` owns a HIP stream and the static buffers of ``batch`` frames.  The image
-  encoder runs ONCE per slot on the whole batch (MIOpen's batch-1 convolutions under-fill 256 CUs:
-  4.9 ms/frame at batch 1, 3.1 ms/frame at batch 4) and is replayed as a hipGraph (its ~450 small
-  kernels are launch-latency bound); then each frame goes through
+  encoder -- 137 launches of the hand-written kernels of csrc/conv3x3.hip, convim2col.hip and
+  encoder_ops.hip, no MIOpen / torch op -- runs ONCE per slot on the whole batch (a batch-1
+  convolution on a 32^2 / 64^2 map under-fills 256 CUs: 3.8 ms/frame at batch 1, 2.1 ms/frame at
+  batch 16) and is replayed as a hipGraph; the slot's skip tables (csrc/query_table.hip) are made
+  in one launch behind it; then each frame goes through
 
       channels-last pack -> octree (5 levels, fused query) -> forward_vertices -> render
 
@@ -164,7 +166,7 @@ class FrameSlot:
                                                     -np.inf, np.inf)
 
     def prepare(self, warmup=2):
-        """Warm up (MIOpen find, scratch arenas); with ``use_graph`` capture the ENCODER into a
+        """Warm up (scratch arenas, GroupNorm accumulator arena); with ``use_graph`` capture the ENCODER into a
         hipGraph.  The C-ABI stages stay eager: they are a handful of asynchronous calls, and a
         graph that also holds them faulted on ROCm 7.2 once tensors were allocated after
         capture."""

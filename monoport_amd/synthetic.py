@@ -252,3 +252,15 @@ def seeded_state_dict(shapes, seed):
             v = 0.1 * rs.standard_normal(shape)
         out[key] = v.astype(np.float32)
     return out
+
+
+def obj_mesh_inputs():
+    """A seeded mesh for the on-disk format check: 500 vertices with coordinates that exercise the
+    %.4f rounding (ties, negative zero, values below 5e-5, large magnitudes), 900 faces, colours in
+    [0, 1].  Regenerated by the tests from the same seed."""
+    rng = np.random.RandomState(4242)
+    v = (rng.standard_normal((500, 3)) * np.array([1.0, 100.0, 1e-3])).astype(np.float32)
+    v[:8, 0] = np.array([0.00005, -0.00005, 0.12345, -0.12345, 0.99995, -0.0, 1e-9, 12345.67895], np.float32)
+    f = rng.randint(0, 500, size=(900, 3)).astype(np.int32)
+    c = rng.rand(500, 3).astype(np.float32)
+    return v, f, c

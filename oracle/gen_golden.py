@@ -343,10 +343,33 @@ def gen_pipeline257(name="pipeline257"):
           % (margin, 100 * sat, 100 * float(((vals > 0.01) & (vals < 0.99)).mean()), t1 - t0, t2 - t1))
 
 
+def gen_obj():
+    """The reference's OBJ writers (monoport/lib/mesh_util.py:223-242) on the seeded mesh: the files'
+    sha256 + sizes + first lines are the fixture."""
+    import hashlib
+    import tempfile
+    from monoport.lib import mesh_util as ref_mesh
+    v, f, c = syn.obj_mesh_inputs()
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for key, call in (("plain", lambda p: ref_mesh.save_obj_mesh(p, v, f)),
+                          ("color", lambda p: ref_mesh.save_obj_mesh_with_color(p, v, f, c))):
+            path = os.path.join(d, key + ".obj")
+            call(path)
+            data = open(path, "rb").read()
+            out[key + "_sha256"] = np.frombuffer(hashlib.sha256(data).digest(), np.uint8).copy()
+            out[key + "_size"] = np.int64(len(data))
+            out[key + "_head"] = np.frombuffer(data[:400], np.uint8).copy()
+    np.savez_compressed(os.path.join(OUT, "obj_format.npz"), **out)
+    print("obj_format", int(out["plain_size"]), int(out["color_size"]))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["query", "misc", "vertices", "color", "encoders", "pipeline",
-                             "dense64", "pipeline257"]
+                             "dense64", "pipeline257", "obj"]
+    if "obj" in which:
+        gen_obj()
     if "query" in which:
         gen_query()
     if "misc" in which:

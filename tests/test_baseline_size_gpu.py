@@ -27,11 +27,19 @@ def _load_mlp(net, layers):
     net.surface_classifier.load_state_dict(sd)
 
 
+QUERY_PATHS = {"table": True, "plain": False}  # ops.SKIP_TABLE: csrc/query_table.hip | query.hip + query_small.hip
+
+
+@pytest.mark.parametrize("path", sorted(QUERY_PATHS))
 @pytest.mark.parametrize("case", sorted(DENSE64_CASES))
-def test_dense64_vs_reference(case):
+def test_dense64_vs_reference(case, path, monkeypatch):
     """BASELINE configs[0]: the dense 64^3 grid through netG.query exactly as the reference calls it
-    (MonoPortNet API, 4-stage feature list), all 262,144 values against the reference's."""
+    (MonoPortNet API, 4-stage feature list), all 262,144 values against the reference's -- on BOTH
+    shipped query paths: through the map's skip table (the default of MonoPortNet.bind) and on the
+    plain kernels (the C-ABI default, netC's path, MONOPORT_SKIP_TABLE=off)."""
+    from monoport_amd import ops
     from monoport_amd.modeling import PIFuNetG
+    monkeypatch.setattr(ops, "SKIP_TABLE", QUERY_PATHS[path])
     g = load_golden("dense64")
     layers, f = dense64_inputs(case)
     net = PIFuNetG().eval()
@@ -42,10 +50,11 @@ def test_dense64_vs_reference(case):
     out = net.query(feats, pts, calibs=torch.from_numpy(g["calib"]).to(DEV))[0][0, 0].cpu().numpy()
     ref = g[case]
     err = float(np.abs(out - ref).max())
-    print("dense64 %s: max|HIP - reference| = %.3g" % (case, err))
+    assert (net._table_cache is not None) == QUERY_PATHS[path]
+    print("dense64 %s [%s path]: max|HIP - reference| = %.3g" % (case, path, err))
     assert np.array_equal((out == 0), (ref == 0)) or case == "out_body"  # identical in-image mask
     assert err <= TOL_REF
-    assert err <= 5e-6  # measured 3.0e-7 on both heads: only the GEMM summation order differs
+    assert err <= 5e-6  # measured 3.0e-7 (plain) / 5.1e-7 (table): only the GEMM summation order differs
 
 
 def test_dense64_with_gpu_encoder_in_the_loop():
@@ -102,15 +111,19 @@ def test_dense64_all_f16x3_encoder_in_the_loop(monkeypatch):
     assert fe <= 1e-4 and err.max() <= TOL_REF
 
 
+@pytest.mark.parametrize("path", sorted(QUERY_PATHS))
 @pytest.mark.parametrize("name", sorted(PIPE257_SCENES))
-def test_pipeline257_vs_reference(name):
+def test_pipeline257_vs_reference(name, path, monkeypatch):
     """BASELINE configs[1] size through the drop-in surface (RTL/main.py:169-195, :389-406):
     Seg3dLossless(17..257) + forward_vertices vs the reference's netG.query / forward_vertices run
     on the CPU, three scenes (two of them not picked for their margin, one with an unsaturated
     field).  Same nodes queried at every level and every queried value within 1e-4 -- outside the
     reach of nodes the REFERENCE evaluated within fp32 noise of the threshold (test_oracle_golden.
-    pipeline257_undecided) -- and the same visible vertices."""
+    pipeline257_undecided) -- and the same visible vertices.  Both shipped query paths (skip
+    table | plain kernels) are held to it."""
+    from monoport_amd import ops
     from monoport_amd.implicit_seg.functional import Seg3dLossless
+    monkeypatch.setattr(ops, "SKIP_TABLE", QUERY_PATHS[path])
     from monoport_amd.modeling import PIFuNetG
     from monoport_amd.recon import forward_vertices, pifu_calib
     g, _ = pipeline257_golden(name)
@@ -133,7 +146,8 @@ def test_pipeline257_vs_reference(name):
     f = torch.from_numpy(fmap)[None].to(DEV)
     feats = [[torch.zeros(1, 256, 2, 2, device=DEV)]] * 3 + [[f]]
     sdf = engine(im_feat_list=feats, calib_tensor=calib)
-    assert sdf.shape == (1, 1, 257, 257, 257)
+    assert sdf.shape == (1, 1, 257, 257, 257) and engine.last_path == "fused"
+    assert (netG._table_cache is not None) == QUERY_PATHS[path]
     vol = sdf[0, 0].cpu().numpy()
     _, undecided, n_amb = pipeline257_check(name, vol, None, engine.last_status[1:].numpy(), TOL_REF)
     X, Y, Z, norm = forward_vertices(sdf, direction="front")
@@ -142,11 +156,11 @@ def test_pipeline257_vs_reference(name):
         assert np.array_equal(Y.cpu().numpy(), g["Y"].astype(np.int64))
         zerr = float(np.abs(Z.cpu().numpy() - g["Z"]).max())
         nerr = float(np.abs(norm.cpu().numpy() - g["norm"]).max())
-        print("%s: %d vertices, max|dZ| = %.3g voxels, max|dnorm| = %.3g" % (name, X.shape[0], zerr, nerr))
+        print("%s [%s path]: %d vertices, max|dZ| = %.3g voxels, max|dnorm| = %.3g" % (name, path, X.shape[0], zerr, nerr))
         assert zerr <= 1e-3 and nerr <= 1e-4  # measured 3.1e-5 voxels / 2.4e-6
     else:
         same = pipeline257_vertex_agreement(g, X.cpu().numpy(), Y.cpu().numpy(), Z.cpu().numpy())
-        print("%s: %.4f of the reference's %d vertices reproduced" % (name, same, g["X"].shape[0]))
+        print("%s [%s path]: %.4f of the reference's %d vertices reproduced" % (name, path, same, g["X"].shape[0]))
         assert same >= 0.99
 
 

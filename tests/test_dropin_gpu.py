@@ -470,3 +470,121 @@ def test_netg_query_uses_the_skip_table_by_default(monkeypatch):
     assert (got[True][1] - got[False][1]).abs().max().item() <= 2e-6
     # a voxel whose value sits within rounding of the threshold may land on either side
     assert int(((got[True][1] > 0.5) != (got[False][1] > 0.5)).sum()) <= 4
+
+
+def test_reloaded_head_never_meets_a_stale_skip_table(monkeypatch):
+    """A skip table holds products of the head's weights.  load_state_dict re-packs new weights into
+    the SAME PackedMLP (same device buffer), so a table made before the reload would blend the old
+    layer 0 / skip rows into the new hidden layers: mp_mlp_load forgets the head's tables and
+    MonoPortNet.bind keys its cached table on the head's load generation.  After a reload the
+    table path must agree with the plain path on the NEW weights -- through the module and at the
+    ops / C-ABI level."""
+    from monoport_amd import ops
+    from monoport_amd.modeling import PIFuNetG
+    from monoport_amd.recon import pifu_calib
+    netG = PIFuNetG()
+    _load_mlp(netG, syn.body_mlp("G", noise=0.05, seed=81))
+    netG.to(DEV).eval()
+    feats = [[torch.from_numpy(syn.body_feat(256, 128, 128, 4))[None].to(DEV)]]
+    calib = pifu_calib(*syn.scene_camera(35), device=DEV)
+    pts = torch.from_numpy(syn.rand_points(30000, 3, 1.0))[None].to(DEV)
+    old = netG.query(feats, pts, calib)[0].clone()
+    assert netG._table_cache is not None
+    mlp_before = netG.surface_classifier.packed()
+    _load_mlp(netG, syn.rand_mlp("G", 91, 2.0))  # other weights, same modules / same PackedMLP
+    new_tab = netG.query(feats, pts, calib)[0].clone()
+    assert netG.surface_classifier.packed() is mlp_before and netG._table_cache is not None
+    monkeypatch.setattr(ops, "SKIP_TABLE", False)
+    new_plain = netG.query(feats, pts, calib)[0].clone()
+    assert netG._table_cache is None  # switching the flag off releases the cached table
+    d_old = (new_tab - old).abs().max().item()
+    d = (new_tab - new_plain).abs().max().item()
+    print("reloaded head: |table - plain| = %.3g, |new - old| = %.3g" % (d, d_old))
+    assert d_old > 1e-2 and d <= 2e-6
+    # ops level: a table registered by hand is forgotten by load_layer (the C side drops it)
+    layers_a, layers_b = syn.body_mlp("G", noise=0.05, seed=81), syn.rand_mlp("G", 91, 2.0)
+    mlp = ops.PackedMLP.from_layers(DEV, layers_a, syn.LAST_OP["G"])
+    fh = ops.pack_features(feats[0][0])
+    handle = ops.skip_table(mlp, fh)
+    with_table = ops.query(mlp, fh, pts, calib, syn.Z_SCALE).clone()
+    for i, (w, b) in enumerate(layers_b):
+        mlp.load_layer(i, torch.from_numpy(w).to(DEV), torch.from_numpy(b).to(DEV))
+    after = ops.query(mlp, fh, pts, calib, syn.Z_SCALE).clone()  # plain kernels: no table left for fh
+    ref = ops.query(ops.PackedMLP.from_layers(DEV, layers_b, syn.LAST_OP["G"]), fh, pts, calib, syn.Z_SCALE)
+    handle.release()
+    assert torch.equal(after, ref) and (after - with_table).abs().max().item() > 1e-2
+
+
+def test_small_queries_do_not_build_a_skip_table():
+    """MonoPortNet.bind makes the 16 GFLOP / 126 MB table only for the octree engine or once the map
+    has served ops.SKIP_TABLE_MIN_POINTS points; a few small netG.query calls stay on the plain
+    kernels (bit-identical to ops.query without a table)."""
+    from monoport_amd import ops
+    from monoport_amd.implicit_seg.functional import Seg3dLossless
+    from monoport_amd.modeling import PIFuNetG
+    from monoport_amd.recon import pifu_calib
+    assert ops.SKIP_TABLE and ops.SKIP_TABLE_MIN_POINTS == 16384
+    netG = PIFuNetG()
+    _load_mlp(netG, syn.body_mlp("G", noise=0.05, seed=81))
+    netG.to(DEV).eval()
+    feats = [[torch.from_numpy(syn.body_feat(256, 128, 128, 4))[None].to(DEV)]]
+    calib = pifu_calib(*syn.scene_camera(35), device=DEV)
+    pts = torch.from_numpy(syn.rand_points(6000, 3, 1.0))[None].to(DEV)
+    a = netG.query(feats, pts, calib)[0].clone()
+    b = netG.query(feats, pts, calib)[0].clone()
+    assert netG._table_cache is None and torch.equal(a, b)  # 12 k points served: plain path
+    plain = ops.query(netG.surface_classifier.packed(), netG._hwc_cache[2], pts, calib, syn.Z_SCALE)
+    assert torch.equal(a, plain)
+    c = netG.query(feats, pts, calib)[0].clone()  # 18 k: the map has earned its table
+    assert netG._table_cache is not None
+    assert 0 < (c - a).abs().max().item() <= 2e-6
+    # a new map starts over ... unless the octree engine binds it
+    feats2 = [[torch.from_numpy(syn.body_feat(256, 128, 128, 5))[None].to(DEV)]]
+    netG.query(feats2, pts, calib)
+    assert netG._table_cache is None
+    eng = Seg3dLossless(query_func=lambda points, feats, calib: netG.query(feats, points.permute(0, 2, 1), calib)[0],
+                        b_min=np.array([[-1., -1., -1.]]), b_max=np.array([[1., 1., 1.]]),
+                        resolutions=[9, 17, 33], faster=True).to(DEV)
+    eng(feats=feats2, calib=calib)
+    assert eng.last_path == "fused" and netG._table_cache is not None
+
+
+def test_trusted_query_func_is_validated_again_periodically():
+    """After VALIDATE_CALLS agreeing frames the engine trusts query_func and only probes it -- but
+    every REVALIDATE_EVERY-th call is validated for real again, so a wrapper whose arithmetic
+    changes later (here: `1 - pred` from some frame on) is caught and honoured through the generic
+    engine instead of being bypassed for good."""
+    from monoport_amd.implicit_seg.functional import Seg3dLossless
+    from monoport_amd.modeling import PIFuNetG
+    from monoport_amd.recon import pifu_calib
+    netG = PIFuNetG()
+    _load_mlp(netG, syn.body_mlp("G", noise=0.05, seed=81))
+    netG.to(DEV).eval()
+    feats = [[torch.from_numpy(syn.body_feat(256, 128, 128, 4))[None].to(DEV)]]
+    calib = pifu_calib(*syn.scene_camera(35), device=DEV)
+    state = {"flip": False, "calls": []}
+
+    def query_func(points, feats, calib):
+        state["calls"].append(points.shape[1])
+        pred = netG.query(feats, points.permute(0, 2, 1), calib)[0]
+        return 1 - pred if state["flip"] else pred
+
+    eng = Seg3dLossless(query_func=query_func, b_min=np.array([[-1., -1., -1.]]), b_max=np.array([[1., 1., 1.]]),
+                        resolutions=[9, 17, 33], faster=True).to(DEV)
+    eng.REVALIDATE_EVERY = 4
+    for _ in range(3 + 8):
+        eng(feats=feats, calib=calib)
+        assert eng.last_path == "fused"
+    # 3 validated, then (3 probes, 1 validated) twice
+    assert state["calls"] == [729] * 3 + [1, 1, 1, 729] * 2
+    inside = eng(feats=feats, calib=calib)
+    state["flip"] = True
+    paths = []
+    import warnings as _w
+    with _w.catch_warnings():
+        _w.simplefilter("ignore")
+        for _ in range(4):
+            out = eng(feats=feats, calib=calib)
+            paths.append(eng.last_path)
+    assert "generic" in paths and paths[-1] == "generic"  # caught within REVALIDATE_EVERY frames, stays caught
+    assert (((out > 0.5) != (inside > 0.5)).float().mean().item()) > 0.5  # the flipped field is what comes back
