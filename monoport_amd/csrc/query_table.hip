@@ -28,6 +28,7 @@
 //     MFMAs of chunk ck (64 registers);  layer 0's bias sits in LDS;
 //   * the skip rows of layers 1-3 are blended into the accumulators when those are initialised,
 //     layer 4's in the final reduction.
+#include <cstdlib>
 #include <cstring>
 
 #include "mp_internal.h"
@@ -309,9 +310,453 @@ __global__ __launch_bounds__(kQueryThreads, MPT_WPS) void pifu_query_tab_kernel(
   }
 }
 
+// ---- round 4: the same query with the waves of a workgroup SPECIALISED --------------------------------
+// In pifu_query_tab_kernel every wave alternates between MFMA phases (the K loops) and phases that
+// keep the matrix pipe idle for that wave: table-row loads, blends, bias / z / leaky ReLU, LDS stores.
+// The second workgroup of the CU is supposed to fill them, but two workgroups that share a SIMD's
+// matrix pipe drift into phase (both slow down while both want the pipe, both leave it together):
+// 90 us per tile against 73 us of MFMA work, 0.72 of the roof.  Here a workgroup is
+//   * 4 CONSUMER waves (one per SIMD): nothing but the K loops of layers 1-3 -- operands from LDS and
+//     the weight stream -- the leaky ReLU of their own accumulators and the layer-4 partial sums.
+//     They never see a point, a texel or the table;
+//   * 4 PRODUCER waves (one per SIMD, VMEM + VALU only): everything that depends on the point.  A lane
+//     owns one point and, per job, the 16 rows of a 32-row block that an accumulator register of the
+//     consumers stands for (the MFMA C layout), and produces
+//       - layer 0's output chunk by chunk:  lrelu(b0 + blend(T0 rows) + z w0z)  -> H0[2] (point-major,
+//         the B operand of layer 1's K loop), one chunk AHEAD of the consumers;
+//       - "pieces" = b_l + blend(T_l rows) + z w_lz for the row blocks of layers 1-3 -> PB, which the
+//         consumers ADD to their accumulators at a fixed point of the K loop (addition order is free);
+//       - the final reduction: bias + the consumers' partial sums + layer 4's blended row + z, the
+//         activation, the in-image mask and the store / scatter.
+// All eight waves meet at 21 barriers per tile in lock step (S0-S7: layer 0 -> 1, one 128-row chunk
+// each; T0-T8: layer 2; U0-U3: layer 3); data written between two barriers is read after the second.
+// The producers' work is placed so that it never has to finish inside a short interval: whole jobs
+// in the long S intervals (6.8 us of MFMA work each), split jobs (loads issued in one interval, blended
+// and written in the next) in the T intervals.  Registers: both roles stay under 128, so a CU holds
+// two workgroups = 16 waves, four per SIMD.
+constexpr int kWsThreads = 512;
+constexpr int kWsH0 = 0;                              // H0[2]: [32 points][128 rows] f32, swizzled (16 KB each)
+constexpr int kWsPB = 2 * kTabPts * kTabHbRow;        // PB: [consumer wave][q][lane] f32x4 (16 KB)
+constexpr int kWsHB = kWsPB + 4 * 4 * 64 * 16;        // HB[2]: [32 points][64 rows] (8 KB each)
+constexpr int kWsRed = kWsHB + 2 * kTabPts * kHbRowBytes;  // red[wave][o][p]
+constexpr int kWsB0 = kWsRed + 4 * 3 * kTabPts * 4;   // layer 0's bias
+constexpr int kWsTend = kWsB0 + kHidden[0] * 4;        // tile_end[f]: tiles of frames 0..f (prefix sums), 16 ints
+constexpr int kWsLds = kWsTend + kMaxFrames * 4;
+
+struct TileLoc {
+  int fi;  // frame of the tile, -1: past the end
+  long long n0;
+};
+// tile -> (frame, first point) from the prefix sums of the frames' tile counts in LDS (filled once per
+// workgroup: the counts live on the device but do not change during the launch)
+__device__ __forceinline__ TileLoc locate_tile(const int *tend, long long gtile, int lane) {
+  TileLoc loc;
+  const int mine = tend[lane & (kMaxFrames - 1)];
+  const unsigned long long below = __ballot(lane < kMaxFrames && gtile >= (long long)mine);
+  const int fi = __builtin_amdgcn_readfirstlane(__popcll(below));
+  if (fi >= kMaxFrames) {
+    loc.fi = -1;
+    loc.n0 = 0;
+    return loc;
+  }
+  const int start = fi ? __builtin_amdgcn_readfirstlane(tend[fi - 1]) : 0;
+  loc.fi = fi;
+  loc.n0 = (gtile - start) * kTabPts;
+  return loc;
+}
+
+// what a producer lane knows about its point
+struct WsPoint {
+  int to[4];    // byte offsets of the four table rows (+ this lane's half of a row group)
+  float tw[4];  // grid_sample weights (0 outside the map / dead point)
+  float zf;     // z * z_scale (0 for a dead point)
+};
+
+template <int COUT>
+__global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack mlp, int fh, int fw, float z_scale,
+                                                                         int act, QuerySet set) {
+  constexpr int P = kTabPts;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int swz = h ^ (j & 15);
+  const WStream ws = make_wstream(mlp.base, mlp.n_floats, lane);
+  float *bias0 = reinterpret_cast<float *>(smem + kWsB0);
+  int *tend = reinterpret_cast<int *>(smem + kWsTend);
+  for (int i = tid; i < kHidden[0]; i += kWsThreads) bias0[i] = (mlp.base + mlp.bias[0])[i];
+  if (tid < kMaxFrames) {
+    int acc = 0;
+    for (int f = 0; f <= tid; ++f)
+      if (f < set.n) {
+        const PointSrc &sf = set.it[f].src;
+        const long long nf = sf.n_dev ? (long long)*sf.n_dev : sf.n;
+        acc += (int)((nf + P - 1) / P);
+      }
+    tend[tid] = acc;
+  }
+  __syncthreads();
+  const long long n_tiles = __builtin_amdgcn_readfirstlane(tend[kMaxFrames - 1]);
+
+  if (wv < 4) {
+    // =============================== consumers: the K loops ===============================
+    const int rs1 = (kHidden[0] / 8) * 64, rs2 = (kHidden[1] / 8) * 64;
+    const int a1 = mlp.ah[1] / 4 + (4 * wv) * rs1;
+    const int a2 = mlp.ah[2] / 4 + (2 * wv) * rs2;
+    const int a3 = mlp.ah[3] / 4 + wv * (kHidden[2] / 8) * 64;
+    const unsigned char *h0row = smem + kWsH0 + j * kTabHbRow;
+    const unsigned char *hbrow = smem + kWsHB + j * kHbRowBytes;
+    unsigned char *hb = smem + kWsHB;
+    const f32x4 *piece = reinterpret_cast<const f32x4 *>(smem + kWsPB) + (wv * 4) * 64 + lane;
+    auto add_piece = [&](f32x16 &acc, const f32x4 (&pc)[4]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * q + i] = acc[4 * q + i] + pc[q][i];
+    };
+    auto read_piece = [&](f32x4 (&pc)[4]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pc[q] = piece[q * 64];
+    };
+    __syncthreads();  // the producers' first chunk
+    for (long long gtile = blockIdx.x;; gtile += gridDim.x) {
+      if (gtile >= n_tiles) break;
+      // ---------------- S0-S7: layer 1 += W1[:, chunk k] * H0 chunk k; piece k / 2 added on odd k ----------------
+      f32x16 acc1[4][1];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc1[m][0][t] = 0.0f;
+      f32x4 ring1[MP32_PF1 + 1][4];
+      seg_prefetch<4, MP32_PF1>(ring1, ws, a1, rs1, 16);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        f32x4 pc[4];
+        if (k & 1) read_piece(pc);
+        seg_main<4, 1, MP32_PF1, kTabHbRow>(acc1, ring1, ws, a1 + k * 16 * 64, rs1, 16,
+                                            h0row + (k & 1) * (P * kTabHbRow), swz);
+        if (k < 7) seg_prefetch<4, MP32_PF1>(ring1, ws, a1 + (k + 1) * 16 * 64, rs1, 16);
+        if (k & 1) add_piece(acc1[k >> 1][0], pc);
+        if (k == 7) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) lrelu(acc1[m][0]);
+          if (wv == 0) {  // T0: layer 2's first K chunk = hidden-1 rows [0, 64)
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) store_hidden(hb, acc1[mm][0], mm, 0, j, h);
+          }
+        }
+        __syncthreads();
+      }
+      // ---------------- T1-T8: layer 2, rows [64 wv, +64), K = 512 hidden in 8 chunks of 64 ----------------
+      f32x16 acc2[2][1];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc2[m][0][t] = 0.0f;
+      {
+        f32x4 ring2[2][2];
+        seg_prefetch<2, 1>(ring2, ws, a2, rs2, 8);
+#pragma unroll
+        for (int ck = 0; ck < 8; ++ck) {
+          f32x4 pc[4];
+          if (ck == 1 || ck == 3) read_piece(pc);  // pieces 4 / 5: written in T1 / T3, read in T2 / T4
+          if (ck < 7 && wv == ((ck + 1) >> 1)) {  // owner of the NEXT chunk: rows [64 (ck + 1), +64)
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+              store_hidden(hb + ((ck + 1) & 1) * (P * kHbRowBytes), acc1[2 * ((ck + 1) & 1) + mm][0], mm, 0, j, h);
+          }
+          seg_main<2, 1, 1, kHbRowBytes>(acc2, ring2, ws, a2 + ck * 8 * 64, rs2, 8,
+                                         hbrow + (ck & 1) * (P * kHbRowBytes), swz);
+          if (ck < 7) seg_prefetch<2, 1>(ring2, ws, a2 + (ck + 1) * 8 * 64, rs2, 8);
+          if (ck == 1) add_piece(acc2[0][0], pc);
+          if (ck == 3) add_piece(acc2[1][0], pc);
+          if (ck == 7) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) lrelu(acc2[m][0]);
+            if (wv == 0) {  // layer 3's first K chunk -> HB[0] (last read in T7)
+#pragma unroll
+              for (int mm = 0; mm < 2; ++mm) store_hidden(hb, acc2[mm][0], mm, 0, j, h);
+            }
+          }
+          __syncthreads();
+        }
+      }
+      // ---------------- U0-U3: layer 3, rows [32 wv, +32), K = 256 hidden in 4 chunks ----------------
+      f32x16 acc3[1][1];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc3[0][0][t] = 0.0f;
+      {
+        f32x4 ring3[4][1];
+        seg_prefetch<1, 3>(ring3, ws, a3, 0, 8);
+#pragma unroll
+        for (int ck = 0; ck < 4; ++ck) {
+          f32x4 pc[4];
+          if (ck == 0) read_piece(pc);  // piece 6: written in T6
+          if (ck < 3 && wv == ck + 1) {
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+              store_hidden(hb + ((ck + 1) & 1) * (P * kHbRowBytes), acc2[mm][0], mm, 0, j, h);
+          }
+          seg_main<1, 1, 3, kHbRowBytes>(acc3, ring3, ws, a3 + ck * 8 * 64, 0, 8,
+                                         hbrow + (ck & 1) * (P * kHbRowBytes), swz);
+          if (ck < 3) seg_prefetch<1, 3>(ring3, ws, a3 + (ck + 1) * 8 * 64, 0, 8);
+          if (ck == 0) add_piece(acc3[0][0], pc);
+          if (ck == 3) {
+            lrelu(acc3[0][0]);
+            // layer 4 on the VALU: this wave's 32 hidden rows; the producers finish the sum
+            float *red = reinterpret_cast<float *>(smem + kWsRed);
+            constexpr int K4 = (kHidden[3] + 256 + 1 + 3) & ~3;
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+              const float *w4 = (mlp.base + mlp.w4) + o * K4 + 32 * wv + 4 * h;
+              float s0 = 0.0f;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 wq = *reinterpret_cast<const f32x4 *>(w4 + 8 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s0 = fmaf(wq[i], acc3[0][0][4 * q + i], s0);
+              }
+              s0 += __shfl_xor(s0, 32);
+              if (h == 0) red[(wv * COUT + o) * P + j] = s0;
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+    __syncthreads();  // the producers' last final pass reads `red` behind this one
+  } else {
+    // =============================== producers: everything per point ===============================
+    const int pw = wv - 4;  // partner of consumer wave pw
+    unsigned char *h0 = smem + kWsH0;
+    f32x4 *piece = reinterpret_cast<f32x4 *>(smem + kWsPB) + (pw * 4) * 64 + lane;
+
+    auto table_rsrc = [&](int fi) {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(set.it[fi].l0), 0, fh * fw * kTableRows * 4,
+                                               0x00020000);
+    };
+    auto setup_point = [&](int fi, long long n0, WsPoint &pt) {
+      const QueryItem &item = set.it[fi];
+      const PointSrc &src = item.src;
+      const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
+      float cal[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) cal[i] = item.calib[i];
+      const long long n = n0 + j;
+      float px = 0, py = 0, pz = 0, x, y, z;
+      uint32_t code;
+      if (n < n_pts) load_point(src, n, px, py, pz, code);
+      project(cal, px, py, pz, x, y, z);
+      pt.zf = n < n_pts ? __fmul_rn(z, z_scale) : 0.0f;
+      const Taps t = make_taps(x, y, fh, fw, kTableRows, n < n_pts && in_image(x, y));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#ifdef MPT_FAKE_GATHER
+        pt.to[k] = k * kTableRows * 4 + 16 * h;
+#else
+        pt.to[k] = (int)t.o[k] * 4 + 16 * h;
+#endif
+        pt.tw[k] = t.w[k];
+      }
+    };
+    // a job = one 32-row block of the table for this lane's point: 16 loads, then the blend
+    auto job_issue = [&](TabRows &tp, const __amdgpu_buffer_rsrc_t &prs, const WsPoint &pt, int row0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          tp[q][k] = __builtin_bit_cast(f32x4,
+                                        __builtin_amdgcn_raw_buffer_load_b128(prs, pt.to[k], (row0 + 8 * q) * 4, 0));
+    };
+    // acc = bias + blend + z * wz for the rows of block `rb` of layer l
+    auto job_finish = [&](f32x16 &acc, const TabRows &tp, const WsPoint &pt, const f32x4 (&bq)[4], const f32x4 (&zq)[4]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * q + i] = bq[q][i];
+      blend_add(acc, tp, pt.tw, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * q + i] = fmaf(zq[q][i], pt.zf, acc[4 * q + i]);
+    };
+    auto load_bz = [&](f32x4 (&bq)[4], f32x4 (&zq)[4], int l, int rb) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bq[q] = wload_bias4(ws, mlp.bias[l] + 32 * rb + 8 * q);
+        zq[q] = wload_bias4(ws, mlp.az[l] + 64 * rb + 8 * q);
+      }
+    };
+    // layer-0 chunk ck of this lane's point -> H0[buf]: this wave's row block 4 ck + pw
+    auto chunk_finish = [&](const TabRows &tp, const WsPoint &pt, int ck, int buf) {
+      const int rb = 4 * ck + pw;
+      f32x4 bq[4], zq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bq[q] = *reinterpret_cast<const f32x4 *>(bias0 + 32 * rb + 8 * q + 4 * h);
+        zq[q] = wload_bias4(ws, mlp.az[0] + 64 * rb + 8 * q);
+      }
+      f32x16 acc;
+      job_finish(acc, tp, pt, bq, zq);
+      lrelu(acc);
+      store_hidden<kTabHbRow>(h0 + buf * (P * kTabHbRow), acc, pw, 0, j, h);
+    };
+    auto piece_finish = [&](const TabRows &tp, const WsPoint &pt, int l, int rb) {
+      f32x4 bq[4], zq[4];
+      load_bz(bq, zq, l, rb);
+      f32x16 acc;
+      job_finish(acc, tp, pt, bq, zq);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 o = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        piece[q * 64] = o;
+      }
+    };
+    // the output of tile (fi, n0): bias + partial sums + layer 4's blended row + z column
+    auto finish_tile = [&](int fi, long long n0) {
+      const int t = pw * 64 + lane;
+      if (t < COUT * P) {
+        const QueryItem &item = set.it[fi];
+        const PointSrc &src = item.src;
+        const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
+        const float *red = reinterpret_cast<const float *>(smem + kWsRed);
+        constexpr int K4 = (kHidden[3] + 256 + 1 + 3) & ~3;
+        const int o = t / P, p = t % P;
+        const long long n = n0 + p;
+        if (n < n_pts) {
+          float v = (mlp.base + mlp.bias[4])[o];
+#pragma unroll
+          for (int part = 0; part < 4; ++part) v += red[(part * COUT + o) * P + p];
+          const float wz = (mlp.base + mlp.w4)[o * K4 + kHidden[3] + 256];
+          float cal[12];
+#pragma unroll
+          for (int i = 0; i < 12; ++i) cal[i] = item.calib[i];
+          float px, py, pz, x, y, z;
+          uint32_t code;
+          load_point(src, n, px, py, pz, code);
+          project(cal, px, py, pz, x, y, z);
+          const bool inside = in_image(x, y);
+          const Taps tp = make_taps(x, y, fh, fw, kTableRows, inside);
+          const float *row = item.l0 + kTableL[4] + o;
+          v += fmaf(row[tp.o[3]], tp.w[3],
+                    fmaf(row[tp.o[2]], tp.w[2], fmaf(row[tp.o[1]], tp.w[1], __fmul_rn(row[tp.o[0]], tp.w[0]))));
+          v = fmaf(wz, __fmul_rn(z, z_scale), v);
+          v = inside ? activate(v, act) : 0.0f;  // MonoPortNet.py:89
+          if (src.packed) {
+            const int ix = code & 1023u, iy = (code >> 10) & 1023u, iz = code >> 20;
+            item.out[((long long)iz * src.level_res + iy) * src.level_res + ix] = v;
+          } else {
+            item.out[o * src.out_stride + n] = v;
+          }
+        }
+      }
+    };
+
+    WsPoint cur = {}, nxt;
+    TileLoc loc = locate_tile(tend, blockIdx.x, lane);
+    __amdgpu_buffer_rsrc_t prs_cur = table_rsrc(loc.fi >= 0 ? loc.fi : 0), prs_nxt;
+    if (loc.fi >= 0) {
+      setup_point(loc.fi, loc.n0, cur);
+      TabRows tp;
+      job_issue(tp, prs_cur, cur, kTableL[0] + 32 * pw);
+      chunk_finish(tp, cur, 0, 0);
+    }
+    prs_nxt = prs_cur;
+    nxt = cur;
+    __syncthreads();  // the first chunk
+    int prev_fi = -1;
+    long long prev_n0 = 0;
+    for (long long gtile = blockIdx.x;; gtile += gridDim.x) {
+      if (loc.fi < 0) break;
+      const TileLoc loc_n = locate_tile(tend, gtile + gridDim.x, lane);
+      // ---------------- S0-S7 ----------------
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k == 0 && prev_fi >= 0) finish_tile(prev_fi, prev_n0);
+        if (k == 1 && loc_n.fi >= 0) {  // the next tile's point, long before it is needed (T7)
+          setup_point(loc_n.fi, loc_n.n0, nxt);
+          prs_nxt = table_rsrc(loc_n.fi);
+        }
+        if (!(k & 1)) {  // piece k / 2: row block 4 pw + k / 2 of layer 1 -> PB (read in S(k + 1))
+          TabRows tp;
+          job_issue(tp, prs_cur, cur, kTableL[1] + 32 * (4 * pw + (k >> 1)));
+          piece_finish(tp, cur, 1, 4 * pw + (k >> 1));
+        }
+        if (k < 7) {  // chunk k + 1 -> H0[(k + 1) & 1] (read in S(k + 1); last read in S(k - 1))
+          TabRows tp;
+          job_issue(tp, prs_cur, cur, kTableL[0] + 32 * (4 * (k + 1) + pw));
+          chunk_finish(tp, cur, k + 1, (k + 1) & 1);
+        }
+        __syncthreads();
+      }
+      // ---------------- T1-T8 (T0 was the tail of S7): split jobs -- loads in one interval, blend + write in the next ----------------
+      {
+        TabRows tp;
+        job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw));  // T1: piece 4 (layer 2, row block 2 pw)
+        piece_finish(tp, cur, 2, 2 * pw);                         //     PB was last read in S7
+        __syncthreads();                                          // end of T1
+        job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw + 1));  // T2: piece 5 in flight (consumers read piece 4)
+        __syncthreads();
+        piece_finish(tp, cur, 2, 2 * pw + 1);  // T3: piece 5 -> PB (read in T4)
+        __syncthreads();
+        job_issue(tp, prs_cur, cur, kTableL[3] + 32 * pw);  // T4: piece 6 in flight (consumers read piece 5)
+        __syncthreads();
+        piece_finish(tp, cur, 3, pw);  // T5: piece 6 -> PB (read in U0)
+        __syncthreads();
+        if (loc_n.fi >= 0) job_issue(tp, prs_nxt, nxt, kTableL[0] + 32 * pw);  // T6: the next tile's chunk 0 in flight
+        __syncthreads();
+        if (loc_n.fi >= 0) chunk_finish(tp, nxt, 0, 0);  // T7: -> H0[0] (last read in S6)
+        __syncthreads();
+        __syncthreads();  // T8
+      }
+      // ---------------- U0-U3: nothing to do ----------------
+      __syncthreads();
+      __syncthreads();
+      __syncthreads();
+      __syncthreads();
+      prev_fi = loc.fi;
+      prev_n0 = loc.n0;
+      loc = loc_n;
+      cur = nxt;
+      prs_cur = prs_nxt;
+    }
+    __syncthreads();
+    if (prev_fi >= 0) finish_tile(prev_fi, prev_n0);
+  }
+}
+
+// MONOPORT_TAB_KERNEL=v1 selects round 3's kernel (every wave does everything) for A/B measurements;
+// read at every launch, so a probe can flip it inside one process
+static bool tab_kernel_v1() {
+  const char *e = getenv("MONOPORT_TAB_KERNEL");
+  return e && e[0] == 'v' && e[1] == '1';
+}
+
+template <int COUT>
+static int launch_query_tabws_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
+                                long long max_points, bool device_counts, hipStream_t st) {
+  if (max_points <= 0) return MP_OK;
+  auto kern = pifu_query_tabws_kernel<COUT>;
+  const void *kern_id = reinterpret_cast<const void *>(kern);
+  if (!ctx->lds_attr_done.count(kern_id)) {
+    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, kWsLds));
+    ctx->lds_attr_done.insert(kern_id);
+  }
+  const long long tiles = (max_points + kTabPts - 1) / kTabPts + (set.n - 1);
+  const long long resident = (long long)ctx->n_cu * 2;
+  // persistent: a workgroup's producers run one chunk ahead of its consumers ACROSS tiles, so a
+  // workgroup should see several tiles; never more workgroups than are resident at once
+  const long long grid = tiles < resident ? tiles : resident;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kWsThreads), kWsLds, st, m.pack(), h, w, z_scale, m.act, set);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
 template <int COUT>
 static int launch_query_tab_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
                               long long max_points, bool device_counts, hipStream_t st) {
+  if (!tab_kernel_v1()) return launch_query_tabws_t<COUT>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
   constexpr int lds = kTabPts * kTabHbRow + kHidden[0] * 4;
   if (max_points <= 0) return MP_OK;
   const long long tiles = (max_points + kTabPts - 1) / kTabPts + (set.n - 1);
