@@ -328,20 +328,35 @@ __global__ __launch_bounds__(kQueryThreads, MPT_WPS) void pifu_query_tab_kernel(
 //         consumers ADD to their accumulators at a fixed point of the K loop (addition order is free);
 //       - the final reduction: bias + the consumers' partial sums + layer 4's blended row + z, the
 //         activation, the in-image mask and the store / scatter.
-// All eight waves meet at 21 barriers per tile in lock step (S0-S7: layer 0 -> 1, one 128-row chunk
-// each; T0-T8: layer 2; U0-U3: layer 3); data written between two barriers is read after the second.
-// The producers' work is placed so that it never has to finish inside a short interval: whole jobs
-// in the long S intervals (6.8 us of MFMA work each), split jobs (loads issued in one interval, blended
-// and written in the next) in the T intervals.  Registers: both roles stay under 128, so a CU holds
+// All eight waves meet at 14 barriers per tile in lock step -- S0-S7: layer 0 -> 1, one 128-row chunk
+// each (256 MFMAs per consumer wave); T0-T3: layer 2 over 128-row K pairs (128 MFMAs); U0-U1: layer 3
+// (64) -- and data written between two barriers is read after the second.  The K pairs of layers 2 / 3
+// borrow a layer-0 chunk buffer, which is idle in those intervals.  The producers' work is placed so
+// that it never has to finish inside a short interval: whole jobs in the long S intervals (6.8 us of
+// MFMA work each), split jobs (loads issued in one interval, blended and written in a later one) in T / U.  Registers: both roles stay under 128, so a CU holds
 // two workgroups = 16 waves, four per SIMD.
 constexpr int kWsThreads = 512;
-constexpr int kWsH0 = 0;                              // H0[2]: [32 points][128 rows] f32, swizzled (16 KB each)
-constexpr int kWsPB = 2 * kTabPts * kTabHbRow;        // PB: [consumer wave][q][lane] f32x4 (16 KB)
-constexpr int kWsHB = kWsPB + 4 * 4 * 64 * 16;        // HB[2]: [32 points][64 rows] (8 KB each)
-constexpr int kWsRed = kWsHB + 2 * kTabPts * kHbRowBytes;  // red[wave][o][p]
-constexpr int kWsB0 = kWsRed + 4 * 3 * kTabPts * 4;   // layer 0's bias
-constexpr int kWsTend = kWsB0 + kHidden[0] * 4;        // tile_end[f]: tiles of frames 0..f (prefix sums), 16 ints
+constexpr int kWsX = 0;                                 // X[3]: [32 points][128 rows] f32, swizzled (16 KB each):
+                                                        //   X[0], X[1] layer-0 chunks; X[2], X[1] the 128-row K pairs of layers 2 / 3
+constexpr int kWsXBytes = kTabPts * kTabHbRow;
+constexpr int kWsPB = 3 * kWsXBytes;                    // PB: [consumer wave][q][lane] f32x4 (16 KB)
+constexpr int kWsRed = kWsPB + 4 * 4 * 64 * 16;         // red[wave][o][p]
+constexpr int kWsBZ0 = kWsRed + 4 * 3 * kTabPts * 4;    // layer 0: [row / 4][bias x 4 | z weight x 4] (8 KB)
+constexpr int kWsB13 = kWsBZ0 + kHidden[0] * 8;         // biases of layers 1-3 (896 floats)
+constexpr int kWsZv = kWsB13 + (kHidden[1] + kHidden[2] + kHidden[3]) * 4;  // zvec[2][32]: z * z_scale of the tile's points, by tile parity
+constexpr int kWsTend = kWsZv + 2 * kTabPts * 4;        // tile_end[f]: tiles of frames 0..f (prefix sums), 16 ints
 constexpr int kWsLds = kWsTend + kMaxFrames * 4;
+
+// timing experiments (tools/ablate.py; wrong results): the producers do no work / no barriers;
+// MPT_WS_PRIO: s_setprio of the consumer waves
+#ifdef MPT_WS_NOBAR
+#define WS_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define WS_SYNC() __syncthreads()
+#endif
+#ifndef MPT_WS_PRIO
+#define MPT_WS_PRIO 1  // measured: 0.819 -> 0.830 of the roof on 885 k points (3 = the same)
+#endif
 
 struct TileLoc {
   int fi;  // frame of the tile, -1: past the end
@@ -383,9 +398,18 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
   const int j = lane & 31, h = lane >> 5;
   const int swz = h ^ (j & 15);
   const WStream ws = make_wstream(mlp.base, mlp.n_floats, lane);
-  float *bias0 = reinterpret_cast<float *>(smem + kWsB0);
+  float *bz0 = reinterpret_cast<float *>(smem + kWsBZ0);
+  float *b13 = reinterpret_cast<float *>(smem + kWsB13);
   int *tend = reinterpret_cast<int *>(smem + kWsTend);
-  for (int i = tid; i < kHidden[0]; i += kWsThreads) bias0[i] = (mlp.base + mlp.bias[0])[i];
+  for (int i = tid; i < kHidden[0]; i += kWsThreads) {
+    bz0[(i >> 2) * 8 + (i & 3)] = (mlp.base + mlp.bias[0])[i];
+    bz0[(i >> 2) * 8 + 4 + (i & 3)] = (mlp.base + mlp.az[0])[(i >> 5) * 64 + (i & 31)];  // az: [row block][64 lanes], rows in lanes 0-31
+  }
+  for (int i = tid; i < kHidden[1] + kHidden[2] + kHidden[3]; i += kWsThreads) {
+    const int l = i < kHidden[1] ? 1 : i < kHidden[1] + kHidden[2] ? 2 : 3;
+    const int r = i - (l == 1 ? 0 : l == 2 ? kHidden[1] : kHidden[1] + kHidden[2]);
+    b13[i] = (mlp.base + mlp.bias[l])[r];
+  }
   if (tid < kMaxFrames) {
     int acc = 0;
     for (int f = 0; f <= tid; ++f)
@@ -401,54 +425,60 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 
   if (wv < 4) {
     // =============================== consumers: the K loops ===============================
+    if (MPT_WS_PRIO) __builtin_amdgcn_s_setprio(MPT_WS_PRIO);
     const int rs1 = (kHidden[0] / 8) * 64, rs2 = (kHidden[1] / 8) * 64;
     const int a1 = mlp.ah[1] / 4 + (4 * wv) * rs1;
     const int a2 = mlp.ah[2] / 4 + (2 * wv) * rs2;
     const int a3 = mlp.ah[3] / 4 + wv * (kHidden[2] / 8) * 64;
-    const unsigned char *h0row = smem + kWsH0 + j * kTabHbRow;
-    const unsigned char *hbrow = smem + kWsHB + j * kHbRowBytes;
-    unsigned char *hb = smem + kWsHB;
+    unsigned char *x = smem + kWsX;
+    const unsigned char *xrow = x + j * kTabHbRow;
     const f32x4 *piece = reinterpret_cast<const f32x4 *>(smem + kWsPB) + (wv * 4) * 64 + lane;
-    auto add_piece = [&](f32x16 &acc, const f32x4 (&pc)[4]) {
+    const float *zvec = reinterpret_cast<const float *>(smem + kWsZv);
+    float zb[1];
+    // acc += piece of this wave (the producers' bias + blended skip rows of one row block), then the
+    // z column as one MFMA k-step (B operand: z of the points in lanes 0-31, 0 in lanes 32-63)
+    auto add_piece = [&](f32x16 (&acc)[1][1], int az_rb) {
+      float az[1];
+      az[0] = wload32(ws, az_rb);
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 pc = piece[q * 64];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[4 * q + i] = acc[4 * q + i] + pc[q][i];
+        for (int i = 0; i < 4; ++i) acc[0][0][4 * q + i] = acc[0][0][4 * q + i] + pc[i];
+      }
+      gemm_z<1, 1>(acc, az, zb);
     };
-    auto read_piece = [&](f32x4 (&pc)[4]) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) pc[q] = piece[q * 64];
-    };
-    __syncthreads();  // the producers' first chunk
-    for (long long gtile = blockIdx.x;; gtile += gridDim.x) {
+    WS_SYNC();  // the producers' first chunk
+    int par = 0;
+    for (long long gtile = blockIdx.x;; gtile += gridDim.x, par ^= 1) {
       if (gtile >= n_tiles) break;
-      // ---------------- S0-S7: layer 1 += W1[:, chunk k] * H0 chunk k; piece k / 2 added on odd k ----------------
+      zb[0] = h == 0 ? zvec[par * P + j] : 0.0f;
+      // ---------------- S0-S7: layer 1 += W1[:, chunk k] * (layer-0 chunk k in X[k & 1]); piece k / 2 added on odd k ----------------
       f32x16 acc1[4][1];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc1[m][0][t] = 0.0f;
-      f32x4 ring1[MP32_PF1 + 1][4];
-      seg_prefetch<4, MP32_PF1>(ring1, ws, a1, rs1, 16);
+      {
+        f32x4 ring1[MP32_PF1 + 1][4];
+        seg_prefetch<4, MP32_PF1>(ring1, ws, a1, rs1, 16);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        f32x4 pc[4];
-        if (k & 1) read_piece(pc);
-        seg_main<4, 1, MP32_PF1, kTabHbRow>(acc1, ring1, ws, a1 + k * 16 * 64, rs1, 16,
-                                            h0row + (k & 1) * (P * kTabHbRow), swz);
-        if (k < 7) seg_prefetch<4, MP32_PF1>(ring1, ws, a1 + (k + 1) * 16 * 64, rs1, 16);
-        if (k & 1) add_piece(acc1[k >> 1][0], pc);
-        if (k == 7) {
+        for (int k = 0; k < 8; ++k) {
+          seg_main<4, 1, MP32_PF1, kTabHbRow>(acc1, ring1, ws, a1 + k * 16 * 64, rs1, 16, xrow + (k & 1) * kWsXBytes, swz);
+          if (k < 7) seg_prefetch<4, MP32_PF1>(ring1, ws, a1 + (k + 1) * 16 * 64, rs1, 16);
+          if (k & 1) add_piece(*reinterpret_cast<f32x16(*)[1][1]>(&acc1[k >> 1]), mlp.az[1] + (4 * wv + (k >> 1)) * 64);
+          if (k == 7) {
 #pragma unroll
-          for (int m = 0; m < 4; ++m) lrelu(acc1[m][0]);
-          if (wv == 0) {  // T0: layer 2's first K chunk = hidden-1 rows [0, 64)
+            for (int m = 0; m < 4; ++m) lrelu(acc1[m][0]);
+            if (wv == 0) {  // layer 2's first K pair = hidden-1 rows [0, 128) -> X[2] (last read in U0 of the previous tile)
 #pragma unroll
-            for (int mm = 0; mm < 2; ++mm) store_hidden(hb, acc1[mm][0], mm, 0, j, h);
+              for (int m = 0; m < 4; ++m) store_hidden<kTabHbRow>(x + 2 * kWsXBytes, acc1[m][0], m, 0, j, h);
+            }
           }
+          WS_SYNC();
         }
-        __syncthreads();
       }
-      // ---------------- T1-T8: layer 2, rows [64 wv, +64), K = 512 hidden in 8 chunks of 64 ----------------
+      // ---------------- T0-T3: layer 2, rows [64 wv, +64); K pair p = hidden-1 rows [128 p, +128) = wave p's accumulators ----------------
       f32x16 acc2[2][1];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -456,53 +486,46 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         for (int t = 0; t < 16; ++t) acc2[m][0][t] = 0.0f;
       {
         f32x4 ring2[2][2];
-        seg_prefetch<2, 1>(ring2, ws, a2, rs2, 8);
+        seg_prefetch<2, 1>(ring2, ws, a2, rs2, 16);
 #pragma unroll
-        for (int ck = 0; ck < 8; ++ck) {
-          f32x4 pc[4];
-          if (ck == 1 || ck == 3) read_piece(pc);  // pieces 4 / 5: written in T1 / T3, read in T2 / T4
-          if (ck < 7 && wv == ((ck + 1) >> 1)) {  // owner of the NEXT chunk: rows [64 (ck + 1), +64)
+        for (int pr = 0; pr < 4; ++pr) {
+          const int buf = (pr & 1) ? 1 : 2;
+          if (pr < 3 && wv == pr + 1) {  // the next pair -> the other buffer (its last readers passed the barrier)
 #pragma unroll
-            for (int mm = 0; mm < 2; ++mm)
-              store_hidden(hb + ((ck + 1) & 1) * (P * kHbRowBytes), acc1[2 * ((ck + 1) & 1) + mm][0], mm, 0, j, h);
+            for (int m = 0; m < 4; ++m) store_hidden<kTabHbRow>(x + ((pr & 1) ? 2 : 1) * kWsXBytes, acc1[m][0], m, 0, j, h);
           }
-          seg_main<2, 1, 1, kHbRowBytes>(acc2, ring2, ws, a2 + ck * 8 * 64, rs2, 8,
-                                         hbrow + (ck & 1) * (P * kHbRowBytes), swz);
-          if (ck < 7) seg_prefetch<2, 1>(ring2, ws, a2 + (ck + 1) * 8 * 64, rs2, 8);
-          if (ck == 1) add_piece(acc2[0][0], pc);
-          if (ck == 3) add_piece(acc2[1][0], pc);
-          if (ck == 7) {
+          seg_main<2, 1, 1, kTabHbRow>(acc2, ring2, ws, a2 + pr * 16 * 64, rs2, 16, xrow + buf * kWsXBytes, swz);
+          if (pr < 3) seg_prefetch<2, 1>(ring2, ws, a2 + (pr + 1) * 16 * 64, rs2, 16);
+          if (pr == 1) add_piece(*reinterpret_cast<f32x16(*)[1][1]>(&acc2[0]), mlp.az[2] + (2 * wv) * 64);  // piece 4: written in T0
+          if (pr == 3) {
+            add_piece(*reinterpret_cast<f32x16(*)[1][1]>(&acc2[1]), mlp.az[2] + (2 * wv + 1) * 64);  // piece 5: written in T2
 #pragma unroll
             for (int m = 0; m < 2; ++m) lrelu(acc2[m][0]);
-            if (wv == 0) {  // layer 3's first K chunk -> HB[0] (last read in T7)
+            if (wv < 2) {  // layer 3's first K pair = hidden-2 rows [0, 128) = waves 0 and 1 -> X[2] (last read in T2)
 #pragma unroll
-              for (int mm = 0; mm < 2; ++mm) store_hidden(hb, acc2[mm][0], mm, 0, j, h);
+              for (int m = 0; m < 2; ++m) store_hidden<kTabHbRow>(x + 2 * kWsXBytes, acc2[m][0], 2 * wv + m, 0, j, h);
             }
           }
-          __syncthreads();
+          WS_SYNC();
         }
       }
-      // ---------------- U0-U3: layer 3, rows [32 wv, +32), K = 256 hidden in 4 chunks ----------------
+      // ---------------- U0-U1: layer 3, rows [32 wv, +32), K = 256 hidden in 2 pairs ----------------
       f32x16 acc3[1][1];
 #pragma unroll
       for (int t = 0; t < 16; ++t) acc3[0][0][t] = 0.0f;
       {
         f32x4 ring3[4][1];
-        seg_prefetch<1, 3>(ring3, ws, a3, 0, 8);
+        seg_prefetch<1, 3>(ring3, ws, a3, 0, 16);
 #pragma unroll
-        for (int ck = 0; ck < 4; ++ck) {
-          f32x4 pc[4];
-          if (ck == 0) read_piece(pc);  // piece 6: written in T6
-          if (ck < 3 && wv == ck + 1) {
+        for (int pr = 0; pr < 2; ++pr) {
+          if (pr == 0 && wv >= 2) {  // the second pair = waves 2 and 3 -> X[1] (last read in T3)
 #pragma unroll
-            for (int mm = 0; mm < 2; ++mm)
-              store_hidden(hb + ((ck + 1) & 1) * (P * kHbRowBytes), acc2[mm][0], mm, 0, j, h);
+            for (int m = 0; m < 2; ++m) store_hidden<kTabHbRow>(x + kWsXBytes, acc2[m][0], 2 * (wv - 2) + m, 0, j, h);
           }
-          seg_main<1, 1, 3, kHbRowBytes>(acc3, ring3, ws, a3 + ck * 8 * 64, 0, 8,
-                                         hbrow + (ck & 1) * (P * kHbRowBytes), swz);
-          if (ck < 3) seg_prefetch<1, 3>(ring3, ws, a3 + (ck + 1) * 8 * 64, 0, 8);
-          if (ck == 0) add_piece(acc3[0][0], pc);
-          if (ck == 3) {
+          seg_main<1, 1, 3, kTabHbRow>(acc3, ring3, ws, a3 + pr * 16 * 64, 0, 16, xrow + (pr ? 1 : 2) * kWsXBytes, swz);
+          if (pr == 0) seg_prefetch<1, 3>(ring3, ws, a3 + 16 * 64, 0, 16);
+          if (pr == 1) {
+            add_piece(acc3, mlp.az[3] + wv * 64);  // piece 6: written in U0
             lrelu(acc3[0][0]);
             // layer 4 on the VALU: this wave's 32 hidden rows; the producers finish the sum
             float *red = reinterpret_cast<float *>(smem + kWsRed);
@@ -521,22 +544,23 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
               if (h == 0) red[(wv * COUT + o) * P + j] = s0;
             }
           }
-          __syncthreads();
+          WS_SYNC();
         }
       }
     }
-    __syncthreads();  // the producers' last final pass reads `red` behind this one
+    WS_SYNC();  // the producers' last final pass reads `red` behind this one
   } else {
     // =============================== producers: everything per point ===============================
     const int pw = wv - 4;  // partner of consumer wave pw
-    unsigned char *h0 = smem + kWsH0;
+    unsigned char *h0 = smem + kWsX;
     f32x4 *piece = reinterpret_cast<f32x4 *>(smem + kWsPB) + (pw * 4) * 64 + lane;
 
     auto table_rsrc = [&](int fi) {
       return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(set.it[fi].l0), 0, fh * fw * kTableRows * 4,
                                                0x00020000);
     };
-    auto setup_point = [&](int fi, long long n0, WsPoint &pt) {
+    float *zvec = reinterpret_cast<float *>(smem + kWsZv);
+    auto setup_point = [&](int fi, long long n0, WsPoint &pt, int zpar) {
       const QueryItem &item = set.it[fi];
       const PointSrc &src = item.src;
       const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
@@ -549,6 +573,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
       if (n < n_pts) load_point(src, n, px, py, pz, code);
       project(cal, px, py, pz, x, y, z);
       pt.zf = n < n_pts ? __fmul_rn(z, z_scale) : 0.0f;
+      if (pw == 0 && h == 0) zvec[zpar * P + j] = pt.zf;  // the consumers' B operand of the z column
       const Taps t = make_taps(x, y, fh, fw, kTableRows, n < n_pts && in_image(x, y));
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -565,52 +590,50 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k) {
+#ifdef MPT_WS_NOLOAD  // timing experiment: the blends without the table loads
+          const f32x4 fake = {pt.tw[k], pt.tw[q], pt.zf, (float)row0};
+          tp[q][k] = fake;
+#else
           tp[q][k] = __builtin_bit_cast(f32x4,
                                         __builtin_amdgcn_raw_buffer_load_b128(prs, pt.to[k], (row0 + 8 * q) * 4, 0));
+#endif
+        }
     };
-    // acc = bias + blend + z * wz for the rows of block `rb` of layer l
-    auto job_finish = [&](f32x16 &acc, const TabRows &tp, const WsPoint &pt, const f32x4 (&bq)[4], const f32x4 (&zq)[4]) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[4 * q + i] = bq[q][i];
-      blend_add(acc, tp, pt.tw, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[4 * q + i] = fmaf(zq[q][i], pt.zf, acc[4 * q + i]);
+    // grid_sample's chain on four rows at once, started from `v0` (the bias, or bias + z column): whole
+    // f32x4 fused multiply-adds -- v_pk_fma_f32, half the VALU issue slots of scalar code, and every
+    // VALU instruction of a producer costs the consumer on its SIMD matrix-pipe time
+    auto blend4 = [&](const f32x4 (&t)[4], const WsPoint &pt, f32x4 v0) {
+#ifdef MPT_WS_NOVALU  // timing experiment: the table loads without the blends
+      return (f32x4)__builtin_elementwise_max(__builtin_elementwise_max(t[0], t[1]), __builtin_elementwise_max(t[2], t[3]));
+#else
+      f32x4 v = __builtin_elementwise_fma(t[0], (f32x4)(pt.tw[0]), v0);
+      v = __builtin_elementwise_fma(t[1], (f32x4)(pt.tw[1]), v);
+      v = __builtin_elementwise_fma(t[2], (f32x4)(pt.tw[2]), v);
+      return __builtin_elementwise_fma(t[3], (f32x4)(pt.tw[3]), v);
+#endif
     };
-    auto load_bz = [&](f32x4 (&bq)[4], f32x4 (&zq)[4], int l, int rb) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        bq[q] = wload_bias4(ws, mlp.bias[l] + 32 * rb + 8 * q);
-        zq[q] = wload_bias4(ws, mlp.az[l] + 64 * rb + 8 * q);
-      }
-    };
-    // layer-0 chunk ck of this lane's point -> H0[buf]: this wave's row block 4 ck + pw
+    // layer-0 chunk ck of this lane's point -> X[buf]: this wave's row block 4 ck + pw;
+    // lrelu(b0 + z w0z + blend) with bias and z weights from LDS
     auto chunk_finish = [&](const TabRows &tp, const WsPoint &pt, int ck, int buf) {
       const int rb = 4 * ck + pw;
-      f32x4 bq[4], zq[4];
+      const int p = j;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        bq[q] = *reinterpret_cast<const f32x4 *>(bias0 + 32 * rb + 8 * q + 4 * h);
-        zq[q] = wload_bias4(ws, mlp.az[0] + 64 * rb + 8 * q);
+        const f32x4 *bz = reinterpret_cast<const f32x4 *>(bz0 + (8 * rb + 2 * q + h) * 8);
+        f32x4 v = __builtin_elementwise_fma(bz[1], (f32x4)(pt.zf), bz[0]);
+        v = blend4(tp[q], pt, v);
+        v = __builtin_elementwise_max(v, v * 0.01f);  // leaky ReLU (SurfaceClassifier.py:58)
+        const int slot = 8 * pw + 2 * q + h;
+        *reinterpret_cast<f32x4 *>(h0 + buf * kWsXBytes + p * kTabHbRow + ((slot ^ (p & 15)) << 4)) = v;
       }
-      f32x16 acc;
-      job_finish(acc, tp, pt, bq, zq);
-      lrelu(acc);
-      store_hidden<kTabHbRow>(h0 + buf * (P * kTabHbRow), acc, pw, 0, j, h);
     };
-    auto piece_finish = [&](const TabRows &tp, const WsPoint &pt, int l, int rb) {
-      f32x4 bq[4], zq[4];
-      load_bz(bq, zq, l, rb);
-      f32x16 acc;
-      job_finish(acc, tp, pt, bq, zq);
+    // piece = bias + blend of row block rb of layer l (b13 offset boff) -> PB; the z column is the consumers'
+    auto piece_finish = [&](const TabRows &tp, const WsPoint &pt, int boff) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 o = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        piece[q * 64] = o;
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(b13 + boff + 8 * q + 4 * h);
+        piece[q * 64] = blend4(tp[q], pt, b);
       }
     };
     // the output of tile (fi, n0): bias + partial sums + layer 4's blended row + z column
@@ -657,72 +680,74 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     TileLoc loc = locate_tile(tend, blockIdx.x, lane);
     __amdgpu_buffer_rsrc_t prs_cur = table_rsrc(loc.fi >= 0 ? loc.fi : 0), prs_nxt;
     if (loc.fi >= 0) {
-      setup_point(loc.fi, loc.n0, cur);
+      setup_point(loc.fi, loc.n0, cur, 0);
       TabRows tp;
       job_issue(tp, prs_cur, cur, kTableL[0] + 32 * pw);
       chunk_finish(tp, cur, 0, 0);
     }
     prs_nxt = prs_cur;
     nxt = cur;
-    __syncthreads();  // the first chunk
-    int prev_fi = -1;
+    WS_SYNC();  // the first chunk
+    int prev_fi = -1, par = 0;
     long long prev_n0 = 0;
-    for (long long gtile = blockIdx.x;; gtile += gridDim.x) {
+    for (long long gtile = blockIdx.x;; gtile += gridDim.x, par ^= 1) {
       if (loc.fi < 0) break;
       const TileLoc loc_n = locate_tile(tend, gtile + gridDim.x, lane);
+      TabRows tp;
       // ---------------- S0-S7 ----------------
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
+#ifndef MPT_WS_NOPROD
         if (k == 0 && prev_fi >= 0) finish_tile(prev_fi, prev_n0);
-        if (k == 1 && loc_n.fi >= 0) {  // the next tile's point, long before it is needed (T7)
-          setup_point(loc_n.fi, loc_n.n0, nxt);
+        if (k == 1 && loc_n.fi >= 0) {  // the next tile's point, long before it is needed (U0)
+          setup_point(loc_n.fi, loc_n.n0, nxt, par ^ 1);
           prs_nxt = table_rsrc(loc_n.fi);
         }
         if (!(k & 1)) {  // piece k / 2: row block 4 pw + k / 2 of layer 1 -> PB (read in S(k + 1))
-          TabRows tp;
           job_issue(tp, prs_cur, cur, kTableL[1] + 32 * (4 * pw + (k >> 1)));
-          piece_finish(tp, cur, 1, 4 * pw + (k >> 1));
+          piece_finish(tp, cur, 32 * (4 * pw + (k >> 1)));
         }
-        if (k < 7) {  // chunk k + 1 -> H0[(k + 1) & 1] (read in S(k + 1); last read in S(k - 1))
-          TabRows tp;
+        if (k < 7) {  // chunk k + 1 -> X[(k + 1) & 1] (read in S(k + 1); last read in S(k - 1) / U1)
           job_issue(tp, prs_cur, cur, kTableL[0] + 32 * (4 * (k + 1) + pw));
           chunk_finish(tp, cur, k + 1, (k + 1) & 1);
+        } else {
+          job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw));  // piece 4 (layer 2, row block 2 pw) in flight
         }
-        __syncthreads();
+#endif
+        WS_SYNC();
       }
-      // ---------------- T1-T8 (T0 was the tail of S7): split jobs -- loads in one interval, blend + write in the next ----------------
-      {
-        TabRows tp;
-        job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw));  // T1: piece 4 (layer 2, row block 2 pw)
-        piece_finish(tp, cur, 2, 2 * pw);                         //     PB was last read in S7
-        __syncthreads();                                          // end of T1
-        job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw + 1));  // T2: piece 5 in flight (consumers read piece 4)
-        __syncthreads();
-        piece_finish(tp, cur, 2, 2 * pw + 1);  // T3: piece 5 -> PB (read in T4)
-        __syncthreads();
-        job_issue(tp, prs_cur, cur, kTableL[3] + 32 * pw);  // T4: piece 6 in flight (consumers read piece 5)
-        __syncthreads();
-        piece_finish(tp, cur, 3, pw);  // T5: piece 6 -> PB (read in U0)
-        __syncthreads();
-        if (loc_n.fi >= 0) job_issue(tp, prs_nxt, nxt, kTableL[0] + 32 * pw);  // T6: the next tile's chunk 0 in flight
-        __syncthreads();
-        if (loc_n.fi >= 0) chunk_finish(tp, nxt, 0, 0);  // T7: -> H0[0] (last read in S6)
-        __syncthreads();
-        __syncthreads();  // T8
-      }
-      // ---------------- U0-U3: nothing to do ----------------
-      __syncthreads();
-      __syncthreads();
-      __syncthreads();
-      __syncthreads();
+      // ---------------- T0-T3, U0-U1: split jobs -- loads in one interval, blend + write in a later one ----------------
+#ifndef MPT_WS_NOPROD
+      piece_finish(tp, cur, kHidden[1] + 32 * (2 * pw));                           // T0: piece 4 -> PB (last read in S7; read in T1)
+      job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw + 1));  //     piece 5 in flight
+#endif
+      WS_SYNC();
+      WS_SYNC();  // T1: the consumers read piece 4
+#ifndef MPT_WS_NOPROD
+      piece_finish(tp, cur, kHidden[1] + 32 * (2 * pw + 1));               // T2: piece 5 -> PB (read in T3)
+      job_issue(tp, prs_cur, cur, kTableL[3] + 32 * pw);  //     piece 6 in flight
+#endif
+      WS_SYNC();
+      WS_SYNC();  // T3: the consumers read piece 5
+#ifndef MPT_WS_NOPROD
+      piece_finish(tp, cur, kHidden[1] + kHidden[2] + 32 * pw);                                            // U0: piece 6 -> PB (read in U1)
+      if (loc_n.fi >= 0) job_issue(tp, prs_nxt, nxt, kTableL[0] + 32 * pw);  //     the next tile's chunk 0 in flight
+#endif
+      WS_SYNC();
+#ifndef MPT_WS_NOPROD
+      if (loc_n.fi >= 0) chunk_finish(tp, nxt, 0, 0);  // U1: -> X[0] (last read in S6)
+#endif
+      WS_SYNC();
       prev_fi = loc.fi;
       prev_n0 = loc.n0;
       loc = loc_n;
       cur = nxt;
       prs_cur = prs_nxt;
     }
-    __syncthreads();
+    WS_SYNC();
+#ifndef MPT_WS_NOPROD
     if (prev_fi >= 0) finish_tile(prev_fi, prev_n0);
+#endif
   }
 }
 

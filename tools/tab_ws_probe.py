@@ -37,6 +37,12 @@ def main():
     tables = torch.empty((frames, 128, 128, ops.SKIP_TABLE_ROWS), device=dev)
     handles = [ops.skip_table(mlp, feats[i], out=tables[i]) for i in range(frames)]
     out, vols, rows = {}, {}, {}
+    if os.environ.get("MONOPORT_ABLATE"):  # a side build (possibly with wrong results): timing only
+        tq = timed(lambda: ops.query(mlp, feats[0], p, cal, syn.Z_SCALE))
+        tr = timed(lambda: ops.recon_batch(mlp, feats, [cal] * frames, syn.Z_SCALE, [-1] * 3, [1] * 3, res), reps=5)
+        print("  %-10s %8.3f ms per %d points = %6.1f TFLOP/s executed (%.3f of 157.3)  |  recon_batch x%d %8.3f ms = %.3f ms per frame"
+              % (os.environ["MONOPORT_ABLATE"], tq, n, n * EXEC_FLOP / tq / 1e9, n * EXEC_FLOP / tq / 1e9 / 157.3, frames, tr, tr / frames))
+        return
     for name in ("v1", "ws"):
         os.environ["MONOPORT_TAB_KERNEL"] = name
         out[name] = ops.query(mlp, feats[0], p, cal, syn.Z_SCALE).clone()
