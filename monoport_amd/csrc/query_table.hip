@@ -494,7 +494,9 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #pragma unroll
             for (int m = 0; m < 4; ++m) store_hidden<kTabHbRow>(x + ((pr & 1) ? 2 : 1) * kWsXBytes, acc1[m][0], m, 0, j, h);
           }
+#ifndef MPT_WS_SONLY  // timing experiment: layer 1 only
           seg_main<2, 1, 1, kTabHbRow>(acc2, ring2, ws, a2 + pr * 16 * 64, rs2, 16, xrow + buf * kWsXBytes, swz);
+#endif
           if (pr < 3) seg_prefetch<2, 1>(ring2, ws, a2 + (pr + 1) * 16 * 64, rs2, 16);
           if (pr == 1) add_piece(*reinterpret_cast<f32x16(*)[1][1]>(&acc2[0]), mlp.az[2] + (2 * wv) * 64);  // piece 4: written in T0
           if (pr == 3) {
@@ -522,7 +524,9 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #pragma unroll
             for (int m = 0; m < 2; ++m) store_hidden<kTabHbRow>(x + kWsXBytes, acc2[m][0], 2 * (wv - 2) + m, 0, j, h);
           }
+#ifndef MPT_WS_SONLY
           seg_main<1, 1, 3, kTabHbRow>(acc3, ring3, ws, a3 + pr * 16 * 64, 0, 16, xrow + (pr ? 1 : 2) * kWsXBytes, swz);
+#endif
           if (pr == 0) seg_prefetch<1, 3>(ring3, ws, a3 + 16 * 64, 0, 16);
           if (pr == 1) {
             add_piece(acc3, mlp.az[3] + wv * 64);  // piece 6: written in U0

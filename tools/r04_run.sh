@@ -60,4 +60,13 @@ tests) run_tests ;;
 bench)
   timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.err
   bench_line $out/bench.json default ;;
+benchq)  # headline only, no extras
+  timeout 600 python bench.py --no-extras --no-cpu-baseline > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.err
+  bench_line $out/bench.json quick
+  python - $out/bench.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(json.dumps(d["roofline"])[:1500])
+PY
+  ;;
 esac
