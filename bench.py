@@ -19,7 +19,10 @@ line with the driver's contract fields plus
 
   "roofline"      the fused query kernel against the f32 MFMA peak (HIP-event timed, live): priced
                   on the FLOPs it executes, with the reference's per-point FLOPs beside it
-                  (`algorithmic`) -- the skip tables hoist 42 % of them out of the per-point work
+                  (`algorithmic`) -- the skip tables hoist 42 % of them out of the per-point work;
+                  `roofline.step` = the query launches AND skip_table_kernel as one rate (both
+                  pricings); `roofline.traffic` = memory-side bytes per launch from the committed PMC
+                  passes at this frames-per-launch (10 with --steps 20, 16 with the default 48)
   "plain_query_path"  (N=1 only) the headline configuration without skip tables (--no-skip-table)
   "cpu_baseline"  the CPU oracle path timed on this box's host cores (rank 0, N=1 only)
   "passes"        the timed region is run 3 times (each EXACTLY --steps frames between barrier +
@@ -133,24 +136,23 @@ def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, 
     return pipe
 
 
-TRAFFIC_PROFILE = "r03_query_traffic.json"  # 16 frames per launch (r02_query_traffic.json: 10)
+TRAFFIC_PROFILE = "r04_query_traffic.json"  # PMC passes at 10 and 16 frames per launch
 
 
 def traffic_from_profile(precision, levels, with_color, frames_per_launch):
-    """HBM-side bytes per fused-query launch from the committed PMC pass (separate rocprofv3
+    """HBM-side bytes per fused-query launch from the committed PMC passes (separate rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE runs of tools/traffic_probe.py, corrected as
     MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process, so the
-    figure is reported ONLY for the configuration the pass covered (f32 kernel, 5 levels, geometry
-    only, same frames per launch) and is None for every other run or when the profile is absent."""
+    figure is reported ONLY for the configurations the passes covered (f32 skip-table kernel, 5 levels,
+    geometry only, 10 or 16 frames per launch: --steps 20 and the default --steps 48) and is None
+    for every other run or when the profile is absent."""
     if precision != "f32" or levels != 5 or with_color:
         return None
     path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
     try:
         with open(path) as f:
             prof = json.load(f)
-        if int(prof["frames_per_launch"]) != int(frames_per_launch):
-            return None
-        return prof["bytes_per_launch_avg"]
+        return prof["by_frames_per_launch"][str(int(frames_per_launch))]["bytes_per_launch_avg"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -356,6 +358,20 @@ def roofline_leg(job, pipe, batch, resolutions, with_color):
     n_warm, n_frames = job.warm, job.steps + job.warm
     slot = pipe.slots[0]
     prof_status, prof_vcount = [], []
+    table_ms = None
+    if slot.tables is not None:  # the skip tables of one slot submission (skip_table_kernel), per frame
+        mlp = slot.net.surface_classifier.packed()
+        nb = min(batch, slot.feat_hwc_all.shape[0])
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(slot.stream):
+            for rep in range(6):
+                if rep == 1:
+                    ev0.record(slot.stream)
+                handle = ops.skip_table_batch(mlp, slot.feat_hwc_all[:nb], out=slot.tables[:nb])
+            ev1.record(slot.stream)
+        slot.stream.synchronize()
+        slot._table_handle = handle
+        table_ms = ev0.elapsed_time(ev1) / 5 / nb
     cap = 8 * job.steps + 64
     ops.profile_begin(job.device, max_records=cap)
     for s0 in range(n_warm, n_frames, batch):
@@ -390,12 +406,33 @@ def roofline_leg(job, pipe, batch, resolutions, with_color):
     flops = launch_pts.reshape(-1)[:n_launch].astype(np.float64) * FLOP_PER_POINT
     achieved = flops.sum() / (launch_ms[:n_launch].sum() * 1e-3) / 1e12 if n_launch else 0.0
     out = {"achieved": achieved, "launches": int(n_launch), "launch_ms": launch_ms[:n_launch],
-           "launch_pts": launch_pts.reshape(-1)[:n_launch], "points_per_level": launch_pts.sum(0)}
+           "launch_pts": launch_pts.reshape(-1)[:n_launch], "points_per_level": launch_pts.sum(0),
+           "skip_table_ms_per_frame": table_ms, "frames": int(sum(st.shape[0] for st in prof_status))}
     if with_color and c_ms:
         out["color_achieved"] = (np.sum(c_pts, dtype=np.float64) * FLOP_PER_POINT_C
                                  / (np.sum(c_ms) * 1e-3) / 1e12)
         out["color_points_per_frame"] = float(np.sum(c_pts)) / job.steps
     return out
+
+
+def roofline_step(roof, skip_on, peak_tflops):
+    """ALL kernels that produce the field of a frame -- the fused-query launches and, with skip tables,
+    skip_table_kernel -- as one rate, in both FLOP pricings: `executed` (what the kernels multiply:
+    1,380,354 FLOP per point + 16.1 GFLOP per frame of tables) and `algorithmic` (the reference's
+    2,363,906 FLOP per point, SURVEY 8d, nothing credited for the tables)."""
+    if not roof["launches"] or not roof.get("frames"):
+        return None
+    q_ms = float(roof["launch_ms"].sum())
+    pts = float(roof["launch_pts"].sum())
+    frames = roof["frames"]
+    t_ms = (roof["skip_table_ms_per_frame"] or 0.0) * frames if skip_on else 0.0
+    ex_flop = pts * (FLOP_PER_POINT_SKIP_TABLE if skip_on else FLOP_PER_POINT) + (FLOP_SKIP_TABLE_PER_FRAME * frames if skip_on else 0)
+    al_flop = pts * FLOP_PER_POINT
+    sec = (q_ms + t_ms) * 1e-3
+    return {"kernels": "fused-query launches" + (" + skip_table_kernel" if skip_on else ""),
+            "query_ms_per_frame": q_ms / frames, "skip_table_ms_per_frame": t_ms / frames if skip_on else None,
+            "executed": {"tflops": ex_flop / sec / 1e12, "frac": ex_flop / sec / 1e12 / peak_tflops},
+            "algorithmic": {"tflops": al_flop / sec / 1e12, "frac": al_flop / sec / 1e12 / peak_tflops}}
 
 
 def breakdown_leg(job, pipe, batch, resolutions):
@@ -979,8 +1016,9 @@ def main(argv=None):
             "mpts_per_s": main_res["points"] / main_res["elapsed"] / 1e6,
             "breakdown": breakdown,
             "roofline": {
-                "kernel": ("pifu_query_tab_kernel<1> (fused MLP on 32-point tiles; the products with the sampled feature "
-                           "blended from the frame's skip table, skip_table_kernel)" if skip_on else
+                "kernel": ("pifu_query_tabws_kernel<1> (fused MLP on 32-point tiles, wave-specialised: 4 MFMA-only consumer "
+                           "waves + 4 producer waves that blend the products with the sampled feature from the frame's "
+                           "skip table, skip_table_kernel)" if skip_on else
                            "pifu_query_kernel<256,1> (fused gather + MLP; launches of < 2048 tiles run on its "
                            "32-point-tile twin pifu_query_t32_kernel<1,false>)" if args.precision == "f32"
                            else "pifu_query16_kernel<1,%d> (fused gather + MLP, %s)" % (terms, args.precision)),
@@ -1010,6 +1048,7 @@ def main(argv=None):
                                          "`value`) and the query blends four table rows per point; --no-skip-table "
                                          "runs every FLOP per point" % FLOP_SKIP_TABLE_PER_FRAME)
                                 if skip_on else "equal to the executed FLOPs"},
+                "step": roofline_step(roof, skip_on, peak_tflops),
             },
         }
         out.update(extras)

@@ -381,10 +381,11 @@ __device__ __forceinline__ TileLoc locate_tile(const int *tend, long long gtile,
 }
 
 // what a producer lane knows about its point
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct WsPoint {
-  int to[4];    // byte offsets of the four table rows (+ this lane's half of a row group)
-  float tw[4];  // grid_sample weights (0 outside the map / dead point)
-  float zf;     // z * z_scale (0 for a dead point)
+  int to[4];     // byte offsets of the four table rows (+ this lane's half of a row group)
+  f32x2 tw2[4];  // grid_sample weights (0 outside the map / dead point), each twice: packed-FMA operands
+  float zf;      // z * z_scale (0 for a dead point)
 };
 
 template <int COUT>
@@ -432,17 +433,18 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     const int a3 = mlp.ah[3] / 4 + wv * (kHidden[2] / 8) * 64;
     unsigned char *x = smem + kWsX;
     const unsigned char *xrow = x + j * kTabHbRow;
-    const f32x4 *piece = reinterpret_cast<const f32x4 *>(smem + kWsPB) + (wv * 4) * 64 + lane;
+    // a piece of this wave ([wave][q][lane] f32x4 in any 16 KB region: 0-2 = X[0..2], 3 = PB)
+    const f32x4 *piece0 = reinterpret_cast<const f32x4 *>(smem + kWsX) + (wv * 4) * 64 + lane;
     const float *zvec = reinterpret_cast<const float *>(smem + kWsZv);
     float zb[1];
     // acc += piece of this wave (the producers' bias + blended skip rows of one row block), then the
     // z column as one MFMA k-step (B operand: z of the points in lanes 0-31, 0 in lanes 32-63)
-    auto add_piece = [&](f32x16 (&acc)[1][1], int az_rb) {
+    auto add_piece = [&](f32x16 (&acc)[1][1], int az_rb, int region) {
       float az[1];
       az[0] = wload32(ws, az_rb);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 pc = piece[q * 64];
+        const f32x4 pc = piece0[region * (kWsXBytes / 16) + q * 64];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[0][0][4 * q + i] = acc[0][0][4 * q + i] + pc[i];
       }
@@ -466,44 +468,46 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         for (int k = 0; k < 8; ++k) {
           seg_main<4, 1, MP32_PF1, kTabHbRow>(acc1, ring1, ws, a1 + k * 16 * 64, rs1, 16, xrow + (k & 1) * kWsXBytes, swz);
           if (k < 7) seg_prefetch<4, MP32_PF1>(ring1, ws, a1 + (k + 1) * 16 * 64, rs1, 16);
-          if (k & 1) add_piece(*reinterpret_cast<f32x16(*)[1][1]>(&acc1[k >> 1]), mlp.az[1] + (4 * wv + (k >> 1)) * 64);
+          if (k & 1) add_piece(*reinterpret_cast<f32x16(*)[1][1]>(&acc1[k >> 1]), mlp.az[1] + (4 * wv + (k >> 1)) * 64, 3);
           if (k == 7) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) lrelu(acc1[m][0]);
-            if (wv == 0) {  // layer 2's first K pair = hidden-1 rows [0, 128) -> X[2] (last read in U0 of the previous tile)
+            // layer 2 reads K = hidden 1 in four 128-row pairs = the accumulators of waves 0..3: pairs 0, 1 ->
+            // X[2], X[0] here (last read in U0 of the previous tile / S6), pairs 2, 3 -> X[1], PB at the top of T0
+            if (wv < 2) {
 #pragma unroll
-              for (int m = 0; m < 4; ++m) store_hidden<kTabHbRow>(x + 2 * kWsXBytes, acc1[m][0], m, 0, j, h);
+              for (int m = 0; m < 4; ++m) store_hidden<kTabHbRow>(x + (wv == 0 ? 2 : 0) * kWsXBytes, acc1[m][0], m, 0, j, h);
             }
           }
           WS_SYNC();
         }
       }
-      // ---------------- T0-T3: layer 2, rows [64 wv, +64); K pair p = hidden-1 rows [128 p, +128) = wave p's accumulators ----------------
+      // ---------------- T0-T3: layer 2, rows [64 wv, +64); K pair p = hidden-1 rows [128 p, +128) in X[2], X[0], X[1], PB ----------------
       f32x16 acc2[2][1];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc2[m][0][t] = 0.0f;
+      if (wv >= 2) {  // behind the barrier of S7: X[1] (chunk 7) and PB (piece 3) have been read
+#pragma unroll
+        for (int m = 0; m < 4; ++m) store_hidden<kTabHbRow>(x + (wv == 2 ? 1 : 3) * kWsXBytes, acc1[m][0], m, 0, j, h);
+      }
       {
         f32x4 ring2[2][2];
         seg_prefetch<2, 1>(ring2, ws, a2, rs2, 16);
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
-          const int buf = (pr & 1) ? 1 : 2;
-          if (pr < 3 && wv == pr + 1) {  // the next pair -> the other buffer (its last readers passed the barrier)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) store_hidden<kTabHbRow>(x + ((pr & 1) ? 2 : 1) * kWsXBytes, acc1[m][0], m, 0, j, h);
-          }
+          const int buf = pr == 0 ? 2 : pr == 1 ? 0 : pr == 2 ? 1 : 3;
 #ifndef MPT_WS_SONLY  // timing experiment: layer 1 only
           seg_main<2, 1, 1, kTabHbRow>(acc2, ring2, ws, a2 + pr * 16 * 64, rs2, 16, xrow + buf * kWsXBytes, swz);
 #endif
           if (pr < 3) seg_prefetch<2, 1>(ring2, ws, a2 + (pr + 1) * 16 * 64, rs2, 16);
-          if (pr == 1) add_piece(*reinterpret_cast<f32x16(*)[1][1]>(&acc2[0]), mlp.az[2] + (2 * wv) * 64);  // piece 4: written in T0
+          if (pr == 2) add_piece(*reinterpret_cast<f32x16(*)[1][1]>(&acc2[0]), mlp.az[2] + (2 * wv) * 64, 2);  // piece 4: written to X[2] in T1
           if (pr == 3) {
-            add_piece(*reinterpret_cast<f32x16(*)[1][1]>(&acc2[1]), mlp.az[2] + (2 * wv + 1) * 64);  // piece 5: written in T2
+            add_piece(*reinterpret_cast<f32x16(*)[1][1]>(&acc2[1]), mlp.az[2] + (2 * wv + 1) * 64, 0);  // piece 5: written to X[0] in T2
 #pragma unroll
             for (int m = 0; m < 2; ++m) lrelu(acc2[m][0]);
-            if (wv < 2) {  // layer 3's first K pair = hidden-2 rows [0, 128) = waves 0 and 1 -> X[2] (last read in T2)
+            if (wv < 2) {  // layer 3's first K pair = hidden-2 rows [0, 128) = waves 0 and 1 -> X[2] (piece 4 was read in T2)
 #pragma unroll
               for (int m = 0; m < 2; ++m) store_hidden<kTabHbRow>(x + 2 * kWsXBytes, acc2[m][0], 2 * wv + m, 0, j, h);
             }
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         seg_prefetch<1, 3>(ring3, ws, a3, 0, 16);
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-          if (pr == 0 && wv >= 2) {  // the second pair = waves 2 and 3 -> X[1] (last read in T3)
+          if (pr == 0 && wv >= 2) {  // the second pair = waves 2 and 3 -> X[1] (last read in T2)
 #pragma unroll
             for (int m = 0; m < 2; ++m) store_hidden<kTabHbRow>(x + kWsXBytes, acc2[m][0], 2 * (wv - 2) + m, 0, j, h);
           }
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #endif
           if (pr == 0) seg_prefetch<1, 3>(ring3, ws, a3 + 16 * 64, 0, 16);
           if (pr == 1) {
-            add_piece(acc3, mlp.az[3] + wv * 64);  // piece 6: written in U0
+            add_piece(acc3, mlp.az[3] + wv * 64, 3);  // piece 6: written to PB in U0
             lrelu(acc3[0][0]);
             // layer 4 on the VALU: this wave's 32 hidden rows; the producers finish the sum
             float *red = reinterpret_cast<float *>(smem + kWsRed);
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     // =============================== producers: everything per point ===============================
     const int pw = wv - 4;  // partner of consumer wave pw
     unsigned char *h0 = smem + kWsX;
-    f32x4 *piece = reinterpret_cast<f32x4 *>(smem + kWsPB) + (pw * 4) * 64 + lane;
+    f32x4 *piece0 = reinterpret_cast<f32x4 *>(smem + kWsX) + (pw * 4) * 64 + lane;  // + region * 16 KB (3 = PB)
 
     auto table_rsrc = [&](int fi) {
       return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(set.it[fi].l0), 0, fh * fw * kTableRows * 4,
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #else
         pt.to[k] = (int)t.o[k] * 4 + 16 * h;
 #endif
-        pt.tw[k] = t.w[k];
+        pt.tw2[k] = (f32x2)(t.w[k]);
       }
     };
     // a job = one 32-row block of the table for this lane's point: 16 loads, then the blend
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
 #ifdef MPT_WS_NOLOAD  // timing experiment: the blends without the table loads
-          const f32x4 fake = {pt.tw[k], pt.tw[q], pt.zf, (float)row0};
+          const f32x4 fake = {pt.tw2[k][0], pt.tw2[q][0], pt.zf, (float)row0};
           tp[q][k] = fake;
 #else
           tp[q][k] = __builtin_bit_cast(f32x4,
@@ -611,10 +615,13 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #ifdef MPT_WS_NOVALU  // timing experiment: the table loads without the blends
       return (f32x4)__builtin_elementwise_max(__builtin_elementwise_max(t[0], t[1]), __builtin_elementwise_max(t[2], t[3]));
 #else
-      f32x4 v = __builtin_elementwise_fma(t[0], (f32x4)(pt.tw[0]), v0);
-      v = __builtin_elementwise_fma(t[1], (f32x4)(pt.tw[1]), v);
-      v = __builtin_elementwise_fma(t[2], (f32x4)(pt.tw[2]), v);
-      return __builtin_elementwise_fma(t[3], (f32x4)(pt.tw[3]), v);
+      f32x4 v = v0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // weights kept as register PAIRS: v_pk_fma_f32 takes them without a v_mov per use
+        const f32x4 w = {pt.tw2[k][0], pt.tw2[k][1], pt.tw2[k][0], pt.tw2[k][1]};
+        v = __builtin_elementwise_fma(t[k], w, v);
+      }
+      return v;
 #endif
     };
     // layer-0 chunk ck of this lane's point -> X[buf]: this wave's row block 4 ck + pw;
@@ -633,11 +640,11 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
       }
     };
     // piece = bias + blend of row block rb of layer l (b13 offset boff) -> PB; the z column is the consumers'
-    auto piece_finish = [&](const TabRows &tp, const WsPoint &pt, int boff) {
+    auto piece_finish = [&](const TabRows &tp, const WsPoint &pt, int boff, int region) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 b = *reinterpret_cast<const f32x4 *>(b13 + boff + 8 * q + 4 * h);
-        piece[q * 64] = blend4(tp[q], pt, b);
+        piece0[region * (kWsXBytes / 16) + q * 64] = blend4(tp[q], pt, b);
       }
     };
     // the output of tile (fi, n0): bias + partial sums + layer 4's blended row + z column
@@ -709,7 +716,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         }
         if (!(k & 1)) {  // piece k / 2: row block 4 pw + k / 2 of layer 1 -> PB (read in S(k + 1))
           job_issue(tp, prs_cur, cur, kTableL[1] + 32 * (4 * pw + (k >> 1)));
-          piece_finish(tp, cur, 32 * (4 * pw + (k >> 1)));
+          piece_finish(tp, cur, 32 * (4 * pw + (k >> 1)), 3);
         }
         if (k < 7) {  // chunk k + 1 -> X[(k + 1) & 1] (read in S(k + 1); last read in S(k - 1) / U1)
           job_issue(tp, prs_cur, cur, kTableL[0] + 32 * (4 * (k + 1) + pw));
@@ -721,25 +728,25 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         WS_SYNC();
       }
       // ---------------- T0-T3, U0-U1: split jobs -- loads in one interval, blend + write in a later one ----------------
+      WS_SYNC();  // T0: every region holds a K pair of layer 2 or is being filled with one
 #ifndef MPT_WS_NOPROD
-      piece_finish(tp, cur, kHidden[1] + 32 * (2 * pw));                           // T0: piece 4 -> PB (last read in S7; read in T1)
+      piece_finish(tp, cur, kHidden[1] + 32 * (2 * pw), 2);         // T1: piece 4 -> X[2] (pair 0 was read in T0; read in T2)
       job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw + 1));  //     piece 5 in flight
 #endif
       WS_SYNC();
-      WS_SYNC();  // T1: the consumers read piece 4
 #ifndef MPT_WS_NOPROD
-      piece_finish(tp, cur, kHidden[1] + 32 * (2 * pw + 1));               // T2: piece 5 -> PB (read in T3)
-      job_issue(tp, prs_cur, cur, kTableL[3] + 32 * pw);  //     piece 6 in flight
+      piece_finish(tp, cur, kHidden[1] + 32 * (2 * pw + 1), 0);  // T2: piece 5 -> X[0] (pair 1 was read in T1; read in T3)
+      job_issue(tp, prs_cur, cur, kTableL[3] + 32 * pw);         //     piece 6 in flight
 #endif
       WS_SYNC();
-      WS_SYNC();  // T3: the consumers read piece 5
+      WS_SYNC();  // T3: the consumers read pair 3 in PB and piece 5
 #ifndef MPT_WS_NOPROD
-      piece_finish(tp, cur, kHidden[1] + kHidden[2] + 32 * pw);                                            // U0: piece 6 -> PB (read in U1)
+      piece_finish(tp, cur, kHidden[1] + kHidden[2] + 32 * pw, 3);            // U0: piece 6 -> PB (read in U1)
       if (loc_n.fi >= 0) job_issue(tp, prs_nxt, nxt, kTableL[0] + 32 * pw);  //     the next tile's chunk 0 in flight
 #endif
       WS_SYNC();
 #ifndef MPT_WS_NOPROD
-      if (loc_n.fi >= 0) chunk_finish(tp, nxt, 0, 0);  // U1: -> X[0] (last read in S6)
+      if (loc_n.fi >= 0) chunk_finish(tp, nxt, 0, 0);  // U1: -> X[0] (piece 5 was read in T3)
 #endif
       WS_SYNC();
       prev_fi = loc.fi;

@@ -32,7 +32,7 @@ def main(directory, prefix, command):
     with open(trace) as f:
         for r in csv.DictReader(f):
             # the f32 kernels: 32-point tiles (netG) / 64-point tiles -- not pifu_query16_kernel
-            if ("pifu_query_tab_kernel<1>" in r["Kernel_Name"] or "pifu_query_t32_kernel<1>" in r["Kernel_Name"]
+            if ("pifu_query_tab" in r["Kernel_Name"] or "pifu_query_t32_kernel<1>" in r["Kernel_Name"]
                     or "pifu_query_kernel<256, 1" in r["Kernel_Name"]):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:40],
                              r["Grid_Size_X"], r["Workgroup_Size_X"]))

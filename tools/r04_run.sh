@@ -56,6 +56,40 @@ wspmc)  # counters of the table query kernel: product (ws), round 3's (v1), and 
   unset MONOPORT_ABLATE MONOPORT_TAB_KERNEL
   cat $out/pmc_summary.txt
   ;;
+traffic)  # the PMC passes behind roofline.traffic at 10 and 16 frames per launch (counters only, separate runs)
+  cd /tmp && export TMPDIR=/tmp
+  for b in 10 16; do
+    export MONOPORT_TRAFFIC_BATCH=$b
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$b -- python $R/tools/traffic_probe.py run > $out/pmc_fetch_$b.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$b -- python $R/tools/traffic_probe.py run > $out/pmc_write_$b.log 2>&1
+    (cd $R && python tools/traffic_probe.py parse $out/pmc_fetch_$b $out/pmc_write_$b $out/traffic_$b.json > $out/traffic_parse_$b.log 2>&1)
+    tail -2 $out/pmc_fetch_$b.log | cut -c1-200
+    rm -rf $out/pmc_fetch_$b $out/pmc_write_$b
+  done
+  unset MONOPORT_TRAFFIC_BATCH
+  cd $R
+  python - $out <<'PY'
+import json,sys,os
+out=sys.argv[1]
+by={}
+for b in (10,16):
+    d=json.load(open(os.path.join(out,"traffic_%d.json"%b)))
+    by[str(b)]=d
+merged={"source":"tools/r04_run.sh traffic: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/traffic_probe.py run at 10 and 16 frames per mp_recon_batch (bench.py --steps 20 / default --steps 48)","by_frames_per_launch":by}
+json.dump(merged,open(os.path.join(out,"r04_query_traffic.json"),"w"),indent=1)
+for b,d in by.items():
+    print(b,"frames/launch: avg %.3f GB per launch; per level (GB):"%(d["bytes_per_launch_avg"]/1e9),[round(x/1e9,3) for x in d["bytes_per_level_launch"]], "WRITE KB", [round(x) for x in d["WRITE_SIZE_per_level"]])
+PY
+  ;;
+prof)  # kernel trace + stats of the default bench with the per-launch point counts of the roofline leg
+  cd /tmp && export TMPDIR=/tmp
+  CMD="python bench.py --warmup 5 --no-alt --no-dropin --no-cpu-baseline"
+  MONOPORT_BENCH_LAUNCH_LOG=$out/launch_log.json rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/bench.py --warmup 5 --no-alt --no-dropin --no-cpu-baseline > $out/bench_prof.log 2>&1
+  cd $R
+  python tools/profile_summary.py $out/trace $out/r04_bench "$CMD" 10 $out/launch_log.json > $out/summary.log 2>&1
+  tail -1 $out/bench_prof.log | cut -c1-300; cat $out/summary.log | tail -30
+  rm -rf $out/trace
+  ;;
 tests) run_tests ;;
 bench)
   timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.err

@@ -44,7 +44,7 @@ def counter_rows(directory, counter):
         with open(path) as f:
             for r in csv.DictReader(f):
                 name = r["Kernel_Name"]
-                if r["Counter_Name"] == counter and ("pifu_query_tab_kernel" in name or "pifu_query_t32_kernel" in name
+                if r["Counter_Name"] == counter and ("pifu_query_tab" in name or "pifu_query_t32_kernel" in name
                                                      or "pifu_query_kernel" in name):
                     rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), "t32" in name or "tab" in name))
     rows.sort()
