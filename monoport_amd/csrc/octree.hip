@@ -14,6 +14,7 @@
 //   3. the fused query kernel (query.hip) reads the list and its device-side count, and scatters
 //      exact occupancies straight into the level volume.
 // No host synchronisation anywhere: counts stay on the device (`status`).
+#include <cstdlib>
 #include <cstring>
 
 #include "mp_internal.h"
@@ -52,12 +53,13 @@ size_t recon_scratch_bytes(const int *res, int n_levels) {
 
 // ---- level 0 ---------------------------------------------------------------------------------
 __global__ void iota_nodes_kernel(int r, uint32_t *__restrict__ packed, u64 *__restrict__ ev,
-                                  int w64, int32_t *__restrict__ count) {
+                                  int w64, int32_t *__restrict__ count, int y_major) {
   const int total = r * r * r;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t == 0) *count = total;
   if (t < total) {
-    const int x = t % r, y = (t / r) % r, z = t / (r * r);
+    const int x = t % r, a = (t / r) % r, b = t / (r * r);
+    const int y = y_major ? b : a, z = y_major ? a : b;  // list order (see select_compact_kernel)
     packed[t] = (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20);
   }
   if (t < r * r * w64) {  // every node of level 0 is evaluated
@@ -170,7 +172,19 @@ __global__ __launch_bounds__(256) void upsample_classify_kernel(const float *__r
 // one dz are loaded branch-free (out-of-range rows read row 0 and are masked) so the 3 (2D+1)
 // word loads are in flight together: on the small grids of levels 1-2 the kernel is a handful of
 // waves and purely latency-bound.
-template <int D>
+// The ORDER of the point list is free (results are scattered by node code) and decides what the query
+// kernel's table / feature gathers find in cache: the list is filled in the order of the work items
+// (one atomic per wave, waves start in index order), and an item is (w, z, y) with **y outermost**.  For
+// the reference's turntable cameras (rotation about the y axis, RTL/main.py) world y is image y, so the
+// points of a y slab sample two texel rows whatever their x and z -- a few MB of table rows that stay
+// in the XCD's L2 -- and consecutive tiles of 32 points stay compact in image space.  z-major order
+// (MONOPORT_OCTREE_ORDER=z, the round-3 order) revisits a texel once per z plane, 25 MB of rows apart.
+static bool octree_y_major() {
+  const char *e = getenv("MONOPORT_OCTREE_ORDER");
+  return !(e && e[0] == 'z');
+}
+
+template <int D, bool YMAJOR>
 __global__ __launch_bounds__(256) void select_compact_kernel(
     const u64 *__restrict__ bnd, const u64 *__restrict__ ev_prev, int rp, int w64p,
     u64 *__restrict__ ev, int r, int w64, uint32_t *__restrict__ packed,
@@ -181,8 +195,13 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
   int w = 0, y = 0, z = 0;
   if (item < n_items) {
     w = item % (unsigned)w64;
-    y = (item / (unsigned)w64) % (unsigned)r;
-    z = item / (unsigned)(w64 * r);
+    if (YMAJOR) {
+      z = (item / (unsigned)w64) % (unsigned)r;
+      y = item / (unsigned)(w64 * r);
+    } else {
+      y = (item / (unsigned)w64) % (unsigned)r;
+      z = item / (unsigned)(w64 * r);
+    }
     u64 acc = 0;
     for (int dz = -D; dz <= D; ++dz) {
       const int zz = z + dz;
@@ -219,7 +238,7 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
     const int nbits = min(64, r - 64 * w);
     const u64 in_range = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
     sel = acc & ~done & in_range;
-    ev[item] = done | sel;
+    ev[((long long)z * r + y) * w64 + w] = done | sel;
   }
   // wave-level exclusive prefix of popcounts, one atomic per wave
   const int lane = threadIdx.x & 63;
@@ -248,15 +267,22 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
 static void launch_select(int box, unsigned blocks, hipStream_t st, const u64 *bnd,
                           const u64 *ev_prev, int rp, int w64p, u64 *ev, int r, int w64,
                           uint32_t *packed, int32_t *count) {
-  if (box == 9)
-    hipLaunchKernelGGL(select_compact_kernel<4>, dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp,
-                       w64p, ev, r, w64, packed, count);
-  else if (box == 7)
-    hipLaunchKernelGGL(select_compact_kernel<3>, dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp,
-                       w64p, ev, r, w64, packed, count);
-  else
-    hipLaunchKernelGGL(select_compact_kernel<1>, dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp,
-                       w64p, ev, r, w64, packed, count);
+  const bool ym = octree_y_major();
+#define MP_SELECT(D)                                                                                              \
+  if (ym)                                                                                                         \
+    hipLaunchKernelGGL((select_compact_kernel<D, true>), dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp, w64p, \
+                       ev, r, w64, packed, count);                                                                \
+  else                                                                                                            \
+    hipLaunchKernelGGL((select_compact_kernel<D, false>), dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp, w64p, \
+                       ev, r, w64, packed, count)
+  if (box == 9) {
+    MP_SELECT(4);
+  } else if (box == 7) {
+    MP_SELECT(3);
+  } else {
+    MP_SELECT(1);
+  }
+#undef MP_SELECT
 }
 
 // ---- conflict re-examination (the upstream engine's faster=False mode) ------------------------
@@ -339,7 +365,7 @@ int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int
   if (!prev) {
     const int total = r * r * r;
     hipLaunchKernelGGL(iota_nodes_kernel, dim3((total + 255) / 256), dim3(256), 0, st, r, packed,
-                       ev_cur, w64, count);
+                       ev_cur, w64, count, (int)octree_y_major());
   } else {
     MP_HIP(ctx, hipMemsetAsync(count, 0, sizeof(int32_t), st));
     const long long items = (long long)r * r * w64;
@@ -429,7 +455,7 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
     const int r = res[0], total = r * r * r;
     for (int f = 0; f < n_frames; ++f) {
       hipLaunchKernelGGL(iota_nodes_kernel, dim3((total + 255) / 256), dim3(256), 0, st, r,
-                         packed[f], lv[f][0].ev, words64(r), status[f] + 1);
+                         packed[f], lv[f][0].ev, words64(r), status[f] + 1, (int)octree_y_major());
       QueryItem &q = set.it[f];
       q.out = lv[f][0].occ;
       q.src.stride = (rf - 1) / (r - 1);

@@ -354,6 +354,9 @@ constexpr int kWsLds = kWsTend + kMaxFrames * 4;
 #else
 #define WS_SYNC() __syncthreads()
 #endif
+#ifndef MPT_TAB_AUX
+#define MPT_TAB_AUX 0  // cache policy of the table-row loads (2 = nt: stream past the L2-resident weights)
+#endif
 #ifndef MPT_WS_PRIO
 #define MPT_WS_PRIO 1  // measured: 0.819 -> 0.830 of the roof on 885 k points (3 = the same)
 #endif
@@ -423,6 +426,17 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
   }
   __syncthreads();
   const long long n_tiles = __builtin_amdgcn_readfirstlane(tend[kMaxFrames - 1]);
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own
+  // L2.  Tiles that are neighbours in the list share texels (table rows) and frames, so XCD x takes the
+  // CONTIGUOUS eighth [x T / 8, (x + 1) T / 8) of the tile list and its workgroups walk through it side
+  // by side: a table row fetched into an L2 is reused there instead of being fetched by all eight.
+#ifdef MPT_WS_FLAT_ORDER  // A/B: the plain grid-stride order
+  const long long tile_first = blockIdx.x, tile_step = gridDim.x, tile_end = n_tiles;
+#else
+  const int xcd = blockIdx.x & 7, n_xcd = gridDim.x < 8 ? (int)gridDim.x : 8;  // XCDs this launch reaches
+  const long long tile_step = ((int)gridDim.x - xcd + 7) >> 3;                   // its workgroups on this XCD
+  const long long tile_first = n_tiles * xcd / n_xcd + (blockIdx.x >> 3), tile_end = n_tiles * (xcd + 1) / n_xcd;
+#endif
 
   if (wv < 4) {
     // =============================== consumers: the K loops ===============================
@@ -452,8 +466,8 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     };
     WS_SYNC();  // the producers' first chunk
     int par = 0;
-    for (long long gtile = blockIdx.x;; gtile += gridDim.x, par ^= 1) {
-      if (gtile >= n_tiles) break;
+    for (long long gtile = tile_first;; gtile += tile_step, par ^= 1) {
+      if (gtile >= tile_end) break;
       zb[0] = h == 0 ? zvec[par * P + j] : 0.0f;
       // ---------------- S0-S7: layer 1 += W1[:, chunk k] * (layer-0 chunk k in X[k & 1]); piece k / 2 added on odd k ----------------
       f32x16 acc1[4][1];
@@ -603,8 +617,8 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
           const f32x4 fake = {pt.tw2[k][0], pt.tw2[q][0], pt.zf, (float)row0};
           tp[q][k] = fake;
 #else
-          tp[q][k] = __builtin_bit_cast(f32x4,
-                                        __builtin_amdgcn_raw_buffer_load_b128(prs, pt.to[k], (row0 + 8 * q) * 4, 0));
+          tp[q][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, pt.to[k], (row0 + 8 * q) * 4,
+                                                                                     MPT_TAB_AUX));
 #endif
         }
     };
@@ -688,7 +702,8 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     };
 
     WsPoint cur = {}, nxt;
-    TileLoc loc = locate_tile(tend, blockIdx.x, lane);
+    const TileLoc no_tile = {-1, 0};
+    TileLoc loc = tile_first < tile_end ? locate_tile(tend, tile_first, lane) : no_tile;
     __amdgpu_buffer_rsrc_t prs_cur = table_rsrc(loc.fi >= 0 ? loc.fi : 0), prs_nxt;
     if (loc.fi >= 0) {
       setup_point(loc.fi, loc.n0, cur, 0);
@@ -701,9 +716,9 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     WS_SYNC();  // the first chunk
     int prev_fi = -1, par = 0;
     long long prev_n0 = 0;
-    for (long long gtile = blockIdx.x;; gtile += gridDim.x, par ^= 1) {
+    for (long long gtile = tile_first;; gtile += tile_step, par ^= 1) {
       if (loc.fi < 0) break;
-      const TileLoc loc_n = locate_tile(tend, gtile + gridDim.x, lane);
+      const TileLoc loc_n = gtile + tile_step < tile_end ? locate_tile(tend, gtile + tile_step, lane) : no_tile;
       TabRows tp;
       // ---------------- S0-S7 ----------------
 #pragma unroll

@@ -90,6 +90,33 @@ prof)  # kernel trace + stats of the default bench with the per-launch point cou
   tail -1 $out/bench_prof.log | cut -c1-300; cat $out/summary.log | tail -30
   rm -rf $out/trace
   ;;
+order)  # point-list order of the octree (y-major default | z-major) x tile order of the table kernel: time + traffic
+  for ord in y z; do
+    export MONOPORT_OCTREE_ORDER=$ord
+    echo "== octree order $ord"
+    timeout 300 python tools/tab_ws_probe.py 2>&1 | tail -1
+    MONOPORT_ABLATE=wsflat timeout 300 python tools/tab_ws_probe.py 2>&1 | tail -1
+    (cd /tmp && export TMPDIR=/tmp MONOPORT_TRAFFIC_BATCH=16
+     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf_$ord -- python $R/tools/traffic_probe.py run > $out/pf_$ord.log 2>&1
+     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw_$ord -- python $R/tools/traffic_probe.py run > $out/pw_$ord.log 2>&1)
+    python tools/traffic_probe.py parse $out/pf_$ord $out/pw_$ord $out/traffic_$ord.json | grep -A6 bytes_per_level_launch | tr -d '\n '; echo
+    rm -rf $out/pf_$ord $out/pw_$ord
+  done
+  unset MONOPORT_OCTREE_ORDER
+  ;;
+abtraffic)  # time + level traffic (16 frames per launch) of side builds in $ABLATE next to the product
+  for name in product $ABLATE; do
+    if [ $name = product ]; then unset MONOPORT_ABLATE; else export MONOPORT_ABLATE=$name; fi
+    echo "== $name"
+    timeout 300 python tools/tab_ws_probe.py 2>&1 | tail -1
+    (cd /tmp && export TMPDIR=/tmp MONOPORT_TRAFFIC_BATCH=16
+     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf_$name -- python $R/tools/traffic_probe.py run > $out/pf_$name.log 2>&1
+     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw_$name -- python $R/tools/traffic_probe.py run > $out/pw_$name.log 2>&1)
+    python tools/traffic_probe.py parse $out/pf_$name $out/pw_$name $out/traffic_$name.json | grep -A6 bytes_per_level_launch | tr -d '\n '; echo
+    rm -rf $out/pf_$name $out/pw_$name
+  done
+  unset MONOPORT_ABLATE
+  ;;
 tests) run_tests ;;
 bench)
   timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.err

@@ -24,6 +24,9 @@ BATCH, LEVELS = int(os.environ.get("MONOPORT_TRAFFIC_BATCH", "16")), 5
 
 def run():
     import torch
+    from monoport_amd import _lib
+    if os.environ.get("MONOPORT_ABLATE"):  # a side library of tools/ablate.py
+        _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmp_ablate%s.so" % os.environ["MONOPORT_ABLATE"])
     import bench
     from monoport_amd import synthetic as syn
     from monoport_amd.recon import pifu_calib
