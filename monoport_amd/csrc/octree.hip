@@ -174,11 +174,15 @@ __global__ __launch_bounds__(256) void upsample_classify_kernel(const float *__r
 // waves and purely latency-bound.
 // The ORDER of the point list is free (results are scattered by node code) and decides what the query
 // kernel's table / feature gathers find in cache: the list is filled in the order of the work items
-// (one atomic per wave, waves start in index order), and an item is (w, z, y) with **y outermost**.  For
-// the reference's turntable cameras (rotation about the y axis, RTL/main.py) world y is image y, so the
-// points of a y slab sample two texel rows whatever their x and z -- a few MB of table rows that stay
-// in the XCD's L2 -- and consecutive tiles of 32 points stay compact in image space.  z-major order
-// (MONOPORT_OCTREE_ORDER=z, the round-3 order) revisits a texel once per z plane, 25 MB of rows apart.
+// (one atomic per wave, waves start in index order), and an item is (w, y in slab, z, slab) with SLABS
+// OF kYSlab ROWS OF y OUTERMOST.  For the reference's turntable cameras (rotation about the y axis,
+// RTL/main.py) world y is image y, so the points of a slab sample kYSlab / 2 + 1 texel rows whatever
+// their x and z -- a few MB of table rows that stay in the XCD's L2 -- and consecutive tiles of 32 points
+// stay compact in image space.  z-major order (MONOPORT_OCTREE_ORDER=z, the round-3 order) revisits a
+// texel once per z plane, 25 MB of rows apart.  Inside a slab the items walk y fastest, so a wave still
+// reads whole rows of flag words next to each other (y alone outermost made them 10 KB apart:
+// select_compact 43 -> 125 us at 257^3).
+constexpr int kYSlab = 8;
 static bool octree_y_major() {
   const char *e = getenv("MONOPORT_OCTREE_ORDER");
   return !(e && e[0] == 'z');
@@ -189,19 +193,25 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
     const u64 *__restrict__ bnd, const u64 *__restrict__ ev_prev, int rp, int w64p,
     u64 *__restrict__ ev, int r, int w64, uint32_t *__restrict__ packed,
     int32_t *__restrict__ count) {
-  const unsigned n_items = (unsigned)(r * r * w64);  // <= 1023 * 1023 * 16
+  // items: z-major r * r * w64; slab order ceil(r / kYSlab) * kYSlab * r * w64 (rows past r are empty)
+  const unsigned n_items = (unsigned)((YMAJOR ? (r + kYSlab - 1) / kYSlab * kYSlab : r) * r * w64);  // <= 1024 * 1023 * 16
   const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
   u64 sel = 0;
   int w = 0, y = 0, z = 0;
-  if (item < n_items) {
+  bool live = item < n_items;
+  if (live) {
     w = item % (unsigned)w64;
     if (YMAJOR) {
-      z = (item / (unsigned)w64) % (unsigned)r;
-      y = item / (unsigned)(w64 * r);
+      const unsigned t = item / (unsigned)w64;
+      z = (t / kYSlab) % (unsigned)r;
+      y = (t % kYSlab) + kYSlab * (t / (unsigned)(kYSlab * r));
+      live = y < r;
     } else {
       y = (item / (unsigned)w64) % (unsigned)r;
       z = item / (unsigned)(w64 * r);
     }
+  }
+  if (live) {
     u64 acc = 0;
     for (int dz = -D; dz <= D; ++dz) {
       const int zz = z + dz;
@@ -264,10 +274,11 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
 
 // 9^3, 7^3, 3^3 boxes at levels 1, 2, 3+ (the upstream engine's "faster" schedule)
 
-static void launch_select(int box, unsigned blocks, hipStream_t st, const u64 *bnd,
-                          const u64 *ev_prev, int rp, int w64p, u64 *ev, int r, int w64,
-                          uint32_t *packed, int32_t *count) {
+static void launch_select(int box, hipStream_t st, const u64 *bnd, const u64 *ev_prev, int rp, int w64p, u64 *ev,
+                          int r, int w64, uint32_t *packed, int32_t *count) {
   const bool ym = octree_y_major();
+  const long long items = (long long)(ym ? (r + kYSlab - 1) / kYSlab * kYSlab : r) * r * w64;
+  const unsigned blocks = (unsigned)((items + 255) / 256);
 #define MP_SELECT(D)                                                                                              \
   if (ym)                                                                                                         \
     hipLaunchKernelGGL((select_compact_kernel<D, true>), dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp, w64p, \
@@ -368,12 +379,10 @@ int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int
                        ev_cur, w64, count, (int)octree_y_major());
   } else {
     MP_HIP(ctx, hipMemsetAsync(count, 0, sizeof(int32_t), st));
-    const long long items = (long long)r * r * w64;
     hipLaunchKernelGGL(upsample_classify_kernel,
                        dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp), dim3(256), 0,
                        st, prev, rp, cur, r, balance, bnd, w64);
-    launch_select(box, (unsigned)((items + 255) / 256), st, bnd, ev_prev, rp, words64(rp), ev_cur, r,
-                  w64, packed, count);
+    launch_select(box, st, bnd, ev_prev, rp, words64(rp), ev_cur, r, w64, packed, count);
   }
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
@@ -471,13 +480,12 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
   }
   for (int l = 1; l < n_levels; ++l) {
     const int r = res[l], rp = res[l - 1], w64 = words64(r);
-    const long long items = (long long)r * r * w64;
     for (int f = 0; f < n_frames; ++f) {
       hipLaunchKernelGGL(upsample_classify_kernel,
                          dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp), dim3(256),
                          0, st, lv[f][l - 1].occ, rp, lv[f][l].occ, r, balance, lv[f][l].bnd, w64);
-      launch_select(octree_box_of_level(l), (unsigned)((items + 255) / 256), st, lv[f][l].bnd, lv[f][l - 1].ev, rp,
-                    words64(rp), lv[f][l].ev, r, w64, packed[f], status[f] + 1 + l);
+      launch_select(octree_box_of_level(l), st, lv[f][l].bnd, lv[f][l - 1].ev, rp, words64(rp), lv[f][l].ev, r, w64,
+                    packed[f], status[f] + 1 + l);
       QueryItem &q = set.it[f];
       q.out = lv[f][l].occ;
       q.src.stride = (rf - 1) / (r - 1);

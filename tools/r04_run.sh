@@ -117,6 +117,21 @@ abtraffic)  # time + level traffic (16 frames per launch) of side builds in $ABL
   done
   unset MONOPORT_ABLATE
   ;;
+octree)  # one frame's octree kernels under rocprofv3, by point-list order
+  cd /tmp && export TMPDIR=/tmp
+  for ord in y z; do
+    MONOPORT_OCTREE_ORDER=$ord rocprofv3 --kernel-trace --stats --output-format csv -d $out/oct_$ord -- python $R/tools/octree_probe.py > $out/oct_$ord.log 2>&1
+    echo "== order $ord: $(grep recon $out/oct_$ord.log)"
+    python - $out/oct_$ord <<'PY'
+import csv,glob,sys,os
+for p in glob.glob(os.path.join(sys.argv[1],"**","*kernel_stats.csv"),recursive=True):
+    for r in csv.DictReader(open(p)):
+        if any(k in r["Name"] for k in ("select_compact","upsample","iota","query")):
+            print("   %-46s calls %4s avg %8.1f us" % (r["Name"][:46], r["Calls"], float(r["AverageNs"])/1e3))
+PY
+    rm -rf $out/oct_$ord
+  done
+  ;;
 tests) run_tests ;;
 bench)
   timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.err
