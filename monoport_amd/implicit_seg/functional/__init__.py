@@ -172,6 +172,36 @@ class Seg3dLossless(nn.Module):
         self.last_status, self.last_path = st, "fused"
         return None if int(st[0]) == 0 else volume[None, None]
 
+    def forward_many(self, kwargs_list):
+        """``[self(**kw) for kw in kwargs_list]`` for up to 16 frames at once (monoport_amd extension;
+        the hook of a coalescing recon stage, stage_pipeline.Coalesced).  When the engine is in its
+        trusted state (see ``forward``) every frame is bound through its one-point probe and ALL of
+        them go through one ``mp_recon_batch`` -- every octree level of all frames in one fused-query
+        launch, one host sync for all statuses -- with results identical to the per-frame calls bit
+        for bit.  In any other state (not yet validated, ``validate = "always"``, a re-validation
+        due, a binding that changed) the frames are served one by one by ``forward``."""
+        n = len(kwargs_list)
+        if (n < 2 or n > 16 or not self.faster or self.validate == "always" or self._agreed < self.VALIDATE_CALLS
+                or self._since_check + n >= self.REVALIDATE_EVERY):
+            return [self(**kw) for kw in kwargs_list]
+        probe = torch.zeros((1, 1, 3), dtype=torch.float32, device=self._device_tag.device)
+        bindings = []
+        for kw in kwargs_list:
+            with record_query(capture_only=True) as rec:
+                self.query_func(points=probe, **kw)
+            b = rec.binding
+            if b is None or rec.calls != 1 or self._binding_key(b) != self._trusted_key:
+                return [self(**kw) for kw in kwargs_list]  # forward() re-validates
+            bindings.append(b)
+        b0 = bindings[0]
+        volumes, status = ops.recon_batch(b0.mlp, [b.feat_hwc for b in bindings], [b.calib for b in bindings],
+                                          b0.z_scale, self.b_min[0], self.b_max[0], self.resolutions,
+                                          self.balance_value)
+        st = status.cpu()  # the one host sync of the whole batch
+        self._since_check += n
+        self.last_status, self.last_path = st[-1], "fused"
+        return [None if int(st[i, 0]) == 0 else volumes[i][None, None] for i in range(n)]
+
     def forward_async(self, **kwargs):
         """Fused path only, no host sync and no validation of ``query_func`` (the caller vouches
         that it is a plain MonoPortNet.query call): (volume [R,R,R], status int32[1+levels]) on

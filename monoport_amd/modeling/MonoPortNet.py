@@ -6,6 +6,7 @@ called once per octree level on 10^4..10^5 points -- is ONE hand-written HIP ker
 (csrc/query.hip): projection, in-image mask, depth feature, bilinear feature gather, the
 skip-connected MLP on f32 MFMA, final activation and mask.
 """
+import collections
 import threading
 import weakref
 
@@ -82,9 +83,12 @@ class MonoPortNet(nn.Module):
         self.surface_classifier = _REGISTRY[opt_net.head.IMF](opt_net.head)
         self.projection = _REGISTRY[opt_net.projection]
         self.normalizer = _REGISTRY[opt_net.normalizer.IMF](opt_net.normalizer)
-        self._hwc_cache = None  # (weakrefs of source maps, versions, packed map)
-        self._table_cache = None  # (packed map, its version, mlp, skip table, mlp generation) of the last bind
-        self._served = (None, 0)  # (packed map, query points it has served so far)
+        # per bound feature map, most recent last (a stage pipeline keeps several frames in flight, and a
+        # coalescing recon stage binds up to 16 of them before it launches): key -> (weakrefs of the
+        # source maps, packed channels-last map); id(packed) -> [packed, its version, mlp, skip table or
+        # None, mlp generation, query points served so far]
+        self._hwc_cache = collections.OrderedDict()
+        self._table_cache = collections.OrderedDict()
 
     # ---- encoder ---------------------------------------------------------------------------------
     def filter(self, images, feat_prior=None):
@@ -99,15 +103,20 @@ class MonoPortNet(nn.Module):
         return feats_stages
 
     # ---- hot path --------------------------------------------------------------------------------
+    MAX_BOUND_MAPS = 16  # frames whose packed map / skip table are kept (kMaxFrames of mp_recon_batch)
+
     def _packed_features(self, feats):
         """Channels-last copy of this stage's maps, cached per source tensors so the five octree
         levels of one frame (and repeated calls) pack once."""
         key = tuple((f.data_ptr(), f._version, tuple(f.shape)) for f in feats)
-        c = self._hwc_cache
-        if c is not None and c[0] == key and all(r() is f for r, f in zip(c[1], feats)):
-            return c[2]
+        c = self._hwc_cache.get(key)
+        if c is not None and all(r() is f for r, f in zip(c[0], feats)):
+            self._hwc_cache.move_to_end(key)
+            return c[1]
         packed = ops.pack_features(list(feats))
-        self._hwc_cache = (key, [weakref.ref(f) for f in feats], packed)
+        self._hwc_cache[key] = ([weakref.ref(f) for f in feats], packed)
+        while len(self._hwc_cache) > self.MAX_BOUND_MAPS:
+            self._hwc_cache.popitem(last=False)
         return packed
 
     def bind(self, feats_stages, calibs, n_points=0, for_engine=False):
@@ -128,38 +137,46 @@ class MonoPortNet(nn.Module):
             raise RuntimeError("surface_classifier and the feature maps must be on one GPU "
                                "(RTL/main.py:382-387 moves the features first)")
         packed = self._packed_features(feats)
-        served = (self._served[1] if self._served[0] is packed else 0) + int(n_points)
-        self._served = (packed, served)
-        self._skip_table(mlp, packed, for_engine or served >= ops.SKIP_TABLE_MIN_POINTS)
+        self._skip_table(mlp, packed, int(n_points), for_engine)
         return QueryBinding(self, mlp, packed, calibs, self.normalizer.scale)
 
-    def _skip_table(self, mlp, packed, worth_it=True):
+    def _skip_table(self, mlp, packed, n_points=0, for_engine=True):
         """The skip table of the bound feature map (ops.skip_table: the MLP's products with the
         sampled feature, taken once per texel instead of once per query point), registered for the
         map so that every query of the frame -- this module's and the octree engine's -- blends
         table rows.  A table costs 16 GFLOP / 126 MB whatever follows, the work of ~16 k plain-path
-        points: it is made when the octree engine binds the map (``worth_it``: a reconstruction of
-        ~3e5 points follows) or once the map has served ops.SKIP_TABLE_MIN_POINTS query points;
-        a few small ``query`` calls stay on the plain kernels (the two paths differ by f32
-        rounding, 1-5e-7).  netG heads in exact f32 only; MONOPORT_SKIP_TABLE=off (ops.SKIP_TABLE)
-        switches it off."""
-        c = self._table_cache
+        points: it is made when the octree engine binds the map (a reconstruction of ~3e5 points
+        follows) or once the map has served ops.SKIP_TABLE_MIN_POINTS query points; a few small
+        ``query`` calls stay on the plain kernels (the two paths differ by f32 rounding, 1-5e-7).
+        netG heads in exact f32 only; MONOPORT_SKIP_TABLE=off (ops.SKIP_TABLE) switches it off.
+        The tables of the last MAX_BOUND_MAPS maps stay registered (frames in flight)."""
+        cache = self._table_cache
+        for k in [k for k, e in cache.items()  # entries of recycled / rewritten maps or of other weights
+                  if e[0]._version != e[1] or e[2] is not mlp or e[4] != mlp.generation or not ops.SKIP_TABLE]:
+            e = cache.pop(k)
+            if e[3] is not None:
+                e[3].release()
+        e = cache.get(id(packed))
+        if e is None or e[0] is not packed:
+            e = cache[id(packed)] = [packed, packed._version, mlp, None, mlp.generation, 0]
+        cache.move_to_end(id(packed))
+        e[5] += n_points
         h, w, ch = packed.shape
         wanted = ops.SKIP_TABLE and ch == 256 and mlp.precision == "f32" and (h * w) % 64 == 0
-        if wanted and not worth_it and not (c is not None and c[0] is packed):
-            wanted = False  # not yet: keep whatever state there is for OTHER maps out of the way below
-        # mlp.generation: SurfaceClassifier.packed() re-packs new weights (load_state_dict,
-        # load_legacy_pifu, in-place updates) into the SAME PackedMLP -- the table is stale then
-        if (wanted and c is not None and c[0] is packed and c[1] == packed._version and c[2] is mlp
-                and c[4] == mlp.generation):
-            return
-        if c is not None:
-            c[3].release()
-            self._table_cache = None
-        if not wanted:
-            return
-        # the handle keeps map and table alive and unregisters them when it is dropped
-        self._table_cache = (packed, packed._version, mlp, ops.skip_table(mlp, packed), mlp.generation)
+        if wanted and e[3] is None and (for_engine or e[5] >= ops.SKIP_TABLE_MIN_POINTS):
+            # the handle keeps map and table alive and unregisters them when it is dropped
+            e[3] = ops.skip_table(mlp, packed)
+        while len(cache) > self.MAX_BOUND_MAPS:
+            _, old = cache.popitem(last=False)
+            if old[3] is not None:
+                old[3].release()
+
+    def has_skip_table(self, packed=None):
+        """Whether the most recently bound map (or ``packed``) has a registered skip table."""
+        if not self._table_cache:
+            return False
+        e = self._table_cache.get(id(packed)) if packed is not None else next(reversed(self._table_cache.values()))
+        return e is not None and e[3] is not None
 
     def query(self, feats_stages, points, calibs=None, transforms=None):
         """points [B,3,N] world coords -> [ [B,Cout,N] ] (MonoPortNet.py:48-91, eval mode).

@@ -35,6 +35,24 @@ def forward_vertices(sdf, direction="front"):
     return x[:c], y[:c], z[:c], n[:c]
 
 
+@torch.no_grad()
+def forward_vertices_many(sdfs, direction="front"):
+    """``[forward_vertices(s, direction) for s in sdfs]`` with ONE host sync for all the vertex
+    counts (monoport_amd extension; the hook of a coalescing stage, stage_pipeline.Coalesced)."""
+    raws = [None if s is None else ops.forward_vertices_raw(s, direction) for s in sdfs]
+    live = [r for r in raws if r is not None]
+    counts = torch.cat([r[4] for r in live]).cpu().tolist() if live else []
+    out, k = [], 0
+    for r in raws:
+        if r is None:
+            out.append((None, None, None, None))
+        else:
+            c = int(counts[k])
+            k += 1
+            out.append((r[0][:c], r[1][:c], r[2][:c], r[3][:c]))
+    return out
+
+
 def color_matrix(b_min, b_max, resolution):
     """voxel -> world matrix of RTL/main.py:204-210."""
     mat = np.eye(4, dtype=np.float32)

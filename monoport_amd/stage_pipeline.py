@@ -14,10 +14,20 @@ so this module re-creates the part of it the reconstruction demo relies on (RTL/
 * at most ``max_in_flight`` frames are admitted at once (the reference primes ``2 * num_workers``,
   dataloader.py:776-777, :891).
 
-MI355X-specific addition: each stage thread owns a HIP stream; a frame is handed to the next
-stage together with an event recorded on the producer's stream, and the consumer's stream waits
-on it.  Stages therefore overlap on the GPU (not only on the host) without any
-``synchronize`` call.
+MI355X-specific additions:
+
+* each stage thread owns a HIP stream; a frame is handed to the next stage together with an event
+  recorded on the producer's stream, and the consumer's stream waits on it.  Stages therefore
+  overlap on the GPU (not only on the host) without any ``synchronize`` call;
+* a processor may be a ``Coalesced(fn, fn_many)``: when frames have queued up in front of its stage
+  (the stage is the bottleneck), the stage takes up to ``max_batch`` of them at once and serves them
+  with ONE call of ``fn_many(list) -> list`` -- one batched encoder pass, one ``mp_recon_batch``, one
+  host sync for all their vertex counts -- instead of ``len(list)`` calls of ``fn``.  Per-frame
+  semantics and FIFO order are unchanged (results leave in submission order; with an empty queue a
+  frame is served alone, by ``fn``); an exception inside ``fn_many`` is re-tried frame by frame so
+  that it lands on the frame that caused it.  The reference's stages are one Python thread per
+  frame step on a host that spends most of its time in the GIL; this is what the drop-in surface
+  needs to reach the batched kernels.
 """
 import queue
 import sys
@@ -56,6 +66,17 @@ class StageError:
                            % (self.stage, self.exc_type.__name__, self.exc)) from self.exc
 
 
+class Coalesced:
+    """A stage processor that can serve several queued frames in one call (see the module
+    docstring): ``fn(item) -> item`` and ``fn_many([item, ...]) -> [item, ...]`` (same order)."""
+
+    def __init__(self, fn, fn_many, max_batch=8):
+        self.fn, self.fn_many, self.max_batch = fn, fn_many, max(1, int(max_batch))
+
+    def __call__(self, item):
+        return self.fn(item)
+
+
 class StagePipeline:
     def __init__(self, source, processors, device=None, max_in_flight=2, stage_streams=True):
         """``source``: iterable of input items (the reference's data stream);
@@ -77,8 +98,10 @@ class StagePipeline:
             torch.cuda.set_device(self.device)
             if self.use_streams:
                 stream = torch.cuda.Stream(device=self.device)
+        held = None  # an item taken off the queue while coalescing that has to wait for its turn
         while True:
-            item = q_in.get()
+            item = held if held is not None else q_in.get()
+            held = None
             if item is _END:
                 q_out.put(_END)
                 return
@@ -86,20 +109,49 @@ class StagePipeline:
             if isinstance(payload, StageError):
                 q_out.put((payload, None))
                 continue
+            batch = [item]
+            if isinstance(fn, Coalesced):  # whatever else is ALREADY waiting, up to max_batch frames
+                while len(batch) < fn.max_batch:
+                    try:
+                        nxt = q_in.get_nowait()
+                    except queue.Empty:
+                        break
+                    if nxt is _END or isinstance(nxt[0], StageError):
+                        held = nxt
+                        break
+                    batch.append(nxt)
+
+            def run(items):
+                payloads = [p for p, _ in items]
+                if stream is None:
+                    results = fn.fn_many(payloads) if len(items) > 1 else [fn(payloads[0])]
+                    return [(r, None) for r in results]
+                with torch.cuda.stream(stream):
+                    for p, ev in items:
+                        if ev is not None:
+                            stream.wait_event(ev)
+                        _record_streams(p, stream)
+                    results = fn.fn_many(payloads) if len(items) > 1 else [fn(payloads[0])]
+                    done = torch.cuda.Event()
+                    done.record(stream)
+                return [(r, done) for r in results]
+
             try:
-                if stream is not None:
-                    with torch.cuda.stream(stream):
-                        if event is not None:
-                            stream.wait_event(event)
-                        _record_streams(payload, stream)
-                        result = fn(payload)
-                        done = torch.cuda.Event()
-                        done.record(stream)
-                    q_out.put((result, done))
-                else:
-                    q_out.put((fn(payload), None))
+                outs = run(batch)
+                if len(outs) != len(batch):
+                    raise RuntimeError("fn_many returned %d results for %d frames" % (len(outs), len(batch)))
             except Exception:  # noqa: BLE001 -- forwarded to the consumer like ExceptionWrapper
-                q_out.put((StageError(idx, sys.exc_info()), None))
+                first = sys.exc_info()
+                outs = []
+                if len(batch) == 1:
+                    outs.append((StageError(idx, first), None))
+                for one in (batch if len(batch) > 1 else []):  # frame by frame: the error lands on its frame
+                    try:
+                        outs.extend(run([one]))
+                    except Exception:  # noqa: BLE001
+                        outs.append((StageError(idx, sys.exc_info()), None))
+            for o in outs:
+                q_out.put(o)
 
     def _feeder(self, q0, slots):
         try:

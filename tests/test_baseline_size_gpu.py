@@ -50,7 +50,7 @@ def test_dense64_vs_reference(case, path, monkeypatch):
     out = net.query(feats, pts, calibs=torch.from_numpy(g["calib"]).to(DEV))[0][0, 0].cpu().numpy()
     ref = g[case]
     err = float(np.abs(out - ref).max())
-    assert (net._table_cache is not None) == QUERY_PATHS[path]
+    assert net.has_skip_table() == QUERY_PATHS[path]
     print("dense64 %s [%s path]: max|HIP - reference| = %.3g" % (case, path, err))
     assert np.array_equal((out == 0), (ref == 0)) or case == "out_body"  # identical in-image mask
     assert err <= TOL_REF
@@ -147,7 +147,7 @@ def test_pipeline257_vs_reference(name, path, monkeypatch):
     feats = [[torch.zeros(1, 256, 2, 2, device=DEV)]] * 3 + [[f]]
     sdf = engine(im_feat_list=feats, calib_tensor=calib)
     assert sdf.shape == (1, 1, 257, 257, 257) and engine.last_path == "fused"
-    assert (netG._table_cache is not None) == QUERY_PATHS[path]
+    assert netG.has_skip_table() == QUERY_PATHS[path]
     vol = sdf[0, 0].cpu().numpy()
     _, undecided, n_amb = pipeline257_check(name, vol, None, engine.last_status[1:].numpy(), TOL_REF)
     X, Y, Z, norm = forward_vertices(sdf, direction="front")

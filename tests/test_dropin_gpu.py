@@ -457,13 +457,13 @@ def test_netg_query_uses_the_skip_table_by_default(monkeypatch):
     got = {}
     for flag in (True, False):
         monkeypatch.setattr(ops, "SKIP_TABLE", flag)
-        netG._hwc_cache = None  # a fresh bind (the cache key is the source tensors)
+        netG._hwc_cache.clear()  # a fresh bind (the cache key is the source tensors)
         out = netG.query(feats, pts, calib)[0]
         eng = Seg3dLossless(query_func=query_func, faster=True, **box).to(DEV)
         sdf = eng(feats=feats, calib=calib)
         assert eng.last_path == "fused"
         got[flag] = (out.clone(), sdf.clone(), eng.last_status.clone())
-        assert (netG._table_cache is not None) == flag
+        assert netG.has_skip_table() == flag
     d = (got[True][0] - got[False][0]).abs().max().item()
     print("netG.query: |skip table - plain| = %.3g" % d)
     assert 0 < d <= 2e-6
@@ -489,14 +489,14 @@ def test_reloaded_head_never_meets_a_stale_skip_table(monkeypatch):
     calib = pifu_calib(*syn.scene_camera(35), device=DEV)
     pts = torch.from_numpy(syn.rand_points(30000, 3, 1.0))[None].to(DEV)
     old = netG.query(feats, pts, calib)[0].clone()
-    assert netG._table_cache is not None
+    assert netG.has_skip_table()
     mlp_before = netG.surface_classifier.packed()
     _load_mlp(netG, syn.rand_mlp("G", 91, 2.0))  # other weights, same modules / same PackedMLP
     new_tab = netG.query(feats, pts, calib)[0].clone()
-    assert netG.surface_classifier.packed() is mlp_before and netG._table_cache is not None
+    assert netG.surface_classifier.packed() is mlp_before and netG.has_skip_table()
     monkeypatch.setattr(ops, "SKIP_TABLE", False)
     new_plain = netG.query(feats, pts, calib)[0].clone()
-    assert netG._table_cache is None  # switching the flag off releases the cached table
+    assert not netG.has_skip_table()  # switching the flag off releases the cached table
     d_old = (new_tab - old).abs().max().item()
     d = (new_tab - new_plain).abs().max().item()
     print("reloaded head: |table - plain| = %.3g, |new - old| = %.3g" % (d, d_old))
@@ -532,21 +532,21 @@ def test_small_queries_do_not_build_a_skip_table():
     pts = torch.from_numpy(syn.rand_points(6000, 3, 1.0))[None].to(DEV)
     a = netG.query(feats, pts, calib)[0].clone()
     b = netG.query(feats, pts, calib)[0].clone()
-    assert netG._table_cache is None and torch.equal(a, b)  # 12 k points served: plain path
-    plain = ops.query(netG.surface_classifier.packed(), netG._hwc_cache[2], pts, calib, syn.Z_SCALE)
+    assert not netG.has_skip_table() and torch.equal(a, b)  # 12 k points served: plain path
+    plain = ops.query(netG.surface_classifier.packed(), next(reversed(netG._hwc_cache.values()))[1], pts, calib, syn.Z_SCALE)
     assert torch.equal(a, plain)
     c = netG.query(feats, pts, calib)[0].clone()  # 18 k: the map has earned its table
-    assert netG._table_cache is not None
+    assert netG.has_skip_table()
     assert 0 < (c - a).abs().max().item() <= 2e-6
     # a new map starts over ... unless the octree engine binds it
     feats2 = [[torch.from_numpy(syn.body_feat(256, 128, 128, 5))[None].to(DEV)]]
     netG.query(feats2, pts, calib)
-    assert netG._table_cache is None
+    assert not netG.has_skip_table()
     eng = Seg3dLossless(query_func=lambda points, feats, calib: netG.query(feats, points.permute(0, 2, 1), calib)[0],
                         b_min=np.array([[-1., -1., -1.]]), b_max=np.array([[1., 1., 1.]]),
                         resolutions=[9, 17, 33], faster=True).to(DEV)
     eng(feats=feats2, calib=calib)
-    assert eng.last_path == "fused" and netG._table_cache is not None
+    assert eng.last_path == "fused" and netG.has_skip_table()
 
 
 def test_trusted_query_func_is_validated_again_periodically():
@@ -588,3 +588,58 @@ def test_trusted_query_func_is_validated_again_periodically():
             paths.append(eng.last_path)
     assert "generic" in paths and paths[-1] == "generic"  # caught within REVALIDATE_EVERY frames, stays caught
     assert (((out > 0.5) != (inside > 0.5)).float().mean().item()) > 0.5  # the flipped field is what comes back
+
+
+def test_coalesced_stages_give_the_per_frame_results():
+    """stage_pipeline.Coalesced + Seg3dLossless.forward_many + forward_vertices_many: a recon stage that
+    serves several queued frames with one mp_recon_batch returns, per frame, exactly what the per-frame
+    stage returns (volumes and vertices bit for bit), in FIFO order; an untrusted engine serves the
+    frames one by one."""
+    from monoport_amd.implicit_seg.functional import Seg3dLossless
+    from monoport_amd.modeling import PIFuNetG
+    from monoport_amd.recon import forward_vertices, forward_vertices_many, pifu_calib
+    from monoport_amd.stage_pipeline import Coalesced, StagePipeline
+    netG = PIFuNetG()
+    _load_mlp(netG, syn.body_mlp("G", noise=0.05, seed=81))
+    netG.to(DEV).eval()
+
+    def query_func(points, feats, calib):
+        return netG.query(feats, points.permute(0, 2, 1), calib)[0]
+
+    res = [9, 17, 33, 65]
+    eng = Seg3dLossless(query_func=query_func, b_min=np.array([[-1., -1., -1.]]), b_max=np.array([[1., 1., 1.]]),
+                        resolutions=res, faster=True).to(DEV)
+    frames = [dict(feats=[[torch.from_numpy(syn.body_feat(256, 128, 128, 4 + i))[None].to(DEV)]],
+                   calib=pifu_calib(*syn.scene_camera(10 * i), device=DEV)) for i in range(6)]
+    many0 = eng.forward_many(frames[:3])  # not validated yet: frame by frame through forward()
+    assert eng._agreed == 3 and eng.last_path == "fused"
+    singles = [eng(**f) for f in frames]
+    verts = [forward_vertices(s) for s in singles]
+    batch = eng.forward_many(frames)  # trusted now: one mp_recon_batch
+    assert all(torch.equal(a, b) for a, b in zip(batch, singles)) and all(torch.equal(a, b) for a, b in zip(many0, singles[:3]))
+    for v, w in zip(forward_vertices_many(batch), verts):
+        assert all(torch.equal(a, b) for a, b in zip(v, w))
+    # through the pipeline: the recon stage is held back until five frames wait in front of it
+    import threading
+    gate, sizes = threading.Event(), []
+
+    def hold(d):
+        if d["i"] == 0:
+            gate.wait(10)
+        return d
+
+    def many(ds):
+        sizes.append(len(ds))
+        return [{**d, "sdf": s} for d, s in zip(ds, eng.forward_many([frames[d["i"]] for d in ds]))]
+
+    def source():
+        for i in range(6):
+            yield {"i": i}
+        gate.set()
+
+    stages = [Coalesced(hold, lambda ds: [hold(d) for d in ds], 8),
+              Coalesced(lambda d: {**d, "sdf": eng(**frames[d["i"]])}, many, max_batch=8)]
+    with torch.no_grad():
+        outs = list(StagePipeline(source(), stages, device=DEV, max_in_flight=8))
+    assert [d["i"] for d in outs] == list(range(6)) and max(sizes) > 1
+    assert all(torch.equal(d["sdf"], singles[d["i"]]) for d in outs)

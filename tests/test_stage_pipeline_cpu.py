@@ -85,3 +85,51 @@ def test_none_results_pass_through():
     out = list(StagePipeline(range(4), [lambda x: None if x % 2 else x,
                                         lambda v: None if v is None else v + 10]))
     assert out == [10, None, 12, None]
+
+
+def test_coalesced_stage_serves_queued_frames_together_in_order():
+    """A Coalesced processor takes whatever is already queued in front of its stage (up to max_batch)
+    in ONE fn_many call; results leave in submission order; a frame that arrives alone is served by
+    fn; an exception inside fn_many is re-tried frame by frame and lands on the frame that caused it."""
+    import threading
+    import time
+    from monoport_amd.stage_pipeline import Coalesced, StagePipeline
+    gate = threading.Event()
+    sizes, singles = [], []
+
+    def slow_first(x):  # holds the first frame until the others have queued up behind it
+        if x == 0:
+            gate.wait(5)
+        return x
+
+    def one(x):
+        singles.append(x)
+        if x == 5:
+            raise ValueError("frame five")
+        return x * 10
+
+    def many(xs):
+        sizes.append(len(xs))
+        if 5 in xs:
+            raise ValueError("somewhere in the batch")
+        return [x * 10 for x in xs]
+
+    def source():
+        for i in range(8):
+            yield i
+        time.sleep(0.2)
+        gate.set()
+
+    # stage 0 parks frame 0; frames 1.. cannot overtake it (FIFO), so they queue up in front of stage 0
+    # ... and, once released, arrive at stage 1 in a burst
+    pipe = StagePipeline(source(), [Coalesced(slow_first, lambda xs: [slow_first(x) for x in xs], 8),
+                                    Coalesced(one, many, max_batch=4)], device=None, max_in_flight=8)
+    got, err = [], None
+    try:
+        for v in pipe:
+            got.append(v)
+    except RuntimeError as e:
+        err = e
+    assert got == [0, 10, 20, 30, 40]  # FIFO, up to the failing frame
+    assert err is not None and "frame five" in str(err) and isinstance(err.__cause__, ValueError)
+    assert max(sizes) > 1 and max(sizes) <= 4  # frames were served together

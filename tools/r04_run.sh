@@ -132,6 +132,14 @@ PY
     rm -rf $out/oct_$ord
   done
   ;;
+dropin)
+  timeout 900 python bench.py --mode dropin > $out/dropin.json 2> $out/dropin.err; tail -c 300 $out/dropin.err
+  python - $out/dropin.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("coalesced", round(d["value"],1), d["passes"], "| per-frame stages", round(d["per_frame_stages"]["value"],1), d["per_frame_stages"]["passes"], "| latency", round(d["latency_ms_single_frame"],2))
+PY
+  ;;
 tests) run_tests ;;
 bench)
   timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.err
