@@ -168,6 +168,7 @@ int launch_copy(mp_ctx *ctx, const float *src, float *dst, long long n, hipStrea
 int launch_absmax(mp_ctx *ctx, const float *src, long long n, unsigned int *out_bits, hipStream_t st);
 int launch_absmax_accumulate(mp_ctx *ctx, const float *src, long long n, unsigned int *out_bits,
                              hipStream_t st);
+bool find_skip_tables(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, QuerySet &tset);
 // query_small.hip: the netG f32 query on 32-point tiles, for launches of fewer than
 // kSmallGateTiles 64-point tiles
 constexpr int kSmallGateTiles = 2048;

@@ -453,15 +453,7 @@ static int launch_query_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h,
   bool table = false;
   QuerySet tset;  // the set with the layer-0 tables filled in (mp_skip_table), if every frame has one
   if constexpr (C == 256 && !DIRECT) {
-    if (!ctx->skip_tables.empty()) {
-      tset = set;
-      table = true;
-      for (int f = 0; f < set.n && table; ++f) {
-        auto it = ctx->skip_tables.find(set.it[f].feat);
-        table = it != ctx->skip_tables.end() && it->second.mlp_buf == m.buf && it->second.h == h && it->second.w == w;
-        if (table) tset.it[f].l0 = it->second.table;
-      }
-    }
+    table = find_skip_tables(ctx, m, set, h, w, tset);
     gate = query_small_gate();
     if (gate == 1) {
       small = 1;
@@ -495,6 +487,19 @@ static int launch_query_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h,
   }
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
+}
+
+// tset = set with the skip table of every frame's feature map filled in; false unless EVERY map has a table
+// registered that was made with this head and map size (mp_skip_table)
+bool find_skip_tables(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, QuerySet &tset) {
+  if (ctx->skip_tables.empty()) return false;
+  tset = set;
+  for (int f = 0; f < set.n; ++f) {
+    auto it = ctx->skip_tables.find(set.it[f].feat);
+    if (it == ctx->skip_tables.end() || it->second.mlp_buf != m.buf || it->second.h != h || it->second.w != w) return false;
+    tset.it[f].l0 = it->second.table;
+  }
+  return true;
 }
 
 int launch_query_set(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,

@@ -48,6 +48,9 @@
 // software-pipelined layer-0/1 loop over 32-row chunks (6.97 vs 6.65 ms), MP16_CS=2 (column split,
 // duplicated loads: 9.3 ms) and the skip-connection MFMAs of layer 1 issued under the layer-0
 // conversion (correct, the interleave comes out as written, neutral: 6.60-6.62 vs 6.57-6.59 ms).
+#include <cstdlib>
+#include <type_traits>
+
 #include "mp_internal.h"
 #include "query_common.h"
 
@@ -123,10 +126,17 @@ __device__ __forceinline__ void seg_prefetch16(AFrag (&ring)[PF + 1][MR], const 
 // acc += A * B over n_groups k16-steps.  b: LDS address of this lane's point row for column block
 // 0 (+ n * 32 * ROWB for block n); the hi slot of group g is ((2g + hh) ^ (p & 15)) << 4 = (2g ^
 // swz) << 4 with swz = hh ^ (p & 15), the lo slot sits LO bytes further.
-template <int MR, int NR, int PF, int ROWB, int LO_SLOT, int TERMS>
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// hook(g) is called behind the MFMAs of every RS-th k16 group g (g = RS - 1, 2 RS - 1, ...): work that is
+// independent of this segment (the table blends of query16's skip-table variant) placed INSIDE the K loop,
+// so that its loads are in flight and its VALU work issues between runs of MFMAs
+template <int MR, int NR, int PF, int ROWB, int LO_SLOT, int TERMS, typename Hook = NoHook>
 __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[PF + 1][MR],
                                            const WStream &ws, int a, int rb_stride, int n_groups,
-                                           const unsigned char *b, int swz) {
+                                           const unsigned char *b, int swz, Hook hook = Hook()) {
   constexpr int RS = PF + 1;
   // B operands are double-buffered too: the ds_reads of group g+1 are issued before the MFMAs of
   // group g (a lone wave per SIMD has nobody to hide the ~130-cycle LDS latency behind)
@@ -211,6 +221,7 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
         if (NM > NV + ND) __builtin_amdgcn_sched_group_barrier(0x008, NM - NV - ND, 0);
       }
 #endif
+      if (r == RS - 1) hook(g);
     }
   }
 }
@@ -721,6 +732,355 @@ __global__ __launch_bounds__(kThreads16 * CS, NB >= 3 ? CS : 2) void pifu_query1
   }
 }
 
+// ---- round 4: the split-precision query through the SKIP TABLE of the feature map ---------------------
+// query_table.hip's observation applied here: the products of weights with the sampled feature (layer 0
+// and the skip segments of layers 1-4, 42 % of a point's multiply-adds and of this kernel's weight
+// stream, which is what bounds it) are taken once per texel by skip_table_kernel -- in exact f32, from
+// the f32 weights, whatever the precision of the hidden GEMMs -- and a point blends four table rows.
+// The 96 KB of split features, their gather, layer 0's MFMAs and every skip-segment MFMA are gone; what
+// is left on the matrix pipe is 1024 -> 512 -> 256 -> 128 on split-f16 operands and the z columns.
+//   * layer 0: lrelu(b0 + z w0z + blend(T0 rows)) in f32 on the VALU, split into halves, written to the
+//     128-row hidden chunk of the NEXT K step (the chunk buffer is double-buffered now: one barrier per
+//     chunk); the table loads of a tile-blend (32 rows x 32 points: 16 loads per lane) are issued one
+//     hook ahead INSIDE layer 1's K loop (seg_main16's hook) and blended two k16 groups later;
+//   * skip rows of layers 1-3: blended when the layer's accumulators are initialised, S_l (bias + blend),
+//     the three column blocks of a row block in flight together (exposed latency, ~1 us per row block:
+//     inside the K loops the tile index of an accumulator register would have to be known at run time);
+//   * layer 4's feature row is blended in the final reduction.
+// Same tile (96 points), same four waves with 512 registers each, one workgroup per CU.
+typedef f32x4 TabRows16[4][4];  // [q][tap]
+typedef float f32x2_16 __attribute__((ext_vector_type(2)));
+constexpr int kQ16TabHb = 96 * kHRow128;                       // one 128-row chunk of the 96-point tile
+constexpr int kQ16TabLds = 2 * kQ16TabHb + kHidden[0] * 8;      // two chunks + layer 0's [bias | z weight] table
+
+template <int COUT, int TERMS>
+__global__ __launch_bounds__(kThreads16, 1) void pifu_query16_tab_kernel(MlpPack mlp32, MlpPack16 mlp, int fh, int fw,
+                                                                        float z_scale, int act, QuerySet set) {
+  constexpr int NB = 3, P = 96;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *hb = smem;  // hb[2]
+  float *bz0 = reinterpret_cast<float *>(smem + 2 * kQ16TabHb);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hh = lane >> 5;
+  const int swz = hh ^ (j & 15);
+  const float *wbase = mlp32.base;
+  const WStream w32 = make_wstream(mlp32.base, mlp32.n_floats, lane);
+  const WStream ws = make_wstream(static_cast<const float *>(mlp.base), mlp.n16 * 4, lane);
+  for (int i = tid; i < kHidden[0]; i += kThreads16) {
+    bz0[(i >> 2) * 8 + (i & 3)] = (wbase + mlp32.bias[0])[i];
+    bz0[(i >> 2) * 8 + 4 + (i & 3)] = (wbase + mlp32.az[0])[(i >> 5) * 64 + (i & 31)];
+  }
+  __syncthreads();
+
+  for (long long gtile = blockIdx.x;; gtile += gridDim.x) {
+    int fi = -1;
+    long long tile0 = 0;
+    {
+      long long acc = 0;
+#pragma unroll
+      for (int f = 0; f < kMaxFrames; ++f) {
+        if (f < set.n) {
+          const PointSrc &s = set.it[f].src;
+          const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
+          const long long t = (nf + P - 1) / P;
+          if (fi < 0 && gtile < acc + t) {
+            fi = f;
+            tile0 = acc;
+          }
+          acc += t;
+        }
+      }
+    }
+    if (fi < 0) break;
+    const QueryItem &item = set.it[fi];
+    const float *__restrict__ calib = item.calib;
+    float *__restrict__ out = item.out;
+    const PointSrc &src = item.src;
+    const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
+    const long long n0 = (gtile - tile0) * P;
+    const __amdgpu_buffer_rsrc_t prs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(item.l0), 0, fh * fw * kTableRows * 4, 0x00020000);
+
+    // ---------------- this lane's three points (one per column block) ----------------
+    int to[NB][4];
+    f32x2_16 tw2[NB][4];
+    float zf[NB];
+    ZPair zc[NB];
+    {
+      float cal[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) cal[i] = calib[i];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const long long pn = n0 + 32 * n + j;
+        float px = 0, py = 0, pz = 0, x, y, z;
+        uint32_t code;
+        if (pn < n_pts) load_point(src, pn, px, py, pz, code);
+        project(cal, px, py, pz, x, y, z);
+        zf[n] = pn < n_pts ? __fmul_rn(z, z_scale) : 0.0f;
+        const float zm = hh == 0 ? zf[n] : 0.0f;  // B operand of the z column: k = 0 of lanes 0-31
+        zc[n].hi = (_Float16)zm;
+        zc[n].lo = (_Float16)(zm - (float)zc[n].hi);
+        const Taps t = make_taps(x, y, fh, fw, kTableRows, pn < n_pts && in_image(x, y));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          to[n][k] = (int)t.o[k] * 4 + 16 * hh;
+          tw2[n][k] = (f32x2_16)(t.w[k]);
+        }
+      }
+    }
+    auto rows_issue = [&](TabRows16 &tp, int n, int row0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          tp[q][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, to[n][k], (row0 + 8 * q) * 4, 0));
+    };
+    auto blend4 = [&](const f32x4 (&t)[4], int n, f32x4 v) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 w = {tw2[n][k][0], tw2[n][k][1], tw2[n][k][0], tw2[n][k][1]};
+        v = __builtin_elementwise_fma(t[k], w, v);
+      }
+      return v;
+    };
+    // layer-0 rows of block rb for column block n: lrelu(b0 + z w0z + blend), split, -> chunk buffer hbuf
+    auto l0_finish = [&](const TabRows16 &tp, int n, int rb, unsigned char *hbuf) {
+      f32x16 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 *bz = reinterpret_cast<const f32x4 *>(bz0 + (8 * rb + 2 * q + hh) * 8);
+        const f32x4 x = blend4(tp[q], n, __builtin_elementwise_fma(bz[1], (f32x4)(zf[n]), bz[0]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[4 * q + i] = x[i];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) convert_store_q128(hbuf, v, q, wv, n, j, hh, 1.0f);
+    };
+    // acc += S * blend(rows) : the skip rows of a layer, into an accumulator tile that holds S * (...)
+    auto skip_finish = [&](f32x16 &acc, const TabRows16 &tp, int n, float S) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const f32x4 x = blend4(tp[q], n, z4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * q + i] = fmaf(x[i], S, acc[4 * q + i]);
+      }
+    };
+
+    // accumulator tiles of a layer start as S (bias + blended skip rows): the table loads of the NB tiles of
+    // one row block in flight together (three sets of 64 registers; this is straight-line code once per
+    // tile, before the K loops need their rings -- the rows inside the K loops would want the tile index
+    // of an accumulator register at run time)
+    auto init_skip = [&](f32x16 (&acc)[NB], int l, int rb, float S) {
+      init_from_bias16(acc[0], w32, mlp32.bias[l] + 32 * rb, S);
+#pragma unroll
+      for (int n = 1; n < NB; ++n) acc[n] = acc[0];
+      TabRows16 tp[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) rows_issue(tp[n], n, kTableL[l] + 32 * rb);
+#pragma unroll
+      for (int n = 0; n < NB; ++n) skip_finish(acc[n], tp[n], n, S);
+      __builtin_amdgcn_sched_barrier(0);  // one row block at a time
+    };
+
+    // ---------------- layers 0 + 1, fused over 128-row chunks of layer 0 ----------------
+    f32x16 acc1[4][NB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) init_skip(acc1[m], 1, 4 * wv + m, mlp.scale[1]);
+    {
+      const int rs1 = (kHidden[0] / 16) * 128;
+      const int a1 = mlp.ah[1] + (4 * wv) * rs1;
+      TabRows16 tpa;
+      // chunk 0 -> hb[0] (its loads are exposed once per tile)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        rows_issue(tpa, n, kTableL[0] + 32 * wv);
+        l0_finish(tpa, n, wv, hb);
+      }
+      __syncthreads();
+      AFrag ring1[2][4];
+      // one chunk: layer 1 += W1[:, chunk ck] * hb[ck & 1]; under it the three tile-blends of chunk ck + 1
+      // -> hb[(ck + 1) & 1]: loads issued one hook (two k16 groups = 2300 cycles of MFMAs) ahead.
+      // (Also built: the chunk as one straight-line block with a sched_group_barrier pipeline that puts 4
+      // non-MFMA instructions behind every MFMA -- slower, 4.60 vs 4.37 ms per 885 k points.)
+#pragma unroll 1
+      for (int ck = 0; ck < kHidden[0] / 128; ++ck) {
+        const bool more = ck < kHidden[0] / 128 - 1;
+        const int rbn = 4 * (ck + 1) + wv;
+        unsigned char *nxt = hb + ((ck + 1) & 1) * kQ16TabHb;
+        seg_prefetch16<4, 1, TERMS>(ring1, ws, a1 + ck * 8 * 128, rs1, 8);
+        if (more) rows_issue(tpa, 0, kTableL[0] + 32 * rbn);
+        auto hook = [&](int g) {
+          if (!more) return;
+          if (g == 1) {
+            l0_finish(tpa, 0, rbn, nxt);
+            rows_issue(tpa, 1, kTableL[0] + 32 * rbn);
+          } else if (g == 3) {
+            l0_finish(tpa, 1, rbn, nxt);
+            rows_issue(tpa, 2, kTableL[0] + 32 * rbn);
+          } else if (g == 5) {
+            l0_finish(tpa, 2, rbn, nxt);
+          }
+        };
+        seg_main16<4, NB, 1, kHRow128, 16, TERMS>(acc1, ring1, ws, a1 + ck * 8 * 128, rs1, 8,
+                                                  hb + (ck & 1) * kQ16TabHb + j * kHRow128, swz, hook);
+        __syncthreads();
+      }
+      gemm_z16<4, NB, TERMS>(acc1, ws, mlp.az[1] + (4 * wv) * 128, zc);
+      const float inv1 = 1.0f / mlp.scale[1];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) finish16(acc1[m][n], inv1);
+    }
+
+    // ---------------- layer 2: rows [64 wv, +64); K = 512 hidden in 8 chunks of 64 (16 rows from each wave) ----------------
+    f32x16 acc2[2][NB];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) init_skip(acc2[m], 2, 2 * wv + m, mlp.scale[2]);
+    {
+      const int rs2 = (kHidden[1] / 16) * 128;
+      const int a2 = mlp.ah[2] + (2 * wv) * rs2;
+      AFrag ring2[2][2];
+      seg_prefetch16<2, 1, TERMS>(ring2, ws, a2, rs2, 4);
+#pragma unroll
+      for (int n = 0; n < NB; ++n) store_hidden16_part(hb, acc1[0][n], 0, wv, n, j, hh);
+      __syncthreads();
+#pragma unroll
+      for (int ck = 0; ck < 8; ++ck) {
+        if (ck < 7) {  // the next chunk -> the other buffer (its readers passed the barrier)
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+            store_hidden16_part(hb + ((ck + 1) & 1) * kQ16TabHb, acc1[(ck + 1) >> 1][n], (ck + 1) & 1, wv, n, j, hh);
+        }
+        seg_main16<2, NB, 1, kHRow, 8, TERMS>(acc2, ring2, ws, a2 + ck * 4 * 128, rs2, 4,
+                                              hb + (ck & 1) * kQ16TabHb + j * kHRow, swz);
+        if (ck < 7) seg_prefetch16<2, 1, TERMS>(ring2, ws, a2 + (ck + 1) * 4 * 128, rs2, 4);
+        __syncthreads();
+      }
+      gemm_z16<2, NB, TERMS>(acc2, ws, mlp.az[2] + (2 * wv) * 128, zc);
+      const float inv2 = 1.0f / mlp.scale[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) finish16(acc2[m][n], inv2);
+    }
+
+    // ---------------- layer 3: rows [32 wv, +32); K = 256 hidden in 4 chunks ----------------
+    f32x16 acc3[1][NB];
+    init_skip(acc3[0], 3, wv, mlp.scale[3]);
+    {
+      const int a3 = mlp.ah[3] + wv * (kHidden[2] / 16) * 128;
+      AFrag ring3[4][1];
+      seg_prefetch16<1, 3, TERMS>(ring3, ws, a3, 0, 4);
+#pragma unroll
+      for (int n = 0; n < NB; ++n) store_hidden16_part(hb, acc2[0][n], 0, wv, n, j, hh);
+      __syncthreads();
+#pragma unroll
+      for (int ck = 0; ck < 4; ++ck) {
+        if (ck < 3) {
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+            store_hidden16_part(hb + ((ck + 1) & 1) * kQ16TabHb, acc2[(ck + 1) >> 1][n], (ck + 1) & 1, wv, n, j, hh);
+        }
+        seg_main16<1, NB, 3, kHRow, 8, TERMS>(acc3, ring3, ws, a3 + ck * 4 * 128, 0, 4,
+                                              hb + (ck & 1) * kQ16TabHb + j * kHRow, swz);
+        if (ck < 3) seg_prefetch16<1, 3, TERMS>(ring3, ws, a3 + (ck + 1) * 4 * 128, 0, 4);
+        __syncthreads();
+      }
+      gemm_z16<1, NB, TERMS>(acc3, ws, mlp.az[3] + wv * 128, zc);
+      const float inv3 = 1.0f / mlp.scale[3];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) finish16(acc3[0][n], inv3);
+    }
+
+    // ---------------- layer 4 on the VALU: hidden part per wave, table row + z in the reduction ----------------
+    float *red = reinterpret_cast<float *>(hb);  // red[wave][o][p]; both chunk buffers are idle (last barrier above)
+    constexpr int K4 = (kHidden[3] + 256 + 1 + 3) & ~3;
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+      const float *w4 = wbase + mlp32.w4 + o * K4 + 32 * wv + 4 * hh;
+      float sv[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) sv[n] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 wq = *reinterpret_cast<const f32x4 *>(w4 + 8 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int n = 0; n < NB; ++n) sv[n] = fmaf(wq[i], acc3[0][n][4 * q + i], sv[n]);
+      }
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        sv[n] += __shfl_xor(sv[n], 32);
+        if (hh == 0) red[(wv * COUT + o) * P + 32 * n + j] = sv[n];
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < COUT * P; idx += kThreads16) {
+      const int o = idx / P, p = idx % P;
+      const long long n = n0 + p;
+      if (n < n_pts) {
+        float v = (wbase + mlp32.bias[4])[o];
+#pragma unroll
+        for (int part = 0; part < 4; ++part) v += red[(part * COUT + o) * P + p];
+        float cal[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cal[i] = calib[i];
+        float px, py, pz, x, y, z;
+        uint32_t code;
+        load_point(src, n, px, py, pz, code);
+        project(cal, px, py, pz, x, y, z);
+        const bool inside = in_image(x, y);
+        const Taps t = make_taps(x, y, fh, fw, kTableRows, inside);
+        const float *row = item.l0 + kTableL[4] + o;
+        v += fmaf(row[t.o[3]], t.w[3], fmaf(row[t.o[2]], t.w[2], fmaf(row[t.o[1]], t.w[1], __fmul_rn(row[t.o[0]], t.w[0]))));
+        v = fmaf((wbase + mlp32.w4)[o * K4 + kHidden[3] + 256], __fmul_rn(z, z_scale), v);
+        v = inside ? activate(v, act) : 0.0f;  // MonoPortNet.py:89
+        if (src.packed) {
+          const int ix = code & 1023u, iy = (code >> 10) & 1023u, iz = code >> 20;
+          out[((long long)iz * src.level_res + iy) * src.level_res + ix] = v;
+        } else {
+          out[o * src.out_stride + n] = v;
+        }
+      }
+    }
+    __syncthreads();  // red / hb are rewritten by the next tile
+  }
+}
+
+template <int COUT, int TERMS>
+static int launch_query16_tab_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
+                                long long max_points, bool device_counts, hipStream_t st) {
+  constexpr int P = 96;
+  auto kern = pifu_query16_tab_kernel<COUT, TERMS>;
+  const void *kern_id = reinterpret_cast<const void *>(kern);
+  if (!ctx->lds_attr_done.count(kern_id)) {
+    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, kQ16TabLds));
+    ctx->lds_attr_done.insert(kern_id);
+  }
+  if (max_points <= 0) return MP_OK;
+  const long long tiles = (max_points + P - 1) / P + (set.n - 1);
+  const long long resident = (long long)ctx->n_cu;
+  const long long grid = device_counts ? (tiles < resident ? tiles : resident)
+                                       : (tiles < 8 * resident ? tiles : 8 * resident);
+  const bool prof = 2 * (ctx->prof_used + 1) <= (int)ctx->prof_events.size();
+  if (prof) MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], st));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads16), kQ16TabLds, st, m.pack(), m.pack16(), h, w, z_scale,
+                     m.act, set);
+  if (prof) {
+    MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], st));
+    ++ctx->prof_used;
+  }
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
 template <int COUT, int TERMS, int NB, int CS>
 static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w,
                             float z_scale, long long max_points, bool device_counts,
@@ -753,6 +1113,28 @@ static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int 
 int launch_query16(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
                    long long max_points, bool device_counts, hipStream_t st) {
   if (m.c != 256) return fail(ctx, MP_ERR_UNSUPPORTED, "f16x3 query kernel is built for C = 256");
+  // Through the skip tables when every map has one -- for f16x3 only by default: measured on 885 k lattice points /
+  // a 16-frame reconstruction, f16x3 5.14 -> 4.37 ms / 1.99 -> 1.93 ms per frame; f16w 3.63 -> 3.68 / 1.53 -> 1.69
+  // and plain f16 2.69 -> 3.28 / 1.25 -> 1.54 LOSE (fewer MFMAs and fragments to save, the same blends to pay:
+  // a wave that is alone on its SIMD pays for every VALU and VMEM instruction with matrix-pipe time).
+  // MONOPORT_TAB16=all routes every precision (tests, tools/tab16_probe.py), =off none.
+  const char *t16 = getenv("MONOPORT_TAB16");
+  const bool want_tab = t16 && t16[0] == 'a' ? true : t16 && t16[0] == 'o' ? false : m.precision == MP_PREC_F16X3;
+  QuerySet tset;
+  if (want_tab && MP16_NB == 3 && MP16_CS == 1 && find_skip_tables(ctx, m, set, h, w, tset)) {
+    if ((long long)h * w * kTableRows * 4 >= (1LL << 31))
+      return fail(ctx, MP_ERR_UNSUPPORTED, "table query: %dx%d map is too large for 32-bit table offsets", h, w);
+#define MP_Q16TCASE(CO, PREC, TERMS) \
+  if (m.cout == CO && m.precision == PREC)   \
+    return launch_query16_tab_t<CO, TERMS>(ctx, m, tset, h, w, z_scale, max_points, device_counts, st);
+    MP_Q16TCASE(1, MP_PREC_F16X3, 3)
+    MP_Q16TCASE(3, MP_PREC_F16X3, 3)
+    MP_Q16TCASE(1, MP_PREC_F16W, 2)
+    MP_Q16TCASE(3, MP_PREC_F16W, 2)
+    MP_Q16TCASE(1, MP_PREC_F16, 1)
+    MP_Q16TCASE(3, MP_PREC_F16, 1)
+#undef MP_Q16TCASE
+  }
 #define MP_Q16CASE(CO, PREC, TERMS)                                                         \
   if (m.cout == CO && m.precision == PREC)                                                 \
     return launch_query16_t<CO, TERMS, MP16_NB, MP16_CS>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);

@@ -148,7 +148,8 @@ class MonoPortNet(nn.Module):
         points: it is made when the octree engine binds the map (a reconstruction of ~3e5 points
         follows) or once the map has served ops.SKIP_TABLE_MIN_POINTS query points; a few small
         ``query`` calls stay on the plain kernels (the two paths differ by f32 rounding, 1-5e-7).
-        netG heads in exact f32 only; MONOPORT_SKIP_TABLE=off (ops.SKIP_TABLE) switches it off.
+        netG heads (C = 256), any precision of the hidden GEMMs -- the table itself is always exact f32;
+        MONOPORT_SKIP_TABLE=off (ops.SKIP_TABLE) switches it off.
         The tables of the last MAX_BOUND_MAPS maps stay registered (frames in flight)."""
         cache = self._table_cache
         for k in [k for k, e in cache.items()  # entries of recycled / rewritten maps or of other weights
@@ -162,7 +163,7 @@ class MonoPortNet(nn.Module):
         cache.move_to_end(id(packed))
         e[5] += n_points
         h, w, ch = packed.shape
-        wanted = ops.SKIP_TABLE and ch == 256 and mlp.precision == "f32" and (h * w) % 64 == 0
+        wanted = ops.SKIP_TABLE and ch == 256 and (h * w) % 64 == 0
         if wanted and e[3] is None and (for_engine or e[5] >= ops.SKIP_TABLE_MIN_POINTS):
             # the handle keeps map and table alive and unregisters them when it is dropped
             e[3] = ops.skip_table(mlp, packed)

@@ -130,7 +130,7 @@ class FrameSlot:
         if not self.hwc_direct:
             for b in range(n):
                 ops.pack_features(feat[b:b + 1], out=self.feats_hwc[b])
-        if self.tables is not None and mlp.precision == "f32":
+        if self.tables is not None:  # every precision of a netG head blends table rows (query_table.hip, query16.hip)
             # (re)made after every encoder pass; the handle of the previous pass unregisters the same
             # pointers only if they still point at its table views, so dropping it here is harmless
             self._table_handle = ops.skip_table_batch(mlp, self.feat_hwc_all[:n], out=self.tables[:n])

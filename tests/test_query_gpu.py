@@ -496,3 +496,48 @@ def test_skip_table_registry_semantics(ops, oracle):
         ops.skip_table(mlp_c, ops.pack_features(torch.zeros(1, 512, 64, 64, device=dev)))
     with pytest.raises(MonoportError, match="skip table"):
         ops.skip_table(mlp, ops.pack_features(torch.zeros(1, 256, 10, 10, device=dev)))
+
+
+@pytest.mark.parametrize("precision,tol64", [("f16x3", None), ("f16w", 3e-4), ("f16", 5e-3)])
+@pytest.mark.parametrize("name", ["query_G_rand", "query_G_body"])
+def test_f16_kernels_through_the_skip_table(ops, oracle, name, precision, tol64, monkeypatch):
+    """Round 4: the split-precision kernels blend the (exact f32) skip table too (pifu_query16_tab_kernel):
+    layer 0 and the skip rows come from the table, the hidden GEMMs run on f16 MFMA as before.  f16x3 is
+    held to the f32 bars (1e-4 against the reference, no noisier than the reference's own fp32 evaluation,
+    within 2e-6 of the exact-f32 table path); f16w / f16 to the looser bounds of their plain kernels --
+    and they may only get BETTER, since 42 % of the products are now exact f32.  (Only f16x3 takes this
+    kernel by default -- it is the one precision that gets faster; MONOPORT_TAB16=all routes the others.)"""
+    monkeypatch.setenv("MONOPORT_TAB16", "all")
+    g = load_golden(name)
+    kind, layers, f, p = query_inputs(name)
+    dev = "cuda:0"
+    mlp = ops.PackedMLP.from_layers(dev, layers, syn.LAST_OP[kind])
+    fh = ops.pack_features(torch.from_numpy(f)[None].to(dev))
+    pts = torch.from_numpy(p)[None].to(dev)
+    cal = torch.from_numpy(g["calib"]).to(dev)
+    ref64 = oracle.query(f, p, g["calib"][0], layers, syn.LAST_OP[kind], syn.Z_SCALE, precision="f64")
+    mlp.set_precision(precision)
+    plain16 = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
+    try:
+        table = ops.skip_table(mlp, fh)
+        out = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
+        for n in (1, 95, 96, 97, 1000):  # ragged tails of the 96-point tile
+            part = ops.query(mlp, fh, pts[:, :, :n].contiguous(), cal, syn.Z_SCALE)[0].cpu().numpy()
+            assert np.array_equal(part, out[:, :n]), n
+        mlp.set_precision("f32")
+        tab32 = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)[0].cpu().numpy()
+    finally:
+        ops.skip_table_release(mlp.ctx)
+    assert np.isfinite(out).all() and not np.array_equal(out, plain16)  # the table kernel ran
+    err, err_plain, err_ref = np.abs(out - ref64).max(), np.abs(plain16 - ref64).max(), np.abs(g["out"] - ref64).max()
+    print("%s %s through the table: |gpu-f64| %.3g (plain %s kernel %.3g, reference %.3g), |%s table - f32 table| %.3g"
+          % (name, precision, err, precision, err_plain, err_ref, precision, np.abs(out - tab32).max()))
+    if precision == "f16x3":
+        assert np.abs(out - g["out"]).max() <= TOL_REF
+        assert err <= max(2 * err_ref, 1e-5) and np.abs(out - tab32).max() <= 2e-6
+    else:
+        assert err <= tol64 and err <= 1.5 * err_plain + 1e-6
+    xyz = oracle.orthogonal(p, g["calib"][0])
+    outside = np.minimum(1 - np.abs(xyz[0]), 1 - np.abs(xyz[1])) < -1e-6
+    assert (out[:, outside] == 0).all()
+    del table

@@ -140,6 +140,13 @@ d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("coalesced", round(d["value"],1), d["passes"], "| per-frame stages", round(d["per_frame_stages"]["value"],1), d["per_frame_stages"]["passes"], "| latency", round(d["latency_ms_single_frame"],2))
 PY
   ;;
+tab16)  # the f16 query kernels through the skip table: hang check, probe, their tests
+  timeout 240 python tools/tab16_probe.py quick > $out/probe_quick.txt 2>&1; rc=$?
+  tail -8 $out/probe_quick.txt
+  if [ $rc -ne 0 ]; then echo "quick probe rc=$rc -- stopping"; exit 1; fi
+  timeout 400 python tools/tab16_probe.py > $out/probe.txt 2>&1; echo "probe rc=$?"; tail -8 $out/probe.txt
+  timeout 600 python -m pytest tests/test_query_gpu.py -q -m gpu -k "f16 or fp16" 2>&1 | tail -8
+  ;;
 tests) run_tests ;;
 bench)
   timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.err
