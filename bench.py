@@ -556,6 +556,32 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
         feats[-1][0][0, 0:2].copy_(planes)  # synthetic body planes, as in the headline run
         return {**d, "feat_tensor_G": feats}
 
+    debug = os.environ.get("MONOPORT_DROPIN_DEBUG") == "1"
+    call_log = []
+
+    def logged(name, fn):
+        if not debug:
+            return fn
+
+        def wrapper(x):
+            import threading
+            import traceback
+            t0 = time.perf_counter()
+            me = threading.get_ident()
+            done = threading.Event()
+
+            def watch():  # where a call that takes longer than 0.3 s is stuck
+                if not done.wait(0.3):
+                    fr = sys._current_frames().get(me)
+                    print("SLOW %s x%d:\n%s" % (name, len(x) if isinstance(x, list) else 1,
+                                                "".join(traceback.format_stack(fr)[-8:])), file=sys.stderr, flush=True)
+            threading.Thread(target=watch, daemon=True).start()
+            out = fn(x)
+            done.set()
+            call_log.append((name, len(x) if isinstance(x, list) else 1, time.perf_counter() - t0))
+            return out
+        return wrapper
+
     def filt_many(ds):
         feats = netG.filter(torch.cat([d["input_netG"] for d in ds]))
         out = []
@@ -584,16 +610,17 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
         def vertices_one(d):
             return {**d, **dict(zip(["X", "Y", "Z", "norm"], forward_vertices(d["sdf"], direction="front")))}
 
-        wrap = (lambda one, many: Coalesced(one, many, max_batch=8)) if coalesce else (lambda one, many: one)
+        wrap = ((lambda one, many, name: Coalesced(logged(name, one), logged(name, many), max_batch=8)) if coalesce
+                else (lambda one, many, name: logged(name, one)))
         return [
             lambda data: {"input": data.to(device, non_blocking=True)},                    # main.py:327
             camera,                                                                       # :330-336
             lambda d: {**d, "calib_tensor": pifu_calib(d["extrinsic"], d["intrinsic"], device=device)},
             lambda d: {**d, "input_netG": (((d["input"][:, 0:3] * 0.5 + 0.5) - mean) / std)
                        * d["input"][:, 3:4]},                                             # :353-357
-            wrap(filt, filt_many),                                                        # :367-370
-            wrap(recon_one, recon_many),                                                  # :390-395
-            wrap(vertices_one, vertices_many),                                            # :401-406
+            wrap(filt, filt_many, "filter"),                                              # :367-370
+            wrap(recon_one, recon_many, "recon"),                                         # :390-395
+            wrap(vertices_one, vertices_many, "vertices"),                                # :401-406
             lambda d: {**d, "render_norm": colorization(None, None, d["X"], d["Y"], d["Z"],
                                                         d["calib_tensor"], d["norm"],
                                                         resolution=r_last)},              # :418-428
@@ -641,10 +668,28 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         assert out_count == n_warm + n_frames and engine.last_path == "fused" and last["render_norm"] is not None
+        if debug:
+            st = torch.cuda.memory_stats()
+            print("dropin pass coalesce=%s: %.1f recon/s; device allocs %d frees %d retries %d, reserved %.1f GB; %d calls, "
+                  "batch sizes %s; slow calls: %s"
+                  % (coalesce, n_frames / elapsed, st.get("num_device_alloc", -1), st.get("num_device_free", -1),
+                     st.get("num_alloc_retries", -1), torch.cuda.memory_reserved() / 2 ** 30, len(call_log),
+                     sorted(set(b for _, b, _ in call_log)),
+                     " ".join("%s x%d %.0fms" % (n, b, 1e3 * t) for n, b, t in call_log if t > 0.1)), file=sys.stderr, flush=True)
+            call_log.clear()
         return elapsed
 
     def mode(coalesce, in_flight):
-        one_pass(coalesce, in_flight)  # untimed: first use of every encoder batch size a coalescing stage can meet
+        if coalesce:
+            # untimed: first use of every encoder batch size the coalescing filter stage can meet, ON THAT STAGE'S
+            # STREAM (stage 4 of the list) -- torch's allocator pools blocks per stream, and a first batched encoder
+            # pass on a cold pool costs 1.5-1.8 s of hipMalloc (profiles/r04g_dropin_passes.txt)
+            from monoport_amd.stage_pipeline import stage_stream
+            with torch.no_grad(), torch.cuda.stream(stage_stream(device, 4)):
+                for b in range(1, 9):
+                    netG.filter(torch.zeros((b, 3, 512, 512), device=device))
+            torch.cuda.synchronize()
+        one_pass(coalesce, in_flight)  # untimed
         runs = sorted(one_pass(coalesce, in_flight) for _ in range(passes))
         med = runs[len(runs) // 2]
         return {"value": n_frames / med, "unit": "recon/s", "ms_per_step": med / n_frames * 1e3,

@@ -148,6 +148,8 @@ ENCODER_GRAPH_MAX_BATCH = int(os.environ.get("MONOPORT_ENCODER_GRAPH_MAX_BATCH",
 class _GraphedForward:
     """Per-module cache of captured forwards: key -> (graph, static input, static outputs)."""
 
+    MAX_ENTRIES = 20
+
     def __init__(self):
         self.entries = {}
         self.lock = threading.Lock()
@@ -181,9 +183,14 @@ class _GraphedForward:
                     with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                         outs = fn(x_static)
                     side.synchronize()
-                if len(self.entries) >= 8:  # shapes keep changing: do not hoard graph pools
-                    self.entries.clear()
+                # a coalescing stage (stage_pipeline.Coalesced) meets every batch size from 1 to its max_batch:
+                # keep that many captures, and when shapes keep changing beyond that drop the one that has not
+                # been used for the longest time (clearing all of them re-captured ~1.7 s per shape, over and over)
+                while len(self.entries) >= self.MAX_ENTRIES:
+                    self.entries.pop(next(iter(self.entries)))
                 entry = self.entries[key] = (graph, x_static, outs)
+            else:
+                self.entries[key] = self.entries.pop(key)  # most recently used last
             graph, x_static, outs = entry
             x_static.copy_(x)
             graph.replay()

@@ -14,7 +14,11 @@ so this module re-creates the part of it the reconstruction demo relies on (RTL/
 * at most ``max_in_flight`` frames are admitted at once (the reference primes ``2 * num_workers``,
   dataloader.py:776-777, :891).
 
-MI355X-specific additions:
+Additions:
+
+* the stage threads run with the autograd grad mode of the thread that iterates the pipeline (grad
+  mode is thread-local in torch: without this a ``with torch.no_grad():`` around the consuming loop
+  would not reach the stages);
 
 * each stage thread owns a HIP stream; a frame is handed to the next stage together with an event
   recorded on the producer's stream, and the consumer's stream waits on it.  Stages therefore
@@ -36,6 +40,24 @@ import threading
 import torch
 
 _END = object()
+# Stage streams are kept for the life of the process, one per (device, stage index): torch's caching
+# allocator pools memory PER STREAM, so a pipeline that made fresh streams every time it is iterated
+# would find none of the blocks its predecessor cached and go back to hipMalloc for every activation
+# (measured: 1.5-1.9 s for the first batched encoder call of a pass).
+_STREAMS = {}
+_STREAMS_LOCK = threading.Lock()
+
+
+def stage_stream(device, idx):
+    """The HIP stream stage ``idx`` of every StagePipeline on ``device`` runs on (public: a caller can warm a
+    stage up on its own stream, e.g. run a batched encoder once per batch size a Coalesced stage can meet, so
+    that the allocator pool of that stream holds the blocks before the first frame arrives)."""
+    key = (str(device), idx)
+    with _STREAMS_LOCK:
+        st = _STREAMS.get(key)
+        if st is None:
+            st = _STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 def _record_streams(obj, stream, depth=0):
@@ -89,15 +111,20 @@ class StagePipeline:
         self.use_streams = bool(stage_streams and self.device is not None
                                 and self.device.type == "cuda")
         self._threads = []
+        self._grad_enabled = True
 
     # ---- worker bodies ------------------------------------------------------------------------
     def _stage_loop(self, idx, fn, q_in, q_out):
         torch.set_num_threads(1)
+        # autograd's grad mode is thread-local: a `with torch.no_grad():` around the loop that consumes the
+        # pipeline would not reach the stage threads, and netG.filter -- which RTL/main.py:367-370 calls
+        # undecorated -- would stay on the differentiable (MIOpen) path instead of the inference kernels
+        torch.set_grad_enabled(self._grad_enabled)
         stream = None
         if self.device is not None and self.device.type == "cuda":
             torch.cuda.set_device(self.device)
             if self.use_streams:
-                stream = torch.cuda.Stream(device=self.device)
+                stream = stage_stream(self.device, idx)
         held = None  # an item taken off the queue while coalescing that has to wait for its turn
         while True:
             item = held if held is not None else q_in.get()
@@ -164,6 +191,7 @@ class StagePipeline:
 
     # ---- consumer ---------------------------------------------------------------------------------
     def __iter__(self):
+        self._grad_enabled = torch.is_grad_enabled()  # of the consuming thread, handed to the stage threads
         queues = [queue.Queue() for _ in range(len(self.processors) + 1)]
         slots = threading.Semaphore(self.max_in_flight)
         self._threads = [threading.Thread(target=self._feeder, args=(queues[0], slots), daemon=True)]

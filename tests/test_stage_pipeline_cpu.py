@@ -133,3 +133,17 @@ def test_coalesced_stage_serves_queued_frames_together_in_order():
     assert got == [0, 10, 20, 30, 40]  # FIFO, up to the failing frame
     assert err is not None and "frame five" in str(err) and isinstance(err.__cause__, ValueError)
     assert max(sizes) > 1 and max(sizes) <= 4  # frames were served together
+
+
+def test_stage_threads_inherit_the_consumers_grad_mode():
+    """torch's grad mode is thread-local; the stage threads take the mode of the thread that iterates the
+    pipeline, so `with torch.no_grad():` around the consuming loop reaches netG.filter in its stage."""
+    import torch
+    from monoport_amd.stage_pipeline import StagePipeline
+    seen = []
+    pipe = lambda: StagePipeline(iter(range(3)), [lambda x: (seen.append(torch.is_grad_enabled()), x)[1]], device=None)
+    with torch.no_grad():
+        assert list(pipe()) == [0, 1, 2]
+    assert seen == [False] * 3
+    seen.clear()
+    assert list(pipe()) == [0, 1, 2] and seen == [True] * 3

@@ -147,10 +147,29 @@ tab16)  # the f16 query kernels through the skip table: hang check, probe, their
   timeout 400 python tools/tab16_probe.py > $out/probe.txt 2>&1; echo "probe rc=$?"; tail -8 $out/probe.txt
   timeout 600 python -m pytest tests/test_query_gpu.py -q -m gpu -k "f16 or fp16" 2>&1 | tail -8
   ;;
+shapes)  # headline by slot layout / encoder launch mode
+  for flags in "" "--no-graph" "--depth 4 --batch 8 --steps 64" "--depth 6 --batch 8 --steps 96" "--depth 2 --batch 16 --steps 64" "--depth 4 --batch 8 --steps 64 --no-graph" "--depth 6 --batch 4 --steps 96"; do
+    timeout 600 python bench.py --no-extras --no-cpu-baseline $flags > $out/b.json 2> $out/b.err
+    bench_line $out/b.json "$flags"
+  done
+  ;;
 tests) run_tests ;;
 bench)
   timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.err
   bench_line $out/bench.json default ;;
+bench20)  # the driver's invocation
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench20.json 2> $out/bench20.err; tail -c 300 $out/bench20.err
+  bench_line $out/bench20.json steps20
+  python - $out/bench20.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r=d["roofline"]
+print("traffic", r["traffic"], "step", r["step"])
+for k in ("plain_query_path","in_flight_8","alt_precision","with_color","levels6_f16w","dropin","mesh","cpu_baseline"):
+    v=d.get(k)
+    if v: print(k, {kk:(round(vv,3) if isinstance(vv,float) else vv) for kk,vv in v.items() if kk in ("value","roofline_frac","passes","latency_ms_single_frame","mesh_ms","per_frame_stages")})
+PY
+  ;;
 benchq)  # headline only, no extras
   timeout 600 python bench.py --no-extras --no-cpu-baseline > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.err
   bench_line $out/bench.json quick
