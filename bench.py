@@ -564,20 +564,8 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
             return fn
 
         def wrapper(x):
-            import threading
-            import traceback
             t0 = time.perf_counter()
-            me = threading.get_ident()
-            done = threading.Event()
-
-            def watch():  # where a call that takes longer than 0.3 s is stuck
-                if not done.wait(0.3):
-                    fr = sys._current_frames().get(me)
-                    print("SLOW %s x%d:\n%s" % (name, len(x) if isinstance(x, list) else 1,
-                                                "".join(traceback.format_stack(fr)[-8:])), file=sys.stderr, flush=True)
-            threading.Thread(target=watch, daemon=True).start()
             out = fn(x)
-            done.set()
             call_log.append((name, len(x) if isinstance(x, list) else 1, time.perf_counter() - t0))
             return out
         return wrapper
@@ -649,25 +637,26 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
     latency_ms = float(np.median(lat[3:])) * 1e3
 
     # throughput: the same list on the stage pipeline (thread + stream per stage, FIFO order)
-    n_frames = max(n_frames, 48)  # long enough for the queues to reach their steady state
+    n_frames = max(n_frames, 96)  # long against the pipeline's fill and drain, which are INSIDE the timed region
     passes = max(passes, 5)
 
     def one_pass(coalesce, in_flight):
         def source():
-            for i in range(n_warm + n_frames):
+            for i in range(n_frames):
                 yield frames[i % N_IMAGES]
 
-        out_count, t0, last = 0, None, None
+        # the clock runs from an EMPTY pipeline to an empty pipeline (fill and drain included): starting it
+        # after a few warm-up outputs would count frames that are already half way through the stages
+        out_count, last = 0, None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         with torch.no_grad():
             for d in StagePipeline(source(), processors([0], coalesce), device=device, max_in_flight=in_flight):
                 out_count += 1
                 last = d
-                if out_count == n_warm:
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        assert out_count == n_warm + n_frames and engine.last_path == "fused" and last["render_norm"] is not None
+        assert out_count == n_frames and engine.last_path == "fused" and last["render_norm"] is not None
         if debug:
             st = torch.cuda.memory_stats()
             print("dropin pass coalesce=%s: %.1f recon/s; device allocs %d frees %d retries %d, reserved %.1f GB; %d calls, "
