@@ -90,16 +90,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, const float (&v
   double *cs1 = reinterpret_cast<double *>(smem);         // [CW][NCH][2] per-channel sums of y
   double *cs2 = reinterpret_cast<double *>(smem + 2048);  // ... of y2
   auto to_lds = [&](double *cs, float (&a1)[TN], float (&a2)[TN]) {
-    // sum over the 32 lanes that share h (the pixels); lanes j == 0 then hold the row sums
+    // sum over the 32 lanes that share h (the pixels); lane kHalfSumLane of each half then holds the row sums
 #pragma unroll
     for (int tt = 0; tt < TN; ++tt) {
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-        a1[tt] += __shfl_xor(a1[tt], o);
-        a2[tt] += __shfl_xor(a2[tt], o);
-      }
+      a1[tt] = half_wave_sum(a1[tt]);
+      a2[tt] = half_wave_sum(a2[tt]);
     }
-    if (j == 0) {
+    if (j == kHalfSumLane) {
 #pragma unroll
       for (int tt = 0; tt < TN; ++tt) {
         const int t = t0 + tt;
@@ -1306,13 +1303,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
       // the next stack after x + bl(.) + al(.)), handed on before the bulk stores (gn_tail.h)
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-          s1[t] += __shfl_xor(s1[t], o);
-          s2[t] += __shfl_xor(s2[t], o);
-        }
+        s1[t] = half_wave_sum(s1[t]);
+        s2[t] = half_wave_sum(s2[t]);
       }
-      if (j == 0) {
+      if (j == kHalfSumLane) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
           const int lc = 32 * (MRW * wv + m) + (t & 3) + 8 * (t >> 2) + 4 * h;

@@ -166,14 +166,11 @@ __global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
   if (gn_wanted(p.fin)) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-        s1[t] += __shfl_xor(s1[t], o);
-        s2[t] += __shfl_xor(s2[t], o);
-      }
+      s1[t] = half_wave_sum(s1[t]);
+      s2[t] = half_wave_sum(s2[t]);
     }
     double *cs = reinterpret_cast<double *>(smem);  // [CW][NCH][2]
-    if (j == 0) {
+    if (j == kHalfSumLane) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int idx = cwi * NCH + 32 * rbi + (t & 3) + 8 * (t >> 2) + 4 * h;

@@ -32,9 +32,31 @@
 //   * accumulators must be ZERO before the producing launch: the callers clear one arena per
 //     encoder pass (one memset for ~130 GroupNorms).
 #pragma once
+#include <type_traits>
+
 #include "encoder_kernels.h"
 
 namespace mp {
+
+// Sum of v over the 32 lanes that share lane >> 5 (the 32 pixels of a C-layout tile row): the total is valid in
+// the lanes with (lane & 31) >= 16 -- callers let lane kHalfSumLane of each half write it.  Five DPP additions
+// (xor 1, xor 2, row_half_mirror, row_mirror, row_bcast15), no LDS round trip: __shfl_xor compiles to
+// ds_bpermute_b32 + s_waitcnt, and the statistics epilogue of a 3x3 convolution tile had 320 of those
+// (13 k cycles next to a 37 k-cycle K loop for 64 -> 64 channels).
+constexpr int kHalfSumLane = 16;
+__device__ __forceinline__ float half_wave_sum(float v) {
+  auto dpp = [](float x, auto ctrl_tag) {
+    constexpr int ctrl = decltype(ctrl_tag)::value;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror: the other quad pair of each 8
+  v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror: all 16 lanes of a row hold the row sum
+  // row_bcast15 into rows 1 and 3: lanes 16-31 / 48-63 add the sum of lanes 0-15 / 32-47
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+  return v;
+}
 
 // x -> (hi, lo) with x = hi * 2^-16 + lo * 2^-64, lo in [0, 2^48); exact for |x| < 2^36, rounded to a
 // multiple of 2^-16 above that (a double has no finer bits there); needs |x| < 2^46.

@@ -153,6 +153,10 @@ shapes)  # headline by slot layout / encoder launch mode
     bench_line $out/b.json "$flags"
   done
   ;;
+conv)  # the encoder's convolutions per shape (batch 1 and 16) + the encoder tests
+  MODES=auto timeout 600 python tools/conv_bench.py 1 16 > $out/conv_bench.txt 2>&1; tail -45 $out/conv_bench.txt | cut -c1-110
+  timeout 600 python -m pytest tests/test_conv_gpu.py tests/test_encoder_dataflow_gpu.py -q -m gpu 2>&1 | tail -4
+  ;;
 tests) run_tests ;;
 bench)
   timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.err
