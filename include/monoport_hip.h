@@ -104,7 +104,7 @@ int mp_mlp_set_precision(mp_ctx *ctx, int mlp, int precision);
 int mp_feat_pack_hwc(mp_ctx *ctx, const float *src_chw, int c_src, int h, int w, float *dst_hwc,
                      int c_dst, int c_offset, mp_stream stream);
 
-/* Optional accelerator of the exact-f32 query of a netG head (C = 256): the SKIP TABLE of a feature
+/* Optional accelerator of the query of a netG head (C = 256; exact f32 and f16x3 kernels): the SKIP TABLE of a feature
  * map.  SurfaceClassifier (heads/SurfaceClassifier.py:39-71) multiplies weights with the SAMPLED
  * feature in every layer -- layer 0's 1024 x 256 block and the skip connections of layers 1-4 (:55)
  * -- and the sampled feature is a bilinear blend of four texels (geometry.py:4-16).  A linear map

@@ -19,7 +19,11 @@
 // test_skip_table_*); the bar is 1e-4.  The plain kernels stay the default of the C-ABI: a launch
 // comes here only if every one of its feature maps has a registered table (mp_skip_table).
 //
-// Decomposition (32-point tiles, as query_small.hip; two workgroups per CU):
+// TWO query kernels live here: pifu_query_tabws_kernel (round 4, the one that ships: the waves of a
+// workgroup specialised into MFMA-only consumers and table-blending producers, further down) and
+// pifu_query_tab_kernel (round 3, every wave does everything; kept for A/B, MONOPORT_TAB_KERNEL=v1).
+//
+// Decomposition of the round-3 kernel (32-point tiles, as query_small.hip; two workgroups per CU):
 //   * a lane owns ONE point (p = lane & 31) and the rows its MFMA accumulator registers stand for
 //     (C layout: rows 8 q + 4 h + i of a 32-row block), so a blend lands exactly where the MFMA
 //     path would have left the product and everything downstream (z column, leaky ReLU, the
