@@ -541,3 +541,38 @@ def test_f16_kernels_through_the_skip_table(ops, oracle, name, precision, tol64,
     outside = np.minimum(1 - np.abs(xyz[0]), 1 - np.abs(xyz[1])) < -1e-6
     assert (out[:, outside] == 0).all()
     del table
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_three_output_head_through_the_skip_table(ops, oracle, precision):
+    """The Cout = 3 instantiations of the table query kernels (pifu_query_tabws_kernel<3>,
+    pifu_query16_tab_kernel<3, 3>): a 3-channel tanh head on a 256-channel map, table path against the
+    plain kernel of the same precision and against the fp32 oracle, ragged sizes included."""
+    layers = syn.rand_mlp("G", 34, 2.0)
+    rs = np.random.RandomState(5)
+    w4 = layers[-1][0]
+    layers[-1] = (rs.uniform(-0.1, 0.1, (3, w4.shape[1])).astype(np.float32), rs.uniform(-0.1, 0.1, (3,)).astype(np.float32))
+    f = syn.rand_feat(256, 64, 64, 6)
+    p = syn.rand_points(5000, 9, 1.1)
+    calib = oracle.pifu_calib(*syn.scene_camera(40))
+    dev = "cuda:0"
+    mlp = ops.PackedMLP.from_layers(dev, layers, 2)  # tanh
+    mlp.set_precision(precision)
+    fh = ops.pack_features(torch.from_numpy(f)[None].to(dev))
+    pts, cal = torch.from_numpy(p)[None].to(dev), torch.from_numpy(calib).to(dev)
+    plain = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)
+    try:
+        table = ops.skip_table(mlp, fh)
+        out = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)
+        for n in (1, 31, 33, 97, 1000):
+            part = ops.query(mlp, fh, pts[:, :, :n].contiguous(), cal, syn.Z_SCALE)
+            assert torch.equal(part, out[:, :, :n]), n
+    finally:
+        ops.skip_table_release(mlp.ctx)
+    ref = oracle.query(f, p, calib[0], layers, 2, syn.Z_SCALE, precision="f32")
+    assert out.shape == (1, 3, 5000) and not torch.equal(out, plain)
+    d_plain = (out - plain).abs().max().item()
+    d_ref = np.abs(out[0].cpu().numpy() - ref).max()
+    print("Cout = 3 %s: |table - plain| %.3g, |table - f32 oracle| %.3g" % (precision, d_plain, d_ref))
+    assert d_plain <= 2e-6 and d_ref <= TOL_ORACLE
+    del table
