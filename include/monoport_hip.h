@@ -117,12 +117,13 @@ int mp_feat_pack_hwc(mp_ctx *ctx, const float *src_chw, int c_src, int h, int w,
  * The call also REGISTERS the table for feat_hwc in the context: every later fused query launch
  * (mp_query*, mp_recon*) whose feature maps ALL have a registered table made with the same head
  * and map size uses it; others run the plain path.  The caller owns `table`
- * ([H, W, MP_SKIP_TABLE_ROWS] f32, 16-byte aligned; H * W a multiple of 64), must call mp_skip_table
+ * ([H, W, MP_SKIP_TABLE_ROWS] f32, 16-byte aligned -- 128-byte aligned keeps every 32-row block of a texel in
+ * one cache line, which is what the row length of 61 x 32 floats is for; H * W a multiple of 64), must call mp_skip_table
  * again after it rewrites the feature map (stream-ordered with the queries, like any producer), and
  * mp_skip_table_release(ctx, feat_hwc, table) before freeing either buffer (table NULL: whatever is
  * registered for feat_hwc; otherwise only if it still is that table; feat_hwc NULL: everything).
  * mp_mlp_destroy and mp_mlp_load (new weights) drop the tables made with that head. */
-#define MP_SKIP_TABLE_ROWS 1924
+#define MP_SKIP_TABLE_ROWS 1952
 int mp_skip_table(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, float *table,
                 mp_stream stream);
 /* The same for n_maps maps stored back to back ([n_maps, H, W, C] -> table [n_maps, H, W, MP_SKIP_TABLE_ROWS]):

@@ -20,7 +20,10 @@ constexpr int kHidden[4] = {1024, 512, 256, 128};  // SurfaceClassifier.py:76 / 
 // rows of a feature map's skip table (mp_skip_table): the feature segments of layers 0-3 back to back
 // (1024 + 512 + 256 + 128), then the last layer's (<= 3 outputs, padded to one 16-byte slot)
 constexpr int kTableL[5] = {0, 1024, 1536, 1792, 1920};
-constexpr int kTableRows = 1924;
+// 1923 used floats, padded to 61 x 32: a texel's row is then 61 cache lines of 128 bytes and every 32-row block a
+// query lane group reads (128 bytes) is ONE line -- with the minimal padding (1924) a texel's row started 16 bytes
+// further every texel and 7 of 8 blocks straddled two lines: twice the lines per gathered block (round 4)
+constexpr int kTableRows = 1952;
 
 // Device-side view of one packed SurfaceClassifier (see pack.hip for the fragment order).
 // One base pointer + float offsets keeps the kernel's SGPR footprint small.

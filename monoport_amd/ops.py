@@ -193,7 +193,7 @@ SKIP_TABLE = os.environ.get("MONOPORT_SKIP_TABLE", "on") != "off"
 # MonoPortNet.bind makes a table for a map once it has served this many query points (or at once for
 # the octree engine): the table costs what ~16 k points cost on the plain kernels
 SKIP_TABLE_MIN_POINTS = int(os.environ.get("MONOPORT_SKIP_TABLE_MIN_POINTS", "16384"))
-SKIP_TABLE_ROWS = 1924  # kTableRows: the feature segments of layers 0-3 (1024 + 512 + 256 + 128) + the last layer's, padded
+SKIP_TABLE_ROWS = 1952  # kTableRows: the feature segments of layers 0-3 (1024 + 512 + 256 + 128) + the last layer's, padded to 61 cache lines
 
 
 class SkipTable:
@@ -238,7 +238,7 @@ def skip_table(mlp, feat_hwc, out=None):
     on maps that all have a table blends four table rows per point instead of multiplying those
     weights with the sampled feature on the MFMAs (42 % of a point's FLOPs).  The result differs
     from the plain path by f32 rounding only.  Returns a SkipTable handle (``.table`` is the
-    [H,W,1924] tensor); the registration lasts until ``.release()`` or the handle's collection.
+    [H,W,1952] tensor); the registration lasts until ``.release()`` or the handle's collection.
     Call again after rewriting the feature map."""
     ctx = mlp.ctx
     h, w, c = feat_hwc.shape
@@ -252,7 +252,7 @@ def skip_table(mlp, feat_hwc, out=None):
 
 
 def skip_table_batch(mlp, feat_hwc_all, out=None):
-    """mp_skip_table_batch: the tables of B maps stored back to back [B,H,W,256] -> [B,H,W,1924] in
+    """mp_skip_table_batch: the tables of B maps stored back to back [B,H,W,256] -> [B,H,W,1952] in
     one launch; each map feat_hwc_all[i] is registered with its table out[i].  Returns a SkipTable
     handle for all of them."""
     ctx = mlp.ctx
