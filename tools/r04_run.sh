@@ -38,9 +38,9 @@ wsab)  # side builds of tools/ablate.py (names in $ABLATE) next to the product
   timeout 180 python tools/tab_ws_probe.py quick > $out/probe_quick.txt 2>&1; rc=$?
   tail -3 $out/probe_quick.txt
   if [ $rc -ne 0 ]; then echo "quick probe rc=$rc -- stopping"; exit 1; fi
-  timeout 300 python tools/tab_ws_probe.py > $out/probe.txt 2>&1; echo "probe rc=$?"; tail -3 $out/probe.txt
+  timeout 300 python tools/tab_ws_probe.py > $out/probe.txt 2>&1; echo "probe rc=$?"; tail -5 $out/probe.txt
   for name in $ABLATE; do
-    MONOPORT_ABLATE=$name timeout 200 python tools/tab_ws_probe.py 2>&1 | tail -1 | tee -a $out/ablate.txt
+    MONOPORT_ABLATE=$name timeout 200 python tools/tab_ws_probe.py 2>&1 | tail -2 | tee -a $out/ablate.txt
   done
   ;;
 wspmc)  # counters of the table query kernel: product (ws), round 3's (v1), and side builds in $ABLATE

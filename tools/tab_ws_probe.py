@@ -37,7 +37,11 @@ def main():
     tables = torch.empty((frames, 128, 128, ops.SKIP_TABLE_ROWS), device=dev)
     handles = [ops.skip_table(mlp, feats[i], out=tables[i]) for i in range(frames)]
     out, vols, rows = {}, {}, {}
+    # a launch shaped like octree level 0 of a 16-frame batch: 78,608 points, every one with its own texels
+    sc = torch.from_numpy(syn.rand_points(78608, 3, 0.95))[None].to(dev)
     if os.environ.get("MONOPORT_ABLATE"):  # a side build (possibly with wrong results): timing only
+        ts = timed(lambda: ops.query(mlp, feats[0], sc, cal, syn.Z_SCALE), reps=20)
+        print("  %-10s scattered 78608 points: %.3f ms = %.3f of 157.3" % (os.environ["MONOPORT_ABLATE"], ts, 78608 * EXEC_FLOP / ts / 1e9 / 157.3))
         tq = timed(lambda: ops.query(mlp, feats[0], p, cal, syn.Z_SCALE))
         tr = timed(lambda: ops.recon_batch(mlp, feats, [cal] * frames, syn.Z_SCALE, [-1] * 3, [1] * 3, res), reps=5)
         print("  %-10s %8.3f ms per %d points = %6.1f TFLOP/s executed (%.3f of 157.3)  |  recon_batch x%d %8.3f ms = %.3f ms per frame"
@@ -62,6 +66,10 @@ def main():
           % ((out["ws"] - out["v1"]).abs().max().item(), n,
              max((a - b).abs().max().item() for a, b in zip(vols["ws"], vols["v1"])),
              sum(int(((a > 0.5) != (b > 0.5)).sum()) for a, b in zip(vols["ws"], vols["v1"]))))
+    for name in ("v1", "ws"):
+        os.environ["MONOPORT_TAB_KERNEL"] = name
+        ts = timed(lambda: ops.query(mlp, feats[0], sc, cal, syn.Z_SCALE), reps=20)
+        print("  %-3s scattered 78608 points: %.3f ms = %.3f of 157.3" % (name, ts, 78608 * EXEC_FLOP / ts / 1e9 / 157.3))
     for name, (tq, tr, t1) in rows.items():
         print("  %-3s %8.3f ms per %d points = %6.1f TFLOP/s executed (%.3f of 157.3)  |  recon_batch x%d %8.3f ms = %.3f ms per frame  |  one frame %.3f ms"
               % (name, tq, n, n * EXEC_FLOP / tq / 1e9, n * EXEC_FLOP / tq / 1e9 / 157.3, frames, tr, tr / frames, t1))
