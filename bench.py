@@ -136,23 +136,24 @@ def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, 
     return pipe
 
 
-TRAFFIC_PROFILE = "r04_query_traffic.json"  # PMC passes at 10 and 16 frames per launch
+TRAFFIC_PROFILE = "r04_query_traffic.json"  # PMC passes at slot batches of 10, 16 and 20 frames
 
 
-def traffic_from_profile(precision, levels, with_color, frames_per_launch):
+def traffic_from_profile(precision, levels, with_color, slot_batch):
     """HBM-side bytes per fused-query launch from the committed PMC passes (separate rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE runs of tools/traffic_probe.py, corrected as
     MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process, so the
     figure is reported ONLY for the configurations the passes covered (f32 skip-table kernel, 5 levels,
-    geometry only, 10 or 16 frames per launch: --steps 20 and the default --steps 48) and is None
-    for every other run or when the profile is absent."""
+    geometry only, slot batches of 20 / 16 / 10 frames: --steps 20, the default --steps 48, --steps 20
+    --batch 10; a batch of 20 is launches of 16 + 4 frames, averaged) and is None for every other run or
+    when the profile is absent."""
     if precision != "f32" or levels != 5 or with_color:
         return None
     path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
     try:
         with open(path) as f:
             prof = json.load(f)
-        return prof["by_frames_per_launch"][str(int(frames_per_launch))]["bytes_per_launch_avg"]
+        return prof["by_slot_batch"][str(int(slot_batch))]["bytes_per_launch_avg"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -290,9 +291,20 @@ class Job:
         return got
 
 
+SINGLE_SUBMISSION_STEPS = 24
+
+
 def pick_batch(steps, upper):
-    """The largest divisor of --steps not above `upper`: no slot submission is short (a short
+    """Frames per slot submission.  Up to SINGLE_SUBMISSION_STEPS steps: ALL of them in one submission (one
+    batched encoder pass, the octree level by level in launches of <= 16 frames) -- a timed region that short is
+    mostly pipeline fill and drain when it is cut into two slots of 10 (measured at the driver's --steps 20:
+    173.0 recon/s, passes 5.78-5.79 ms, against 166-169 with passes 5.7-6.6).  Above that: the largest divisor
+    of --steps not above `upper` (--batch; 16 when not given), so that no slot submission is short (a short
     batch would still pay the full-batch encoder)."""
+    if upper is None:  # no --batch given: the policy above
+        if steps <= SINGLE_SUBMISSION_STEPS:
+            return steps
+        upper = 16
     return max(b for b in range(1, max(1, min(upper, steps)) + 1) if steps % b == 0)
 
 
@@ -807,11 +819,12 @@ def parse_args(argv):
                          "frames per slot; round 2 timed 20 = two submissions of 10)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--depth", type=int, default=3, help="pipeline slots (streams) per GPU")
-    ap.add_argument("--batch", type=int, default=16,
+    ap.add_argument("--batch", type=int, default=None,
                     help="frames per slot (upper bound): their encoder passes run as one batch and "
-                         "their octree levels as one fused-query launch; depth x batch frames are in "
-                         "flight.  The largest divisor of --steps not above this is used, so no slot "
-                         "submission is short (a short batch would still pay the full-batch encoder)")
+                         "their octree levels as fused-query launches of <= 16 frames; depth x batch frames are "
+                         "in flight.  The largest divisor of --steps not above this is used, so no slot "
+                         "submission is short (a short batch would still pay the full-batch encoder).  Not "
+                         "given: 16, and runs of <= 24 steps go into ONE submission (pick_batch)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="K > 0: exactly K frames in flight across the node (K / --gpus per rank; "
                          "BASELINE configs[3] is K = 8) instead of --depth x --batch per GPU; the "
@@ -977,7 +990,9 @@ def main(argv=None):
         vol_f32 = last_slot.volumes[last_slot.n_active - 1].clone()
         # a SECOND pipeline (own network copy, own captured graphs): the f32 pipeline and its graphs
         # stay untouched for the breakdown leg below
-        r16, pipe16 = measure_config(job, depth, batch, use_graph, resolutions, False, "f16x3",
+        # slots of <= 16 frames here even for a short run: with the f16 kernels a frame has more non-MFMA time,
+        # and two slots overlapping each other beat one long submission (290 vs 321 recon/s at --steps 20)
+        r16, pipe16 = measure_config(job, depth, pick_batch(args.steps, args.batch or 16), use_graph, resolutions, False, "f16x3",
                                      args.passes, roofline=False)
         last_slot = pipe16.slots[(pipe16.n_submitted - 1) % len(pipe16.slots)]
         vol_alt = last_slot.volumes[last_slot.n_active - 1]
@@ -1022,7 +1037,7 @@ def main(argv=None):
         # BASELINE configs[4]: 513^3, fp16 weights; parity deltas against the exact-f32 kernel on
         # the same features and camera
         res6 = RESOLUTIONS + [513]
-        r6, p6 = measure_config(job, depth, batch, use_graph, res6, False, "f16w", args.passes)
+        r6, p6 = measure_config(job, depth, pick_batch(args.steps, args.batch or 16), use_graph, res6, False, "f16w", args.passes)
         s6 = p6.slots[0]
         s6.wait()
         mlp32 = ops.PackedMLP.from_layers(device, syn.body_mlp("G", noise=0.05, seed=1),
@@ -1107,12 +1122,12 @@ def main(argv=None):
                 "peak": peak_tflops,
                 "unit": "TFLOP/s",
                 "frac": roof["achieved"] * (FLOP_PER_POINT_SKIP_TABLE / FLOP_PER_POINT if skip_on else 1.0) / peak_tflops,
-                "traffic": traffic_from_profile(args.precision, args.levels, args.with_color,
-                                                min(batch, MAX_RECON_BATCH)),
+                "traffic": traffic_from_profile(args.precision, args.levels, args.with_color, batch),
                 "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                    "this configuration)" % TRAFFIC_PROFILE),
                 "launches": roof["launches"],
-                "frames_per_launch": min(batch, MAX_RECON_BATCH),
+                "frames_per_launch": (min(batch, MAX_RECON_BATCH) if batch <= MAX_RECON_BATCH or batch % MAX_RECON_BATCH == 0
+                                      else [MAX_RECON_BATCH, batch % MAX_RECON_BATCH]),
                 "avg_launch_ms": float(roof["launch_ms"].mean()) if roof["launches"] else None,
                 "flop_per_point": FLOP_PER_POINT_SKIP_TABLE if skip_on else FLOP_PER_POINT,
                 "algorithmic": {"flop_per_point": FLOP_PER_POINT, "achieved": roof["achieved"],

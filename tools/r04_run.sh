@@ -58,7 +58,7 @@ wspmc)  # counters of the table query kernel: product (ws), round 3's (v1), and 
   ;;
 traffic)  # the PMC passes behind roofline.traffic at 10 and 16 frames per launch (counters only, separate runs)
   cd /tmp && export TMPDIR=/tmp
-  for b in 10 16; do
+  for b in 10 16 20; do
     export MONOPORT_TRAFFIC_BATCH=$b
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$b -- python $R/tools/traffic_probe.py run > $out/pmc_fetch_$b.log 2>&1
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$b -- python $R/tools/traffic_probe.py run > $out/pmc_write_$b.log 2>&1
@@ -72,10 +72,10 @@ traffic)  # the PMC passes behind roofline.traffic at 10 and 16 frames per launc
 import json,sys,os
 out=sys.argv[1]
 by={}
-for b in (10,16):
+for b in (10,16,20):
     d=json.load(open(os.path.join(out,"traffic_%d.json"%b)))
     by[str(b)]=d
-merged={"source":"tools/r04_run.sh traffic: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/traffic_probe.py run at 10 and 16 frames per mp_recon_batch (bench.py --steps 20 / default --steps 48)","by_frames_per_launch":by}
+merged={"source":"tools/r04_run.sh traffic: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/traffic_probe.py run at slot batches of 10, 16 and 20 frames (bench.py --steps 20 --batch 10 / default --steps 48 / --steps 20: launches of 16 + 4 frames)","by_slot_batch":by}
 json.dump(merged,open(os.path.join(out,"r04_query_traffic.json"),"w"),indent=1)
 for b,d in by.items():
     print(b,"frames/launch: avg %.3f GB per launch; per level (GB):"%(d["bytes_per_launch_avg"]/1e9),[round(x/1e9,3) for x in d["bytes_per_level_launch"]], "WRITE KB", [round(x) for x in d["WRITE_SIZE_per_level"]])
@@ -156,6 +156,12 @@ shapes)  # headline by slot layout / encoder launch mode
 conv)  # the encoder's convolutions per shape (batch 1 and 16) + the encoder tests
   MODES=auto timeout 600 python tools/conv_bench.py 1 16 > $out/conv_bench.txt 2>&1; tail -45 $out/conv_bench.txt | cut -c1-110
   timeout 600 python -m pytest tests/test_conv_gpu.py tests/test_encoder_dataflow_gpu.py -q -m gpu 2>&1 | tail -4
+  ;;
+shapes20)  # the driver's --steps 20 by slot layout
+  for flags in "" "--batch 5" "--batch 4" "--batch 20" "--batch 10 --depth 2" "--batch 5 --depth 4" "--batch 2"; do
+    timeout 600 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline $flags > $out/b.json 2> $out/b.err
+    bench_line $out/b.json "$flags"
+  done
   ;;
 tests) run_tests ;;
 bench)

@@ -51,12 +51,21 @@ def counter_rows(directory, counter):
                                                      or "pifu_query_kernel" in name):
                     rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), "t32" in name or "tab" in name))
     rows.sort()
-    # with the skip tables (default) every level is ONE dispatch of pifu_query_tab_kernel; on the plain
-    # path (MONOPORT_SKIP_TABLE=off) levels 1-4 are a gated pair
-    if not any(not t32 for _, _, t32 in rows[-2 * LEVELS:]):
-        rows = rows[-2 * LEVELS:]
-        assert len(rows) == 2 * LEVELS, len(rows)
-        return [v for _, v, _ in rows]
+    # with the skip tables (default) every level is ONE dispatch of the table kernel per chunk of <= 16 frames
+    # (a slot batch of 20 = chunks of 16 + 4: the chunks of a level are added up); on the plain path
+    # (MONOPORT_SKIP_TABLE=off) levels 1-4 are a gated pair
+    chunks = (BATCH + 15) // 16
+    if not any(not t32 for _, _, t32 in rows[-2 * LEVELS * chunks:]):
+        rows = rows[-2 * LEVELS * chunks:]
+        assert len(rows) == 2 * LEVELS * chunks, len(rows)
+        vals = [v for _, v, _ in rows]
+        # dispatch order inside a batch: level 0 of every chunk, then level 1 of every chunk, ... (mp_recon_batch
+        # is called per chunk: chunk-major) -- pipeline.py calls mp_recon_batch once per chunk, so it is chunk-major
+        out = []
+        for b in range(2):
+            per = vals[b * LEVELS * chunks:(b + 1) * LEVELS * chunks]
+            out += [sum(per[c * LEVELS + l] for c in range(chunks)) for l in range(LEVELS)]
+        return out
     per_batch = 1 + 2 * (LEVELS - 1)
     rows = rows[-2 * per_batch:]
     assert len(rows) == 2 * per_batch, len(rows)
@@ -89,8 +98,9 @@ def parse(fetch_dir, write_dir, out_path):
         "WRITE_SIZE_per_level": per_level_write,
         "correction": "FETCH_SIZE doubled (128-B requests tallied at 64 B for 16 B/lane coalesced "
                       "reads on gfx950), WRITE_SIZE as is",
-        "frames_per_launch": BATCH,
-        "bytes_per_launch_avg": sum(bytes_level) / LEVELS,
+        "slot_batch": BATCH,
+        "launches_per_level": (BATCH + 15) // 16,
+        "bytes_per_launch_avg": sum(bytes_level) / (LEVELS * ((BATCH + 15) // 16)),
         "bytes_per_level_launch": bytes_level,
     }
     with open(out_path, "w") as f:
