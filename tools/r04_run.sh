@@ -50,8 +50,9 @@ wspmc)  # counters of the table query kernel: product (ws), round 3's (v1), and 
     rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/pmc_a_$v -- python $R/tools/skip_table_pmc_probe.py > $out/pmc_a_$v.log 2>&1
     rocprofv3 --pmc SQ_IFETCH SQ_IFETCH_LEVEL SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $out/pmc_b_$v -- python $R/tools/skip_table_pmc_probe.py > $out/pmc_b_$v.log 2>&1
     rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum --output-format csv -d $out/pmc_c_$v -- python $R/tools/skip_table_pmc_probe.py > $out/pmc_c_$v.log 2>&1
-    for ps in a b c; do echo "== $v pass $ps"; python $R/tools/pmc_summary.py $out/pmc_${ps}_$v | grep -v skip_table | tail -1; tail -1 $out/pmc_${ps}_$v.log | cut -c1-300; done >> $out/pmc_summary.txt 2>&1
-    rm -rf $out/pmc_a_$v $out/pmc_b_$v $out/pmc_c_$v
+    rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_d_$v -- python $R/tools/skip_table_pmc_probe.py > $out/pmc_d_$v.log 2>&1
+    for ps in a b c d; do echo "== $v pass $ps"; python $R/tools/pmc_summary.py $out/pmc_${ps}_$v | grep -v skip_table | tail -1; done >> $out/pmc_summary.txt 2>&1
+    rm -rf $out/pmc_a_$v $out/pmc_b_$v $out/pmc_c_$v $out/pmc_d_$v
   done
   unset MONOPORT_ABLATE MONOPORT_TAB_KERNEL
   cat $out/pmc_summary.txt
