@@ -15,6 +15,7 @@
 // the output on (gn_tail.h).  Algorithmic work 2 KS^2 Cin Cout FLOP per output pixel; these layers are
 // 12 % of netC's and 0.6 % of netG's encoder FLOPs, so the kernel is built for simplicity: the
 // gather is not overlapped with the MFMAs inside a workgroup (a second workgroup per CU fills in).
+// Round 4: the tile is K-major and the gather coalesced (one k per wave-load, lane = pixel).
 #include "mp_internal.h"
 #include "query_common.h"
 #include "gn_tail.h"
@@ -49,11 +50,15 @@ __global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
   constexpr int PX = 32 * NR * CW;         // output pixels per workgroup (one row segment)
   constexpr int TAPS = KS * KS;
   constexpr int KC = ceil8(CC * TAPS);     // K per chunk
-  constexpr int RS = KC + 4;               // LDS row stride in floats (an odd number of 16-byte slots)
   constexpr int NG = KC / 8;               // MFMA groups (8 deep) per chunk
-  constexpr int NE = (PX * KC + 255) / 256;
+  static_assert(PX == 64, "the gather gives every lane of a wave one of the tile's 64 pixels");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float *bt = reinterpret_cast<float *>(smem);  // [PX][RS]
+  // im2col tile, K-MAJOR [KC][64 pixels] (round 4): a wave gathers ONE k = (channel, tap) for the 64 pixels per load
+  // -- consecutive (stride-`stride`) addresses of one input row, where the pixel-major tile of round 3 had
+  // every lane of a load in a different channel plane (64 cache lines per load; 57 TFLOP/s) -- and writes 64
+  // consecutive floats.  The MFMA B operand (4 consecutive k of one pixel) becomes four ds_read_b32 of
+  // consecutive lanes instead of one ds_read_b128: conflict-free either way.
+  float *bt = reinterpret_cast<float *>(smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -88,15 +93,14 @@ __global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
     // (scale, shift) of the chunk's input channels, once per chunk instead of once per gathered element
     if (norm && tid < CC) gn_scale_shift(p.gn, img, chunk * CC + tid, gn_stats, ss_tab[2 * tid], ss_tab[2 * tid + 1]);
     __syncthreads();  // the previous chunk's tile has been consumed; ss_tab is visible
-    // ---- gather: element e = (pixel, k), k fastest (conflict-free LDS writes) ----
-#pragma unroll 2
-    for (int it = 0; it < NE; ++it) {
-      const int e = tid + 256 * it;
-      if (e < PX * KC) {
-        const int px = e / KC, k = e - px * KC;
+    // ---- gather: wave wv takes k = wv, wv + 4, ...; lane = pixel ----
+    {
+      const int ix0 = (ox0 + lane) * p.stride - p.pad;
+#pragma unroll 4
+      for (int k = wv; k < KC; k += 4) {  // wave-uniform
         const int c = k / TAPS, r = k - c * TAPS;
         const int ky = r / KS, kx = r - ky * KS;
-        int iy = oy * p.stride - p.pad + ky, ix = (ox0 + px) * p.stride - p.pad + kx;
+        int iy = oy * p.stride - p.pad + ky, ix = ix0 + kx;
         bool ok = k < CC * TAPS;
         if (p.reflect) {
           iy = iy < 0 ? -iy : (iy >= p.h ? 2 * p.h - 2 - iy : iy);
@@ -106,29 +110,31 @@ __global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
         }
         float v = 0.0f;
         if (ok) {
-          const int ci = chunk * CC + c;
-          v = xin[ci * hw_in + (long long)iy * p.w + ix];
+          v = xin[(chunk * CC + c) * hw_in + (long long)iy * p.w + ix];
           if (norm) {
             v = fmaf(v, ss_tab[2 * c], ss_tab[2 * c + 1]);
             if (p.relu) v = fmaxf(v, 0.0f);
           }
         }
-        bt[px * RS + k] = v;
+        bt[k * PX + lane] = v;
       }
     }
     __syncthreads();
     // ---- MFMAs over the chunk ----
+    auto b_read = [&](int n, int g) {
+      const float *col = bt + (8 * g + 4 * h) * PX + 32 * (cwi * NR + n) + j;
+      const f32x4 b = {col[0], col[PX], col[2 * PX], col[3 * PX]};
+      return b;
+    };
     f32x4 bcur[NR];
 #pragma unroll
-    for (int n = 0; n < NR; ++n)
-      bcur[n] = *reinterpret_cast<const f32x4 *>(bt + (32 * (cwi * NR + n) + j) * RS + 4 * h);
+    for (int n = 0; n < NR; ++n) bcur[n] = b_read(n, 0);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       f32x4 bnxt[NR];
       if (g + 1 < NG) {
 #pragma unroll
-        for (int n = 0; n < NR; ++n)
-          bnxt[n] = *reinterpret_cast<const f32x4 *>(bt + (32 * (cwi * NR + n) + j) * RS + 8 * (g + 1) + 4 * h);
+        for (int n = 0; n < NR; ++n) bnxt[n] = b_read(n, g + 1);
       }
       const f32x4 a = ring[g % 6];
       if (g + 6 < NG) ring[g % 6] = wload128(ws, a_base + (g + 6) * 64);
@@ -220,7 +226,7 @@ int launch_convk_pack(mp_ctx *ctx, const float *w, int cout, int cin, int ks, fl
 template <int RBW, int NR, int KS, int CC>
 static int launch_convk_t(mp_ctx *ctx, const ConvKArgs &a, hipStream_t st) {
   constexpr int PX = 32 * NR * (4 / RBW);
-  constexpr int lds_tile = PX * (ceil8(CC * KS * KS) + 4) * 4;
+  constexpr int lds_tile = PX * ceil8(CC * KS * KS) * 4;
   constexpr int lds = lds_tile > 4096 ? lds_tile : 4096;
   auto kern = convk_kernel<RBW, NR, KS, CC>;
   const void *kern_id = reinterpret_cast<const void *>(kern);

@@ -164,6 +164,12 @@ shapes20)  # the driver's --steps 20 by slot layout
     bench_line $out/b.json "$flags"
   done
   ;;
+color)  # configs[2] + the convk tests
+  timeout 600 python -m pytest tests/test_conv_gpu.py tests/test_encoder_dataflow_gpu.py tests/test_dropin_gpu.py -q -m gpu -k "convk or netc or encoder or stem" 2>&1 | tail -3
+  timeout 600 python bench.py --with-color --no-extras --no-cpu-baseline > $out/color.json 2> $out/color.err; tail -c 200 $out/color.err
+  bench_line $out/color.json with-color
+  timeout 300 python tools/netc_encoder_probe.py 2>&1 | tail -6
+  ;;
 tests) run_tests ;;
 bench)
   timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.err
