@@ -45,7 +45,14 @@ __global__ void convk_pack_kernel(const float *__restrict__ w, int cout, int cin
 }
 
 template <int RBW, int NR, int KS, int CC>
-__global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
+#ifndef MPT_CONVK_WG
+#define MPT_CONVK_WG 2  // side builds (tools/ablate.py): 4 fits 128 registers with spills
+#endif
+__global__ __launch_bounds__(256, MPT_CONVK_WG) void convk_kernel(ConvKArgs p) {
+#ifndef MPT_CONVK_RING
+#define MPT_CONVK_RING 6
+#endif
+  constexpr int kRing = MPT_CONVK_RING;  // weight fragments in flight
   constexpr int CW = 4 / RBW;
   constexpr int PX = 32 * NR * CW;         // output pixels per workgroup (one row segment)
   constexpr int TAPS = KS * KS;
@@ -85,41 +92,86 @@ __global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[n][t] = 0.0f;
 
+  // The gather of chunk c + 1 is IN FLIGHT under the MFMAs of chunk c: its raw values wait in registers
+  // (up to (CC * KS / 4 + 1) * KS per thread) and are normalised and written to the tile at the top of the next iteration.
+  // addresses: one buffer resource over the image's input planes; the lane part is the COLUMN of a tap (KS
+  // values, mirrored / or pushed out of range so that the load returns 0), the row and the channel plane go
+  // into the scalar offset -- KS lane registers instead of one 64-bit address per gathered value
+  const __amdgpu_buffer_rsrc_t xrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xin), 0, (int)(p.cin * hw_in * 4), 0x00020000);
+  constexpr int kOob = 0x7ffffff0;  // beyond num_records: the raw buffer load returns 0
+  int colo[KS];
+#pragma unroll
+  for (int kx = 0; kx < KS; ++kx) {
+    int ix = (ox0 + lane) * p.stride - p.pad + kx;
+    bool okx = true;
+    if (p.reflect)
+      ix = ix < 0 ? -ix : (ix >= p.w ? 2 * p.w - 2 - ix : ix);
+    else
+      okx = ix >= 0 && ix < p.w;
+    colo[kx] = okx ? ix * 4 : kOob;
+  }
+  // wave wv gathers the tile rows of the (channel, ky) pairs wv, wv + 4, ...: KS loads per pair that differ in
+  // the lane offset colo[kx] only (kx a compile-time index: no per-load address registers to keep alive)
+  constexpr int NP = (CC * KS + 3) / 4;
+  auto pair_of = [&](int ip, int &c, int &iy, bool &ok) {  // all scalar
+    const int pr = wv + 4 * ip;
+    c = pr / KS;
+    const int ky = pr - c * KS;
+    iy = oy * p.stride - p.pad + ky;
+    ok = pr < CC * KS;
+    if (p.reflect)
+      iy = iy < 0 ? -iy : (iy >= p.h ? 2 * p.h - 2 - iy : iy);
+    else
+      ok = ok && iy >= 0 && iy < p.h;
+  };
+  float raw[NP * KS];
+  auto gather_load = [&](int chunk) {
+#pragma unroll
+    for (int ip = 0; ip < NP; ++ip) {
+      int c, iy;
+      bool ok;
+      pair_of(ip, c, iy, ok);
+      const int soff = ok ? (int)(((long long)(chunk * CC + c) * hw_in + (long long)iy * p.w) * 4) : 0;
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx)
+        raw[ip * KS + kx] =
+            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? colo[kx] : kOob, soff, 0));
+    }
+  };
+  // the K padding rows of the tile (CC * TAPS .. KC) are zero for every chunk
+  for (int e = tid; e < (KC - CC * TAPS) * PX; e += 256) bt[CC * TAPS * PX + e] = 0.0f;
+  gather_load(0);
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     const int a_base = (rb * n_chunks + chunk) * NG * 64;
-    f32x4 ring[6];
+    f32x4 ring[kRing];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) ring[k] = wload128(ws, a_base + (k < NG ? k : NG - 1) * 64);
+    for (int k = 0; k < kRing; ++k) ring[k] = wload128(ws, a_base + (k < NG ? k : NG - 1) * 64);
     // (scale, shift) of the chunk's input channels, once per chunk instead of once per gathered element
     if (norm && tid < CC) gn_scale_shift(p.gn, img, chunk * CC + tid, gn_stats, ss_tab[2 * tid], ss_tab[2 * tid + 1]);
     __syncthreads();  // the previous chunk's tile has been consumed; ss_tab is visible
-    // ---- gather: wave wv takes k = wv, wv + 4, ...; lane = pixel ----
-    {
-      const int ix0 = (ox0 + lane) * p.stride - p.pad;
-#pragma unroll 4
-      for (int k = wv; k < KC; k += 4) {  // wave-uniform
-        const int c = k / TAPS, r = k - c * TAPS;
-        const int ky = r / KS, kx = r - ky * KS;
-        int iy = oy * p.stride - p.pad + ky, ix = ix0 + kx;
-        bool ok = k < CC * TAPS;
-        if (p.reflect) {
-          iy = iy < 0 ? -iy : (iy >= p.h ? 2 * p.h - 2 - iy : iy);
-          ix = ix < 0 ? -ix : (ix >= p.w ? 2 * p.w - 2 - ix : ix);
-        } else {
-          ok = ok && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-        }
-        float v = 0.0f;
-        if (ok) {
-          v = xin[(chunk * CC + c) * hw_in + (long long)iy * p.w + ix];
-          if (norm) {
-            v = fmaf(v, ss_tab[2 * c], ss_tab[2 * c + 1]);
+    // ---- the gathered values of this chunk -> the tile: wave wv holds k = wv, wv + 4, ...; lane = pixel ----
+#pragma unroll
+    for (int ip = 0; ip < NP; ++ip) {
+      int c, iy;
+      bool ok;
+      pair_of(ip, c, iy, ok);
+      if (wv + 4 * ip < CC * KS) {
+        const float sc = norm ? ss_tab[2 * c] : 1.0f, sh = norm ? ss_tab[2 * c + 1] : 0.0f;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          float v = raw[ip * KS + kx];
+          // (a value gathered from outside the image is 0 and stays 0: padding comes after GroupNorm + ReLU)
+          if (norm && ok && colo[kx] != kOob) {
+            v = fmaf(v, sc, sh);
             if (p.relu) v = fmaxf(v, 0.0f);
           }
+          bt[((wv + 4 * ip) * KS + kx) * PX + lane] = v;
         }
-        bt[k * PX + lane] = v;
       }
     }
     __syncthreads();
+    if (chunk + 1 < n_chunks) gather_load(chunk + 1);  // lands under the MFMAs below
     // ---- MFMAs over the chunk ----
     auto b_read = [&](int n, int g) {
       const float *col = bt + (8 * g + 4 * h) * PX + 32 * (cwi * NR + n) + j;
@@ -136,8 +188,8 @@ __global__ __launch_bounds__(256, 2) void convk_kernel(ConvKArgs p) {
 #pragma unroll
         for (int n = 0; n < NR; ++n) bnxt[n] = b_read(n, g + 1);
       }
-      const f32x4 a = ring[g % 6];
-      if (g + 6 < NG) ring[g % 6] = wload128(ws, a_base + (g + 6) * 64);
+      const f32x4 a = ring[g % kRing];
+      if (g + kRing < NG) ring[g % kRing] = wload128(ws, a_base + (g + kRing) * 64);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
