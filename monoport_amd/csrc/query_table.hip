@@ -349,17 +349,80 @@ constexpr int kWsBZ0 = kWsRed + 4 * 3 * kTabPts * 4;    // layer 0: [row / 4][bi
 constexpr int kWsB13 = kWsBZ0 + kHidden[0] * 8;         // biases of layers 1-3 (896 floats)
 constexpr int kWsZv = kWsB13 + (kHidden[1] + kHidden[2] + kHidden[3]) * 4;  // zvec[2][32]: z * z_scale of the tile's points, by tile parity
 constexpr int kWsTend = kWsZv + 2 * kTabPts * 4;        // tile_end[f]: tiles of frames 0..f (prefix sums), 16 ints
-constexpr int kWsLds = kWsTend + kMaxFrames * 4;
+// What the producers need to know about a frame, staged once per workgroup.  Per tile they would otherwise chain
+// scalar loads from the kernel arguments (dynamic frame index; a miss in the scalar cache goes to the kernarg
+// buffer), the device-side point counter and the calibration: 25 k cycles per tile for the point load alone
+// (tools/tab_ws_stamp_probe.py).
+struct WsFrame {
+  float cal[12];
+  const float *pts;
+  const uint32_t *packed;
+  float *out;
+  const float *l0;
+  long long sn, sc, out_stride;
+  int stride, level_res;
+  float res_final, half_step, bmin[3], blen[3];
+  int npts, pad;
+};
+static_assert(sizeof(WsFrame) == 152, "two workgroups per CU: 2 x kWsLds <= 160 KB");
+constexpr int kWsFrames = kWsTend + kMaxFrames * 4;
+constexpr int kWsLds = kWsFrames + kMaxFrames * (int)sizeof(WsFrame);
+static_assert(2 * (kWsLds + 320) <= 160 * 1024, "two workgroups per CU (+ the 288 bytes of static LDS of the stamp build)");
 
 // timing experiments (tools/ablate.py; wrong results): the producers do no work / no barriers;
 // MPT_WS_PRIO: s_setprio of the consumer waves
 #ifdef MPT_WS_NOBAR
 #define WS_SYNC() __builtin_amdgcn_sched_barrier(0)
+#elif defined(MPT_WS_STAMP)
+// side build (tools/tab_ws_stamp_probe.py): per barrier of the tile schedule and per role, the cycles wave 0 / 4 of
+// workgroup 0 spent WORKING before it arrived and WAITING at it; the sums replace the first outputs of frame 0
+#define WS_SYNC()                                                                        \
+  do {                                                                                   \
+    const long long t0_ = __builtin_amdgcn_s_memtime();                                  \
+    __syncthreads();                                                                     \
+    const long long t1_ = __builtin_amdgcn_s_memtime();                                  \
+    if (lane == 0 && (wv & 3) == 0) {                                                    \
+      atomicAdd(&ws_stamp[((wv >> 2) * 16 + (ws_sidx & 15)) * 2], (unsigned)(t0_ - ws_leave)); \
+      atomicAdd(&ws_stamp[((wv >> 2) * 16 + (ws_sidx & 15)) * 2 + 1], (unsigned)(t1_ - t0_));   \
+    }                                                                                    \
+    ws_leave = t1_;                                                                      \
+    ++ws_sidx;                                                                           \
+  } while (0)
 #else
 #define WS_SYNC() __syncthreads()
 #endif
+#ifdef MPT_WS_STAMP  // ticks since the last barrier at a point inside an interval (all loads drained first), summed in slot i
+#define WS_MARK(i)                                                                              \
+  do {                                                                                          \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+    if (lane == 0 && wv == 4) atomicAdd(&ws_mark[i], (unsigned)(__builtin_amdgcn_s_memtime() - ws_leave)); \
+  } while (0)
+#else
+#define WS_MARK(i)
+#endif
 #ifndef MPT_TAB_AUX
 #define MPT_TAB_AUX 0  // cache policy of the table-row loads (2 = nt: stream past the L2-resident weights)
+#endif
+#ifndef MPT_WS_PIECE_AHEAD
+#define MPT_WS_PIECE_AHEAD 0  // (measured: no gain) 1: the loads of a layer-1 piece are issued one interval before the piece is written
+#endif
+#ifndef MPT_WS_FINISH_AT
+#define MPT_WS_FINISH_AT 8  // the interval (8 = T0) in which the producers store the previous tile's outputs
+#endif
+#ifndef MPT_WS_SETUP_AT
+#define MPT_WS_SETUP_AT 7  // ... and in which they project the next tile's points
+#endif
+#ifndef MPT_WS_P4_FIRST
+#define MPT_WS_P4_FIRST 1  // S7: the rows of piece 4 requested before (1) or after (0) the next tile's points are set up
+#endif
+#ifndef MPT_WS_R4_LATE
+#define MPT_WS_R4_LATE 1  // layer 4's skip row of the next tile's points: in T3 (0: with the projection)
+#endif
+#ifndef MPT_WS_SPRIO
+#define MPT_WS_SPRIO 3  // s_setprio of the producers while they set up the next tile's points / store the outputs
+#endif
+#ifndef MPT_WS_PPRIO
+#define MPT_WS_PPRIO 0  // s_setprio of the producer waves
 #endif
 #ifndef MPT_WS_PRIO
 #define MPT_WS_PRIO 1  // measured: 0.819 -> 0.830 of the roof on 885 k points (3 = the same)
@@ -393,6 +456,9 @@ struct WsPoint {
   int to[4];     // byte offsets of the four table rows (+ this lane's half of a row group)
   f32x2 tw2[4];  // grid_sample weights (0 outside the map / dead point), each twice: packed-FMA operands
   float zf;      // z * z_scale (0 for a dead point)
+  float r4;      // layer 4's blended skip row of output 2 * (producer wave) + (lane >> 5)
+  uint32_t code; // packed lattice coordinates (scatter address of the output)
+  int ok;        // bit 0: the point exists, bit 1: it projects into the image
 };
 
 template <int COUT>
@@ -427,8 +493,41 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         acc += (int)((nf + P - 1) / P);
       }
     tend[tid] = acc;
+    if (tid < set.n) {
+      const QueryItem &it = set.it[tid];
+      WsFrame &fr = reinterpret_cast<WsFrame *>(smem + kWsFrames)[tid];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) fr.cal[i] = it.calib[i];
+      fr.pts = it.src.pts;
+      fr.packed = it.src.packed;
+      fr.out = it.out;
+      fr.l0 = it.l0;
+      fr.sn = it.src.sn;
+      fr.sc = it.src.sc;
+      fr.out_stride = it.src.out_stride;
+      fr.stride = it.src.stride;
+      fr.level_res = it.src.level_res;
+      fr.res_final = it.src.res_final;
+      fr.half_step = it.src.half_step;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        fr.bmin[i] = it.src.bmin[i];
+        fr.blen[i] = it.src.blen[i];
+      }
+      fr.npts = (int)(it.src.n_dev ? (long long)*it.src.n_dev : it.src.n);
+    }
   }
+#ifdef MPT_WS_STAMP
+  __shared__ unsigned ws_stamp[64];
+  __shared__ unsigned ws_mark[8];
+  if (tid < 64) ws_stamp[tid] = 0;
+  if (tid < 8) ws_mark[tid] = 0;
+  int ws_sidx = 15;  // the barrier before the first tile; the one behind the last tile lands in slot 14
+#endif
   __syncthreads();
+#ifdef MPT_WS_STAMP
+  long long ws_leave = __builtin_amdgcn_s_memtime();
+#endif
   const long long n_tiles = __builtin_amdgcn_readfirstlane(tend[kMaxFrames - 1]);
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own
   // L2.  Tiles that are neighbours in the list share texels (table rows) and frames, so XCD x takes the
@@ -468,10 +567,27 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
       }
       gemm_z<1, 1>(acc, az, zb);
     };
+    // accumulator tile m of this wave -> rows [32 m, +32) of a 128-row K buffer, point-major: store_hidden's
+    // addresses from ONE register -- slot 8 m + 2 q + h, swizzled = (j * 512 | swz << 4) ^ ((8 m + 2 q) << 4).
+    // (16 precomputed offsets would sit in registers for the whole kernel: the compiler hoists them out of
+    // the tile loop and spills four of them -- reloads with s_waitcnt vmcnt(0) in front of the weight
+    // prefetch; the asm below pins the computation inside the loop)
+    int st0 = j * kTabHbRow | (swz << 4);
+    auto store_k = [&](int region, const f32x16 &v, int m) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        *reinterpret_cast<f32x4 *>(x + region * kWsXBytes + (st0 ^ ((8 * m + 2 * q) << 4))) = o;
+      }
+    };
     WS_SYNC();  // the producers' first chunk
     int par = 0;
     for (long long gtile = tile_first;; gtile += tile_step, par ^= 1) {
       if (gtile >= tile_end) break;
+#ifdef MPT_WS_STAMP
+      ws_sidx = 0;
+#endif
+      asm volatile("" : "+v"(st0));
       zb[0] = h == 0 ? zvec[par * P + j] : 0.0f;
       // ---------------- S0-S7: layer 1 += W1[:, chunk k] * (layer-0 chunk k in X[k & 1]); piece k / 2 added on odd k ----------------
       f32x16 acc1[4][1];
@@ -494,7 +610,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
             // X[2], X[0] here (last read in U0 of the previous tile / S6), pairs 2, 3 -> X[1], PB at the top of T0
             if (wv < 2) {
 #pragma unroll
-              for (int m = 0; m < 4; ++m) store_hidden<kTabHbRow>(x + (wv == 0 ? 2 : 0) * kWsXBytes, acc1[m][0], m, 0, j, h);
+              for (int m = 0; m < 4; ++m) store_k(wv == 0 ? 2 : 0, acc1[m][0], m);
             }
           }
           WS_SYNC();
@@ -508,7 +624,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         for (int t = 0; t < 16; ++t) acc2[m][0][t] = 0.0f;
       if (wv >= 2) {  // behind the barrier of S7: X[1] (chunk 7) and PB (piece 3) have been read
 #pragma unroll
-        for (int m = 0; m < 4; ++m) store_hidden<kTabHbRow>(x + (wv == 2 ? 1 : 3) * kWsXBytes, acc1[m][0], m, 0, j, h);
+        for (int m = 0; m < 4; ++m) store_k(wv == 2 ? 1 : 3, acc1[m][0], m);
       }
       {
         f32x4 ring2[2][2];
@@ -527,7 +643,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
             for (int m = 0; m < 2; ++m) lrelu(acc2[m][0]);
             if (wv < 2) {  // layer 3's first K pair = hidden-2 rows [0, 128) = waves 0 and 1 -> X[2] (piece 4 was read in T2)
 #pragma unroll
-              for (int m = 0; m < 2; ++m) store_hidden<kTabHbRow>(x + 2 * kWsXBytes, acc2[m][0], 2 * wv + m, 0, j, h);
+              for (int m = 0; m < 2; ++m) store_k(2, acc2[m][0], 2 * wv + m);
             }
           }
           WS_SYNC();
@@ -544,7 +660,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         for (int pr = 0; pr < 2; ++pr) {
           if (pr == 0 && wv >= 2) {  // the second pair = waves 2 and 3 -> X[1] (last read in T2)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) store_hidden<kTabHbRow>(x + kWsXBytes, acc2[m][0], 2 * (wv - 2) + m, 0, j, h);
+            for (int m = 0; m < 2; ++m) store_k(1, acc2[m][0], 2 * (wv - 2) + m);
           }
 #ifndef MPT_WS_SONLY
           seg_main<1, 1, 3, kTabHbRow>(acc3, ring3, ws, a3 + pr * 16 * 64, 0, 16, xrow + (pr ? 1 : 2) * kWsXBytes, swz);
@@ -578,29 +694,73 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
   } else {
     // =============================== producers: everything per point ===============================
     const int pw = wv - 4;  // partner of consumer wave pw
+    if (MPT_WS_PPRIO) __builtin_amdgcn_s_setprio(MPT_WS_PPRIO);
     unsigned char *h0 = smem + kWsX;
+    int st1 = (j * kTabHbRow | (swz << 4)) ^ (pw << 7);  // see the consumers' store_k
     f32x4 *piece0 = reinterpret_cast<f32x4 *>(smem + kWsX) + (pw * 4) * 64 + lane;  // + region * 16 KB (3 = PB)
 
+    // (the frame index is wave-uniform, but not provably so for the compiler: without the readfirstlanes every
+    // table load is wrapped in a waterfall loop over the descriptor)
+    const WsFrame *frames = reinterpret_cast<const WsFrame *>(smem + kWsFrames);
     auto table_rsrc = [&](int fi) {
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(set.it[fi].l0), 0, fh * fw * kTableRows * 4,
-                                               0x00020000);
+      const unsigned long long a = reinterpret_cast<unsigned long long>(frames[__builtin_amdgcn_readfirstlane(fi)].l0);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+      return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>((unsigned long long)hi << 32 | lo), 0,
+                                               fh * fw * kTableRows * 4, 0x00020000);
     };
     float *zvec = reinterpret_cast<float *>(smem + kWsZv);
-    auto setup_point = [&](int fi, long long n0, WsPoint &pt, int zpar) {
-      const QueryItem &item = set.it[fi];
-      const PointSrc &src = item.src;
-      const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
+    // The point of this lane in tile (fi, n0), in two steps so that its round trips hide behind other work:
+    // point_load (the coordinates: one dependent load -- the point count comes from LDS) an interval before
+    // point_setup (projection, texels, weights, and layer 4's skip row for finish_tile).
+    struct RawPoint {
+      float px, py, pz;
+      uint32_t code;
+      int live;
+    };
+    auto point_load = [&](int fi, long long n0, RawPoint &rp) {  // load_point (query_common.h) on the staged frame
+      const WsFrame &fr = frames[fi];
+      const long long n = n0 + j;
+      rp.px = rp.py = rp.pz = 0.0f;
+      rp.code = 0;
+      rp.live = n < fr.npts;
+      if (rp.live) {
+        if (fr.packed) {
+          rp.code = fr.packed[n];
+        } else {
+          rp.px = fr.pts[n * fr.sn];
+          rp.py = fr.pts[n * fr.sn + fr.sc];
+          rp.pz = fr.pts[n * fr.sn + 2 * fr.sc];
+        }
+      }
+    };
+    auto point_setup = [&](int fi, const RawPoint &rp, WsPoint &pt, int zpar) {
+      const WsFrame &fr = frames[fi];
       float cal[12];
 #pragma unroll
-      for (int i = 0; i < 12; ++i) cal[i] = item.calib[i];
-      const long long n = n0 + j;
-      float px = 0, py = 0, pz = 0, x, y, z;
-      uint32_t code;
-      if (n < n_pts) load_point(src, n, px, py, pz, code);
+      for (int i = 0; i < 12; ++i) cal[i] = fr.cal[i];
+      float px = rp.px, py = rp.py, pz = rp.pz;
+      if (fr.packed && rp.live) {  // lattice_coord (query_common.h), the same operation sequence
+        const int idx[3] = {(int)(rp.code & 1023u), (int)((rp.code >> 10) & 1023u), (int)(rp.code >> 20)};
+        float c3[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float c = (float)(idx[a] * fr.stride);
+          const float u = __fadd_rn(__fdiv_rn(c, fr.res_final), fr.half_step);
+          c3[a] = __fadd_rn(__fmul_rn(u, fr.blen[a]), fr.bmin[a]);
+        }
+        px = c3[0];
+        py = c3[1];
+        pz = c3[2];
+      }
+      float x, y, z;
       project(cal, px, py, pz, x, y, z);
-      pt.zf = n < n_pts ? __fmul_rn(z, z_scale) : 0.0f;
+      pt.zf = rp.live ? __fmul_rn(z, z_scale) : 0.0f;
       if (pw == 0 && h == 0) zvec[zpar * P + j] = pt.zf;  // the consumers' B operand of the z column
-      const Taps t = make_taps(x, y, fh, fw, kTableRows, n < n_pts && in_image(x, y));
+      const bool inside = in_image(x, y);
+      const Taps t = make_taps(x, y, fh, fw, kTableRows, rp.live && inside);
+      pt.code = rp.code;
+      pt.ok = (rp.live ? 1 : 0) | (inside ? 2 : 0);
+      pt.r4 = 0.0f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
 #ifdef MPT_FAKE_GATHER
@@ -610,6 +770,27 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #endif
         pt.tw2[k] = (f32x2)(t.w[k]);
       }
+    };
+    constexpr int K4 = (kHidden[3] + 256 + 1 + 3) & ~3;
+    // layer 4's blended skip row of this lane's output (what finish_tile adds): its own round trip, taken in an
+    // interval in which the producers have nothing else to do
+    auto point_r4 = [&](int fi, WsPoint &pt) {
+      if (2 * pw + h < COUT && (pt.ok & 1)) {
+        const float *row = frames[fi].l0 + kTableL[4] + 2 * pw + h;
+        const int o0 = (pt.to[0] - 16 * h) >> 2, o1 = (pt.to[1] - 16 * h) >> 2, o2 = (pt.to[2] - 16 * h) >> 2,
+                  o3 = (pt.to[3] - 16 * h) >> 2;
+        const float bias4 = (mlp.base + mlp.bias[4])[2 * pw + h];
+        const float wz4 = (mlp.base + mlp.w4)[(2 * pw + h) * K4 + kHidden[3] + 256];
+        const float r = fmaf(row[o3], pt.tw2[3][0],
+                             fmaf(row[o2], pt.tw2[2][0], fmaf(row[o1], pt.tw2[1][0], __fmul_rn(row[o0], pt.tw2[0][0]))));
+        pt.r4 = r + fmaf(wz4, pt.zf, bias4);  // + the z column and the bias
+      }
+    };
+    auto setup_point = [&](int fi, long long n0, WsPoint &pt, int zpar) {
+      RawPoint rp;
+      point_load(fi, n0, rp);
+      point_setup(fi, rp, pt, zpar);
+      point_r4(fi, pt);
     };
     // a job = one 32-row block of the table for this lane's point: 16 loads, then the blend
     auto job_issue = [&](TabRows &tp, const __amdgpu_buffer_rsrc_t &prs, const WsPoint &pt, int row0) {
@@ -646,15 +827,13 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     // lrelu(b0 + z w0z + blend) with bias and z weights from LDS
     auto chunk_finish = [&](const TabRows &tp, const WsPoint &pt, int ck, int buf) {
       const int rb = 4 * ck + pw;
-      const int p = j;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 *bz = reinterpret_cast<const f32x4 *>(bz0 + (8 * rb + 2 * q + h) * 8);
         f32x4 v = __builtin_elementwise_fma(bz[1], (f32x4)(pt.zf), bz[0]);
         v = blend4(tp[q], pt, v);
         v = __builtin_elementwise_max(v, v * 0.01f);  // leaky ReLU (SurfaceClassifier.py:58)
-        const int slot = 8 * pw + 2 * q + h;
-        *reinterpret_cast<f32x4 *>(h0 + buf * kWsXBytes + p * kTabHbRow + ((slot ^ (p & 15)) << 4)) = v;
+        *reinterpret_cast<f32x4 *>(h0 + buf * kWsXBytes + (st1 ^ ((2 * q) << 4))) = v;  // slot 8 pw + 2 q + h, swizzled
       }
     };
     // piece = bias + blend of row block rb of layer l (b13 offset boff) -> PB; the z column is the consumers'
@@ -665,55 +844,42 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         piece0[region * (kWsXBytes / 16) + q * 64] = blend4(tp[q], pt, b);
       }
     };
-    // the output of tile (fi, n0): bias + partial sums + layer 4's blended row + z column
-    auto finish_tile = [&](int fi, long long n0) {
-      const int t = pw * 64 + lane;
-      if (t < COUT * P) {
-        const QueryItem &item = set.it[fi];
-        const PointSrc &src = item.src;
-        const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
+    // the output of tile (fi, n0), whose points are `pt`: bias + the consumers' partial sums + layer 4's blended
+    // row + z column.  Lane (j, h) of producer wave pw stores output 2 pw + h of point j; everything that
+    // needs the point was loaded by setup_point a tile earlier -- no global load stands between the
+    // partial sums and the store (with them, this was the longest producer interval of the tile: the
+    // consumers waited 7 % of their time at its barrier, tools/tab_ws_stamp_probe.py)
+    const int my_o = 2 * pw + h;
+    auto finish_tile = [&](const WsPoint &pt, int fi, long long n0) {
+      if (my_o < COUT && (pt.ok & 1)) {
+        const WsFrame &fr = frames[fi];
         const float *red = reinterpret_cast<const float *>(smem + kWsRed);
-        constexpr int K4 = (kHidden[3] + 256 + 1 + 3) & ~3;
-        const int o = t / P, p = t % P;
-        const long long n = n0 + p;
-        if (n < n_pts) {
-          float v = (mlp.base + mlp.bias[4])[o];
+        float v = red[my_o * P + j];
 #pragma unroll
-          for (int part = 0; part < 4; ++part) v += red[(part * COUT + o) * P + p];
-          const float wz = (mlp.base + mlp.w4)[o * K4 + kHidden[3] + 256];
-          float cal[12];
-#pragma unroll
-          for (int i = 0; i < 12; ++i) cal[i] = item.calib[i];
-          float px, py, pz, x, y, z;
-          uint32_t code;
-          load_point(src, n, px, py, pz, code);
-          project(cal, px, py, pz, x, y, z);
-          const bool inside = in_image(x, y);
-          const Taps tp = make_taps(x, y, fh, fw, kTableRows, inside);
-          const float *row = item.l0 + kTableL[4] + o;
-          v += fmaf(row[tp.o[3]], tp.w[3],
-                    fmaf(row[tp.o[2]], tp.w[2], fmaf(row[tp.o[1]], tp.w[1], __fmul_rn(row[tp.o[0]], tp.w[0]))));
-          v = fmaf(wz, __fmul_rn(z, z_scale), v);
-          v = inside ? activate(v, act) : 0.0f;  // MonoPortNet.py:89
-          if (src.packed) {
-            const int ix = code & 1023u, iy = (code >> 10) & 1023u, iz = code >> 20;
-            item.out[((long long)iz * src.level_res + iy) * src.level_res + ix] = v;
-          } else {
-            item.out[o * src.out_stride + n] = v;
-          }
+        for (int part = 1; part < 4; ++part) v += red[(part * COUT + my_o) * P + j];
+        v += pt.r4;
+        v = (pt.ok & 2) ? activate(v, act) : 0.0f;  // MonoPortNet.py:89
+        if (fr.packed) {
+          const int ix = pt.code & 1023u, iy = (pt.code >> 10) & 1023u, iz = pt.code >> 20;
+          fr.out[((long long)iz * fr.level_res + iy) * fr.level_res + ix] = v;
+        } else {
+          fr.out[my_o * fr.out_stride + n0 + j] = v;
         }
       }
     };
 
-    WsPoint cur = {}, nxt;
+    WsPoint cur = {}, nxt, prev = {};
     const TileLoc no_tile = {-1, 0};
     TileLoc loc = tile_first < tile_end ? locate_tile(tend, tile_first, lane) : no_tile;
     __amdgpu_buffer_rsrc_t prs_cur = table_rsrc(loc.fi >= 0 ? loc.fi : 0), prs_nxt;
+    TabRows tp;  // the rows of the job in flight; it may cross a barrier (and the end of a tile)
     if (loc.fi >= 0) {
       setup_point(loc.fi, loc.n0, cur, 0);
-      TabRows tp;
       job_issue(tp, prs_cur, cur, kTableL[0] + 32 * pw);
       chunk_finish(tp, cur, 0, 0);
+#if MPT_WS_PIECE_AHEAD
+      job_issue(tp, prs_cur, cur, kTableL[1] + 32 * (4 * pw));  // piece 0 in flight
+#endif
     }
     prs_nxt = prs_cur;
     nxt = cur;
@@ -722,31 +888,70 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     long long prev_n0 = 0;
     for (long long gtile = tile_first;; gtile += tile_step, par ^= 1) {
       if (loc.fi < 0) break;
+#ifdef MPT_WS_STAMP
+      ws_sidx = 0;
+#endif
       const TileLoc loc_n = gtile + tile_step < tile_end ? locate_tile(tend, gtile + tile_step, lane) : no_tile;
-      TabRows tp;
       // ---------------- S0-S7 ----------------
+      // Even k: piece k / 2 (row block 4 pw + k / 2 of layer 1) -> PB, read in S(k + 1) -- its loads were issued at
+      // the end of the interval before, so the interval holds ONE load round trip (chunk k + 1), like the odd ones.
+      // S7, where the producers have next to nothing to do: the previous tile's outputs, the next tile's points.
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
 #ifndef MPT_WS_NOPROD
-        if (k == 0 && prev_fi >= 0) finish_tile(prev_fi, prev_n0);
-        if (k == 1 && loc_n.fi >= 0) {  // the next tile's point, long before it is needed (U0)
+        if (k == MPT_WS_FINISH_AT && k < 7 && prev_fi >= 0) finish_tile(prev, prev_fi, prev_n0);
+        if (k == MPT_WS_SETUP_AT && k < 7 && loc_n.fi >= 0) {
           setup_point(loc_n.fi, loc_n.n0, nxt, par ^ 1);
           prs_nxt = table_rsrc(loc_n.fi);
         }
-        if (!(k & 1)) {  // piece k / 2: row block 4 pw + k / 2 of layer 1 -> PB (read in S(k + 1))
+        if (k == 0) asm volatile("" : "+v"(st1));
+        if (!(k & 1)) {
+#if !MPT_WS_PIECE_AHEAD
           job_issue(tp, prs_cur, cur, kTableL[1] + 32 * (4 * pw + (k >> 1)));
+#endif
           piece_finish(tp, cur, 32 * (4 * pw + (k >> 1)), 3);
         }
         if (k < 7) {  // chunk k + 1 -> X[(k + 1) & 1] (read in S(k + 1); last read in S(k - 1) / U1)
           job_issue(tp, prs_cur, cur, kTableL[0] + 32 * (4 * (k + 1) + pw));
           chunk_finish(tp, cur, k + 1, (k + 1) & 1);
+#if MPT_WS_PIECE_AHEAD
+          if ((k & 1) && k < 7) job_issue(tp, prs_cur, cur, kTableL[1] + 32 * (4 * pw + ((k + 1) >> 1)));  // piece (k + 1) / 2 in flight
+#endif
         } else {
-          job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw));  // piece 4 (layer 2, row block 2 pw) in flight
+          // S7, where the producers have the least to do: the next tile's points (needed in U0) and the
+          // previous tile's outputs.  Nothing is in flight at its top, so the outputs (which wait for a few
+          // spilled values: s_waitcnt vmcnt(0)) go between the point load and the table rows of piece 4.
+          WS_MARK(0);
+          // the next tile's points are a chain of dependent steps (count, load, divide, project, texels) on the
+          // critical path of the interval: they run at raised priority -- at the consumers' priority or below, a
+          // producer instruction waits ~100 cycles for an issue slot between the MFMAs
+          if (MPT_WS_SPRIO) __builtin_amdgcn_s_setprio(MPT_WS_SPRIO);
+          RawPoint raw_n = {};
+          if (MPT_WS_SETUP_AT == 7 && loc_n.fi >= 0) point_load(loc_n.fi, loc_n.n0, raw_n);
+          WS_MARK(1);
+          if (MPT_WS_FINISH_AT == 7 && prev_fi >= 0) finish_tile(prev, prev_fi, prev_n0);
+          if (MPT_WS_P4_FIRST) job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw));  // piece 4 (layer 2, row block 2 pw) in flight
+          WS_MARK(2);
+          if (MPT_WS_SETUP_AT == 7 && loc_n.fi >= 0) {
+            point_setup(loc_n.fi, raw_n, nxt, par ^ 1);
+            if (!MPT_WS_R4_LATE) point_r4(loc_n.fi, nxt);
+            prs_nxt = table_rsrc(loc_n.fi);
+          }
+          if (MPT_WS_SPRIO) __builtin_amdgcn_s_setprio(MPT_WS_PPRIO);
+          WS_MARK(3);
+          if (!MPT_WS_P4_FIRST) job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw));  // with all 64 row registers free until here
         }
 #endif
         WS_SYNC();
       }
       // ---------------- T0-T3, U0-U1: split jobs -- loads in one interval, blend + write in a later one ----------------
+#ifndef MPT_WS_NOPROD
+      if (MPT_WS_FINISH_AT == 8 && prev_fi >= 0) {  // T0: nothing else to do
+        if (MPT_WS_SPRIO) __builtin_amdgcn_s_setprio(MPT_WS_SPRIO);
+        finish_tile(prev, prev_fi, prev_n0);
+        if (MPT_WS_SPRIO) __builtin_amdgcn_s_setprio(MPT_WS_PPRIO);
+      }
+#endif
       WS_SYNC();  // T0: every region holds a K pair of layer 2 or is being filled with one
 #ifndef MPT_WS_NOPROD
       piece_finish(tp, cur, kHidden[1] + 32 * (2 * pw), 2);         // T1: piece 4 -> X[2] (pair 0 was read in T0; read in T2)
@@ -758,6 +963,9 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
       job_issue(tp, prs_cur, cur, kTableL[3] + 32 * pw);         //     piece 6 in flight
 #endif
       WS_SYNC();
+#ifndef MPT_WS_NOPROD
+      if (MPT_WS_SETUP_AT == 7 && MPT_WS_R4_LATE && loc_n.fi >= 0) point_r4(loc_n.fi, nxt);  // T3: nothing else to do
+#endif
       WS_SYNC();  // T3: the consumers read pair 3 in PB and piece 5
 #ifndef MPT_WS_NOPROD
       piece_finish(tp, cur, kHidden[1] + kHidden[2] + 32 * pw, 3);            // U0: piece 6 -> PB (read in U1)
@@ -765,20 +973,31 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #endif
       WS_SYNC();
 #ifndef MPT_WS_NOPROD
-      if (loc_n.fi >= 0) chunk_finish(tp, nxt, 0, 0);  // U1: -> X[0] (piece 5 was read in T3)
+      if (loc_n.fi >= 0) {
+        chunk_finish(tp, nxt, 0, 0);  // U1: -> X[0] (piece 5 was read in T3)
+#if MPT_WS_PIECE_AHEAD
+        job_issue(tp, prs_nxt, nxt, kTableL[1] + 32 * (4 * pw));  // the next tile's piece 0 in flight
+#endif
+      }
 #endif
       WS_SYNC();
       prev_fi = loc.fi;
       prev_n0 = loc.n0;
+      prev = cur;
       loc = loc_n;
       cur = nxt;
       prs_cur = prs_nxt;
     }
     WS_SYNC();
 #ifndef MPT_WS_NOPROD
-    if (prev_fi >= 0) finish_tile(prev_fi, prev_n0);
+    if (prev_fi >= 0) finish_tile(prev, prev_fi, prev_n0);
 #endif
   }
+#ifdef MPT_WS_STAMP
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < 64) set.it[0].out[tid] = (float)ws_stamp[tid];
+  if (blockIdx.x == 0 && tid < 8) set.it[0].out[64 + tid] = (float)ws_mark[tid];
+#endif
 }
 
 // MONOPORT_TAB_KERNEL=v1 selects round 3's kernel (every wave does everything) for A/B measurements;

@@ -91,6 +91,21 @@ prof)  # kernel trace + stats of the default bench with the per-launch point cou
   tail -1 $out/bench_prof.log | cut -c1-300; cat $out/summary.log | tail -30
   rm -rf $out/trace
   ;;
+profhl)  # kernel stats of the headline configuration alone (no extras): where a frame's GPU time goes
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/bench.py --no-extras --no-cpu-baseline > $out/bench.log 2>&1
+  cd $R
+  tail -1 $out/bench.log | cut -c1-200
+  f=$(find $out/trace -name "*kernel_stats.csv" | head -1)
+  python - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+for r in rows[:28]:
+    print("%6.2f %%  %7d calls  avg %9.1f us  %s" % (100 * float(r["TotalDurationNs"]) / tot, int(r["Calls"]), float(r["AverageNs"]) / 1e3, r["Name"][:90]))
+PY
+  cp "$f" $out/headline_kernel_stats.csv; rm -rf $out/trace
+  ;;
 order)  # point-list order of the octree (y-major default | z-major) x tile order of the table kernel: time + traffic
   for ord in y z; do
     export MONOPORT_OCTREE_ORDER=$ord
@@ -169,6 +184,11 @@ color)  # configs[2] + the convk tests
   timeout 600 python bench.py --with-color --no-extras --no-cpu-baseline > $out/color.json 2> $out/color.err; tail -c 200 $out/color.err
   bench_line $out/color.json with-color
   timeout 300 python tools/netc_encoder_probe.py 2>&1 | tail -6
+  ;;
+levels)  # the headline bench + the per-level fractions of its roofline leg
+  MONOPORT_BENCH_LAUNCH_LOG=$out/launch_log.json timeout 600 python bench.py --no-extras --no-cpu-baseline > $out/bench.json 2> $out/bench.err
+  bench_line $out/bench.json headline
+  python tools/launch_levels.py $out/launch_log.json | tee $out/levels.txt
   ;;
 tests) run_tests ;;
 bench)
