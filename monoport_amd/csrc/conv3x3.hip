@@ -1202,6 +1202,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
   const int rb0 = (int)blockIdx.y * (4 * MRW) + MRW * wv;  // first 32-row block of this wave
   const int a_base = rb0 * rb_stride;
   auto a_load = [&](int m, int s, int part) {
+#ifdef MPC_AHOT  // timing experiment: the weight stream always hits the same fragment
+    s = 0;
+#endif
     return wload128(ws, a_base + m * rb_stride + (min(s, steps - 1) * FPS + part) * 64);
   };
   // A fragments kAhead steps ahead of their MFMAs: one step (16 MFMAs = 0.4 us at MRW = 2) does not

@@ -11,6 +11,6 @@ else
   for v in "" convNOLOAD convNOSTORE convAHOT convNOIO; do
     echo "== ${v:-product}"
     if [ -n "$v" ]; then export MONOPORT_HIP_LIB=$R/monoport_amd/lib/libmp_ablate$v.so; else unset MONOPORT_HIP_LIB; fi
-    MODES=auto python tools/conv_bench.py 10 2>&1 | grep -v amdgpu.ids
+    MODES=auto python tools/conv_bench.py ${BATCH:-10} 2>&1 | grep -v amdgpu.ids
   done
 fi
