@@ -454,7 +454,8 @@ __device__ __forceinline__ TileLoc locate_tile(const int *tend, long long gtile,
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct WsPoint {
   int to[4];     // byte offsets of the four table rows (+ this lane's half of a row group)
-  f32x2 tw2[4];  // grid_sample weights (0 outside the map / dead point), each twice: packed-FMA operands
+  f32x2 tw[2];   // grid_sample weights (0 outside the map / dead point) as two register PAIRS: v_pk_fma_f32 broadcasts
+                 // either half of a pair (op_sel), a lone register would need a v_mov per use
   float zf;      // z * z_scale (0 for a dead point)
   float r4;      // layer 4's blended skip row of output 2 * (producer wave) + (lane >> 5)
   uint32_t code; // packed lattice coordinates (scatter address of the output)
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #else
         pt.to[k] = (int)t.o[k] * 4 + 16 * h;
 #endif
-        pt.tw2[k] = (f32x2)(t.w[k]);
+        pt.tw[k >> 1][k & 1] = t.w[k];
       }
     };
     constexpr int K4 = (kHidden[3] + 256 + 1 + 3) & ~3;
@@ -781,8 +782,8 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
                   o3 = (pt.to[3] - 16 * h) >> 2;
         const float bias4 = (mlp.base + mlp.bias[4])[2 * pw + h];
         const float wz4 = (mlp.base + mlp.w4)[(2 * pw + h) * K4 + kHidden[3] + 256];
-        const float r = fmaf(row[o3], pt.tw2[3][0],
-                             fmaf(row[o2], pt.tw2[2][0], fmaf(row[o1], pt.tw2[1][0], __fmul_rn(row[o0], pt.tw2[0][0]))));
+        const float r = fmaf(row[o3], pt.tw[1][1],
+                             fmaf(row[o2], pt.tw[1][0], fmaf(row[o1], pt.tw[0][1], __fmul_rn(row[o0], pt.tw[0][0]))));
         pt.r4 = r + fmaf(wz4, pt.zf, bias4);  // + the z column and the bias
       }
     };
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
 #ifdef MPT_WS_NOLOAD  // timing experiment: the blends without the table loads
-          const f32x4 fake = {pt.tw2[k][0], pt.tw2[q][0], pt.zf, (float)row0};
+          const f32x4 fake = {pt.tw[k >> 1][k & 1], pt.tw[q >> 1][q & 1], pt.zf, (float)row0};
           tp[q][k] = fake;
 #else
           tp[q][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, pt.to[k], (row0 + 8 * q) * 4,
@@ -817,7 +818,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
       f32x4 v = v0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {  // weights kept as register PAIRS: v_pk_fma_f32 takes them without a v_mov per use
-        const f32x4 w = {pt.tw2[k][0], pt.tw2[k][1], pt.tw2[k][0], pt.tw2[k][1]};
+        const f32x4 w = (f32x4)(pt.tw[k >> 1][k & 1]);
         v = __builtin_elementwise_fma(t[k], w, v);
       }
       return v;
