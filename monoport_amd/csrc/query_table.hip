@@ -872,6 +872,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     WsPoint cur = {}, nxt, prev = {};
     const TileLoc no_tile = {-1, 0};
     TileLoc loc = tile_first < tile_end ? locate_tile(tend, tile_first, lane) : no_tile;
+    TileLoc loc_ahead = tile_first + tile_step < tile_end ? locate_tile(tend, tile_first + tile_step, lane) : no_tile;
     __amdgpu_buffer_rsrc_t prs_cur = table_rsrc(loc.fi >= 0 ? loc.fi : 0), prs_nxt;
     TabRows tp;  // the rows of the job in flight; it may cross a barrier (and the end of a tile)
     if (loc.fi >= 0) {
@@ -892,7 +893,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #ifdef MPT_WS_STAMP
       ws_sidx = 0;
 #endif
-      const TileLoc loc_n = gtile + tile_step < tile_end ? locate_tile(tend, gtile + tile_step, lane) : no_tile;
+      const TileLoc loc_n = loc_ahead;  // located in the previous tile's T0: S0 is the producers' longest interval
       // ---------------- S0-S7 ----------------
       // Even k: piece k / 2 (row block 4 pw + k / 2 of layer 1) -> PB, read in S(k + 1) -- its loads were issued at
       // the end of the interval before, so the interval holds ONE load round trip (chunk k + 1), like the odd ones.
@@ -953,6 +954,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         if (MPT_WS_SPRIO) __builtin_amdgcn_s_setprio(MPT_WS_PPRIO);
       }
 #endif
+      loc_ahead = gtile + 2 * tile_step < tile_end ? locate_tile(tend, gtile + 2 * tile_step, lane) : no_tile;
       WS_SYNC();  // T0: every region holds a K pair of layer 2 or is being filled with one
 #ifndef MPT_WS_NOPROD
       piece_finish(tp, cur, kHidden[1] + 32 * (2 * pw), 2);         // T1: piece 4 -> X[2] (pair 0 was read in T0; read in T2)
