@@ -1125,6 +1125,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
   f32x4 stg[4];
   int c0_staged = -1;  // first channel (of segment 1) in stg, -1: segment 2 (plain)
   __shared__ float gn_stats[64];  // (mean, rstd) of x1's 32 groups (csrc/gn_tail.h)
+  // (scale, shift) of every channel of segment 1, once per workgroup: the staging of a chunk took them per
+  // wave and channel from the statistics + gamma / beta -- ~100 VALU instructions and 32 loads per chunk and wave
+  __shared__ __attribute__((aligned(16))) float ss1[2 * 512];
   auto stage_load = [&](int chunk) {
     const int c0 = chunk * kC1K + 16 * wv;  // first channel in the concatenated K
     const bool seg2 = c0 >= p.c1;
@@ -1147,13 +1150,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
     const int sw = lane & 15;
     float sc[16], sh[16];  // wave-uniform
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if (c0_staged >= 0) {
-        gn_scale_shift(p.gn1, img, c0_staged + k, gn_stats, sc[k], sh[k]);
-      } else {
-        sc[k] = 1.0f;
-        sh[k] = 0.0f;
-      }
+    for (int q = 0; q < 8; ++q) {
+      f32x4 t4 = {1.0f, 0.0f, 1.0f, 0.0f};
+      if (c0_staged >= 0) t4 = *reinterpret_cast<const f32x4 *>(ss1 + 2 * (c0_staged + 2 * q));
+      sc[2 * q] = t4[0];
+      sh[2 * q] = t4[1];
+      sc[2 * q + 1] = t4[2];
+      sh[2 * q + 1] = t4[3];
     }
     if constexpr (!F16) {
 #pragma unroll
@@ -1192,6 +1195,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int t = 0; t < 16; ++t) acc[m][n][t] = 0.0f;
+  if constexpr (!F16) {  // the bias starts the sums (the split-f16 sums are scaled: their bias is added at the end)
+    if (p.bias) {
+#pragma unroll
+      for (int m = 0; m < MRW; ++m)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const float b = p.bias[32 * ((int)blockIdx.y * (4 * MRW) + MRW * wv + m) + (t & 3) + 8 * (t >> 2) + 4 * h];
+          acc[m][0][t] = b;
+          acc[m][1][t] = b;
+        }
+    }
+  }
 
   // K steps per chunk: 8 groups of 8 (f32) / 4 steps of 16 (f16); fragments of row block rb, step s:
   //   f32: ((rb * kgt + s) * 64 + lane) float4;  f16: ((rb * kst + s) * 2 + part) * 64 + lane h8
@@ -1220,6 +1235,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
 
   stage_load(0);
   gn_load_stats(p.gn1, img, gn_stats);
+  __syncthreads();
+  for (int c = tid; c < p.c1; c += 256) gn_scale_shift(p.gn1, img, c, gn_stats, ss1[2 * c], ss1[2 * c + 1]);
   __syncthreads();
   stage_store(0, smem);
   __syncthreads();
@@ -1283,19 +1300,30 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
   const float inv_scale = F16 ? 1.0f / conv16_scale(*wmax) : 1.0f;
   constexpr int NCH = 128 * MRW;  // output channels of this workgroup
   double *cs = reinterpret_cast<double *>(smem);  // [NCH][2] per-channel (sum, sum of squares)
+  // output / residual addresses: one buffer resource per image, the lane part (4 h channels down, pixel px0 + j)
+  // in ONE register, the channel of accumulator register t in the scalar offset, the second column block in the
+  // instruction's immediate -- no per-element 64-bit address arithmetic on the VALU
+  const long long img_off = (long long)img * p.cout * p.hw;
+  const int img_bytes = p.cout * p.hw * 4;
+  const __amdgpu_buffer_rsrc_t rs_res =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res + img_off : p.x1), 0, p.res ? img_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y =
+      __builtin_amdgcn_make_buffer_rsrc(p.y ? p.y + img_off : const_cast<float *>(p.x1), 0, p.y ? img_bytes : 0, 0x00020000);
+  const int vo = (4 * h * p.hw + px0 + j) * 4;
+  auto so_of = [&](int m, int t) { return (32 * (rb0 + m) + (t & 3) + 8 * (t >> 2)) * p.hw * 4; };  // scalar
 #pragma unroll
   for (int m = 0; m < MRW; ++m) {
     float s1[16], s2[16];  // one row block at a time: 64 live sums next to 128 accumulators spilled
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-      const int co = 32 * (rb0 + m) + (t & 3) + 8 * (t >> 2) + 4 * h;
-      const float b = p.bias ? p.bias[co] : 0.0f;
+      float b = 0.0f;
+      if constexpr (F16) b = p.bias ? p.bias[32 * (rb0 + m) + (t & 3) + 8 * (t >> 2) + 4 * h] : 0.0f;
       s1[t] = s2[t] = 0.0f;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        const long long o = ((long long)img * p.cout + co) * p.hw + px0 + 32 * n + j;
-        float v = acc[m][n][t] * inv_scale + b;
-        if (p.res) v += p.res[o];
+        float v = F16 ? acc[m][n][t] * inv_scale + b : acc[m][n][t];
+        if (p.res)
+          v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, vo + 128 * n, so_of(m, t), 0));
         acc[m][n][t] = v;
         s1[t] += v;
         s2[t] = fmaf(v, v, s2[t]);
@@ -1342,10 +1370,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
     for (int m = 0; m < MRW; ++m)
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        const int co = 32 * (rb0 + m) + (t & 3) + 8 * (t >> 2) + 4 * h;
 #pragma unroll
         for (int n = 0; n < 2; ++n)
-          p.y[((long long)img * p.cout + co) * p.hw + px0 + 32 * n + j] = acc[m][n][t];
+        {
+          const float v = acc[m][n][t];  // (a named float: __builtin_bit_cast on the vector element stores element 0 for every t)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rs_y, vo + 128 * n, so_of(m, t), 0);
+        }
       }
   }
   if (p.y_hwc) {
@@ -1413,6 +1443,8 @@ int launch_conv1x1(mp_ctx *ctx, Conv1Args a, int f16, const float *wmax, long lo
     return fail(ctx, MP_ERR_UNSUPPORTED,
                 "conv1x1: needs C1, C2 multiples of 64, H*W a multiple of 64 and 128 or 256 output channels "
                 "(got %d + %d -> %d, %d)", a.c1, a.c2, a.cout, a.hw);
+  if (a.c1 > 512)
+    return fail(ctx, MP_ERR_UNSUPPORTED, "conv1x1: at most 512 channels in segment 1 (got %d)", a.c1);
   if (a.cout != 256 && (gn_wanted(a.fin) || a.y_hwc))
     return fail(ctx, MP_ERR_UNSUPPORTED, "conv1x1: statistics / channels-last output are built for 256 channels");
   a.wp_floats = a.cout * (a.c1 + a.c2);
@@ -1432,9 +1464,11 @@ int launch_conv1x1(mp_ctx *ctx, Conv1Args a, int f16, const float *wmax, long lo
     a.gn1.n = a.n_img;
     a.gn1.count = (double)(a.c1 / 32) * a.hw;
   }
-  // two 32-row blocks per wave (one workgroup = all 256 rows of 64 pixels) unless that leaves slots
-  // empty: then one block per wave and the row halves as separate workgroups (blockIdx.y)
-  int mrw = a.cout == 256 && (long long)tiles * a.n_img >= 512 ? 2 : 1;
+  // one 32-row block per wave, the row halves of 256 output channels as separate workgroups (blockIdx.y): since
+  // the epilogue addresses through buffer resources (round 4) that form needs 121 registers -- four workgroups
+  // per CU -- and beats two blocks per wave (166 registers, three workgroups) on every shape of the encoder
+  // (batch 16: conv_last 100 vs 97, l 106 vs 106, bl|al 103 vs 86 TFLOP/s); mp_conv3x3_tune can still force 2
+  int mrw = 1;
   if (g_conv1_mrw > 0 && a.cout == 256) mrw = g_conv1_mrw;
   const int lds = a.y_hwc ? kC1Px * 512 * mrw : 2 * kC1Px * kC1Row;
   void (*kern)(Conv1Args, const float *) =
