@@ -72,19 +72,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, const float (&v
   const int j = lane & 31, h = lane >> 5;
   const int hw = p.h * p.w;
   const int ch0 = NCH * blockIdx.y + 32 * rbi;
-  const long long o1 = ((long long)img * p.cout + ch0) * hw;
-  const long long o2 = ((long long)img * p.y2_c + p.y2_off + ch0) * hw;
   const bool cat = p.y2 != nullptr;
   const bool st1 = gn_wanted(p.fin), st2 = cat && gn_wanted(p.fin2);
   const int tid = threadIdx.x;
-  // offset of value (n, tt) inside this wave's 32-channel block of an image (recomputed where it is
-  // used: keeping 16 NR 64-bit offsets alive cost a whole occupancy step)
-  auto off = [&](int n, int tt) {
+  // Addresses (round 4): one buffer resource per tensor and image; the lane part of value (n, tt) -- 4 h channels
+  // down, the pixel of column block n -- in NR registers, the channel of register tt in the scalar offset.  No
+  // per-element 64-bit address arithmetic on the VALU (recomputing it per use was the price of not keeping 16 NR
+  // offsets alive) and a smaller register footprint.
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+      p.y ? p.y + (long long)img * p.cout * hw : const_cast<float *>(p.x), 0, p.y ? p.cout * hw * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(
+      cat ? p.y2 + (long long)img * p.y2_c * hw : const_cast<float *>(p.x), 0, cat ? p.y2_c * hw * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(cat ? p.res + (long long)img * p.y2_c * hw : p.x), 0, cat ? p.y2_c * hw * 4 : 0, 0x00020000);
+  int vo[NR];
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
     const int cb = cwi * NR + n;
     const int ty = (32 * cb) / p.tw, tx = (32 * cb) - ty * p.tw;
+    vo[n] = (4 * h * hw + (y0 + ty) * p.w + x0 + tx + j) * 4;
+  }
+  auto so1 = [&](int tt) {  // scalar
     const int t = t0 + tt;
-    return ((t & 3) + 8 * (t >> 2) + 4 * h) * hw + (y0 + ty) * p.w + x0 + tx + j;
+    return (ch0 + (t & 3) + 8 * (t >> 2)) * hw * 4;
   };
+  auto so2 = [&](int tt) { return so1(tt) + p.y2_off * hw * 4; };
   // ---- statistics: the per-channel sums of all waves meet in LDS, wave 0 folds them into the
   // workgroup's per-group sums (fixed order) and hands them on (gn_tail.h: fire-and-forget) ----
   double *cs1 = reinterpret_cast<double *>(smem);         // [CW][NCH][2] per-channel sums of y
@@ -111,7 +123,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, const float (&v
 #pragma unroll
     for (int n = 0; n < NR; ++n)
 #pragma unroll
-      for (int tt = 0; tt < TN; ++tt) u[n][tt] = p.res[o2 + off(n, tt)];
+      for (int tt = 0; tt < TN; ++tt)
+        u[n][tt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, vo[n], so2(tt), 0));
   }
   if (st1) {
     float s1[TN], s2[TN];
@@ -168,8 +181,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, const float (&v
   for (int n = 0; n < NR; ++n)
 #pragma unroll
     for (int tt = 0; tt < TN; ++tt) {
-      if (p.y) p.y[o1 + off(n, tt)] = v[n][tt];
-      if (cat) p.y2[o2 + off(n, tt)] = u[n][tt];
+      const float a = v[n][tt], b = cat ? u[n][tt] : 0.0f;
+      if (p.y) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(a), rs_y, vo[n], so1(tt), 0);
+      if (cat) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(b), rs_y2, vo[n], so2(tt), 0);
     }
 #endif
 }
