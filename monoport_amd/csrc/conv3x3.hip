@@ -31,6 +31,7 @@ namespace mp {
 
 constexpr int kCK = 16;           // input channels per LDS chunk
 constexpr int kPixBytes = kCK * 4;  // 64 bytes per staged pixel
+constexpr int kMaxCin = 512;  // input channels of a 3x3 launch (the per-workgroup (scale, shift) table)
 #ifndef MP_CONV_WPS
 #define MP_CONV_WPS 2  // waves per SIMD the register allocator is held to (tools/ablate.py A/B)
 #endif
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
   }
   const float *xin = p.x + (long long)img * p.cin * hw;
   __shared__ float gn_stats[64];  // (mean, rstd) of the input's 32 groups (csrc/gn_tail.h)
+  __shared__ float ss_in[2 * kMaxCin];  // (scale, shift) of every input channel, once per workgroup (filled below)
 
   f32x4 stg[kStageIters];
   int ch_staged = 0;  // first channel of the chunk in stg (wave-uniform)
@@ -252,7 +254,10 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
   auto stage_store = [&](unsigned char *buf) {
     float sc[4], sh[4];  // wave-uniform
 #pragma unroll
-    for (int k = 0; k < 4; ++k) gn_scale_shift(p.gn, img, ch_staged + k, gn_stats, sc[k], sh[k]);
+    for (int k = 0; k < 4; ++k) {
+      sc[k] = ss_in[2 * (ch_staged + k)];
+      sh[k] = ss_in[2 * (ch_staged + k) + 1];
+    }
 #pragma unroll
     for (int it = 0; it < kStageIters; ++it) {
       const int lp = lane + 64 * it;
@@ -301,6 +306,11 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
 
   stage_load(0);
   gn_load_stats(p.gn, img, gn_stats);
+  __syncthreads();
+  // (scale, shift) per input channel from the statistics + gamma / beta: by one thread per channel, once -- the
+  // staging of every chunk took them again per wave (LDS reads, two loads from L2 and four VALU instructions per
+  // channel, with the loads' round trip in front of the chunk's barrier)
+  for (int c = tid; c < p.cin; c += 256) gn_scale_shift(p.gn, img, c, gn_stats, ss_in[2 * c], ss_in[2 * c + 1]);
   __syncthreads();
   stage_store(smem);
   __syncthreads();
@@ -413,6 +423,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_sk_kernel(ConvArgs p) {
   }
   const float *xin = p.x + (long long)img * p.cin * hw;
   __shared__ float gn_stats[64];  // (mean, rstd) of the input's 32 groups (csrc/gn_tail.h)
+  __shared__ float ss_in[2 * kMaxCin];  // (scale, shift) of every input channel, once per workgroup (filled below)
 
   // lane = pixel, all 16 channels of the chunk
   f32x4 stg[kStageIters][4];
@@ -441,7 +452,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_sk_kernel(ConvArgs p) {
     for (int q = 0; q < 4; ++q) {
       float sc[4], sh[4];  // wave-uniform
 #pragma unroll
-      for (int k = 0; k < 4; ++k) gn_scale_shift(p.gn, img, ch_staged + 4 * q + k, gn_stats, sc[k], sh[k]);
+      for (int k = 0; k < 4; ++k) {
+        sc[k] = ss_in[2 * (ch_staged + 4 * q + k)];
+        sh[k] = ss_in[2 * (ch_staged + 4 * q + k) + 1];
+      }
 #pragma unroll
       for (int it = 0; it < kStageIters; ++it) {
         const int lp = lane + 64 * it;
@@ -479,6 +493,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_sk_kernel(ConvArgs p) {
 
   if (wv < n_chunks) stage_load(wv);  // in flight while the input's GroupNorm statistics are read
   gn_load_stats(p.gn, img, gn_stats);
+  __syncthreads();
+  // (scale, shift) per input channel from the statistics + gamma / beta: by one thread per channel, once -- the
+  // staging of every chunk took them again per wave (LDS reads, two loads from L2 and four VALU instructions per
+  // channel, with the loads' round trip in front of the chunk's barrier)
+  for (int c = tid; c < p.cin; c += 256) gn_scale_shift(p.gn, img, c, gn_stats, ss_in[2 * c], ss_in[2 * c + 1]);
   __syncthreads();
   if (wv < n_chunks) {
     const int a_base = rb * kgt * 64;
@@ -643,6 +662,7 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
   }
   const float *xin = p.x + (long long)img * p.cin * hw;
   __shared__ float gn_stats[64];  // (mean, rstd) of the input's 32 groups (csrc/gn_tail.h)
+  __shared__ float ss_in[2 * kMaxCin];  // (scale, shift) of every input channel, once per workgroup (filled below)
 
   f32x4 stg[kStageIters];
   int ch_staged = 0;  // first channel of the chunk in stg (wave-uniform)
@@ -661,7 +681,10 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
   auto stage_store = [&](unsigned char *buf) {
     float sc[4], sh[4];  // wave-uniform
 #pragma unroll
-    for (int k = 0; k < 4; ++k) gn_scale_shift(p.gn, img, ch_staged + k, gn_stats, sc[k], sh[k]);
+    for (int k = 0; k < 4; ++k) {
+      sc[k] = ss_in[2 * (ch_staged + k)];
+      sh[k] = ss_in[2 * (ch_staged + k) + 1];
+    }
 #pragma unroll
     for (int it = 0; it < kStageIters; ++it) {
       const int lp = lane + 64 * it;
@@ -712,6 +735,11 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
 
   stage_load(0);
   gn_load_stats(p.gn, img, gn_stats);
+  __syncthreads();
+  // (scale, shift) per input channel from the statistics + gamma / beta: by one thread per channel, once -- the
+  // staging of every chunk took them again per wave (LDS reads, two loads from L2 and four VALU instructions per
+  // channel, with the loads' round trip in front of the chunk's barrier)
+  for (int c = tid; c < p.cin; c += 256) gn_scale_shift(p.gn, img, c, gn_stats, ss_in[2 * c], ss_in[2 * c + 1]);
   __syncthreads();
   stage_store(smem);
   __syncthreads();
@@ -979,6 +1007,8 @@ int launch_conv3x3(mp_ctx *ctx, ConvArgs a, const float *wmax16, const long long
     return fail(ctx, MP_ERR_UNSUPPORTED,
                 "conv3x3: needs Cin %% 16 == 0, Cout %% 32 == 0, H and W powers of two (W >= 32, H >= 8); got %d -> %d at %dx%d",
                 cin, cout, h, w);
+  if (cin > kMaxCin)
+    return fail(ctx, MP_ERR_UNSUPPORTED, "conv3x3: at most %d input channels (got %d)", kMaxCin, cin);
   a.wp_floats = cout * cin * 9;
   const ConvPlan c = conv_plan(cout, n, h, w, wmax16 != nullptr);
   a.tw = c.tw;
