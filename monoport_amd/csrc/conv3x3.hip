@@ -305,12 +305,14 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
   for (int k = 0; k < 6; ++k) ring[k] = wload128(ws, a_base + min(k, kgt - 1) * 64);
 
   stage_load(0);
+  GnAffine affine;
+  gn_affine_load(p.gn, p.cin, affine);
   gn_load_stats(p.gn, img, gn_stats);
   __syncthreads();
   // (scale, shift) per input channel from the statistics + gamma / beta: by one thread per channel, once -- the
   // staging of every chunk took them again per wave (LDS reads, two loads from L2 and four VALU instructions per
   // channel, with the loads' round trip in front of the chunk's barrier)
-  for (int c = tid; c < p.cin; c += 256) gn_scale_shift(p.gn, img, c, gn_stats, ss_in[2 * c], ss_in[2 * c + 1]);
+  gn_table_fill(p.gn, img, p.cin, gn_stats, affine, ss_in);
   __syncthreads();
   stage_store(smem);
   __syncthreads();
@@ -492,12 +494,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_sk_kernel(ConvArgs p) {
     for (int t = 0; t < 16; ++t) acc[n][t] = 0.0f;
 
   if (wv < n_chunks) stage_load(wv);  // in flight while the input's GroupNorm statistics are read
+  GnAffine affine;
+  gn_affine_load(p.gn, p.cin, affine);
   gn_load_stats(p.gn, img, gn_stats);
   __syncthreads();
   // (scale, shift) per input channel from the statistics + gamma / beta: by one thread per channel, once -- the
   // staging of every chunk took them again per wave (LDS reads, two loads from L2 and four VALU instructions per
   // channel, with the loads' round trip in front of the chunk's barrier)
-  for (int c = tid; c < p.cin; c += 256) gn_scale_shift(p.gn, img, c, gn_stats, ss_in[2 * c], ss_in[2 * c + 1]);
+  gn_table_fill(p.gn, img, p.cin, gn_stats, affine, ss_in);
   __syncthreads();
   if (wv < n_chunks) {
     const int a_base = rb * kgt * 64;
@@ -734,12 +738,14 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs
   for (int k = 0; k < 6; ++k) ring[k] = hload16(ws, a_base + min(k >> 1, kst - 1) * 128 + (k & 1) * 64);
 
   stage_load(0);
+  GnAffine affine;
+  gn_affine_load(p.gn, p.cin, affine);
   gn_load_stats(p.gn, img, gn_stats);
   __syncthreads();
   // (scale, shift) per input channel from the statistics + gamma / beta: by one thread per channel, once -- the
   // staging of every chunk took them again per wave (LDS reads, two loads from L2 and four VALU instructions per
   // channel, with the loads' round trip in front of the chunk's barrier)
-  for (int c = tid; c < p.cin; c += 256) gn_scale_shift(p.gn, img, c, gn_stats, ss_in[2 * c], ss_in[2 * c + 1]);
+  gn_table_fill(p.gn, img, p.cin, gn_stats, affine, ss_in);
   __syncthreads();
   stage_store(smem);
   __syncthreads();
@@ -1278,9 +1284,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
       for (int part = 0; part < FPS; ++part) ring[q][m][part] = a_load(m, q, part);
 
   stage_load(0);
+  GnAffine affine;
+  gn_affine_load(p.gn1, p.c1, affine);
   gn_load_stats(p.gn1, img, gn_stats);
   __syncthreads();
-  for (int c = tid; c < p.c1; c += 256) gn_scale_shift(p.gn1, img, c, gn_stats, ss1[2 * c], ss1[2 * c + 1]);
+  gn_table_fill(p.gn1, img, p.c1, gn_stats, affine, ss1);
   __syncthreads();
   stage_store(0, smem);
   __syncthreads();

@@ -158,4 +158,44 @@ __device__ __forceinline__ void gn_scale_shift(const GnIn &g, int img, int c, co
   }
 }
 
+// Consumer, all 256 threads: the (scale, shift) table of the normalised tensor's channels in LDS, one thread
+// per channel (two for up to 512 channels).  gamma / beta are requested BEFORE the statistics barrier
+// (gn_affine_load, next to the first activation loads) and combined with the statistics after it
+// (gn_table_fill): a workgroup's prologue holds one round trip to L2 instead of two -- at batch 1 the small
+// convolutions are 12-30 us launches.
+struct GnAffine {
+  float g[2], b[2];
+};
+__device__ __forceinline__ void gn_affine_load(const GnIn &gn, int channels, GnAffine &a) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    a.g[i] = a.b[i] = 0.0f;
+    if (gn.acc && c < channels) {
+      a.g[i] = gn.gamma[c];
+      a.b[i] = gn.beta[c];
+    }
+  }
+}
+__device__ __forceinline__ void gn_table_fill(const GnIn &gn, int img, int channels, const float *lds_stats,
+                                              const GnAffine &a, float *ss /*[channels][2]*/) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < channels) {
+      float sc, sh;
+      if (gn.acc) {
+        const int grp = c / (gn.c / 32);
+        const float mean = lds_stats[2 * grp], rstd = lds_stats[2 * grp + 1];
+        sc = rstd * a.g[i];
+        sh = a.b[i] - mean * sc;
+      } else {
+        gn_scale_shift(gn, img, c, lds_stats, sc, sh);
+      }
+      ss[2 * c] = sc;
+      ss[2 * c + 1] = sh;
+    }
+  }
+}
+
 }  // namespace mp
