@@ -81,10 +81,13 @@ __global__ __launch_bounds__(256, MPT_CONVK_WG) void convk_kernel(ConvKArgs p) {
   const float *xin = p.x + (long long)img * p.cin * hw_in;
   const bool norm = gn_active(p.gn);
   __shared__ float gn_stats[64];  // (mean, rstd) of the input's 32 groups (csrc/gn_tail.h)
-  __shared__ float ss_tab[2 * (CC > 16 ? CC : 16)];
+  __shared__ float ss_tab[2 * 512];  // (scale, shift) of every input channel, once per workgroup (gn_tail.h)
   const WStream ws = make_wstream(p.wp, p.wp_floats, lane);
+  GnAffine affine;
+  gn_affine_load(p.gn, p.cin, affine);
   gn_load_stats(p.gn, img, gn_stats);
   __syncthreads();
+  if (norm) gn_table_fill(p.gn, img, p.cin, gn_stats, affine, ss_tab);  // visible behind the first chunk's barrier
 
   f32x16 acc[NR];
 #pragma unroll
@@ -148,8 +151,7 @@ __global__ __launch_bounds__(256, MPT_CONVK_WG) void convk_kernel(ConvKArgs p) {
 #pragma unroll
     for (int k = 0; k < kRing; ++k) ring[k] = wload128(ws, a_base + (k < NG ? k : NG - 1) * 64);
     // (scale, shift) of the chunk's input channels, once per chunk instead of once per gathered element
-    if (norm && tid < CC) gn_scale_shift(p.gn, img, chunk * CC + tid, gn_stats, ss_tab[2 * tid], ss_tab[2 * tid + 1]);
-    __syncthreads();  // the previous chunk's tile has been consumed; ss_tab is visible
+    __syncthreads();  // the previous chunk's tile has been consumed
     // ---- the gathered values of this chunk -> the tile: wave wv holds k = wv, wv + 4, ...; lane = pixel ----
 #pragma unroll
     for (int ip = 0; ip < NP; ++ip) {
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256, MPT_CONVK_WG) void convk_kernel(ConvKArgs p) {
       bool ok;
       pair_of(ip, c, iy, ok);
       if (wv + 4 * ip < CC * KS) {
-        const float sc = norm ? ss_tab[2 * c] : 1.0f, sh = norm ? ss_tab[2 * c + 1] : 0.0f;
+        const float sc = norm ? ss_tab[2 * (chunk * CC + c)] : 1.0f, sh = norm ? ss_tab[2 * (chunk * CC + c) + 1] : 0.0f;
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
           float v = raw[ip * KS + kx];
@@ -313,6 +315,7 @@ int launch_convk(mp_ctx *ctx, ConvKArgs a, long long partial_cap, hipStream_t st
   }
   if (gn_active(a.gn)) {
     if (a.cin % 32) return fail(ctx, MP_ERR_ARG, "convk: a GroupNorm(32, Cin) input needs Cin %% 32 == 0");
+    if (a.cin > 512) return fail(ctx, MP_ERR_UNSUPPORTED, "convk: a GroupNorm input of at most 512 channels (got %d)", a.cin);
     if (a.gn.acc && (!a.gn.gamma || !a.gn.beta))
       return fail(ctx, MP_ERR_ARG, "convk: GroupNorm hand-over without gamma / beta");
     a.gn.c = a.cin;
