@@ -486,13 +486,20 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     b13[i] = (mlp.base + mlp.bias[l])[r];
   }
   if (tid < kMaxFrames) {
-    int acc = 0;
-    for (int f = 0; f <= tid; ++f)
-      if (f < set.n) {
-        const PointSrc &sf = set.it[f].src;
-        const long long nf = sf.n_dev ? (long long)*sf.n_dev : sf.n;
-        acc += (int)((nf + P - 1) / P);
-      }
+    // tiles of frames 0..tid: every lane reads ITS frame's device-side counter (one round trip for the
+    // workgroup), the prefix sum runs over the lanes -- a loop over the frames per lane was 2 x 16 dependent
+    // loads in front of the first tile (tens of microseconds of a 1 ms level-0 launch)
+    int mine = 0;
+    if (tid < set.n) {
+      const PointSrc &sf = set.it[tid].src;
+      mine = (int)(sf.n_dev ? (long long)*sf.n_dev : sf.n);
+    }
+    int acc = (mine + P - 1) / P;
+#pragma unroll
+    for (int o = 1; o < kMaxFrames; o <<= 1) {
+      const int up = __shfl_up(acc, o);
+      if (tid >= o) acc += up;
+    }
     tend[tid] = acc;
     if (tid < set.n) {
       const QueryItem &it = set.it[tid];
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         fr.bmin[i] = it.src.bmin[i];
         fr.blen[i] = it.src.blen[i];
       }
-      fr.npts = (int)(it.src.n_dev ? (long long)*it.src.n_dev : it.src.n);
+      fr.npts = mine;
     }
   }
 #ifdef MPT_WS_STAMP
