@@ -2,7 +2,11 @@
 # Round 4 gpurun command lines, one script: tools/r04_run.sh STEP [OUTDIR]
 #   ws      quick hang check + A/B probe of the wave-specialised table kernel, full GPU suite, bench A/B
 #   tests   full GPU suite only
-#   bench   default bench line
+#   bench   default bench line        bench20  the driver's invocation        benchq  headline only
+#   levels  headline bench + per-level roof fractions of its roofline leg (tools/launch_levels.py)
+#   profhl  rocprofv3 kernel shares of the headline configuration alone       prof  kernel stats of the full bench for profiles/
+#   traffic the --pmc FETCH_SIZE / WRITE_SIZE passes behind roofline.traffic  wspmc  counters of the table kernel
+#   wsab    side builds of tools/ablate.py ($ABLATE) next to the product      conv / color / dropin / tab16 / octree / order / shapes*
 R=${GRAFT_REPO_ROOT:-/root/repo}
 step=${1:-ws}
 out=$R/gpurun_out/${2:-r04_$step}; mkdir -p $out
