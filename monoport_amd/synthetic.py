@@ -158,6 +158,26 @@ def body_mlp(kind="G", k=40.0, c=2.0, noise=0.0, seed=0):
     return layers
 
 
+def readout_body_mlp(readout, r0, thick, k=40.0, c=2.0, noise=0.0, seed=0):
+    """F-body on ENCODER features: the slab |z| < t(x, y) whose half thickness is a linear readout of the
+    256 feature channels, t = thick * (readout . feat - r0) -- positive where the readout exceeds r0
+    (inside the silhouette of the input image for a readout fitted to the encoder's output, see
+    oracle/gen_golden.py: gen_pipeline257_color), negative elsewhere (always outside).
+
+    layer 0:  h0 = k (z - t),  h1 = k (-t - z)          (z = z_feat / Z_SCALE)
+    layers 1-3 / last layer / ``noise`` as in ``body_mlp``.  Every feature channel moves the surface:
+    the encoder is in the loop of every octree decision."""
+    layers = body_mlp("G", k=k, c=c, noise=noise, seed=seed)
+    w0, b0 = layers[0]
+    r = np.asarray(readout, np.float64).reshape(256)
+    for row, sign in ((0, 1.0), (1, -1.0)):
+        w0[row, :] = 0
+        w0[row, :256] = (-k * thick * r).astype(np.float32)
+        w0[row, 256] = np.float32(sign * k / Z_SCALE)
+        b0[row] = np.float32(k * thick * r0)
+    return layers
+
+
 def body_feat(c=256, h=128, w=128, seed=0, scale=1.0, figure="figure"):
     """Seeded feature map whose channels 0/1 carry the body depth planes."""
     f = rand_feat(c, h, w, seed, scale)

@@ -343,6 +343,103 @@ def gen_pipeline257(name="pipeline257"):
           % (margin, 100 * sat, 100 * float(((vals > 0.01) & (vals < 0.99)).mean()), t1 - t0, t2 - t1))
 
 
+# BASELINE configs[2]: both encoders in the loop (RTL/main.py:366-379), geometry + per-vertex colour.
+COLOR257 = dict(img_g=75, img_c=76, enc_g=71, enc_c=72, head_g=dict(k=40.0, c=2.0, noise=0.05, seed=395),
+                thick=0.12, head_c=("rand", 77, 0.6), step=115)
+
+
+@torch.no_grad()
+def gen_pipeline257_color(name="pipeline257_color"):
+    """BASELINE configs[2] end to end through the REFERENCE's modules: image -> netG.filter ->
+    netC.filter(image_c, feat_prior=feat_G[-1][-1]) (RTL/main.py:366-379) -> the 17..257 octree with the
+    reference's netG.query as query_func (:169-183; the schedule is OUR restatement, implicit_seg is
+    not vendored) -> the reference's forward_vertices (:401-406) -> the texture branch of
+    ``colorization`` (:228-248) with the reference's orthogonal and netC.query.
+
+    The netG head is synthetic.readout_body_mlp: a slab whose half thickness is a linear readout of
+    the 256 ENCODER channels, fitted here to the reference encoder's output so that it is positive
+    inside the silhouette of the input image.  The readout vector is an INPUT of the scene that only
+    the reference can produce; it is stored in the fixture next to the reference's outputs."""
+    import time
+    import recon as ref_recon
+    from monoport.lib.modeling.geometry import orthogonal
+    from oracle import pifu_oracle as orc
+    cfg = COLOR257
+    netg, netc = ref_net("G"), ref_net("C")
+    for net, seed in ((netg, cfg["enc_g"]), (netc, cfg["enc_c"])):
+        shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
+        net.image_filter.load_state_dict(
+            {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, seed).items()})
+    img_g = torch.from_numpy(syn.synthetic_image(cfg["img_g"]))[None]
+    img_c = torch.from_numpy(syn.synthetic_image(cfg["img_c"]))[None]
+    t0 = time.perf_counter()
+    feats_g = netg.filter(img_g)                                   # RTL/main.py:366-369
+    t1 = time.perf_counter()
+    feats_c = netc.filter(img_c, feat_prior=feats_g[-1][-1])       # :372-379
+    t2 = time.perf_counter()
+    # the readout: channels weighted by how well they separate the silhouette from the background
+    f = feats_g[-1][0][0].numpy().astype(np.float64)
+    zf, _ = syn.body_depth_maps(128, 128)
+    inside = zf > -3
+    d = (f[:, inside].mean(1) - f[:, ~inside].mean(1)) / (f[:, inside].std(1) + f[:, ~inside].std(1) + 1e-9)
+    readout = (d / np.abs(d).sum()).astype(np.float32)
+    r = np.tensordot(readout.astype(np.float64), f, 1)
+    r0 = float(np.float32(0.5 * (r[inside].mean() + r[~inside].mean())))
+    thick = float(np.float32(cfg["thick"] / (r[inside].mean() - r0)))
+    load_mlp(netg, syn.readout_body_mlp(readout, r0, thick, **cfg["head_g"]))
+    load_mlp(netc, syn.rand_mlp("C", cfg["head_c"][1], cfg["head_c"][2]))
+    ext, intr = syn.scene_camera(cfg["step"])
+    calib = ref_recon.pifu_calib(ext, intr, device="cpu")
+    res = [17, 33, 65, 129, 257]
+    rf = res[-1]
+    queried = np.zeros((rf, rf, rf), bool)
+
+    def query_func(points):  # RTL/main.py:169-183 on [3,N] numpy
+        pt = torch.from_numpy(points.T.copy())[None]
+        samples = pt.repeat(1, 1, 1).permute(0, 2, 1)
+        return netg.query(feats_g, points=samples, calibs=calib)[0][0, 0].numpy()
+
+    stats = []
+    t3 = time.perf_counter()
+    sdf = orc.seg3d_lossless(query_func, [-1, -1, -1], [1, 1, 1], res, stats=stats, evaluated_out=queried)
+    t4 = time.perf_counter()
+    X, Y, Z, norm = ref_recon.forward_vertices(torch.from_numpy(sdf)[None, None], "front")
+    t5 = time.perf_counter()
+    # RTL/main.py:201-210, :228-248
+    canvas = torch.ones((rf, rf, 3), dtype=torch.float32)
+    b_min, b_max = torch.tensor([-1.0, -1.0, -1.0]), torch.tensor([1.0, 1.0, 1.0])
+    mat = torch.eye(4, dtype=torch.float32)
+    length = b_max - b_min
+    for i in range(3):
+        mat[i, i] = length[i] / rf
+    mat[0:3, 3] = b_min
+    verts = torch.stack([X.float(), Y.float(), rf - Z.float()], dim=1)
+    samples = verts.unsqueeze(0).repeat(1, 1, 1).permute(0, 2, 1)
+    samples = orthogonal(samples, mat.unsqueeze(0))
+    preds = netc.query(feats_c, points=samples, calibs=calib)[0]
+    color = (preds[0] * 0.5 + 0.5).t()
+    t6 = time.perf_counter()
+    image = canvas.clone()
+    image[X, Y, :] = color
+    img_n = canvas.clone()
+    img_n[X, Y, :] = ((norm + 1) / 2).clamp(0, 1)
+    vals = sdf[queried]
+    margin = float(np.abs(vals - 0.5).min())
+    times = dict(filter_g=t1 - t0, filter_c=t2 - t1, octree_query=t4 - t3, forward_vertices=t5 - t4,
+                 color_query=t6 - t5)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), queried=np.packbits(queried.reshape(-1)),
+        values=vals.astype(np.float32), stats=np.array(stats), X=X.numpy().astype(np.int16),
+        Y=Y.numpy().astype(np.int16), Z=Z.numpy(), norm=norm.numpy(), color=color.numpy(),
+        tex_image=image.numpy(), norm_image=img_n.numpy(), calib=calib.numpy(), readout=readout,
+        r0=np.float32(r0), thick=np.float32(thick), margin=np.float64(margin),
+        featG_slice=feats_g[-1][0][0, ::8, ::8, ::8].numpy(), featC_slice=feats_c[0][0][0, ::8, ::8, ::8].numpy(),
+        meta=np.array(["COLOR257=%r; reference CPU times (%d threads): %r" % (cfg, torch.get_num_threads(), times)]))
+    print(name, stats, sum(stats), int(X.shape[0]), "verts; margin %.3g; readout inside %.3f outside %.3f r0 %.3f "
+          "thick %.4f; colour range [%.3f, %.3f]; times %r"
+          % (margin, r[inside].mean(), r[~inside].mean(), r0, thick, float(color.min()), float(color.max()), times))
+
+
 def gen_obj():
     """The reference's OBJ writers (monoport/lib/mesh_util.py:223-242) on the seeded mesh: the files'
     sha256 + sizes + first lines are the fixture."""
@@ -367,7 +464,7 @@ def gen_obj():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["query", "misc", "vertices", "color", "encoders", "pipeline",
-                             "dense64", "pipeline257", "obj"]
+                             "dense64", "obj", "pipeline257_color"] + sorted(PIPE257_SCENES)
     if "obj" in which:
         gen_obj()
     if "query" in which:
@@ -387,3 +484,5 @@ if __name__ == "__main__":
     for name in PIPE257_SCENES:
         if name in which:
             gen_pipeline257(name)
+    if "pipeline257_color" in which:
+        gen_pipeline257_color()

@@ -189,3 +189,102 @@ def test_marching_cubes_257_identical_connectivity(oracle):
     key = e[:, 0] * len(rv) + e[:, 1]
     rev = e[:, 1] * len(rv) + e[:, 0]
     assert len(np.unique(key)) == len(key) and np.array_equal(np.sort(key), np.sort(rev))
+
+
+def _color257_frame_checks(g, tag, vol, stats, X, Y, Z, tex):
+    """One reconstructed frame of the configs[2] scene against the reference-driven fixture: octree
+    nodes / values (modulo nodes within COLOR257_AMBIGUOUS of the threshold), the visible vertices,
+    the [257,257,3] texture render."""
+    from test_oracle_golden import COLOR257_AMBIGUOUS
+    _, undecided, n_amb = pipeline257_check("pipeline257_color", vol, None, stats, TOL_REF, COLOR257_AMBIGUOUS)
+    same = pipeline257_vertex_agreement(g, X, Y, Z)
+    ref_cols = set(zip(g["X"].tolist(), g["Y"].tolist()))
+    cols = set(zip(X.tolist(), Y.tolist()))
+    both = np.array(sorted(ref_cols & cols), np.int64)
+    err = float(np.abs(tex[both[:, 0], both[:, 1]] - g["tex_image"][both[:, 0], both[:, 1]]).max())
+    bg = np.ones(tex.shape[:2], bool)
+    bg[X, Y] = False
+    print("%s: %.5f of the reference's %d vertices (%d columns differ), max|colour - reference| = %.3g"
+          % (tag, same, len(ref_cols), len(ref_cols ^ cols), err))
+    assert same >= 0.995 and len(ref_cols ^ cols) <= 0.005 * len(ref_cols)  # measured: see the printed line
+    assert (tex[bg] == 1.0).all()  # the canvas of ones (RTL/main.py:201-203) wherever no vertex landed
+    # a vertex whose Z moved by 1e-3 voxels samples the same texel neighbourhood: colours within 1e-4
+    assert err <= TOL_REF
+    return err
+
+
+def test_pipeline257_color_vs_reference_per_frame_surface():
+    """BASELINE configs[2] end to end through the drop-in surface, both encoders in the loop, against
+    the fixture the REFERENCE's modules produced (oracle/gen_golden.py gen_pipeline257_color):
+    netG.filter -> netC.filter(image_c, feat_prior=feat_G[-1][-1]) (RTL/main.py:366-379) ->
+    Seg3dLossless 17..257 on the query_func closure (:169-195, :389-394) -> forward_vertices (:401-406)
+    -> colorization's texture branch (:228-248)."""
+    from test_oracle_golden import COLOR257, color257_nets
+    from monoport_amd.implicit_seg.functional import Seg3dLossless
+    from monoport_amd.recon import colorization, forward_vertices, pifu_calib
+    netG, netC, _, g = color257_nets(DEV)
+    cfg = COLOR257
+    img_g = torch.from_numpy(syn.synthetic_image(cfg["img_g"]))[None].to(DEV)
+    img_c = torch.from_numpy(syn.synthetic_image(cfg["img_c"]))[None].to(DEV)
+    with torch.no_grad():
+        feat_G = netG.filter(img_g)
+        feat_C = netC.filter(img_c, feat_prior=feat_G[-1][-1])
+    fe_g = float(np.abs(feat_G[-1][0][0, ::8, ::8, ::8].cpu().numpy() - g["featG_slice"]).max())
+    fe_c = float(np.abs(feat_C[0][0][0, ::8, ::8, ::8].cpu().numpy() - g["featC_slice"]).max())
+    assert fe_g <= 1e-4 and fe_c <= 1e-4
+
+    def query_func(points, im_feat_list, calib_tensor):  # RTL/main.py:169-183
+        assert len(points) == 1
+        samples = points.repeat(1, 1, 1)
+        samples = samples.permute(0, 2, 1)
+        return netG.query(im_feat_list, points=samples, calibs=calib_tensor)[0]
+
+    engine = Seg3dLossless(query_func=query_func, b_min=np.array([[-1., -1., -1.]]),
+                           b_max=np.array([[1., 1., 1.]]), resolutions=PIPE257_RES,
+                           balance_value=0.5, use_cuda_impl=False, faster=True).to(DEV)
+    calib = pifu_calib(*syn.scene_camera(cfg["step"]), device=DEV)
+    assert np.array_equal(calib.cpu().numpy(), g["calib"])
+    sdf = engine(im_feat_list=feat_G, calib_tensor=calib)
+    assert sdf.shape == (1, 1, 257, 257, 257) and engine.last_path == "fused"
+    X, Y, Z, norm = forward_vertices(sdf, direction="front")
+    tex = colorization(netC, feat_C, X, Y, Z, calib, None)
+    assert tex.shape == (257, 257, 3)
+    err = _color257_frame_checks(g, "configs[2] per-frame surface (features within %.2g / %.2g)" % (fe_g, fe_c),
+                                 sdf[0, 0].cpu().numpy(), engine.last_status[1:].numpy(), X.cpu().numpy(),
+                                 Y.cpu().numpy(), Z.cpu().numpy(), tex.cpu().numpy())
+    # the colour chain alone, on the REFERENCE's vertices (no octree coin flip in the way)
+    ref_tex = colorization(netC, feat_C, torch.from_numpy(g["X"].astype(np.int64)).to(DEV),
+                           torch.from_numpy(g["Y"].astype(np.int64)).to(DEV), torch.from_numpy(g["Z"]).to(DEV),
+                           calib, None)
+    e2 = float(np.abs(ref_tex.cpu().numpy() - g["tex_image"]).max())
+    print("colour chain on the reference's vertices: max|colour - reference| = %.3g (whole pipeline %.3g)" % (e2, err))
+    assert e2 <= TOL_REF
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_pipeline257_color_vs_reference_batched_pipeline(batch):
+    """The same scene through FramePipeline(netC=...): batched encoders, one mp_recon_batch for the
+    slot's frames, the colour queries of all frames in ONE mp_query_counted_batch launch
+    (pipeline.FrameSlot._chain) -- every frame of the slot must reproduce the reference's fixture."""
+    from test_oracle_golden import COLOR257, color257_nets
+    from monoport_amd.pipeline import FramePipeline
+    from monoport_amd.recon import pifu_calib
+    netG, netC, _, g = color257_nets(DEV)
+    cfg = COLOR257
+    img_g = torch.from_numpy(syn.synthetic_image(cfg["img_g"]))[None].to(DEV)
+    img_c = torch.from_numpy(syn.synthetic_image(cfg["img_c"]))[None].to(DEV)
+    calib = pifu_calib(*syn.scene_camera(cfg["step"]), device=DEV)
+    pipe = FramePipeline(netG, DEV, depth=1, batch=batch, netC=netC, use_graph=False)
+    try:
+        pipe.prepare()
+        slot = pipe.submit([img_g] * batch, [calib] * batch, images_c=[img_c] * batch)
+        slot.wait()
+        for b in range(batch):
+            x, y, z, _, count = slot.vertices[b]
+            c = int(count.item())
+            _color257_frame_checks(g, "configs[2] FramePipeline batch %d frame %d" % (batch, b),
+                                   slot.volumes[b].cpu().numpy(), slot.status[b, 1:].cpu().numpy(),
+                                   x[:c].cpu().numpy(), y[:c].cpu().numpy(), z[:c].cpu().numpy(),
+                                   slot.renders_tex[b].cpu().numpy())
+    finally:
+        pipe.close()

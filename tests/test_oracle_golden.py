@@ -181,7 +181,7 @@ def pipeline257_inputs(name):
     return syn.body_mlp("G", **head), syn.body_feat(256, 128, 128, feat_seed), step
 
 
-def pipeline257_undecided(g, queried):
+def pipeline257_undecided(g, queried, ambiguous=AMBIGUOUS):
     """Mask of the 257^3 lattice where two fp32-class evaluations of the same field may legitimately
     take different octree decisions: the reach of every reference-queried node whose value is within
     AMBIGUOUS of the threshold.  A flip at level l (node spacing s_l) moves the boundary flags of the
@@ -193,7 +193,7 @@ def pipeline257_undecided(g, queried):
     reach = [spacing[l] + sum((box[m] - 1) // 2 * spacing[m] for m in range(l + 1, 5)) + 2 for l in range(5)]
     vals = np.zeros(queried.shape, np.float32)
     vals[queried] = g["values"]
-    amb = np.argwhere(queried & (np.abs(vals - 0.5) <= AMBIGUOUS))
+    amb = np.argwhere(queried & (np.abs(vals - 0.5) <= ambiguous))
     mask = np.zeros(queried.shape, bool)
     for z, y, x in amb:
         level = next(l for l in range(5) if z % spacing[l] == 0 and y % spacing[l] == 0 and x % spacing[l] == 0)
@@ -202,12 +202,12 @@ def pipeline257_undecided(g, queried):
     return mask, len(amb)
 
 
-def pipeline257_check(name, vol, queried, stats, tol):
+def pipeline257_check(name, vol, queried, stats, tol, ambiguous=AMBIGUOUS):
     """Octree result (volume, queried-node mask or None, per-level counts) against the reference-driven
     fixture: outside the undecided regions the same nodes are queried and every queried value agrees
     within ``tol``; with no undecided node the per-level counts are equal too."""
     g, queried_ref = pipeline257_golden(name)
-    undecided, n_amb = pipeline257_undecided(g, queried_ref)
+    undecided, n_amb = pipeline257_undecided(g, queried_ref, ambiguous)
     firm = queried_ref & ~undecided
     ref_vol = np.zeros(queried_ref.shape, np.float32)
     ref_vol[queried_ref] = g["values"]
@@ -215,7 +215,7 @@ def pipeline257_check(name, vol, queried, stats, tol):
     frac = float(undecided.mean())
     print("%s: %d queried nodes, %d within %.0e of the threshold -> %.2f %% of the lattice undecided; "
           "max|value - reference| over the %d firm nodes = %.3g; margin %.3g"
-          % (name, queried_ref.sum(), n_amb, AMBIGUOUS, 100 * frac, firm.sum(), err, float(g["margin"]) if "margin" in g else -1))
+          % (name, queried_ref.sum(), n_amb, ambiguous, 100 * frac, firm.sum(), err, float(g["margin"]) if "margin" in g else -1))
     assert frac <= 0.25 and err <= tol
     if queried is not None:
         assert np.array_equal(queried & ~undecided, firm)
@@ -256,3 +256,76 @@ def pipeline257_vertex_agreement(g, x, y, z):
     ref = {(int(a), int(b)): float(c) for a, b, c in zip(g["X"], g["Y"], g["Z"])}
     hit = sum(1 for a, b, c in zip(x, y, z) if abs(ref.get((int(a), int(b)), 1e9) - float(c)) <= 2e-3)
     return hit / max(len(ref), 1)
+
+
+# ---- BASELINE configs[2]: both encoders in the loop (oracle/gen_golden.py: gen_pipeline257_color) ----
+# name of the seeds: oracle/gen_golden.py COLOR257
+COLOR257 = dict(img_g=75, img_c=76, enc_g=71, enc_c=72, head_g=dict(k=40.0, c=2.0, noise=0.05, seed=395),
+                head_c=("rand", 77, 0.6), step=115)
+# With an encoder in the loop two fp32 implementations differ by the encoder's rounding, not only the
+# MLP's: features within ~6e-6 (tests/test_baseline_size_gpu.py), worth up to k * thick * 6e-6 / 4 ~
+# 7e-6 on the occupancy through this head -- decisions on values closer to 0.5 may go either way.
+COLOR257_AMBIGUOUS = 2e-5
+
+
+def color257_nets(device="cpu"):
+    """(netG, netC, fixture) of the configs[2] scene on ``device``: seeded encoders, the readout-body
+    head fitted to the REFERENCE encoder's output (vector stored in the fixture), the netC head."""
+    import torch
+    from monoport_amd.modeling import PIFuNetC, PIFuNetG
+    g = load_golden("pipeline257_color")
+    cfg = COLOR257
+    netg, netc = PIFuNetG().eval(), PIFuNetC().eval()
+    for net, seed in ((netg, cfg["enc_g"]), (netc, cfg["enc_c"])):
+        shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
+        net.image_filter.load_state_dict(
+            {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, seed).items()})
+    heads = (syn.readout_body_mlp(g["readout"], float(g["r0"]), float(g["thick"]), **cfg["head_g"]),
+             syn.rand_mlp("C", cfg["head_c"][1], cfg["head_c"][2]))
+    for net, layers in zip((netg, netc), heads):
+        sd = {}
+        for i, (w, b) in enumerate(layers):
+            sd["filters.%d.weight" % i] = torch.from_numpy(w)[:, :, None]
+            sd["filters.%d.bias" % i] = torch.from_numpy(b)
+        net.surface_classifier.load_state_dict(sd)
+        net.to(device)
+    return netg, netc, heads, g
+
+
+def test_pipeline257_color_matches_reference(oracle):
+    """BASELINE configs[2] end to end on the CPU: image -> our modules' torch-CPU encoders ->
+    netC.filter(feat_prior) -> the 17..257 octree driven by the C oracle -> forward_vertices -> the
+    colour chain, against the fixture the REFERENCE's modules produced for the same seeds (encoders,
+    netG.query, forward_vertices, orthogonal, netC.query): same nodes, values, vertices, colours."""
+    import torch
+    netg, netc, (layers_g, layers_c), g = color257_nets("cpu")
+    cfg = COLOR257
+    with torch.no_grad():
+        fg = netg.filter(torch.from_numpy(syn.synthetic_image(cfg["img_g"]))[None])
+        fc = netc.filter(torch.from_numpy(syn.synthetic_image(cfg["img_c"]))[None], feat_prior=fg[-1][-1])
+    assert np.abs(fg[-1][0][0, ::8, ::8, ::8].numpy() - g["featG_slice"]).max() <= 2e-5
+    assert np.abs(fc[0][0][0, ::8, ::8, ::8].numpy() - g["featC_slice"]).max() <= 2e-5
+    feat_g, feat_c = fg[-1][0][0].numpy(), fc[0][0][0].numpy()
+    calib = oracle.pifu_calib(*syn.scene_camera(cfg["step"]))
+    assert np.array_equal(calib, g["calib"])
+    _, queried_ref = pipeline257_golden("pipeline257_color")
+    stats, queried = [], np.zeros_like(queried_ref)
+    vol = oracle.seg3d_lossless(
+        lambda p: oracle.query(feat_g, p, calib[0], layers_g, 1, syn.Z_SCALE, precision="f32")[0],
+        [-1, -1, -1], [1, 1, 1], PIPE257_RES, stats=stats, evaluated_out=queried)
+    _, undecided, n_amb = pipeline257_check("pipeline257_color", vol, queried, stats, 2e-5, COLOR257_AMBIGUOUS)
+    x, y, z, n = oracle.forward_vertices(vol, "front")
+    same = pipeline257_vertex_agreement(g, x, y, z)
+    assert same >= 0.999
+    # colours on the REFERENCE's vertices: isolates the colour chain from the octree's coin flips
+    mat = oracle.color_matrix([-1, -1, -1], [1, 1, 1], 257)
+
+    def color_query(pts):
+        return oracle.query(feat_c, pts, calib[0], layers_c, syn.LAST_OP["C"], syn.Z_SCALE, precision="f32")
+
+    img = oracle.colorization(g["X"].astype(np.int64), g["Y"].astype(np.int64), g["Z"], 257,
+                              color_query=color_query, mat_color=mat)
+    err = float(np.abs(img - g["tex_image"]).max())
+    print("configs[2] on the CPU: %.4f of the reference's %d vertices; max|colour - reference| = %.3g"
+          % (same, g["X"].shape[0], err))
+    assert err <= 1e-4
