@@ -557,9 +557,13 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
         samples = samples.permute(0, 2, 1)
         return netG.query(im_feat_list, points=samples, calibs=calib_tensor)[0]
 
-    engine = Seg3dLossless(query_func=query_func, b_min=np.array([B_MIN], np.float32),
-                           b_max=np.array([B_MAX], np.float32), resolutions=resolutions,
-                           balance_value=0.5, use_cuda_impl=False, faster=True).to(device)
+    # two engines: the class default validates query_func on EVERY frame (one extra 17^3 query + host sync;
+    # what a maintainer gets by swapping the import); validate="first" trusts a closure after three agreeing
+    # frames (re-checked every 32nd) and is what lets a coalescing stage batch frames (forward_many)
+    engines = {v: Seg3dLossless(query_func=query_func, b_min=np.array([B_MIN], np.float32),
+                                b_max=np.array([B_MAX], np.float32), resolutions=resolutions,
+                                balance_value=0.5, use_cuda_impl=False, faster=True, validate=v).to(device)
+               for v in ("always", "first")}
     mean, std = 0.5, 0.5
     r_last = resolutions[-1]
 
@@ -592,14 +596,16 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
         return out
 
     def recon_many(ds):
-        sdfs = engine.forward_many([dict(im_feat_list=d["feat_tensor_G"], calib_tensor=d["calib_tensor"]) for d in ds])
+        sdfs = engines["first"].forward_many([dict(im_feat_list=d["feat_tensor_G"], calib_tensor=d["calib_tensor"]) for d in ds])
         return [{**d, "sdf": sdf} for d, sdf in zip(ds, sdfs)]
 
     def vertices_many(ds):
         vs = forward_vertices_many([d["sdf"] for d in ds], direction="front")
         return [{**d, **dict(zip(["X", "Y", "Z", "norm"], v))} for d, v in zip(ds, vs)]
 
-    def processors(step, coalesce=False):
+    def processors(step, coalesce=False, validate="always"):
+        engine = engines["first" if coalesce else validate]
+
         def camera(d):
             ext, intr = syn.scene_camera(3 * step[0])
             step[0] += 1
@@ -652,7 +658,9 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
     n_frames = max(n_frames, 96)  # long against the pipeline's fill and drain, which are INSIDE the timed region
     passes = max(passes, 5)
 
-    def one_pass(coalesce, in_flight):
+    def one_pass(coalesce, in_flight, validate):
+        engine = engines["first" if coalesce else validate]
+
         def source():
             for i in range(n_frames):
                 yield frames[i % N_IMAGES]
@@ -663,7 +671,7 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with torch.no_grad():
-            for d in StagePipeline(source(), processors([0], coalesce), device=device, max_in_flight=in_flight):
+            for d in StagePipeline(source(), processors([0], coalesce, validate), device=device, max_in_flight=in_flight):
                 out_count += 1
                 last = d
             torch.cuda.synchronize()
@@ -680,7 +688,7 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
             call_log.clear()
         return elapsed
 
-    def mode(coalesce, in_flight):
+    def mode(coalesce, in_flight, validate="first"):
         if coalesce:
             # untimed: first use of every encoder batch size the coalescing filter stage can meet, ON THAT STAGE'S
             # STREAM (stage 4 of the list) -- torch's allocator pools blocks per stream, and a first batched encoder
@@ -690,15 +698,16 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
                 for b in range(1, 9):
                     netG.filter(torch.zeros((b, 3, 512, 512), device=device))
             torch.cuda.synchronize()
-        one_pass(coalesce, in_flight)  # untimed
-        runs = sorted(one_pass(coalesce, in_flight) for _ in range(passes))
+        one_pass(coalesce, in_flight, validate)  # untimed
+        runs = sorted(one_pass(coalesce, in_flight, validate) for _ in range(passes))
         med = runs[len(runs) // 2]
         return {"value": n_frames / med, "unit": "recon/s", "ms_per_step": med / n_frames * 1e3,
                 "passes": {"n": passes, "value_min": n_frames / runs[-1], "value_median": n_frames / med,
                            "value_max": n_frames / runs[0]},
-                "frames_in_flight": in_flight}
+                "frames_in_flight": in_flight, "validate": "first" if coalesce else validate}
 
-    per_frame = mode(False, 8)
+    per_frame = mode(False, 8, "always")
+    per_frame_trusted = mode(False, 8, "first")
     co = mode(True, 16)
     return {
         "surface": "RTL/main.py processors list on StagePipeline: Seg3dLossless(query_func) + forward_vertices + "
@@ -707,7 +716,11 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
         **co,
         "per_frame_stages": {**per_frame,
                              "surface": "the same list, one frame per stage call (the reference's structure), batch 1, "
-                                        "8 frames in flight"},
+                                        "8 frames in flight; Seg3dLossless as constructed by RTL/main.py:188-195 (class "
+                                        "default validate='always': query_func checked on every frame)"},
+        "per_frame_stages_trusted": {**per_frame_trusted,
+                                     "surface": "the same with Seg3dLossless(..., validate='first')"},
+        "latency_validate": "always",
         "latency_ms_single_frame": latency_ms,
         "latency_ms_min": float(np.min(lat[3:])) * 1e3,
         "frames": n_frames,

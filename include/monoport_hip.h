@@ -163,7 +163,7 @@ int mp_query_counted(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, 
                      const float *points, int64_t capacity, const int32_t *count,
                      const float *calib, float z_scale, float *out, mp_stream stream);
 
-/* mp_query_counted over n_frames (1..16) independent frames in ONE launch (the per-vertex colour
+/* mp_query_counted over n_frames (1..32) independent frames in ONE launch (the per-vertex colour
  * queries of all frames of a pipeline slot: ~14 k points each cannot fill 256 CUs alone).
  * feat_hwc / points / count / calib / out are HOST arrays of n_frames device pointers, each as in
  * mp_query_counted (one `capacity` for all); results are identical to n_frames separate calls. */
@@ -184,7 +184,7 @@ int mp_recon(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, c
              const int *resolutions /*host*/, int n_levels, float balance, float *volume,
              int32_t *status, mp_stream stream);
 
-/* mp_recon over n_frames (1..16) independent frames sharing the MLP, box and resolutions: every
+/* mp_recon over n_frames (1..32) independent frames sharing the MLP, box and resolutions: every
  * octree level evaluates the selected nodes of ALL frames in one fused-query launch, so the coarse
  * levels (5-25 k nodes per frame) fill the 256 CUs together.  feat_hwc / calib / volume / status
  * are HOST arrays of n_frames device pointers, each as in mp_recon; results are identical to
@@ -193,6 +193,24 @@ int mp_recon_batch(mp_ctx *ctx, int mlp, int n_frames, const float *const *feat_
                    int w, const float *const *calib, float z_scale, const float *b_min,
                    const float *b_max, const int *resolutions, int n_levels, float balance,
                    float *const *volume, int32_t *const *status, mp_stream stream);
+
+/* mp_recon_batch with the selection rule of the LAST level as an argument.  The un-vendored upstream
+ * engine (implicit_seg, RTL/main.py:188-195 constructs it with faster=True) is recalled to treat its last
+ * level differently from the others; nothing under the reference pins it, so the
+ * rule is the caller's choice:
+ *   MP_FINAL_DILATE3      boundary nodes (0 < upsampled mask < 1) dilated by 3^3, as at levels >= 3: the
+ *                         lossless schedule -- thresholded volume == thresholded dense evaluation on
+ *                         ordinary bodies.  mp_recon / mp_recon_batch use it.
+ *   MP_FINAL_UPSTREAM     only nodes whose upsampled mask is EXACTLY 0.5 (`is_boundary = valid == 0.5`,
+ *                         no dilation): ~4x fewer points at the last level; ~0.4 % of the inside voxels
+ *                         differ from dense evaluation (tests/test_recon_gpu.py::test_final_level_*).
+ *   MP_FINAL_INTERPOLATE  nothing is evaluated at the last level ("last step no examine"): the volume is
+ *                         the trilinear upsample of the level before; status[n_levels] = 0. */
+enum { MP_FINAL_DILATE3 = 0, MP_FINAL_UPSTREAM = 1, MP_FINAL_INTERPOLATE = 2 };
+int mp_recon_batch_ex(mp_ctx *ctx, int mlp, int n_frames, const float *const *feat_hwc, int c, int h,
+                      int w, const float *const *calib, float z_scale, const float *b_min,
+                      const float *b_max, const int *resolutions, int n_levels, float balance,
+                      int final_level, float *const *volume, int32_t *const *status, mp_stream stream);
 
 /* The same engine one level at a time, for an arbitrary Python ``query_func`` (the general
  * Seg3dLossless contract, RTL/main.py:169-195): the caller evaluates the selected nodes itself.
@@ -206,7 +224,9 @@ int mp_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
                      const uint64_t *ev_prev, uint64_t *ev_cur, uint64_t *bnd, int level,
                      float balance, uint32_t *packed, int32_t *count, mp_stream stream);
 /* mp_octree_select with an explicit dilation box (3, 7 or 9) instead of the faster-mode schedule
- * 9 / 7 / 3 by level: the upstream engine's faster=False mode dilates by 3^3 at every level. */
+ * 9 / 7 / 3 by level: the upstream engine's faster=False mode dilates by 3^3 at every level.
+ * box 1: the MP_FINAL_UPSTREAM rule (nodes whose upsampled mask is exactly 0.5, undilated);
+ * box 0: the MP_FINAL_INTERPOLATE rule (upsample only, *count = 0). */
 int mp_octree_select_box(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
                          const uint64_t *ev_prev, uint64_t *ev_cur, uint64_t *bnd, int box,
                          float balance, uint32_t *packed, int32_t *count, mp_stream stream);

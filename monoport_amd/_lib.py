@@ -80,6 +80,8 @@ SIGNATURES = {
                          c_int, c_f32, c_vp, c_vp, c_vp]),
     "mp_recon_batch": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_f32, _pf32, _pf32,
                                _pint, c_int, c_f32, c_vp, c_vp, c_vp]),
+    "mp_recon_batch_ex": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_f32, _pf32, _pf32,
+                                  _pint, c_int, c_f32, c_int, c_vp, c_vp, c_vp]),
     "mp_concat3_add": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_vp]),
     "mp_prepare_inputs": (c_int, [c_vp, c_vp, c_i64, _pf32, _pf32, c_vp, c_vp, c_vp]),
     "mp_octree_select": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_f32, c_vp,

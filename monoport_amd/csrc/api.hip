@@ -559,6 +559,14 @@ int mp_recon_batch(mp_ctx *ctx, int mlp, int n_frames, const float *const *feat_
                    int w, const float *const *calib, float z_scale, const float *b_min,
                    const float *b_max, const int *resolutions, int n_levels, float balance,
                    float *const *volume, int32_t *const *status, mp_stream stream) {
+  return mp_recon_batch_ex(ctx, mlp, n_frames, feat_hwc, c, h, w, calib, z_scale, b_min, b_max, resolutions,
+                           n_levels, balance, MP_FINAL_DILATE3, volume, status, stream);
+}
+
+int mp_recon_batch_ex(mp_ctx *ctx, int mlp, int n_frames, const float *const *feat_hwc, int c, int h,
+                      int w, const float *const *calib, float z_scale, const float *b_min,
+                      const float *b_max, const int *resolutions, int n_levels, float balance,
+                      int final_level, float *const *volume, int32_t *const *status, mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   const Mlp *m = get_mlp(ctx, mlp);
@@ -576,6 +584,9 @@ int mp_recon_batch(mp_ctx *ctx, int mlp, int n_frames, const float *const *feat_
       return fail(ctx, MP_ERR_ARG, "mp_recon: feat_hwc must be 16-byte aligned");
   }
   if (m->cout != 1) return fail(ctx, MP_ERR_ARG, "mp_recon: needs a 1-channel (occupancy) mlp");
+  if (final_level != MP_FINAL_DILATE3 && final_level != MP_FINAL_UPSTREAM && final_level != MP_FINAL_INTERPOLATE)
+    return fail(ctx, MP_ERR_ARG, "mp_recon: final_level must be MP_FINAL_DILATE3 / _UPSTREAM / _INTERPOLATE, got %d",
+                final_level);
   rc = check_resolutions(ctx, "mp_recon", resolutions, n_levels);
   if (rc != MP_OK) return rc;
   DeviceGuard g(ctx->device);
@@ -584,7 +595,7 @@ int mp_recon_batch(mp_ctx *ctx, int mlp, int n_frames, const float *const *feat_
                       &scratch);
   if (rc != MP_OK) return rc;
   return launch_recon(ctx, scratch, *m, n_frames, feat_hwc, h, w, calib, z_scale, b_min, b_max,
-                      resolutions, n_levels, balance, volume, status, (hipStream_t)stream);
+                      resolutions, n_levels, balance, final_level, volume, status, (hipStream_t)stream);
 }
 
 int mp_recon(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, const float *calib,
@@ -604,8 +615,8 @@ static int octree_select_impl(mp_ctx *ctx, const float *prev, int rp, float *cur
     return fail(ctx, MP_ERR_ARG, "mp_octree_select: bad argument");
   if (prev && (!cur || !ev_prev || !bnd || r != 2 * rp - 1 || level < 1))
     return fail(ctx, MP_ERR_ARG, "mp_octree_select: refinement needs cur, ev_prev, bnd and r == 2 rp - 1");
-  if (box != 3 && box != 7 && box != 9)
-    return fail(ctx, MP_ERR_UNSUPPORTED, "mp_octree_select_box: dilation box must be 3, 7 or 9, got %d", box);
+  if (box != 0 && box != 1 && box != 3 && box != 7 && box != 9)
+    return fail(ctx, MP_ERR_UNSUPPORTED, "mp_octree_select_box: dilation box must be 0, 1, 3, 7 or 9, got %d", box);
   DeviceGuard g(ctx->device);
   return launch_octree_select(ctx, prev, rp, cur, r,
                               reinterpret_cast<const unsigned long long *>(ev_prev),

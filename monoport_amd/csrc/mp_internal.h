@@ -70,7 +70,11 @@ struct PointSrc {
 // One launch of the fused query kernels serves up to kMaxFrames independent frames (their own
 // feature map, calibration, points and output): the tiles of all frames form one index space, so
 // the small coarse levels of several frames fill the machine together.
-constexpr int kMaxFrames = 16;
+#ifndef MP_MAX_FRAMES
+#define MP_MAX_FRAMES 32
+#endif
+constexpr int kMaxFrames = MP_MAX_FRAMES;  // a power of two <= 64 (query_table.hip: one lane per frame)
+static_assert((kMaxFrames & (kMaxFrames - 1)) == 0 && kMaxFrames <= 64, "kMaxFrames");
 struct QueryItem {
   const float *feat;   // channels-last feature map [H,W,C]
   const float *calib;  // [3,4] rows of the 4x4
@@ -78,10 +82,62 @@ struct QueryItem {
   PointSrc src;
   const float *l0;     // optional skip table of `feat` [H,W,kTableRows] (mp_skip_table; filled in by the launcher)
 };
+// host-side description of a launch (the launchers turn it into a QuerySetDev)
 struct QuerySet {
   int n;
   QueryItem it[kMaxFrames];
 };
+
+// What the kernels receive (kernel arguments are limited to 4 KB: 32 full QueryItems would be 4.1 KB).
+// The frames of one launch share the point layout (explicit strides, or the lattice of one octree level);
+// per frame only the pointers and the count differ.
+struct QueryItemDev {
+  const float *feat, *calib;
+  float *out;
+  const float *l0;
+  const void *pts;        // PointSrc::packed when `lattice`, else PointSrc::pts
+  const int32_t *n_dev;
+  long long n;
+};
+struct QuerySetDev {
+  int n;
+  int lattice;
+  long long sn, sc, out_stride;
+  int stride, level_res;
+  float res_final, half_step, bmin[3], blen[3];
+  QueryItemDev it[kMaxFrames];
+#ifdef __HIPCC__
+  __device__ __forceinline__ long long count(int f) const {
+    const int32_t *p = it[f].n_dev;
+    return p ? (long long)*p : it[f].n;
+  }
+  __device__ __forceinline__ QueryItem item(int f) const {
+    QueryItem q;
+    const QueryItemDev &d = it[f];
+    q.feat = d.feat;
+    q.calib = d.calib;
+    q.out = d.out;
+    q.l0 = d.l0;
+    q.src.pts = lattice ? nullptr : static_cast<const float *>(d.pts);
+    q.src.packed = lattice ? static_cast<const uint32_t *>(d.pts) : nullptr;
+    q.src.sn = sn;
+    q.src.sc = sc;
+    q.src.out_stride = out_stride;
+    q.src.stride = stride;
+    q.src.level_res = level_res;
+    q.src.res_final = res_final;
+    q.src.half_step = half_step;
+    for (int i = 0; i < 3; ++i) {
+      q.src.bmin[i] = bmin[i];
+      q.src.blen[i] = blen[i];
+    }
+    q.src.n_dev = d.n_dev;
+    q.src.n = d.n;
+    return q;
+  }
+#endif
+};
+static_assert(sizeof(QuerySetDev) + 256 <= 4096, "kernel arguments: the set + two MLP descriptors must stay below 4 KB");
 
 struct Mlp {
   bool used = false;
@@ -172,6 +228,8 @@ int launch_absmax(mp_ctx *ctx, const float *src, long long n, unsigned int *out_
 int launch_absmax_accumulate(mp_ctx *ctx, const float *src, long long n, unsigned int *out_bits,
                              hipStream_t st);
 bool find_skip_tables(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, QuerySet &tset);
+// host set -> kernel argument; MP_ERR_ARG if the frames do not share point layout / lattice
+int compact_query_set(mp_ctx *ctx, const QuerySet &set, QuerySetDev &dset);
 // query_small.hip: the netG f32 query on 32-point tiles, for launches of fewer than
 // kSmallGateTiles 64-point tiles
 constexpr int kSmallGateTiles = 2048;
@@ -196,7 +254,7 @@ size_t recon_scratch_bytes(const int *res, int n_levels);
 int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
                  const float *const *feat_hwc, int h, int w, const float *const *calib,
                  float z_scale, const float *bmin, const float *bmax, const int *res, int n_levels,
-                 float balance, float *const *volume, int32_t *const *status, hipStream_t st);
+                 float balance, int final_level, float *const *volume, int32_t *const *status, hipStream_t st);
 int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
                          const unsigned long long *ev_prev, unsigned long long *ev_cur,
                          unsigned long long *bnd, int box, float balance, uint32_t *packed,

@@ -94,10 +94,17 @@ __device__ __forceinline__ u64 spread32(u64 x) {  // bit i -> bit 2i
   return x;
 }
 
+// `rule` (MP_FINAL_*): which nodes get a flag -- 0: 0 < upsampled mask < 1 (every level of the lossless schedule);
+// 1: upsampled mask == 0.5 exactly, i.e. half of the corners with non-zero weight are inside (the last level of
+// the "upstream" schedule); 2: none (the last level of the "interpolate" schedule).
+__device__ __forceinline__ bool boundary_flag(int in, int all, int rule) {
+  return rule == 0 ? (in > 0 && in < all) : rule == 1 ? (2 * in == all) : false;
+}
+
 __global__ __launch_bounds__(256) void upsample_classify_kernel(const float *__restrict__ prev,
                                                                 int rp, float *__restrict__ cur,
                                                                 int r, float balance,
-                                                                u64 *__restrict__ bnd, int w64) {
+                                                                u64 *__restrict__ bnd, int w64, int rule) {
   const int lane = threadIdx.x & 63;
   const int wpx = (rp + 63) >> 6;  // waves per parent row
   const unsigned plane_item = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -155,8 +162,8 @@ __global__ __launch_bounds__(256) void upsample_classify_kernel(const float *__r
       float *row = cur + ((long long)z * r + y) * r;
       if (valid) row[2 * x0] = v_even;
       if (has_odd) row[2 * x0 + 1] = v_odd;
-      const bool f_even = valid && in0 > 0 && in0 < all0;  // 0 < upsampled mask < 1
-      const bool f_odd = has_odd && (in0 + in1) > 0 && (in0 + in1) < 2 * all0;
+      const bool f_even = valid && boundary_flag(in0, all0, rule);
+      const bool f_odd = has_odd && boundary_flag(in0 + in1, 2 * all0, rule);
       const u64 be = __ballot(f_even), bo = __ballot(f_odd);
       if (lane == 0) {
         u64 *words = bnd + ((long long)z * r + y) * w64 + 2 * wx;
@@ -290,8 +297,10 @@ static void launch_select(int box, hipStream_t st, const u64 *bnd, const u64 *ev
     MP_SELECT(4);
   } else if (box == 7) {
     MP_SELECT(3);
-  } else {
+  } else if (box == 3) {
     MP_SELECT(1);
+  } else {  // box <= 1: the flagged nodes themselves, no dilation
+    MP_SELECT(0);
   }
 #undef MP_SELECT
 }
@@ -379,9 +388,11 @@ int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int
                        ev_cur, w64, count, (int)octree_y_major());
   } else {
     MP_HIP(ctx, hipMemsetAsync(count, 0, sizeof(int32_t), st));
+    // box 1: the undilated "upsampled mask == 0.5" rule; box 0: upsample only (nothing selected)
     hipLaunchKernelGGL(upsample_classify_kernel,
                        dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp), dim3(256), 0,
-                       st, prev, rp, cur, r, balance, bnd, w64);
+                       st, prev, rp, cur, r, balance, bnd, w64,
+                       box == 1 ? MP_FINAL_UPSTREAM : box == 0 ? MP_FINAL_INTERPOLATE : MP_FINAL_DILATE3);
     launch_select(box, st, bnd, ev_prev, rp, words64(rp), ev_cur, r, w64, packed, count);
   }
   MP_HIP(ctx, hipGetLastError());
@@ -417,7 +428,7 @@ int launch_scatter_nodes(mp_ctx *ctx, const uint32_t *packed, const int32_t *cou
 int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
                  const float *const *feat_hwc, int h, int w, const float *const *calib,
                  float z_scale, const float *bmin, const float *bmax, const int *res, int n_levels,
-                 float balance, float *const *volume, int32_t *const *status, hipStream_t st) {
+                 float balance, int final_level, float *const *volume, int32_t *const *status, hipStream_t st) {
   // carve the scratch arena: one private set of level buffers per frame
   const size_t per_frame = recon_scratch_bytes(res, n_levels);
   LevelBufs lv[kMaxFrames][8];
@@ -480,12 +491,16 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
   }
   for (int l = 1; l < n_levels; ++l) {
     const int r = res[l], rp = res[l - 1], w64 = words64(r);
+    // the last level's selection rule (mp_recon_batch_ex): the lossless schedule dilates the boundary by 3^3 there
+    // too; "upstream" evaluates only the nodes whose upsampled mask is exactly 0.5; "interpolate" none
+    const int rule = l == n_levels - 1 ? final_level : MP_FINAL_DILATE3;
     for (int f = 0; f < n_frames; ++f) {
       hipLaunchKernelGGL(upsample_classify_kernel,
                          dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp), dim3(256),
-                         0, st, lv[f][l - 1].occ, rp, lv[f][l].occ, r, balance, lv[f][l].bnd, w64);
-      launch_select(octree_box_of_level(l), st, lv[f][l].bnd, lv[f][l - 1].ev, rp, words64(rp), lv[f][l].ev, r, w64,
-                    packed[f], status[f] + 1 + l);
+                         0, st, lv[f][l - 1].occ, rp, lv[f][l].occ, r, balance, lv[f][l].bnd, w64, rule);
+      if (rule == MP_FINAL_INTERPOLATE) continue;  // status[1 + l] stays 0
+      launch_select(rule == MP_FINAL_UPSTREAM ? 1 : octree_box_of_level(l), st, lv[f][l].bnd, lv[f][l - 1].ev, rp,
+                    words64(rp), lv[f][l].ev, r, w64, packed[f], status[f] + 1 + l);
       QueryItem &q = set.it[f];
       q.out = lv[f][l].occ;
       q.src.stride = (rf - 1) / (r - 1);
@@ -493,6 +508,7 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
       q.src.n_dev = status[f] + 1 + l;
       q.src.n = 0;
     }
+    if (rule == MP_FINAL_INTERPOLATE) continue;
     int rc = launch_query_set(ctx, m, set, h, w, z_scale, (long long)r * r * r * n_frames, true, st);
     if (rc != MP_OK) return rc;
   }

@@ -37,7 +37,7 @@ namespace mp {
 // sampled features and z_feat; no projection, no sampling, no mask.
 template <int C, int COUT, int WPS, bool DIRECT>
 __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
-    MlpPack mlp, int fh, int fw, float z_scale, int act, QuerySet set, int gate_tiles) {
+    MlpPack mlp, int fh, int fw, float z_scale, int act, QuerySetDev set, int gate_tiles) {
   constexpr int ROWB = C * 4;
   constexpr int NGX = C / 8;  // K groups of the feature segment
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -61,11 +61,14 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
     long long tile0 = 0;
     {
       long long acc = 0;
+      // groups of 8 frames: the 8 count loads of a group are in flight together, and the dynamic group offset
+      // keeps the compiler from hoisting all kMaxFrames kernel-argument loads into SGPRs (spills)
+      for (int f0 = 0; f0 < set.n; f0 += 8)
 #pragma unroll
-      for (int f = 0; f < kMaxFrames; ++f) {
+      for (int fk = 0; fk < 8; ++fk) {
+        const int f = f0 + fk;
         if (f < set.n) {
-          const PointSrc &s = set.it[f].src;
-          const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
+          const long long nf = set.count(f);
           const long long t = (nf + kTilePts - 1) / kTilePts;
           if (fi < 0 && gtile < acc + t) {
             fi = f;
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
       if (acc < gate_tiles) break;
     }
     if (fi < 0) break;  // past the last tile of the last frame
-    const QueryItem &item = set.it[fi];
+    const QueryItem item = set.item(fi);
     const float *__restrict__ feat = item.feat;
     const float *__restrict__ calib = item.calib;
     float *__restrict__ out = item.out;
@@ -478,9 +481,13 @@ static int launch_query_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h,
                                   small == 2 ? gate : 0, st);
     if (rc != MP_OK) return rc;
   }
-  if (small != 1)
+  if (small != 1) {
+    QuerySetDev dset;
+    const int rc = compact_query_set(ctx, set, dset);
+    if (rc != MP_OK) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kQueryThreads), lds, st, m.pack(), h, w,
-                       z_scale, m.act, set, small == 2 ? gate : 0);
+                       z_scale, m.act, dset, small == 2 ? gate : 0);
+  }
   if (prof) {
     MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], st));
     ++ctx->prof_used;
@@ -500,6 +507,43 @@ bool find_skip_tables(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int
     tset.it[f].l0 = it->second.table;
   }
   return true;
+}
+
+int compact_query_set(mp_ctx *ctx, const QuerySet &set, QuerySetDev &d) {
+  std::memset(&d, 0, sizeof(d));
+  const PointSrc &s0 = set.it[0].src;
+  d.n = set.n;
+  d.lattice = s0.packed != nullptr;
+  d.sn = s0.sn;
+  d.sc = s0.sc;
+  d.out_stride = s0.out_stride;
+  d.stride = s0.stride;
+  d.level_res = s0.level_res;
+  d.res_final = s0.res_final;
+  d.half_step = s0.half_step;
+  for (int i = 0; i < 3; ++i) {
+    d.bmin[i] = s0.bmin[i];
+    d.blen[i] = s0.blen[i];
+  }
+  for (int f = 0; f < set.n; ++f) {
+    const QueryItem &q = set.it[f];
+    const PointSrc &s = q.src;
+    bool same = (s.packed != nullptr) == (s0.packed != nullptr) && s.sn == s0.sn && s.sc == s0.sc &&
+                s.out_stride == s0.out_stride && s.stride == s0.stride && s.level_res == s0.level_res &&
+                s.res_final == s0.res_final && s.half_step == s0.half_step;
+    for (int i = 0; i < 3; ++i) same = same && s.bmin[i] == s0.bmin[i] && s.blen[i] == s0.blen[i];
+    if (!same)
+      return fail(ctx, MP_ERR_ARG, "query: the frames of one launch must share the point layout / octree level (frame %d differs)", f);
+    QueryItemDev &o = d.it[f];
+    o.feat = q.feat;
+    o.calib = q.calib;
+    o.out = q.out;
+    o.l0 = q.l0;
+    o.pts = s.packed ? static_cast<const void *>(s.packed) : static_cast<const void *>(s.pts);
+    o.n_dev = s.n_dev;
+    o.n = s.n;
+  }
+  return MP_OK;
 }
 
 int launch_query_set(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,

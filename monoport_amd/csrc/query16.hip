@@ -355,7 +355,7 @@ __device__ __forceinline__ void store_hidden16_part(unsigned char *hb, const f32
 // traffic, MFMA count and the chunk-buffer layout are unchanged.
 template <int COUT, int TERMS, int NB, int CS>
 __global__ __launch_bounds__(kThreads16 * CS, NB >= 3 ? CS : 2) void pifu_query16_kernel(
-    MlpPack mlp32, MlpPack16 mlp, int fh, int fw, float z_scale, int act, QuerySet set) {
+    MlpPack mlp32, MlpPack16 mlp, int fh, int fw, float z_scale, int act, QuerySetDev set) {
   constexpr int C = 256;
   constexpr int NGX = C / 16;        // k16 groups of the feature segment
   constexpr int P = 32 * NB;         // points per tile
@@ -392,11 +392,14 @@ __global__ __launch_bounds__(kThreads16 * CS, NB >= 3 ? CS : 2) void pifu_query1
     long long tile0 = 0;
     {
       long long acc = 0;
+      // groups of 8 frames: the 8 count loads of a group are in flight together, and the dynamic group offset
+      // keeps the compiler from hoisting all kMaxFrames kernel-argument loads into SGPRs (spills)
+      for (int f0 = 0; f0 < set.n; f0 += 8)
 #pragma unroll
-      for (int f = 0; f < kMaxFrames; ++f) {
+      for (int fk = 0; fk < 8; ++fk) {
+        const int f = f0 + fk;
         if (f < set.n) {
-          const PointSrc &s = set.it[f].src;
-          const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
+          const long long nf = set.count(f);
           const long long t = (nf + P - 1) / P;
           if (fi < 0 && gtile < acc + t) {
             fi = f;
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(kThreads16 * CS, NB >= 3 ? CS : 2) void pifu_query1
       }
     }
     if (fi < 0) break;  // past the last tile of the last frame
-    const QueryItem &item = set.it[fi];
+    const QueryItem item = set.item(fi);
     const float *__restrict__ feat = item.feat;
     const float *__restrict__ calib = item.calib;
     float *__restrict__ out = item.out;
@@ -755,7 +758,7 @@ constexpr int kQ16TabLds = 2 * kQ16TabHb + kHidden[0] * 8;      // two chunks + 
 
 template <int COUT, int TERMS>
 __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_tab_kernel(MlpPack mlp32, MlpPack16 mlp, int fh, int fw,
-                                                                        float z_scale, int act, QuerySet set) {
+                                                                        float z_scale, int act, QuerySetDev set) {
   constexpr int NB = 3, P = 96;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *hb = smem;  // hb[2]
@@ -780,11 +783,14 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_tab_kernel(MlpPack
     long long tile0 = 0;
     {
       long long acc = 0;
+      // groups of 8 frames: the 8 count loads of a group are in flight together, and the dynamic group offset
+      // keeps the compiler from hoisting all kMaxFrames kernel-argument loads into SGPRs (spills)
+      for (int f0 = 0; f0 < set.n; f0 += 8)
 #pragma unroll
-      for (int f = 0; f < kMaxFrames; ++f) {
+      for (int fk = 0; fk < 8; ++fk) {
+        const int f = f0 + fk;
         if (f < set.n) {
-          const PointSrc &s = set.it[f].src;
-          const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
+          const long long nf = set.count(f);
           const long long t = (nf + P - 1) / P;
           if (fi < 0 && gtile < acc + t) {
             fi = f;
@@ -795,7 +801,7 @@ __global__ __launch_bounds__(kThreads16, 1) void pifu_query16_tab_kernel(MlpPack
       }
     }
     if (fi < 0) break;
-    const QueryItem &item = set.it[fi];
+    const QueryItem item = set.item(fi);
     const float *__restrict__ calib = item.calib;
     float *__restrict__ out = item.out;
     const PointSrc &src = item.src;
@@ -1069,10 +1075,15 @@ static int launch_query16_tab_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, 
   const long long resident = (long long)ctx->n_cu;
   const long long grid = device_counts ? (tiles < resident ? tiles : resident)
                                        : (tiles < 8 * resident ? tiles : 8 * resident);
+  QuerySetDev dset;
+  {
+    const int rc_set = compact_query_set(ctx, set, dset);
+    if (rc_set != MP_OK) return rc_set;
+  }
   const bool prof = 2 * (ctx->prof_used + 1) <= (int)ctx->prof_events.size();
   if (prof) MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], st));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads16), kQ16TabLds, st, m.pack(), m.pack16(), h, w, z_scale,
-                     m.act, set);
+                     m.act, dset);
   if (prof) {
     MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], st));
     ++ctx->prof_used;
@@ -1098,10 +1109,15 @@ static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int 
   const long long resident = (long long)ctx->n_cu * (NB >= 3 ? 1 : 2);  // 160 / 144 / 80 KB of LDS each
   const long long grid = device_counts ? (tiles < resident ? tiles : resident)
                                        : (tiles < 8 * resident ? tiles : 8 * resident);
+  QuerySetDev dset;
+  {
+    const int rc_set = compact_query_set(ctx, set, dset);
+    if (rc_set != MP_OK) return rc_set;
+  }
   const bool prof = 2 * (ctx->prof_used + 1) <= (int)ctx->prof_events.size();
   if (prof) MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], st));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads16 * CS), lds, st, m.pack(), m.pack16(),
-                     h, w, z_scale, m.act, set);
+                     h, w, z_scale, m.act, dset);
   if (prof) {
     MP_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], st));
     ++ctx->prof_used;

@@ -43,7 +43,7 @@ constexpr int kSmallHbRow = 128 * 4;  // bytes per point of a 128-row hidden chu
 
 template <int COUT>
 __global__ __launch_bounds__(kQueryThreads, MP32_T32_WPS) void pifu_query_t32_kernel(
-    MlpPack mlp, int fh, int fw, float z_scale, int act, QuerySet set, int gate_tiles64) {
+    MlpPack mlp, int fh, int fw, float z_scale, int act, QuerySetDev set, int gate_tiles64) {
   constexpr int C = 256;
   constexpr int P = kSmallPts;
   constexpr int ROWB = C * 4;
@@ -64,11 +64,14 @@ __global__ __launch_bounds__(kQueryThreads, MP32_T32_WPS) void pifu_query_t32_ke
     long long tile0 = 0;
     {
       long long acc = 0, acc64 = 0;
+      // groups of 8 frames: the 8 count loads of a group are in flight together, and the dynamic group offset
+      // keeps the compiler from hoisting all kMaxFrames kernel-argument loads into SGPRs (spills)
+      for (int f0 = 0; f0 < set.n; f0 += 8)
 #pragma unroll
-      for (int f = 0; f < kMaxFrames; ++f) {
+      for (int fk = 0; fk < 8; ++fk) {
+        const int f = f0 + fk;
         if (f < set.n) {
-          const PointSrc &s = set.it[f].src;
-          const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
+          const long long nf = set.count(f);
           const long long t = (nf + P - 1) / P;
           if (fi < 0 && gtile < acc + t) {
             fi = f;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(kQueryThreads, MP32_T32_WPS) void pifu_query_t32_ke
       if (gate_tiles64 > 0 && acc64 >= gate_tiles64) break;  // the 64-point kernel serves this launch
     }
     if (fi < 0) break;
-    const QueryItem &item = set.it[fi];
+    const QueryItem item = set.item(fi);
     const float *__restrict__ feat = item.feat;
     const float *__restrict__ calib = item.calib;
     float *__restrict__ out = item.out;
@@ -334,8 +337,13 @@ int launch_query32_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int 
                                  : (tiles < 8 * resident ? tiles : 8 * resident);
   // gated: this kernel only works on launches of < gate_tiles64 64-point tiles
   if (gate_tiles64 > 0 && grid > 2LL * gate_tiles64 + set.n) grid = 2LL * gate_tiles64 + set.n;
+  QuerySetDev dset;
+  {
+    const int rc_set = compact_query_set(ctx, set, dset);
+    if (rc_set != MP_OK) return rc_set;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kQueryThreads), lds, st, m.pack(), h, w, z_scale,
-                     m.act, set, gate_tiles64);
+                     m.act, dset, gate_tiles64);
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
 }

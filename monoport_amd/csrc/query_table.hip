@@ -72,7 +72,7 @@ __device__ __forceinline__ void blend_add(f32x16 &acc, const TabRows &tp, const 
 
 template <int COUT>
 __global__ __launch_bounds__(kQueryThreads, MPT_WPS) void pifu_query_tab_kernel(MlpPack mlp, int fh, int fw, float z_scale,
-                                                                          int act, QuerySet set) {
+                                                                          int act, QuerySetDev set) {
   constexpr int P = kTabPts;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *hb = smem;  // hidden chunk: [32][128 rows] (layer 0 -> 1) or [32][64 rows]; `red` at the end
@@ -92,11 +92,14 @@ __global__ __launch_bounds__(kQueryThreads, MPT_WPS) void pifu_query_tab_kernel(
     long long tile0 = 0;
     {
       long long acc = 0;
+      // groups of 8 frames: the 8 count loads of a group are in flight together, and the dynamic group offset
+      // keeps the compiler from hoisting all kMaxFrames kernel-argument loads into SGPRs (spills)
+      for (int f0 = 0; f0 < set.n; f0 += 8)
 #pragma unroll
-      for (int f = 0; f < kMaxFrames; ++f) {
+      for (int fk = 0; fk < 8; ++fk) {
+        const int f = f0 + fk;
         if (f < set.n) {
-          const PointSrc &s = set.it[f].src;
-          const long long nf = s.n_dev ? (long long)*s.n_dev : s.n;
+          const long long nf = set.count(f);
           const long long t = (nf + P - 1) / P;
           if (fi < 0 && gtile < acc + t) {
             fi = f;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(kQueryThreads, MPT_WPS) void pifu_query_tab_kernel(
       }
     }
     if (fi < 0) break;
-    const QueryItem &item = set.it[fi];
+    const QueryItem item = set.item(fi);
     const float *__restrict__ calib = item.calib;
     float *__restrict__ out = item.out;
     const PointSrc &src = item.src;
@@ -353,21 +356,28 @@ constexpr int kWsTend = kWsZv + 2 * kTabPts * 4;        // tile_end[f]: tiles of
 // scalar loads from the kernel arguments (dynamic frame index; a miss in the scalar cache goes to the kernarg
 // buffer), the device-side point counter and the calibration: 25 k cycles per tile for the point load alone
 // (tools/tab_ws_stamp_probe.py).
-struct WsFrame {
+struct WsFrame {  // per frame
   float cal[12];
-  const float *pts;
-  const uint32_t *packed;
+  const void *pts;  // packed node codes (WsShared::lattice) or explicit coordinates
   float *out;
   const float *l0;
+  int npts, pad;
+};
+struct WsShared {  // the point layout / lattice of the launch, shared by its frames (QuerySetDev)
   long long sn, sc, out_stride;
   int stride, level_res;
   float res_final, half_step, bmin[3], blen[3];
-  int npts, pad;
+  int lattice, pad;
 };
-static_assert(sizeof(WsFrame) == 152, "two workgroups per CU: 2 x kWsLds <= 160 KB");
+static_assert(sizeof(WsFrame) == 80 && sizeof(WsShared) == 72, "two workgroups per CU: 2 x kWsLds <= 160 KB");
 constexpr int kWsFrames = kWsTend + kMaxFrames * 4;
-constexpr int kWsLds = kWsFrames + kMaxFrames * (int)sizeof(WsFrame);
+constexpr int kWsShared = kWsFrames + kMaxFrames * (int)sizeof(WsFrame);
+constexpr int kWsLds = kWsShared + (int)sizeof(WsShared);
+#ifdef MPT_WS_STAMP  // the stamp build adds 288 bytes of static LDS: build it with -DMP_MAX_FRAMES=16
 static_assert(2 * (kWsLds + 320) <= 160 * 1024, "two workgroups per CU (+ the 288 bytes of static LDS of the stamp build)");
+#else
+static_assert(2 * kWsLds <= 160 * 1024, "two workgroups per CU");
+#endif
 
 // timing experiments (tools/ablate.py; wrong results): the producers do no work / no barriers;
 // MPT_WS_PRIO: s_setprio of the consumer waves
@@ -464,7 +474,7 @@ struct WsPoint {
 
 template <int COUT>
 __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack mlp, int fh, int fw, float z_scale,
-                                                                         int act, QuerySet set) {
+                                                                         int act, QuerySetDev set) {
   constexpr int P = kTabPts;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -490,10 +500,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     // workgroup), the prefix sum runs over the lanes -- a loop over the frames per lane was 2 x 16 dependent
     // loads in front of the first tile (tens of microseconds of a 1 ms level-0 launch)
     int mine = 0;
-    if (tid < set.n) {
-      const PointSrc &sf = set.it[tid].src;
-      mine = (int)(sf.n_dev ? (long long)*sf.n_dev : sf.n);
-    }
+    if (tid < set.n) mine = (int)set.count(tid);
     int acc = (mine + P - 1) / P;
 #pragma unroll
     for (int o = 1; o < kMaxFrames; o <<= 1) {
@@ -502,25 +509,28 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     }
     tend[tid] = acc;
     if (tid < set.n) {
-      const QueryItem &it = set.it[tid];
+      const QueryItemDev &it = set.it[tid];
       WsFrame &fr = reinterpret_cast<WsFrame *>(smem + kWsFrames)[tid];
 #pragma unroll
       for (int i = 0; i < 12; ++i) fr.cal[i] = it.calib[i];
-      fr.pts = it.src.pts;
-      fr.packed = it.src.packed;
+      fr.pts = it.pts;
       fr.out = it.out;
       fr.l0 = it.l0;
-      fr.sn = it.src.sn;
-      fr.sc = it.src.sc;
-      fr.out_stride = it.src.out_stride;
-      fr.stride = it.src.stride;
-      fr.level_res = it.src.level_res;
-      fr.res_final = it.src.res_final;
-      fr.half_step = it.src.half_step;
+      if (tid == 0) {
+        WsShared &sh = *reinterpret_cast<WsShared *>(smem + kWsShared);
+        sh.sn = set.sn;
+        sh.sc = set.sc;
+        sh.out_stride = set.out_stride;
+        sh.stride = set.stride;
+        sh.level_res = set.level_res;
+        sh.res_final = set.res_final;
+        sh.half_step = set.half_step;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        fr.bmin[i] = it.src.bmin[i];
-        fr.blen[i] = it.src.blen[i];
+        for (int i = 0; i < 3; ++i) {
+          sh.bmin[i] = set.bmin[i];
+          sh.blen[i] = set.blen[i];
+        }
+        sh.lattice = set.lattice;
       }
       fr.npts = mine;
     }
@@ -710,6 +720,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     // (the frame index is wave-uniform, but not provably so for the compiler: without the readfirstlanes every
     // table load is wrapped in a waterfall loop over the descriptor)
     const WsFrame *frames = reinterpret_cast<const WsFrame *>(smem + kWsFrames);
+    const WsShared &sh = *reinterpret_cast<const WsShared *>(smem + kWsShared);
     auto table_rsrc = [&](int fi) {
       const unsigned long long a = reinterpret_cast<unsigned long long>(frames[__builtin_amdgcn_readfirstlane(fi)].l0);
       const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
@@ -732,12 +743,13 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
       rp.code = 0;
       rp.live = n < fr.npts;
       if (rp.live) {
-        if (fr.packed) {
-          rp.code = fr.packed[n];
+        if (sh.lattice) {
+          rp.code = static_cast<const uint32_t *>(fr.pts)[n];
         } else {
-          rp.px = fr.pts[n * fr.sn];
-          rp.py = fr.pts[n * fr.sn + fr.sc];
-          rp.pz = fr.pts[n * fr.sn + 2 * fr.sc];
+          const float *pts = static_cast<const float *>(fr.pts);
+          rp.px = pts[n * sh.sn];
+          rp.py = pts[n * sh.sn + sh.sc];
+          rp.pz = pts[n * sh.sn + 2 * sh.sc];
         }
       }
     };
@@ -747,14 +759,14 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #pragma unroll
       for (int i = 0; i < 12; ++i) cal[i] = fr.cal[i];
       float px = rp.px, py = rp.py, pz = rp.pz;
-      if (fr.packed && rp.live) {  // lattice_coord (query_common.h), the same operation sequence
+      if (sh.lattice && rp.live) {  // lattice_coord (query_common.h), the same operation sequence
         const int idx[3] = {(int)(rp.code & 1023u), (int)((rp.code >> 10) & 1023u), (int)(rp.code >> 20)};
         float c3[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          const float c = (float)(idx[a] * fr.stride);
-          const float u = __fadd_rn(__fdiv_rn(c, fr.res_final), fr.half_step);
-          c3[a] = __fadd_rn(__fmul_rn(u, fr.blen[a]), fr.bmin[a]);
+          const float c = (float)(idx[a] * sh.stride);
+          const float u = __fadd_rn(__fdiv_rn(c, sh.res_final), sh.half_step);
+          c3[a] = __fadd_rn(__fmul_rn(u, sh.blen[a]), sh.bmin[a]);
         }
         px = c3[0];
         py = c3[1];
@@ -867,11 +879,11 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         for (int part = 1; part < 4; ++part) v += red[(part * COUT + my_o) * P + j];
         v += pt.r4;
         v = (pt.ok & 2) ? activate(v, act) : 0.0f;  // MonoPortNet.py:89
-        if (fr.packed) {
+        if (sh.lattice) {
           const int ix = pt.code & 1023u, iy = (pt.code >> 10) & 1023u, iz = pt.code >> 20;
-          fr.out[((long long)iz * fr.level_res + iy) * fr.level_res + ix] = v;
+          fr.out[((long long)iz * sh.level_res + iy) * sh.level_res + ix] = v;
         } else {
-          fr.out[my_o * fr.out_stride + n0 + j] = v;
+          fr.out[my_o * sh.out_stride + n0 + j] = v;
         }
       }
     };
@@ -1032,7 +1044,12 @@ static int launch_query_tabws_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, 
   // persistent: a workgroup's producers run one chunk ahead of its consumers ACROSS tiles, so a
   // workgroup should see several tiles; never more workgroups than are resident at once
   const long long grid = tiles < resident ? tiles : resident;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kWsThreads), kWsLds, st, m.pack(), h, w, z_scale, m.act, set);
+  QuerySetDev dset;
+  {
+    const int rc_set = compact_query_set(ctx, set, dset);
+    if (rc_set != MP_OK) return rc_set;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kWsThreads), kWsLds, st, m.pack(), h, w, z_scale, m.act, dset);
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
 }
@@ -1049,8 +1066,13 @@ static int launch_query_tab_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, in
   // workgroup per tile up to a few waves of the machine
   const long long grid = device_counts ? (tiles < resident ? tiles : resident)
                                        : (tiles < 8 * resident ? tiles : 8 * resident);
+  QuerySetDev dset;
+  {
+    const int rc_set = compact_query_set(ctx, set, dset);
+    if (rc_set != MP_OK) return rc_set;
+  }
   hipLaunchKernelGGL(pifu_query_tab_kernel<COUT>, dim3((unsigned)grid), dim3(kQueryThreads), lds, st, m.pack(), h, w,
-                     z_scale, m.act, set);
+                     z_scale, m.act, dset);
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
 }

@@ -19,6 +19,16 @@ Constructor flags (upstream names):
   ``use_cuda_impl`` upstream switches the implementation of its interpolation, not its results:
                     accepted, both values run the same HIP kernels.
   ``debug``         accepted (upstream only prints timings).
+  ``final_level``   (monoport_amd extension, faster=True only) the selection rule of the LAST level:
+                    "dilate3" (default) -- the boundary nodes dilated by 3^3 like every level >= 3: the
+                    lossless schedule, thresholded volume == thresholded dense evaluation on ordinary
+                    bodies; "upstream" -- only nodes whose upsampled inside-mask is exactly 0.5
+                    (``is_boundary = valid == 0.5``, no dilation), the rule we recall from the upstream
+                    package's faster mode: ~4x fewer points at that level, ~0.4 % of the inside voxels
+                    differ from dense evaluation; "interpolate" -- nothing is evaluated at the last
+                    level (the other reading of upstream's "last step no examine").  Nothing under the
+                    reference pins this; a maintainer who has implicit_seg
+                    installed picks the mode that reproduces it.
   ``align_corners=True``, ``visualize=True``, ``use_shadow=True``, ``channels != 1``: not built,
                     NotImplementedError at construction.
 """
@@ -36,7 +46,7 @@ from . import utils  # noqa: F401
 class Seg3dLossless(nn.Module):
     def __init__(self, query_func, b_min, b_max, resolutions, channels=1, balance_value=0.5,
                  align_corners=False, visualize=False, debug=False, use_cuda_impl=False,
-                 faster=False, use_shadow=False, **kwargs):
+                 faster=False, use_shadow=False, final_level="dilate3", validate="always", **kwargs):
         super().__init__()
         if kwargs:  # the upstream constructor swallows **kwargs: stay drop-in, but say so
             warnings.warn("Seg3dLossless: ignoring unknown arguments %s" % sorted(kwargs))
@@ -69,17 +79,25 @@ class Seg3dLossless(nn.Module):
         self.channels = channels
         self.balance_value = float(balance_value)
         self.faster = bool(faster)
+        ops._final_level(final_level)  # ValueError for an unknown name
+        if final_level != "dilate3" and not self.faster:
+            raise NotImplementedError("final_level=%r is a variant of the faster=True schedule" % final_level)
+        self.final_level = final_level
         self.use_cuda_impl = bool(use_cuda_impl)  # same kernels either way (see module docstring)
         self.debug = bool(debug)
         self.last_status = None
         self.last_path = None  # "fused" | "generic": which engine served the last call
-        # "first": the first VALIDATE_CALLS calls are validated against query_func (see forward); once
-        # that many in a row agreed with the fused kernel, later calls with the same network head are
-        # trusted and skip the validation query -- except every REVALIDATE_EVERY-th one, which is
-        # validated again, so a query_func whose wrapper arithmetic changes later (a closure flag, a
-        # `1 - pred` from some frame on) is caught within that many frames instead of never.
-        # "always": validate every call (a query_func with per-call state).
-        self.validate = "first"
+        # "always" (the default of this drop-in class): every call evaluates the coarsest level through
+        # query_func for real and compares it with the fused kernel -- a closure whose arithmetic changes
+        # between frames (a flag, `1 - pred` from some frame on) is honoured on the frame it changes; costs
+        # one 17^3 query and one host sync per frame (~0.3 ms).
+        # "first": the first VALIDATE_CALLS calls are validated; once that many in a row agreed with the
+        # fused kernel, later calls with the same network head are trusted and skip the validation query --
+        # except every REVALIDATE_EVERY-th one.  For callers that vouch for their query_func
+        # (stage_pipeline users that never rebind it).
+        if validate not in ("always", "first"):
+            raise ValueError("validate must be 'always' or 'first', got %r" % (validate,))
+        self.validate = validate
         self._agreed = 0          # consecutive validated calls that agreed
         self._since_check = 0     # trusted calls since the last validated one
         self._trusted_key = None  # (id(packed head), precision, z scale) those calls were bound to
@@ -113,7 +131,7 @@ class Seg3dLossless(nn.Module):
                 return out
         self._since_check = 0
         eng = ops.LevelEngine(dev, self.b_min[0], self.b_max[0], self.resolutions,
-                              self.balance_value, self.faster)
+                              self.balance_value, self.faster, self.final_level)
         pts0 = eng.select()
         with record_query() as rec:
             occ0 = self.query_func(points=pts0[None], **kwargs)
@@ -121,7 +139,7 @@ class Seg3dLossless(nn.Module):
         if binding is not None and self.faster:
             volume, status = ops.recon(binding.mlp, binding.feat_hwc, binding.calib, binding.z_scale,
                                        self.b_min[0], self.b_max[0], self.resolutions,
-                                       self.balance_value)
+                                       self.balance_value, final_level=self.final_level)
             eng.scatter(occ0)  # the caller's values on the coarsest lattice, [r0,r0,r0]
             s = (self.resolutions[-1] - 1) // (self.resolutions[0] - 1)
             differs = (volume[::s, ::s, ::s] != eng.cur).any().to(torch.int32).reshape(1)
@@ -138,11 +156,11 @@ class Seg3dLossless(nn.Module):
                           "values differ from the fused kernel's); using the level-at-a-time engine")
             volume, counts = ops.recon_generic(self.query_func, kwargs, dev, self.b_min[0],
                                                self.b_max[0], self.resolutions, self.balance_value,
-                                               self.faster)
+                                               self.faster, final_level=self.final_level)
         else:
             volume, counts = ops.recon_generic(self.query_func, kwargs, dev, self.b_min[0],
                                                self.b_max[0], self.resolutions, self.balance_value,
-                                               self.faster, level0=(eng, occ0))
+                                               self.faster, level0=(eng, occ0), final_level=self.final_level)
         self.last_path = "generic"
         self.last_status = torch.tensor([int(volume is not None)] + counts, dtype=torch.int32)
         return None if volume is None else volume[None, None]
@@ -167,13 +185,13 @@ class Seg3dLossless(nn.Module):
             self._agreed, self._trusted_key = 0, None
             return NotImplemented
         volume, status = ops.recon(b.mlp, b.feat_hwc, b.calib, b.z_scale, self.b_min[0], self.b_max[0],
-                                   self.resolutions, self.balance_value)
+                                   self.resolutions, self.balance_value, final_level=self.final_level)
         st = status.cpu()
         self.last_status, self.last_path = st, "fused"
         return None if int(st[0]) == 0 else volume[None, None]
 
     def forward_many(self, kwargs_list):
-        """``[self(**kw) for kw in kwargs_list]`` for up to 16 frames at once (monoport_amd extension;
+        """``[self(**kw) for kw in kwargs_list]`` for up to ops.MAX_FRAMES frames at once (monoport_amd extension;
         the hook of a coalescing recon stage, stage_pipeline.Coalesced).  When the engine is in its
         trusted state (see ``forward``) every frame is bound through its one-point probe and ALL of
         them go through one ``mp_recon_batch`` -- every octree level of all frames in one fused-query
@@ -181,7 +199,7 @@ class Seg3dLossless(nn.Module):
         for bit.  In any other state (not yet validated, ``validate = "always"``, a re-validation
         due, a binding that changed) the frames are served one by one by ``forward``."""
         n = len(kwargs_list)
-        if (n < 2 or n > 16 or not self.faster or self.validate == "always" or self._agreed < self.VALIDATE_CALLS
+        if (n < 2 or n > ops.MAX_FRAMES or not self.faster or self.validate == "always" or self._agreed < self.VALIDATE_CALLS
                 or self._since_check + n >= self.REVALIDATE_EVERY):
             return [self(**kw) for kw in kwargs_list]
         probe = torch.zeros((1, 1, 3), dtype=torch.float32, device=self._device_tag.device)
@@ -196,7 +214,7 @@ class Seg3dLossless(nn.Module):
         b0 = bindings[0]
         volumes, status = ops.recon_batch(b0.mlp, [b.feat_hwc for b in bindings], [b.calib for b in bindings],
                                           b0.z_scale, self.b_min[0], self.b_max[0], self.resolutions,
-                                          self.balance_value)
+                                          self.balance_value, final_level=self.final_level)
         st = status.cpu()  # the one host sync of the whole batch
         self._since_check += n
         self.last_status, self.last_path = st[-1], "fused"
@@ -215,7 +233,7 @@ class Seg3dLossless(nn.Module):
         if b is None:
             raise NotImplementedError("forward_async needs a query_func ending in MonoPortNet.query")
         return ops.recon(b.mlp, b.feat_hwc, b.calib, b.z_scale, self.b_min[0], self.b_max[0],
-                         self.resolutions, self.balance_value)
+                         self.resolutions, self.balance_value, final_level=self.final_level)
 
 
 class Seg3dTopk(nn.Module):

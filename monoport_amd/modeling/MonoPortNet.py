@@ -1,10 +1,14 @@
 """MonoPortNet: the PIFu geometry / colour network wrapper (mirror of
 monoport/lib/modeling/MonoPortNet.py, same constructor, attributes and method signatures).
 
-``filter`` runs the image encoder under PyTorch-ROCm once per frame.  ``query`` -- the hot path,
-called once per octree level on 10^4..10^5 points -- is ONE hand-written HIP kernel
-(csrc/query.hip): projection, in-image mask, depth feature, bilinear feature gather, the
-skip-connected MLP on f32 MFMA, final activation and mask.
+``filter`` runs the image encoder once per frame as a chain of hand-written HIP kernels
+(modeling/backbones.py over csrc/conv3x3.hip, convim2col.hip, encoder_ops.hip; torch ops only in
+train mode / on CPU tensors).  ``query`` -- the hot path, called once per octree level on
+10^4..10^5 points -- is one fused HIP kernel launch: projection, in-image mask, depth feature,
+bilinear gather, the skip-connected MLP on f32 MFMA, final activation and mask.  Which kernel:
+csrc/query_table.hip when the bound feature map has a skip table (``_skip_table`` below: the
+octree engine's maps, and maps that have served 16 k points), else csrc/query.hip /
+query_small.hip; netC (C = 512) always csrc/query.hip.
 """
 import collections
 import threading
@@ -103,7 +107,17 @@ class MonoPortNet(nn.Module):
         return feats_stages
 
     # ---- hot path --------------------------------------------------------------------------------
-    MAX_BOUND_MAPS = 16  # frames whose packed map / skip table are kept (kMaxFrames of mp_recon_batch)
+    MAX_BOUND_MAPS = ops.MAX_FRAMES  # packed maps / skip tables kept at most (a coalescing stage binds up to kMaxFrames)
+
+    def _drop_dead_maps(self):
+        """Forget the packed copy and the skip table (128 MB) of every feature map whose source tensors
+        have been freed: the reference's one-frame-at-a-time usage then holds ONE map, a pipeline with k
+        frames in flight k of them (the LRU bound only caps a caller that keeps every map alive)."""
+        for key in [k for k, (refs, _) in self._hwc_cache.items() if any(r() is None for r in refs)]:
+            _, packed = self._hwc_cache.pop(key)
+            e = self._table_cache.pop(id(packed), None)
+            if e is not None and e[3] is not None:
+                e[3].release()
 
     def _packed_features(self, feats):
         """Channels-last copy of this stage's maps, cached per source tensors so the five octree
@@ -113,6 +127,7 @@ class MonoPortNet(nn.Module):
         if c is not None and all(r() is f for r, f in zip(c[0], feats)):
             self._hwc_cache.move_to_end(key)
             return c[1]
+        self._drop_dead_maps()
         packed = ops.pack_features(list(feats))
         self._hwc_cache[key] = ([weakref.ref(f) for f in feats], packed)
         while len(self._hwc_cache) > self.MAX_BOUND_MAPS:
@@ -148,9 +163,14 @@ class MonoPortNet(nn.Module):
         points: it is made when the octree engine binds the map (a reconstruction of ~3e5 points
         follows) or once the map has served ops.SKIP_TABLE_MIN_POINTS query points; a few small
         ``query`` calls stay on the plain kernels (the two paths differ by f32 rounding, 1-5e-7).
-        netG heads (C = 256), any precision of the hidden GEMMs -- the table itself is always exact f32;
-        MONOPORT_SKIP_TABLE=off (ops.SKIP_TABLE) switches it off.
-        The tables of the last MAX_BOUND_MAPS maps stay registered (frames in flight)."""
+        netG heads (C = 256) whose precision the C side routes through tables (ops.table_precision: exact
+        f32 and f16x3; f16w / f16 measured slower through them and stay on the plain kernel, so no table
+        is built for them); the table itself is always exact f32; MONOPORT_SKIP_TABLE=off (ops.SKIP_TABLE)
+        switches it off.  The tables of live bound maps stay registered, at most MAX_BOUND_MAPS.
+        Determinism: for plain ``query`` calls the threshold is CUMULATIVE per map, so the same call can
+        return results that differ in the last bits (<= 5e-7, the distance between the two kernels) before
+        and after the map has earned its table; MONOPORT_SKIP_TABLE_MIN_POINTS=0 (always) or
+        MONOPORT_SKIP_TABLE=off (never) make every call take the same path."""
         cache = self._table_cache
         for k in [k for k, e in cache.items()  # entries of recycled / rewritten maps or of other weights
                   if e[0]._version != e[1] or e[2] is not mlp or e[4] != mlp.generation or not ops.SKIP_TABLE]:
@@ -163,7 +183,7 @@ class MonoPortNet(nn.Module):
         cache.move_to_end(id(packed))
         e[5] += n_points
         h, w, ch = packed.shape
-        wanted = ops.SKIP_TABLE and ch == 256 and (h * w) % 64 == 0
+        wanted = ops.SKIP_TABLE and ch == 256 and (h * w) % 64 == 0 and ops.table_precision(mlp.precision)
         if wanted and e[3] is None and (for_engine or e[5] >= ops.SKIP_TABLE_MIN_POINTS):
             # the handle keeps map and table alive and unregisters them when it is dropped
             e[3] = ops.skip_table(mlp, packed)

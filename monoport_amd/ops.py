@@ -193,6 +193,21 @@ SKIP_TABLE = os.environ.get("MONOPORT_SKIP_TABLE", "on") != "off"
 # MonoPortNet.bind makes a table for a map once it has served this many query points (or at once for
 # the octree engine): the table costs what ~16 k points cost on the plain kernels
 SKIP_TABLE_MIN_POINTS = int(os.environ.get("MONOPORT_SKIP_TABLE_MIN_POINTS", "16384"))
+def table_precision(precision):
+    """Whether the fused query of a netG head with this MLP precision blends table rows (mirrors
+    launch_query16 in csrc/query16.hip: f16x3 by default, every f16 variant with MONOPORT_TAB16=all, none
+    with =off; the exact-f32 kernels always do).  Callers that build tables on their own check it first: a
+    table nobody reads costs 16 GFLOP and 128 MB per frame."""
+    if precision == "f32":
+        return True
+    t16 = os.environ.get("MONOPORT_TAB16", "")
+    if t16.startswith("a"):
+        return True
+    if t16.startswith("o"):
+        return False
+    return precision == "f16x3"
+
+
 SKIP_TABLE_ROWS = 1952  # kTableRows: the feature segments of layers 0-3 (1024 + 512 + 256 + 128) + the last layer's, padded to 61 cache lines
 
 
@@ -326,7 +341,7 @@ def query_counted(mlp, feat_hwc, points, count, calib, z_scale, out=None):
 
 
 def query_counted_batch(mlp, feats_hwc, points, counts, calibs, z_scale, outs=None):
-    """mp_query_counted_batch: one fused-query launch for up to 16 frames.  feats_hwc / points
+    """mp_query_counted_batch: one fused-query launch for up to MAX_FRAMES frames.  feats_hwc / points
     ([3,cap] each, one cap) / counts (int32[1] each) / calibs: lists of per-frame device tensors
     -> list of [Cout,cap]."""
     ctx = mlp.ctx
@@ -351,32 +366,31 @@ def query_counted_batch(mlp, feats_hwc, points, counts, calibs, z_scale, outs=No
     return outs
 
 
+# Selection rule of the LAST octree level (include/monoport_hip.h, MP_FINAL_*; Seg3dLossless docstring)
+FINAL_LEVELS = {"dilate3": 0, "upstream": 1, "interpolate": 2}
+MAX_FRAMES = 32  # kMaxFrames: frames per mp_recon_batch / mp_query_counted_batch call
+
+
+def _final_level(final_level):
+    try:
+        return FINAL_LEVELS[final_level]
+    except KeyError:
+        raise ValueError("final_level must be one of %s, got %r" % (sorted(FINAL_LEVELS), final_level)) from None
+
+
 def recon(mlp, feat_hwc, calib, z_scale, b_min, b_max, resolutions, balance=0.5, volume=None,
-          status=None):
+          status=None, final_level="dilate3"):
     """Coarse-to-fine occupancy volume (Seg3dLossless replacement).  Returns (volume [R,R,R]
     f32, status int32[1+levels]) -- both on device, nothing synchronised."""
-    ctx = mlp.ctx
-    h, w, c = feat_hwc.shape
-    res = [int(r) for r in resolutions]
-    r_last = res[-1]
-    dev = feat_hwc.device
-    cal = _calib_dev(calib, dev)
-    if volume is None:
-        volume = torch.empty((r_last, r_last, r_last), dtype=torch.float32, device=dev)
-    if status is None:
-        status = torch.empty((1 + len(res),), dtype=torch.int32, device=dev)
-    bmin = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_min, np.float32).reshape(3)])
-    bmax = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_max, np.float32).reshape(3)])
-    res_c = (ctypes.c_int * len(res))(*res)
-    ctx.check(ctx.lib.mp_recon(ctx.handle, mlp.id, _ptr(feat_hwc), c, h, w, _ptr(cal),
-                               float(z_scale), bmin, bmax, res_c, len(res), float(balance),
-                               _ptr(volume), _ptr(status), _stream(volume)), "mp_recon")
-    return volume, status
+    st = None if status is None else status.reshape(1, -1)
+    volumes, st = recon_batch(mlp, [feat_hwc], [calib], z_scale, b_min, b_max, resolutions, balance,
+                              None if volume is None else [volume], st, final_level)
+    return volumes[0], st[0]
 
 
 def recon_batch(mlp, feats_hwc, calibs, z_scale, b_min, b_max, resolutions, balance=0.5,
-                volumes=None, status=None):
-    """``recon`` over up to 16 independent frames in one call: every octree level evaluates the
+                volumes=None, status=None, final_level="dilate3"):
+    """``recon`` over up to MAX_FRAMES independent frames in one call: every octree level evaluates the
     selected nodes of all frames in ONE fused-query launch (the coarse levels of a single frame
     cannot fill 256 CUs).  feats_hwc: list of [H,W,C] maps; calibs: [B,4,4] (or list of [1,4,4]);
     volumes: list of [R,R,R]; status: [B, 1+levels] int32.  Results equal B separate ``recon``
@@ -402,11 +416,11 @@ def recon_batch(mlp, feats_hwc, calibs, z_scale, b_min, b_max, resolutions, bala
     bmax = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_max, np.float32).reshape(3)])
     res_c = (ctypes.c_int * len(res))(*res)
     ptrs = ctypes.c_void_p * n
-    ctx.check(ctx.lib.mp_recon_batch(
+    ctx.check(ctx.lib.mp_recon_batch_ex(
         ctx.handle, mlp.id, n, ptrs(*[f.data_ptr() for f in feats_hwc]), c, h, w,
         ptrs(*[cb.data_ptr() for cb in cals]), float(z_scale), bmin, bmax, res_c, len(res),
-        float(balance), ptrs(*[v.data_ptr() for v in volumes]),
-        ptrs(*[status[b].data_ptr() for b in range(n)]), _stream(volumes[0])), "mp_recon_batch")
+        float(balance), _final_level(final_level), ptrs(*[v.data_ptr() for v in volumes]),
+        ptrs(*[status[b].data_ptr() for b in range(n)]), _stream(volumes[0])), "mp_recon_batch_ex")
     stream = torch.cuda.current_stream(dev)
     for t in cals:
         t.record_stream(stream)
@@ -422,7 +436,9 @@ class LevelEngine:
     3x3x3 neighbourhoods of nodes whose exact value contradicts the interpolated one are evaluated
     too, until no contradiction is left."""
 
-    def __init__(self, device, b_min, b_max, resolutions, balance=0.5, faster=True):
+    def __init__(self, device, b_min, b_max, resolutions, balance=0.5, faster=True, final_level="dilate3"):
+        self.final_level = final_level
+        _final_level(final_level)
         self.ctx = get_context(device)
         self.dev = torch.device(device)
         self.res = [int(r) for r in resolutions]
@@ -459,6 +475,9 @@ class LevelEngine:
         bnd = torch.empty((words,), dtype=torch.int64, device=dev)
         self.packed = torch.empty((r ** 3,), dtype=torch.int32, device=dev)
         box = 3 if not self.faster else {1: 9, 2: 7}.get(level, 3)
+        if self.faster and level == len(self.res) - 1 and level > 0:
+            # the last level's rule (mp_octree_select_box: 1 = upsampled mask == 0.5, undilated; 0 = none)
+            box = {"dilate3": box, "upstream": 1, "interpolate": 0}[self.final_level]
         ctx.check(ctx.lib.mp_octree_select_box(
             ctx.handle, _ptr(self.prev) if level > 0 else None, self.res[level - 1] if level > 0 else 0,
             _ptr(self.cur), r, _ptr(self.ev_prev) if level > 0 else None, _ptr(self.ev_cur),
@@ -513,12 +532,12 @@ class LevelEngine:
 
 
 def recon_generic(query_func, kwargs, device, b_min, b_max, resolutions, balance=0.5, faster=True,
-                  level0=None):
+                  level0=None, final_level="dilate3"):
     """Seg3dLossless for an ARBITRARY ``query_func(points=[1,N,3], **kwargs) -> [1,1,N]`` on top
     of ``LevelEngine``.  ``level0`` = (engine, occupancies) when the caller has already evaluated
     the coarsest level through the engine.  Returns (volume [R,R,R] or None, per-level counts)."""
     if level0 is None:
-        eng = LevelEngine(device, b_min, b_max, resolutions, balance, faster)
+        eng = LevelEngine(device, b_min, b_max, resolutions, balance, faster, final_level)
         pts = eng.select()
         occ = query_func(points=pts[None], **kwargs)
     else:

@@ -27,7 +27,7 @@ from . import ops
 from .synthetic import Z_SCALE
 
 RESOLUTIONS = (17, 33, 65, 129, 257)  # RTL/main.py:187
-MAX_RECON_BATCH = 16  # kMaxFrames of the C-ABI (include/monoport_hip.h, mp_recon_batch)
+MAX_RECON_BATCH = ops.MAX_FRAMES  # kMaxFrames of the C-ABI (include/monoport_hip.h, mp_recon_batch): 32
 
 
 class FrameSlot:
@@ -35,12 +35,14 @@ class FrameSlot:
     the netC texture stages :373-441 when ``netC`` is given)."""
 
     def __init__(self, netG, device, resolutions=RESOLUTIONS, b_min=(-1, -1, -1), b_max=(1, 1, 1),
-                 balance=0.5, feature_hook=None, use_graph=False, netC=None, batch=1, skip_table=None):
+                 balance=0.5, feature_hook=None, use_graph=False, netC=None, batch=1, skip_table=None,
+                 final_level="dilate3"):
         self.net = netG
         self.netC = netC
         self.device = torch.device(device)
         self.res = [int(r) for r in resolutions]
         self.b_min, self.b_max, self.balance = b_min, b_max, float(balance)
+        self.final_level = final_level  # the last octree level's selection rule (Seg3dLossless docstring)
         self.feature_hook = feature_hook  # optional in-place edit of the [B,C,H,W] feature map
         self.batch = int(batch)
         r = self.res[-1]
@@ -52,8 +54,10 @@ class FrameSlot:
         # one [B,128,128,256] channels-last map; feats_hwc[b] are its per-frame views
         self.feat_hwc_all = torch.empty((b, 128, 128, 256), dtype=torch.float32, device=dev)
         self.feats_hwc = [self.feat_hwc_all[i] for i in range(b)]
-        # skip tables of the slot's maps (ops.SKIP_TABLE unless the caller says otherwise)
-        self.skip_table = ops.SKIP_TABLE if skip_table is None else bool(skip_table)
+        # skip tables of the slot's maps (ops.SKIP_TABLE unless the caller says otherwise) -- only for the MLP
+        # precisions whose query kernel reads them (f32, f16x3): a table nobody reads is 16 GFLOP + 128 MB a frame
+        self.skip_table = ((ops.SKIP_TABLE if skip_table is None else bool(skip_table))
+                           and ops.table_precision(netG.surface_classifier.precision))
         self.tables = (torch.empty((b, 128, 128, ops.SKIP_TABLE_ROWS), dtype=torch.float32, device=dev)
                        if self.skip_table else None)
         self._table_handle = None  # registration of the tables of the last encoder pass
@@ -130,7 +134,7 @@ class FrameSlot:
         if not self.hwc_direct:
             for b in range(n):
                 ops.pack_features(feat[b:b + 1], out=self.feats_hwc[b])
-        if self.tables is not None:  # every precision of a netG head blends table rows (query_table.hip, query16.hip)
+        if self.tables is not None:  # f32 / f16x3 heads blend table rows (query_table.hip, query16.hip)
             # (re)made after every encoder pass; the handle of the previous pass unregisters the same
             # pointers only if they still point at its table views, so dropping it here is harmless
             self._table_handle = ops.skip_table_batch(mlp, self.feat_hwc_all[:n], out=self.tables[:n])
@@ -140,7 +144,7 @@ class FrameSlot:
             b1 = min(b0 + MAX_RECON_BATCH, n)
             ops.recon_batch(mlp, self.feats_hwc[b0:b1], self.calib[b0:b1], Z_SCALE, self.b_min,
                             self.b_max, self.res, self.balance, volumes=self.volumes[b0:b1],
-                            status=self.status[b0:b1])
+                            status=self.status[b0:b1], final_level=self.final_level)
         pts_all = []
         for b in range(n):
             x, y, z, nrm, count = ops.forward_vertices_raw(self.volumes[b], "front")
@@ -153,7 +157,7 @@ class FrameSlot:
                 pts_all.append(ops.vertex_points(x, y, z, count, r, self.mat_color))
         if self.netC is not None:
             # netC.query on the visible vertices (RTL/main.py:231-248) of ALL frames of the slot:
-            # one fused-query launch per chunk of 16 frames (14 k points per frame alone would
+            # one fused-query launch per chunk of 32 frames (14 k points per frame alone would
             # leave most CUs idle)
             for b0 in range(0, n, MAX_RECON_BATCH):
                 b1 = min(b0 + MAX_RECON_BATCH, n)

@@ -279,8 +279,11 @@ def dilation_for_level(level):
     return {1: 9, 2: 7}.get(level, 3)
 
 
+FINAL_LEVELS = ("dilate3", "upstream", "interpolate")
+
+
 def seg3d_lossless(query_func, b_min, b_max, resolutions, balance_value=0.5, stats=None,
-                   evaluated_out=None, faster=True, rounds=None):
+                   evaluated_out=None, faster=True, rounds=None, final_level="dilate3"):
     """Coarse-to-fine occupancy volume [R,R,R] (z,y,x) f32, or None if level 0 is empty.
 
     ``query_func(points[3,N] f32) -> [N] f32``.  Requires resolutions[i+1] == 2*resolutions[i]-1.
@@ -290,7 +293,14 @@ def seg3d_lossless(query_func, b_min, b_max, resolutions, balance_value=0.5, sta
     exact value and interpolated value lie on different sides of the threshold gets its 3x3x3
     neighbourhood (at this level's spacing) evaluated as well, repeated until no new conflict;
     ``stats`` counts those points with their level, ``rounds`` receives the rounds per level.
+    ``final_level`` (faster=True): the selection rule of the LAST level -- "dilate3": like every level
+    >= 3 (the lossless schedule); "upstream": only nodes whose upsampled inside-mask is exactly 0.5, no
+    dilation (``is_boundary = valid == 0.5``, the rule recalled from the upstream package's faster
+    mode); "interpolate": nothing is evaluated there (its "last step no examine").  Unpinned by the
+    reference either way.
     """
+    if final_level not in FINAL_LEVELS or (final_level != "dilate3" and not faster):
+        raise ValueError("final_level %r" % (final_level,))
     res = [int(r) for r in resolutions]
     for a, b in zip(res[:-1], res[1:]):
         if b != 2 * a - 1:
@@ -315,8 +325,14 @@ def seg3d_lossless(query_func, b_min, b_max, resolutions, balance_value=0.5, sta
         stride = (rf - 1) // (r - 1)
         valid = upsample2x((occ > bv).astype(np.float32))
         occ = upsample2x(occ)
-        boundary = (valid > 0) & (valid < 1)
-        sel = dilate_box(boundary, dilation_for_level(level) if faster else 3)
+        last = faster and level == len(res) - 1
+        if last and final_level == "upstream":
+            sel = valid == np.float32(0.5)
+        elif last and final_level == "interpolate":
+            sel = np.zeros((r, r, r), bool)
+        else:
+            boundary = (valid > 0) & (valid < 1)
+            sel = dilate_box(boundary, dilation_for_level(level) if faster else 3)
         ev = np.zeros((r, r, r), bool)
         ev[::2, ::2, ::2] = evaluated
         sel &= ~ev

@@ -570,7 +570,7 @@ def test_trusted_query_func_is_validated_again_periodically():
         return 1 - pred if state["flip"] else pred
 
     eng = Seg3dLossless(query_func=query_func, b_min=np.array([[-1., -1., -1.]]), b_max=np.array([[1., 1., 1.]]),
-                        resolutions=[9, 17, 33], faster=True).to(DEV)
+                        resolutions=[9, 17, 33], faster=True, validate="first").to(DEV)
     eng.REVALIDATE_EVERY = 4
     for _ in range(3 + 8):
         eng(feats=feats, calib=calib)
@@ -588,6 +588,19 @@ def test_trusted_query_func_is_validated_again_periodically():
             paths.append(eng.last_path)
     assert "generic" in paths and paths[-1] == "generic"  # caught within REVALIDATE_EVERY frames, stays caught
     assert (((out > 0.5) != (inside > 0.5)).float().mean().item()) > 0.5  # the flipped field is what comes back
+    # the class default (validate="always") honours the change on the very frame it happens
+    state["flip"] = False
+    dflt = Seg3dLossless(query_func=query_func, b_min=np.array([[-1., -1., -1.]]), b_max=np.array([[1., 1., 1.]]),
+                         resolutions=[9, 17, 33], faster=True).to(DEV)
+    for _ in range(5):
+        dflt(feats=feats, calib=calib)
+        assert dflt.last_path == "fused"
+    state["flip"] = True
+    with _w.catch_warnings():
+        _w.simplefilter("ignore")
+        out = dflt(feats=feats, calib=calib)
+    assert dflt.last_path == "generic"
+    assert (((out > 0.5) != (inside > 0.5)).float().mean().item()) > 0.5
 
 
 def test_coalesced_stages_give_the_per_frame_results():
@@ -608,7 +621,7 @@ def test_coalesced_stages_give_the_per_frame_results():
 
     res = [9, 17, 33, 65]
     eng = Seg3dLossless(query_func=query_func, b_min=np.array([[-1., -1., -1.]]), b_max=np.array([[1., 1., 1.]]),
-                        resolutions=res, faster=True).to(DEV)
+                        resolutions=res, faster=True, validate="first").to(DEV)  # batching needs a trusted closure
     frames = [dict(feats=[[torch.from_numpy(syn.body_feat(256, 128, 128, 4 + i))[None].to(DEV)]],
                    calib=pifu_calib(*syn.scene_camera(10 * i), device=DEV)) for i in range(6)]
     many0 = eng.forward_many(frames[:3])  # not validated yet: frame by frame through forward()

@@ -89,3 +89,31 @@ def test_empty_returns_none(oracle):
 def test_rejects_non_doubling(oracle):
     with pytest.raises(ValueError):
         oracle.seg3d_lossless(lambda p: np.zeros(p.shape[1], np.float32), BMIN, BMAX, [5, 11])
+
+
+def test_final_level_rules(oracle, body_query):
+    """The three selection rules of the LAST level (Seg3dLossless(final_level=...), mp_recon_batch_ex):
+    "dilate3" is the lossless schedule; "upstream" (nodes whose upsampled inside-mask is exactly 0.5,
+    undilated) evaluates a subset of its nodes -- several times fewer -- and "interpolate" none; the
+    coarser levels are the same for all three, and the price of the cheaper rules is stated against
+    dense evaluation (measured here on the 65^3 body: the numbers are printed)."""
+    res = [5, 9, 17, 33, 65]
+    dense = oracle.dense_volume(body_query, BMIN, BMAX, res[-1])
+    out = {}
+    for rule in oracle.FINAL_LEVELS:
+        stats, ev = [], np.zeros((res[-1],) * 3, bool)
+        vol = oracle.seg3d_lossless(body_query, BMIN, BMAX, res, stats=stats, evaluated_out=ev, final_level=rule)
+        wrong = int(((vol > 0.5) != (dense > 0.5)).sum())
+        out[rule] = (vol, stats, ev, wrong)
+        print("final_level=%-11s points per level %s, %d of %d inside voxels differ from dense evaluation"
+              % (rule, stats, wrong, int((dense > 0.5).sum())))
+    d3, up, ip = out["dilate3"], out["upstream"], out["interpolate"]
+    assert d3[3] == 0                                             # lossless
+    assert d3[1][:-1] == up[1][:-1] == ip[1][:-1]                 # the same coarse levels
+    assert ip[1][-1] == 0 and 0 < up[1][-1] < 0.5 * d3[1][-1]     # none / a fraction of the nodes
+    assert not (up[2] & ~d3[2]).any()                             # a subset of the lossless rule's nodes
+    assert np.array_equal(up[0][up[2]], dense[up[2]])             # what was evaluated is exact
+    # the price: 2 % of the inside voxels at 65^3 (0.4 % at 257^3, tests/test_recon_gpu.py), more without any evaluation
+    assert ip[3] >= up[3] > 0 and up[3] <= 0.05 * int((dense > 0.5).sum())
+    with pytest.raises(ValueError):
+        oracle.seg3d_lossless(body_query, BMIN, BMAX, res, final_level="upstream", faster=False)

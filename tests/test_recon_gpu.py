@@ -317,8 +317,16 @@ def test_engine_trusts_a_query_func_after_validated_calls(ops, oracle, body):
         return netG.query(feats, points.permute(0, 2, 1), calib)[0]
 
     res = [9, 17, 33, 65]
+    # the class default validates EVERY call (a drop-in must honour a closure that changes between frames)
+    dflt = Seg3dLossless(query_func=query_func, faster=True, b_min=np.array([[-1., -1., -1.]]),
+                         b_max=np.array([[1., 1., 1.]]), resolutions=res).to(DEV)
+    assert dflt.validate == "always"
+    for frame in range(dflt.VALIDATE_CALLS + 2):
+        dflt(feats=feats, calib=body["cal"])
+    assert calls == [729] * (dflt.VALIDATE_CALLS + 2) and dflt.last_path == "fused"
+    del calls[:]
     eng = Seg3dLossless(query_func=query_func, faster=True, b_min=np.array([[-1., -1., -1.]]),
-                        b_max=np.array([[1., 1., 1.]]), resolutions=res).to(DEV)
+                        b_max=np.array([[1., 1., 1.]]), resolutions=res, validate="first").to(DEV)
     vols = []
     for frame in range(eng.VALIDATE_CALLS + 2):
         vols.append(eng(feats=feats, calib=body["cal"]))
@@ -620,3 +628,81 @@ def test_table_query_kernel_is_repeatable_under_perturbed_timing(ops, oracle, mo
     # unless a value sits within rounding of the threshold)
     assert dv <= 2e-6 or int(((v1[0] > 0.5) != (first[1][0] > 0.5)).sum()) < 50
     del tables
+
+
+@pytest.mark.parametrize("rule", ["upstream", "interpolate"])
+@pytest.mark.parametrize("res", [[9, 17, 33], [17, 33, 65, 129]])
+def test_final_level_rules_bit_exact_vs_oracle_driver(ops, oracle, body, rule, res):
+    """mp_recon_batch_ex(final_level=...): the HIP octree takes exactly the decisions of the CPU restatement
+    of the same rule (both sides evaluate with the same HIP query kernel: identical volumes and counts),
+    one frame alone and as frames of one batch call."""
+    stats = []
+    ref = oracle.seg3d_lossless(body["gpu_query"], BMIN, BMAX, res, stats=stats, final_level=rule)
+    vol, status = ops.recon(body["mlp"], body["fh"], body["cal"], syn.Z_SCALE, BMIN, BMAX, res, final_level=rule)
+    assert list(status.cpu().numpy()) == [1] + stats
+    assert np.array_equal(vol.cpu().numpy(), ref)
+    vols, st = ops.recon_batch(body["mlp"], [body["fh"]] * 3, [body["cal"]] * 3, syn.Z_SCALE, BMIN, BMAX, res,
+                               final_level=rule)
+    assert all(torch.equal(v, vol) for v in vols) and all(list(s) == [1] + stats for s in st.cpu().numpy())
+    with pytest.raises(ValueError):
+        ops.recon(body["mlp"], body["fh"], body["cal"], syn.Z_SCALE, BMIN, BMAX, res, final_level="no-such-rule")
+
+
+def test_final_level_rules_through_seg3d_lossless_257(ops, oracle, body):
+    """Seg3dLossless(final_level=...) at BASELINE configs[1] size through the drop-in surface, fused AND
+    level-at-a-time engines, with the honest price of the cheaper rules against DENSE evaluation of the
+    257^3 lattice (17 M points through the same kernel): "dilate3" reproduces the dense inside-set exactly
+    on this body, "upstream" (the rule recalled from the un-vendored package: mask == 0.5, undilated) and
+    "interpolate" (no evaluation at 257^3) do not -- the numbers are printed and bounded."""
+    from monoport_amd.implicit_seg.functional import Seg3dLossless
+    from monoport_amd.modeling import PIFuNetG
+    netG = PIFuNetG().eval()
+    netG.surface_classifier.load_state_dict(
+        {**{"filters.%d.weight" % i: torch.from_numpy(w)[:, :, None] for i, (w, _) in enumerate(body["layers"])},
+         **{"filters.%d.bias" % i: torch.from_numpy(b) for i, (_, b) in enumerate(body["layers"])}})
+    netG.surface_classifier.to(DEV)
+    feats = [[torch.from_numpy(body["f"])[None].to(DEV)]]
+    res = [17, 33, 65, 129, 257]
+    box = dict(b_min=np.array([BMIN]), b_max=np.array([BMAX]), resolutions=res)
+
+    def query_func(points, feats, calib):
+        return netG.query(feats, points.permute(0, 2, 1), calib)[0]
+
+    def wrapped(points, feats, calib):  # two netG.query calls: not fusable, the level-at-a-time engine serves it
+        netG.query(feats, points[:, :1].permute(0, 2, 1), calib)
+        return query_func(points, feats, calib)
+
+    r = res[-1]
+    g = ((torch.arange(r, device=DEV, dtype=torch.float32) / r) + (1.0 / r) / 2) * 2 - 1
+    dense = torch.empty((r, r, r), device=DEV)
+    for z in range(0, r, 32):  # dense 257^3 in slabs of 32 planes
+        zz, yy, xx = torch.meshgrid(g[z:z + 32], g, g, indexing="ij")
+        pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], 0)[None]
+        dense[z:z + 32] = netG.query(feats, pts, body["cal"])[0][0, 0].reshape(-1, r, r)
+    inside = dense > 0.5
+    n_in = int(inside.sum())
+    got = {}
+    for rule in ("dilate3", "upstream", "interpolate"):
+        eng = Seg3dLossless(query_func=query_func, faster=True, final_level=rule, **box).to(DEV)
+        sdf = eng(feats=feats, calib=body["cal"])
+        assert eng.last_path == "fused"
+        wrong = int(((sdf[0, 0] > 0.5) != inside).sum())
+        inter = int(((sdf[0, 0] > 0.5) & inside).sum())
+        union = int(((sdf[0, 0] > 0.5) | inside).sum())
+        got[rule] = (sdf, eng.last_status.clone(), wrong)
+        print("final_level=%-11s points per level %s (sum %d); %d of %d inside voxels differ from dense "
+              "evaluation (%.3f %%), IoU %.5f" % (rule, eng.last_status[1:].tolist(), int(eng.last_status[1:].sum()),
+                                                 wrong, n_in, 100.0 * wrong / n_in, inter / union))
+        eng_g = Seg3dLossless(query_func=wrapped, faster=True, final_level=rule, **box).to(DEV)
+        gen = eng_g(feats=feats, calib=body["cal"])
+        assert eng_g.last_path == "generic" and eng_g.last_status.tolist() == eng.last_status.tolist()
+        assert torch.equal(gen, sdf)  # the two engines take the same decisions under every rule
+    d3, up, ip = got["dilate3"], got["upstream"], got["interpolate"]
+    assert d3[2] <= 1e-4 * n_in  # lossless (a handful of voxels at most: values within fp32 noise of 0.5)
+    assert d3[1][1:-1].tolist() == up[1][1:-1].tolist() == ip[1][1:-1].tolist()
+    assert int(ip[1][-1]) == 0 and 0 < int(up[1][-1]) < 0.4 * int(d3[1][-1])
+    assert 0 < up[2] <= 0.01 * n_in and up[2] <= ip[2] <= 0.08 * n_in
+    with pytest.raises(NotImplementedError):
+        Seg3dLossless(query_func=query_func, faster=False, final_level="upstream", **box)
+    with pytest.raises(ValueError):
+        Seg3dLossless(query_func=query_func, faster=True, final_level="nope", **box)
