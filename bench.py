@@ -17,12 +17,14 @@ fewer than N GPUs are visible; under ``python -m torch.distributed.run --nproc-p
 bench.py --gpus N ...`` it joins the ranks the launcher made.  Either way rank 0 prints ONE JSON
 line with the driver's contract fields plus
 
-  "roofline"      the fused query kernel against the f32 MFMA peak (HIP-event timed, live): priced
-                  on the FLOPs it executes, with the reference's per-point FLOPs beside it
-                  (`algorithmic`) -- the skip tables hoist 42 % of them out of the per-point work;
-                  `roofline.step` = the query launches AND skip_table_kernel as one rate (both
-                  pricings); `roofline.traffic` = memory-side bytes per launch from the committed PMC
-                  passes at this frames-per-launch (10 with --steps 20, 16 with the default 48)
+  "roofline"      the fused query kernel against the f32 MFMA peak (HIP-event timed, live): `frac` prices the
+                  FLOPs it EXECUTES (`frac_definition`); `like_for_like_frac` = the plain kernel of this run, where
+                  executed = the reference's FLOPs per point; `reference_flops_equivalent` = the reference's
+                  per-point FLOPs over the same launch times as a rate-equivalent and a speed-up (the skip tables
+                  hoist 42 % of them out of the per-point work), never as a fraction;
+                  `roofline.step` = the query launches AND skip_table_kernel as one rate;
+                  `roofline.traffic` = memory-side bytes per launch from the committed PMC
+                  passes at this frames-per-launch (20 with --steps 20, 24 with the default 48)
   "plain_query_path"  (N=1 only) the headline configuration without skip tables (--no-skip-table)
   "cpu_baseline"  the CPU oracle path timed on this box's host cores (rank 0, N=1 only)
   "passes"        the timed region is run 3 times (each EXACTLY --steps frames between barrier +
@@ -110,7 +112,7 @@ def build_netc(device):
 
 
 def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, precision="f32",
-                  batch=1):
+                  batch=1, final_level="dilate3"):
     """`depth` slots of `batch` frames each (monoport_amd/pipeline.py): per slot the batched
     encoder (a hipGraph unless --no-graph), then the stage chain of RTL/main.py:389-428 as
     asynchronous C-ABI calls on the slot's stream."""
@@ -131,12 +133,13 @@ def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, 
 
     pipe = FramePipeline(net, device, depth=depth, batch=batch, resolutions=resolutions or RESOLUTIONS,
                          b_min=B_MIN, b_max=B_MAX, balance=0.5, feature_hook=body_planes_hook,
-                         use_graph=use_graph, netC=build_netc(device) if with_color else None)
+                         use_graph=use_graph, netC=build_netc(device) if with_color else None,
+                         final_level=final_level)
     pipe.prepare()
     return pipe
 
 
-TRAFFIC_PROFILE = "r04_query_traffic.json"  # PMC passes at slot batches of 10, 16 and 20 frames
+TRAFFIC_PROFILE = "r05_query_traffic.json"  # PMC passes at slot batches of 16, 20 and 24 frames (tools/r05_run.sh traffic)
 
 
 def traffic_from_profile(precision, levels, with_color, slot_batch):
@@ -144,9 +147,8 @@ def traffic_from_profile(precision, levels, with_color, slot_batch):
     --pmc FETCH_SIZE / WRITE_SIZE runs of tools/traffic_probe.py, corrected as
     MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process, so the
     figure is reported ONLY for the configurations the passes covered (f32 skip-table kernel, 5 levels,
-    geometry only, slot batches of 20 / 16 / 10 frames: --steps 20, the default --steps 48, --steps 20
-    --batch 10; a batch of 20 is launches of 16 + 4 frames, averaged) and is None for every other run or
-    when the profile is absent."""
+    geometry only, slot batches of 20 / 24 / 16 frames: --steps 20, the default --steps 48, --batch 16)
+    and is None for every other run or when the profile is absent."""
     if precision != "f32" or levels != 5 or with_color:
         return None
     path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
@@ -291,20 +293,14 @@ class Job:
         return got
 
 
-SINGLE_SUBMISSION_STEPS = 24
-
-
 def pick_batch(steps, upper):
-    """Frames per slot submission.  Up to SINGLE_SUBMISSION_STEPS steps: ALL of them in one submission (one
-    batched encoder pass, the octree level by level in launches of <= 16 frames) -- a timed region that short is
-    mostly pipeline fill and drain when it is cut into two slots of 10 (measured at the driver's --steps 20:
-    173.0 recon/s, passes 5.78-5.79 ms, against 166-169 with passes 5.7-6.6).  Above that: the largest divisor
-    of --steps not above `upper` (--batch; 16 when not given), so that no slot submission is short (a short
-    batch would still pay the full-batch encoder)."""
-    if upper is None:  # no --batch given: the policy above
-        if steps <= SINGLE_SUBMISSION_STEPS:
-            return steps
-        upper = 16
+    """Frames per slot submission -- ONE policy for every --steps: the largest divisor of --steps not above
+    `upper` (--batch; MAX_RECON_BATCH = 32 = kMaxFrames of mp_recon_batch when not given), so that no slot
+    submission is short (a short batch would still pay the full-batch encoder) and every octree level of a
+    submission is ONE fused-query launch.  48 steps -> 2 submissions of 24 on two slots; the driver's 20 steps
+    -> one submission of 20 (the frames of such a run complete together: `config.frame_latency_ms` says so);
+    96 -> 3 x 32."""
+    upper = MAX_RECON_BATCH if upper is None else upper
     return max(b for b in range(1, max(1, min(upper, steps)) + 1) if steps % b == 0)
 
 
@@ -429,9 +425,9 @@ def roofline_leg(job, pipe, batch, resolutions, with_color):
 
 def roofline_step(roof, skip_on, peak_tflops):
     """ALL kernels that produce the field of a frame -- the fused-query launches and, with skip tables,
-    skip_table_kernel -- as one rate, in both FLOP pricings: `executed` (what the kernels multiply:
-    1,380,354 FLOP per point + 16.1 GFLOP per frame of tables) and `algorithmic` (the reference's
-    2,363,906 FLOP per point, SURVEY 8d, nothing credited for the tables)."""
+    skip_table_kernel -- as one rate: `executed` (what the kernels multiply: 1,380,354 FLOP per point + 16.1
+    GFLOP per frame of tables; a roofline fraction) and `reference_flops_equivalent` (the reference's 2,363,906
+    FLOP per point, SURVEY 8d, nothing credited for the tables; a speed-up, not a fraction)."""
     if not roof["launches"] or not roof.get("frames"):
         return None
     q_ms = float(roof["launch_ms"].sum())
@@ -444,7 +440,8 @@ def roofline_step(roof, skip_on, peak_tflops):
     return {"kernels": "fused-query launches" + (" + skip_table_kernel" if skip_on else ""),
             "query_ms_per_frame": q_ms / frames, "skip_table_ms_per_frame": t_ms / frames if skip_on else None,
             "executed": {"tflops": ex_flop / sec / 1e12, "frac": ex_flop / sec / 1e12 / peak_tflops},
-            "algorithmic": {"tflops": al_flop / sec / 1e12, "frac": al_flop / sec / 1e12 / peak_tflops}}
+            "reference_flops_equivalent": {"tflops_equivalent": al_flop / sec / 1e12,
+                                           "speedup_vs_reference_flops_at_peak": al_flop / sec / 1e12 / peak_tflops}}
 
 
 def breakdown_leg(job, pipe, batch, resolutions):
@@ -768,13 +765,13 @@ def in_flight_layout(k_total, world):
     return depth, per_rank // depth
 
 
-def build_pipeline(job, depth, batch, use_graph, resolutions, with_color, precision):
+def build_pipeline(job, depth, batch, use_graph, resolutions, with_color, precision, final_level="dilate3"):
     """make_pipeline on every rank, agreed: if hipGraph capture fails on ANY rank (it can next to an
     initialised RCCL communicator, whose watchdog thread touches the runtime) all ranks rebuild
     with eager encoder launches rather than lose the run.  Returns (pipeline, use_graph)."""
     pipe, ok = None, 1
     try:
-        pipe = make_pipeline(job.device, depth, use_graph, resolutions, with_color, precision, batch)
+        pipe = make_pipeline(job.device, depth, use_graph, resolutions, with_color, precision, batch, final_level)
     except RuntimeError as e:
         if not use_graph:
             raise
@@ -789,15 +786,15 @@ def build_pipeline(job, depth, batch, use_graph, resolutions, with_color, precis
         if pipe is not None:
             pipe.close()
         use_graph = False
-        pipe = make_pipeline(job.device, depth, False, resolutions, with_color, precision, batch)
+        pipe = make_pipeline(job.device, depth, False, resolutions, with_color, precision, batch, final_level)
     return pipe, use_graph
 
 
 def measure_config(job, depth, batch, use_graph, resolutions, with_color, precision, passes,
-                   roofline=True):
+                   roofline=True, final_level="dilate3"):
     """Build a pipeline for one configuration, run the timed passes (+ the roofline leg), return
     (summary dict, pipeline).  The caller closes the pipeline."""
-    pipe, use_graph = build_pipeline(job, depth, batch, use_graph, resolutions, with_color, precision)
+    pipe, use_graph = build_pipeline(job, depth, batch, use_graph, resolutions, with_color, precision, final_level)
     elapsed, statuses, checked = timed_passes(job, pipe, batch, with_color, passes)
     # a pass is as slow as its slowest rank; the median pass is the reported one
     per_pass = job.reduce_max(elapsed)
@@ -816,6 +813,7 @@ def measure_config(job, depth, batch, use_graph, resolutions, with_color, precis
         "passes": {"n": passes, "value_min": job.steps * job.world / order[-1],
                    "value_max": job.steps * job.world / order[0],
                    "ms_per_step_all": [e / job.steps * 1e3 for e in per_pass]},
+        "points_per_level": (statuses[:, 1:].sum(0) / float(statuses.shape[0])).tolist() if statuses is not None else None,
         "ms_per_step_per_rank": [e / job.steps * 1e3
                                  for e in job.gather_floats(sorted(elapsed)[len(elapsed) // 2])],
     }
@@ -828,16 +826,16 @@ def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48,
-                    help="frames in the timed region (default 48 = one submission of each of the 3 slots at 16 "
-                         "frames per slot; round 2 timed 20 = two submissions of 10)")
+                    help="frames in the timed region (default 48 = two slot submissions of 24 frames; the driver's "
+                         "20 = one submission of 20)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--depth", type=int, default=3, help="pipeline slots (streams) per GPU")
     ap.add_argument("--batch", type=int, default=None,
                     help="frames per slot (upper bound): their encoder passes run as one batch and "
-                         "their octree levels as fused-query launches of <= 16 frames; depth x batch frames are "
-                         "in flight.  The largest divisor of --steps not above this is used, so no slot "
+                         "their octree levels as fused-query launches of <= 32 frames; up to depth x batch frames "
+                         "are in flight.  The largest divisor of --steps not above this is used, so no slot "
                          "submission is short (a short batch would still pay the full-batch encoder).  Not "
-                         "given: 16, and runs of <= 24 steps go into ONE submission (pick_batch)")
+                         "given: 32 (pick_batch)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="K > 0: exactly K frames in flight across the node (K / --gpus per rank; "
                          "BASELINE configs[3] is K = 8) instead of --depth x --batch per GPU; the "
@@ -859,6 +857,12 @@ def parse_args(argv):
                          "host sync; dropin: `value` is measured through the reference's call surface "
                          "(StagePipeline + Seg3dLossless + forward_vertices), as the default run's "
                          "`dropin` object")
+    ap.add_argument("--final-level", default="dilate3", choices=["dilate3", "upstream", "interpolate"],
+                    help="selection rule of the LAST octree level (Seg3dLossless(final_level=...)): dilate3 = the "
+                         "lossless schedule (default, the headline); upstream = nodes whose upsampled mask is exactly "
+                         "0.5, undilated (the rule recalled from the un-vendored implicit_seg package); interpolate = "
+                         "no evaluation at the last level.  The default run reports the other two as "
+                         "`final_level_rules`")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the headline measurement + roofline (skips every leg below)")
     ap.add_argument("--no-dropin", action="store_true",
@@ -892,7 +896,8 @@ def main(argv=None):
         args.no_dropin = args.no_cpu_baseline = args.no_alt = args.no_configs = True
     if args.no_skip_table:
         ops.SKIP_TABLE = False
-    skip_on = ops.SKIP_TABLE and args.precision == "f32"
+    # whether the fused query of this run blends table rows (f32 and f16x3 heads; ops.table_precision mirrors the C side)
+    skip_on = ops.SKIP_TABLE and ops.table_precision(args.precision)
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # test hook (tests/test_dropin_gpu.py): exercise the N > 1 code path on a ONE-GPU box -- every
@@ -942,7 +947,7 @@ def main(argv=None):
     else:
         depth, batch = args.depth, pick_batch(args.steps, args.batch)
     main_res, pipe = measure_config(job, depth, batch, not args.no_graph, resolutions,
-                                    args.with_color, args.precision, args.passes)
+                                    args.with_color, args.precision, args.passes, final_level=args.final_level)
     use_graph = main_res["use_graph"]
     roof = main_res["roof"]
     r_last = resolutions[-1]
@@ -979,6 +984,49 @@ def main(argv=None):
             "value": rp["value"], "unit": "recon/s", "ms_per_step": rp["ms_per_step"], "passes": rp["passes"],
             "roofline_frac": rp["roof"]["achieved"] / F32_MFMA_PEAK_TFLOPS,
             "roofline_achieved_tflops": rp["roof"]["achieved"], "flop_per_point": FLOP_PER_POINT}
+
+    # the other selection rules of the last octree level (the un-vendored upstream engine's is unpinned: SURVEY 5.7)
+    if world == 1 and not args.no_configs and not args.with_color and args.levels == 5 and args.in_flight == 0 \
+            and args.precision == "f32" and args.final_level == "dilate3":
+        rules = {}
+        last_slot = pipe.slots[(pipe.n_submitted - 1) % len(pipe.slots)]
+        vol_ref = last_slot.volumes[last_slot.n_active - 1].clone()  # frame steps + warm - 1, lossless schedule
+        for rule in ("upstream", "interpolate"):
+            rr, pr = measure_config(job, depth, batch, use_graph, resolutions, False, "f32", args.passes,
+                                    roofline=False, final_level=rule)
+            ls = pr.slots[(pr.n_submitted - 1) % len(pr.slots)]
+            v = ls.volumes[ls.n_active - 1]
+            inside = vol_ref > 0.5
+            rules[rule] = {"value": rr["value"], "unit": "recon/s", "ms_per_step": rr["ms_per_step"], "passes": rr["passes"],
+                           "points_per_level": rr["points_per_level"], "points_per_recon": rr["points"] / args.steps,
+                           "thresholded_voxels_differing_from_dilate3": int(((v > 0.5) != inside).sum().item()),
+                           "inside_voxels": int(inside.sum().item()),
+                           "iou_vs_dilate3": float(((v > 0.5) & inside).sum().item()) / max(float(((v > 0.5) | inside).sum().item()), 1.0)}
+            pr.close()
+            del pr, ls, v
+        extras["final_level_rules"] = {
+            "headline_rule": "dilate3 (boundary nodes dilated by 3^3 at the last level as at levels >= 3: thresholded "
+                             "volume == thresholded dense evaluation; tests/test_recon_gpu.py)",
+            "headline_points_per_level": main_res["points_per_level"],
+            "upstream": {"rule": "nodes whose upsampled inside-mask is exactly 0.5, undilated (`valid == 0.5`, the rule "
+                                 "recalled from the upstream package's faster mode)", **rules["upstream"]},
+            "interpolate": {"rule": "no evaluation at the last level (trilinear upsample of the 129^3 volume)",
+                            **rules["interpolate"]},
+            "note": "Seg3dLossless(final_level=...) / mp_recon_batch_ex; unpinned by the reference (implicit_seg is not "
+                    "vendored): a maintainer picks the rule that reproduces their installed package"}
+        del vol_ref, last_slot
+
+    # the same frames as TWO slot submissions of steps / 2 frames on two streams (frames complete in two groups,
+    # the second group's encoder under the first group's octree): the pipelined counterpart of a one-submission run
+    if world == 1 and not args.no_configs and not args.with_color and args.levels == 5 and args.in_flight == 0 \
+            and args.precision == "f32" and args.steps // batch == 1 and args.steps % 2 == 0 and depth >= 2:
+        r2, p2 = measure_config(job, depth, args.steps // 2, use_graph, resolutions, False, "f32", args.passes,
+                                roofline=False, final_level=args.final_level)
+        p2.close()
+        del p2
+        extras["two_slot_submissions"] = {
+            "config": "the headline frames as 2 submissions of %d frames on two streams" % (args.steps // 2),
+            "value": r2["value"], "unit": "recon/s", "ms_per_step": r2["ms_per_step"], "passes": r2["passes"]}
 
     # BASELINE configs[3]: 8 frames in flight across the node, at every N that divides 8
     if not args.no_configs and args.in_flight == 0 and 8 % world == 0 and not args.with_color \
@@ -1106,7 +1154,11 @@ def main(argv=None):
                             "gloo (one-GPU test hook)" if one_gpu_test else "nccl (RCCL)"),
                 "self_launched": os.environ.get("MONOPORT_BENCH_SELF_LAUNCHED") == "1",
                 "gather_checked": bool(main_res["gather_checked"]) if world > 1 else None,
-                "frames_in_flight_per_rank": depth * batch,
+                "slot_submissions_per_rank": -(-args.steps // batch),
+                "frames_in_flight_per_rank": min(depth, -(-args.steps // batch)) * batch,
+                "frame_latency_ms": main_res["ms_per_step"] * batch * min(depth, -(-args.steps // batch)),
+                "frame_latency_note": "a frame completes with its slot submission: up to this long after it was handed "
+                                      "over (single-frame latency through the drop-in surface: latency_ms_single_frame)",
                 "parallelism": "frame-parallel x%d (one process per GPU, renders gathered to rank 0 "
                                "over %s); per GPU %d slots x %d frames in flight, encoder "
                                "batched per slot%s"
@@ -1114,6 +1166,9 @@ def main(argv=None):
                                   depth, batch,
                                   " and replayed as a hipGraph" if use_graph else ""),
                 "fixture": "F-body analytic head, seeded encoder (monoport_amd/synthetic.py)",
+                "octree_schedule": "Seg3dLossless(faster=True): dilation boxes 9^3 / 7^3 / 3^3 / 3^3, last level: %s"
+                                   % args.final_level,
+                "points_per_level": main_res["points_per_level"],
                 "points_per_recon": main_res["points"] / (args.steps * world),
             },
             "passes": main_res["passes"],
@@ -1126,7 +1181,8 @@ def main(argv=None):
                            "skip table, skip_table_kernel)" if skip_on else
                            "pifu_query_kernel<256,1> (fused gather + MLP; launches of < 2048 tiles run on its "
                            "32-point-tile twin pifu_query_t32_kernel<1,false>)" if args.precision == "f32"
-                           else "pifu_query16_kernel<1,%d> (fused gather + MLP, %s)" % (terms, args.precision)),
+                           else "pifu_query16_tab_kernel<1,%d> (fused MLP through the skip table, %s)" % (terms, args.precision)
+                           if skip_on else "pifu_query16_kernel<1,%d> (fused gather + MLP, %s)" % (terms, args.precision)),
                 "bound": "mfma",
                 # with the skip tables the kernel EXECUTES fewer FLOPs than the reference's MLP has
                 # (`algorithmic` below): `achieved` / `frac` price the executed ones, so that
@@ -1135,24 +1191,32 @@ def main(argv=None):
                 "peak": peak_tflops,
                 "unit": "TFLOP/s",
                 "frac": roof["achieved"] * (FLOP_PER_POINT_SKIP_TABLE / FLOP_PER_POINT if skip_on else 1.0) / peak_tflops,
+                # what `frac` prices: the FLOPs the timed kernel EXECUTES per point (PMC: SQ_INSTS_MFMA x 4096 agrees,
+                # profiles/r04k_pmc_tabws.txt).  The like-for-like figure where executed = the reference's FLOPs per
+                # point is the plain kernel's (`like_for_like_frac`, from the `plain_query_path` leg of this run)
+                "frac_definition": "executed" if skip_on else "executed = algorithmic",
+                "like_for_like_frac": (extras.get("plain_query_path", {}).get("roofline_frac") if skip_on else
+                                       roof["achieved"] / peak_tflops),
                 "traffic": traffic_from_profile(args.precision, args.levels, args.with_color, batch),
                 "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                    "this configuration)" % TRAFFIC_PROFILE),
                 "launches": roof["launches"],
-                "frames_per_launch": (min(batch, MAX_RECON_BATCH) if batch <= MAX_RECON_BATCH or batch % MAX_RECON_BATCH == 0
+                "frames_per_launch": ([min(batch, MAX_RECON_BATCH)] if batch <= MAX_RECON_BATCH or batch % MAX_RECON_BATCH == 0
                                       else [MAX_RECON_BATCH, batch % MAX_RECON_BATCH]),
                 "avg_launch_ms": float(roof["launch_ms"].mean()) if roof["launches"] else None,
                 "flop_per_point": FLOP_PER_POINT_SKIP_TABLE if skip_on else FLOP_PER_POINT,
-                "algorithmic": {"flop_per_point": FLOP_PER_POINT, "achieved": roof["achieved"],
-                                "frac": roof["achieved"] / peak_tflops,
-                                "note": ("the reference's MLP per point (SURVEY 8d) over the same launch times; above 1 "
-                                         "because 2 x 1921 x 256 FLOP per point -- every product of weights with the "
-                                         "sampled feature -- are hoisted out of the per-point work: a linear map "
-                                         "commutes with the bilinear interpolation, so skip_table_kernel takes them "
-                                         "once per texel and frame (%d FLOP per frame, outside these launches, inside "
-                                         "`value`) and the query blends four table rows per point; --no-skip-table "
-                                         "runs every FLOP per point" % FLOP_SKIP_TABLE_PER_FRAME)
-                                if skip_on else "equal to the executed FLOPs"},
+                # the reference's MLP per point over the same launch times is NOT a roofline fraction
+                # when FLOPs are hoisted out of the launches: it is reported as a rate-equivalent and a speed-up
+                "reference_flops_equivalent": {
+                    "flop_per_point": FLOP_PER_POINT, "tflops_equivalent": roof["achieved"],
+                    "speedup_vs_reference_flops_at_peak": roof["achieved"] / peak_tflops,
+                    "note": ("a kernel running the reference's 2,363,906 FLOP per point AT the MFMA peak would be this "
+                             "many times slower than these launches: 2 x 1921 x 256 FLOP per point -- every product of "
+                             "weights with the sampled feature -- are hoisted out of the per-point work (a linear map "
+                             "commutes with the bilinear interpolation: skip_table_kernel takes them once per texel and "
+                             "frame, %d FLOP per frame, outside these launches, inside `value`); --no-skip-table runs "
+                             "every FLOP per point" % FLOP_SKIP_TABLE_PER_FRAME)
+                    if skip_on else "equal to the executed FLOPs"},
                 "step": roofline_step(roof, skip_on, peak_tflops),
             },
         }

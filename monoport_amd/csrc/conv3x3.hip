@@ -32,9 +32,7 @@ namespace mp {
 constexpr int kCK = 16;           // input channels per LDS chunk
 constexpr int kPixBytes = kCK * 4;  // 64 bytes per staged pixel
 constexpr int kMaxCin = 512;  // input channels of a 3x3 launch (the per-workgroup (scale, shift) table)
-#ifndef MP_CONV_WPS
-#define MP_CONV_WPS 2  // waves per SIMD the register allocator is held to (tools/ablate.py A/B)
-#endif
+constexpr int kConvWps = 2;  // waves per SIMD the register allocator is held to
 constexpr int kTileW = 32;        // tiles are 32 pixels wide and PX / 32 rows tall
 // staged pixels (tile + 1 halo) of a PX-pixel tile, and the 64-lane passes a wave needs for them
 constexpr int halo_pixels(int px) { return (px / kTileW + 2) * (kTileW + 2); }
@@ -175,9 +173,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, const float (&v
     }
   }
   // ---- bulk stores ----
-#ifdef MPC_NOSTORE
-  if (p.y && v[0][0] == 123.456f) p.y[0] = v[NR - 1][TN - 1] + (cat ? u[0][0] : 0.0f);
-#else
 #pragma unroll
   for (int n = 0; n < NR; ++n)
 #pragma unroll
@@ -186,11 +181,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, const float (&v
       if (p.y) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(a), rs_y, vo[n], so1(tt), 0);
       if (cat) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(b), rs_y2, vo[n], so2(tt), 0);
     }
-#endif
 }
 
 template <int RBW, int NR>
-__global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, kConvWps) void conv3x3_gn_kernel(ConvArgs p) {
   constexpr int CW = 4 / RBW;
   constexpr int kStageIters = stage_iters(32 * NR * CW);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -243,11 +237,7 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
       const int o = goff[it] < 0 ? 0 : goff[it];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-#ifdef MPC_NOLOAD
-        stg[it][k] = (float)(o + k);
-#else
         stg[it][k] = pl[(long long)k * hw + o];
-#endif
     }
     ch_staged = chunk * kCK + 4 * wv;
   };
@@ -341,11 +331,7 @@ __global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn_kernel(ConvArgs p
             bnxt[n] = *reinterpret_cast<const f32x4 *>(buf + (boff[n][3 * ky + (sn >> 1)] ^ (32 * (sn & 1))));
         }
         const f32x4 a = ring[s];
-#ifdef MPC_AHOT  // timing experiment: the weight stream always hits the same fragment
-        ring[s] = wload128(ws, a_base + s * 64);
-#else
         ring[s] = wload128(ws, a_base + min(kg0 + 6 + s, kgt - 1) * 64);
-#endif
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above the MFMAs (see query.hip)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -624,7 +610,7 @@ __device__ __forceinline__ h8 hload16(const WStream &w, int idx16) {
 }
 
 template <int RBW, int NR>
-__global__ __launch_bounds__(256, MP_CONV_WPS) void conv3x3_gn16_kernel(ConvArgs p, const float *__restrict__ wmax) {
+__global__ __launch_bounds__(256, kConvWps) void conv3x3_gn16_kernel(ConvArgs p, const float *__restrict__ wmax) {
   constexpr int CW = 4 / RBW;
   constexpr int kStageIters = stage_iters(32 * NR * CW);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1187,11 +1173,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-#ifdef MPC_NOLOAD  // timing experiment (tools/conv_ablate.sh): no activation reads
-        stg[q][k] = (float)(lane + q + k);
-#else
         stg[q][k] = pl[(long long)(4 * q + k) * p.hw + px0 + lane];
-#endif
     c0_staged = seg2 ? -1 : c0;
   };
   auto stage_store = [&](int chunk, unsigned char *buf) {
@@ -1267,9 +1249,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
   const int rb0 = (int)blockIdx.y * (4 * MRW) + MRW * wv;  // first 32-row block of this wave
   const int a_base = rb0 * rb_stride;
   auto a_load = [&](int m, int s, int part) {
-#ifdef MPC_AHOT  // timing experiment: the weight stream always hits the same fragment
-    s = 0;
-#endif
     return wload128(ws, a_base + m * rb_stride + (min(s, steps - 1) * FPS + part) * 64);
   };
   // A fragments kAhead steps ahead of their MFMAs: one step (16 MFMAs = 0.4 us at MRW = 2) does not
@@ -1412,12 +1391,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1Args p, const floa
       gn_emit(p.fin, img, (NCH * (int)blockIdx.y) / cpg, ng, tile, a, b);
     }
   }
-#ifdef MPC_NOSTORE  // timing experiment: no output writes (one lane keeps the values alive)
-  if (p.y && acc[0][0][0] == 123.456f) p.y[0] = acc[0][1][3];
-  if (false) {
-#else
   if (p.y) {
-#endif
 #pragma unroll
     for (int m = 0; m < MRW; ++m)
 #pragma unroll

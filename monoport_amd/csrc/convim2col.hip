@@ -44,15 +44,10 @@ __global__ void convk_pack_kernel(const float *__restrict__ w, int cout, int cin
   }
 }
 
+constexpr int kConvkWg = 2;  // workgroups per CU the register allocator is held to (measured: 4 fits 128 registers only with spills)
 template <int RBW, int NR, int KS, int CC>
-#ifndef MPT_CONVK_WG
-#define MPT_CONVK_WG 2  // side builds (tools/ablate.py): 4 fits 128 registers with spills
-#endif
-__global__ __launch_bounds__(256, MPT_CONVK_WG) void convk_kernel(ConvKArgs p) {
-#ifndef MPT_CONVK_RING
-#define MPT_CONVK_RING 6
-#endif
-  constexpr int kRing = MPT_CONVK_RING;  // weight fragments in flight
+__global__ __launch_bounds__(256, kConvkWg) void convk_kernel(ConvKArgs p) {
+  constexpr int kRing = 6;  // weight fragments in flight
   constexpr int CW = 4 / RBW;
   constexpr int PX = 32 * NR * CW;         // output pixels per workgroup (one row segment)
   constexpr int TAPS = KS * KS;

@@ -70,10 +70,7 @@ struct PointSrc {
 // One launch of the fused query kernels serves up to kMaxFrames independent frames (their own
 // feature map, calibration, points and output): the tiles of all frames form one index space, so
 // the small coarse levels of several frames fill the machine together.
-#ifndef MP_MAX_FRAMES
-#define MP_MAX_FRAMES 32
-#endif
-constexpr int kMaxFrames = MP_MAX_FRAMES;  // a power of two <= 64 (query_table.hip: one lane per frame)
+constexpr int kMaxFrames = 32;  // a power of two <= 64 (query_table.hip: one lane per frame)
 static_assert((kMaxFrames & (kMaxFrames - 1)) == 0 && kMaxFrames <= 64, "kMaxFrames");
 struct QueryItem {
   const float *feat;   // channels-last feature map [H,W,C]

@@ -140,13 +140,8 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
         for (int part = 0; part < C / 256; ++part)
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-#ifdef MP32_NTFEAT
-            v[u][part][k] = __builtin_nontemporal_load(
-                reinterpret_cast<const f32x4 *>(feat + t[u].o[k] + 4 * (lane + 64 * part)));
-#else
             v[u][part][k] =
                 *reinterpret_cast<const f32x4 *>(feat + t[u].o[k] + 4 * (lane + 64 * part));
-#endif
 #pragma unroll
       for (int u = 0; u < GB; ++u) {
         const int p = 16 * wv + i0 + u;
@@ -172,10 +167,6 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
     }
     }
     __syncthreads();
-#ifdef MP32_GATHER_ONLY  // timing experiment: the sampling stage alone (projection + 4-tap gather + blend)
-    if (zb[0] == 123.456f) out[0] = xs[tid];
-    continue;
-#endif
 
     const unsigned char *xrow = xs + j * ROWB;       // this lane's point row, column block 0
     const unsigned char *hrow = hb + j * kHbRowBytes;
@@ -192,43 +183,43 @@ __global__ __launch_bounds__(kQueryThreads, WPS) void pifu_query_kernel(
       const int a0 = mlp.ax[0] / 4;           // 16-byte units (segments are 256-byte aligned)
       const int a1 = mlp.ah[1] / 4 + (4 * wv) * (kHidden[0] / 8) * 64;
       const float zz[1] = {zb[cb0]};
-      f32x4 ring0[MP32_PF0 + 1][1];
+      f32x4 ring0[kPrefetch0 + 1][1];
       f32x16 acc0[1][1];
       float az0[1];
-      seg_prefetch<1, MP32_PF0, (kAHot & 1) != 0>(ring0, ws, a0 + rb0 * NGX * 64, 0, NGX);
+      seg_prefetch<1, kPrefetch0, (kAHot & 1) != 0>(ring0, ws, a0 + rb0 * NGX * 64, 0, NGX);
       init_from_bias(acc0[0][0], ws, mlp.bias[0] + 32 * rb0);
       az0[0] = wload32(ws, mlp.az[0] + rb0 * 64);
 #pragma unroll 1
       for (int ck = 0; ck < kHidden[0] / 64; ++ck) {
         // layer-0 rows [64 ck + 32 rb0, +32) x points [32 cb0, +32)
         const int rb = 2 * ck + rb0;
-        seg_main<1, 1, MP32_PF0, ROWB, (kAHot & 1) != 0>(acc0, ring0, ws, a0 + rb * NGX * 64, 0, NGX,
+        seg_main<1, 1, kPrefetch0, ROWB, (kAHot & 1) != 0>(acc0, ring0, ws, a0 + rb * NGX * 64, 0, NGX,
                                 xrow + cb0 * 32 * ROWB, swz);
         // layer-1 weights of this chunk start streaming before the chunk is even stored
-        f32x4 ring1[MP32_PF1 + 1][4];
-        seg_prefetch<4, MP32_PF1, (kAHot & 2) != 0>(ring1, ws, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8);
+        f32x4 ring1[kPrefetch1 + 1][4];
+        seg_prefetch<4, kPrefetch1, (kAHot & 2) != 0>(ring1, ws, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8);
         gemm_z<1, 1>(acc0, az0, zz);
         lrelu(acc0[0][0]);
         store_hidden(hb, acc0[0][0], rb0, cb0, j, h);
         // next chunk's layer-0 operands
         const int rbn = min(rb + 2, kHidden[0] / 32 - 2 + rb0);
-        seg_prefetch<1, MP32_PF0, (kAHot & 1) != 0>(ring0, ws, a0 + rbn * NGX * 64, 0, NGX);
+        seg_prefetch<1, kPrefetch0, (kAHot & 1) != 0>(ring0, ws, a0 + rbn * NGX * 64, 0, NGX);
         init_from_bias(acc0[0][0], ws, mlp.bias[0] + 32 * rbn);
         az0[0] = wload32(ws, mlp.az[0] + rbn * 64);
         MP_CHUNK_SYNC();
         // layer-1 rows [128 wv, +128) += W1[:, 64 ck .. +64) * chunk
-        seg_main<4, 2, MP32_PF1, kHbRowBytes, (kAHot & 2) != 0>(acc1, ring1, ws, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8,
+        seg_main<4, 2, kPrefetch1, kHbRowBytes, (kAHot & 2) != 0>(acc1, ring1, ws, a1 + ck * 8 * 64, (kHidden[0] / 8) * 64, 8,
                                        hrow, swz);
         MP_CHUNK_SYNC();
       }
       // skip segment of layer 1: W1[:, 1024 .. 1024 + C] * x, then the z column
       const int a1x = mlp.ax[1] / 4 + (4 * wv) * NGX * 64;
-      f32x4 ring1[MP32_PF1 + 1][4];
+      f32x4 ring1[kPrefetch1 + 1][4];
       float az1[4];
-      seg_prefetch<4, MP32_PF1>(ring1, ws, a1x, NGX * 64, NGX);
+      seg_prefetch<4, kPrefetch1>(ring1, ws, a1x, NGX * 64, NGX);
 #pragma unroll
       for (int m = 0; m < 4; ++m) az1[m] = wload32(ws, mlp.az[1] + (4 * wv + m) * 64);
-      seg_main<4, 2, MP32_PF1, ROWB>(acc1, ring1, ws, a1x, NGX * 64, NGX, xrow, swz);
+      seg_main<4, 2, kPrefetch1, ROWB>(acc1, ring1, ws, a1x, NGX * 64, NGX, xrow, swz);
       gemm_z<4, 2>(acc1, az1, zb);
 #pragma unroll
       for (int m = 0; m < 4; ++m)

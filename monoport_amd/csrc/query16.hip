@@ -11,7 +11,7 @@
 //     file: layer 1's 128 rows x 96 points per wave are 192 accumulator registers, a layer-0 chunk
 //     48 more -- 240, which fit the 256 AGPRs, so no accumulator tile ever moves between the two
 //     register files (the 128-point tile of round 1 needed 256 + 32 and the allocator shuffled
-//     tiles and spilled 100 registers; MP16_NB=4 still builds it);
+//     tiles and spilled 100 registers; kQ16Nb=4 still builds it);
 //   * LDS: xs[96][hi 512 B | lo 512 B] = 96 KB + one 128-row hidden chunk [96][hi 256 B | lo 256 B]
 //     = 48 KB (144 KB, one workgroup per CU);
 //   * layer 0 is produced in 128-row chunks -- one row block x all three column blocks per wave, so
@@ -45,7 +45,7 @@
 // 96 points per tile, 707 at 128): 0.45-0.47 of the roof here; 0.6 would need a tile of >= 240 points
 // = 240 KB of split features in LDS.  The f32 kernel streams the same bytes per point but spends 4x
 // the matrix-pipe time per fragment, which is why it sits at 0.91.  Also measured and dropped: a
-// software-pipelined layer-0/1 loop over 32-row chunks (6.97 vs 6.65 ms), MP16_CS=2 (column split,
+// software-pipelined layer-0/1 loop over 32-row chunks (6.97 vs 6.65 ms), kQ16Cs=2 (column split,
 // duplicated loads: 9.3 ms) and the skip-connection MFMAs of layer 1 issued under the layer-0
 // conversion (correct, the interleave comes out as written, neutral: 6.60-6.62 vs 6.57-6.59 ms).
 #include <cstdlib>
@@ -58,9 +58,6 @@
 
 namespace mp {
 
-#if defined(MP16_ABLATE) && (MP16_ABLATE == 12 || MP16_ABLATE == 14)  // timing experiment: no barriers (results are garbage)
-#define __syncthreads() ((void)0)
-#endif
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -68,20 +65,13 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads16 = 256;  // 4 waves = one per SIMD, each with the full 512-register file
 constexpr int kXRow = 1024;      // bytes per point in xs: 32 hi slots | 32 lo slots (16 B each)
 constexpr int kHRow = 256;       // bytes per point in the hidden chunk: 8 hi slots | 8 lo slots
-#ifndef MP16_NB
-#define MP16_NB 3  // tile shape the launcher instantiates (see pifu_query16_kernel)
-#endif
-#ifndef MP16_CS
+constexpr int kQ16Nb = 3;  // tile shape the launcher instantiates (see pifu_query16_kernel)
 // column split: 2 = eight waves, two per SIMD (see the kernel).  Correct (the f16 tests pass with
 // it) but MEASURED SLOWER for f16x3 -- 1 M points 9.3 ms vs 7.0 ms: 128 accumulator registers + the
 // A ring + double-buffered hi/lo B fragments do not fit 256 registers (103 spilled, scratch traffic
 // inside the chunk loop) and both waves of a row group load every weight fragment.  Plain f16 gains
 // 5 % (3.63 vs 3.82 ms).  Kept for tools/ablate.py; the product uses 1.
-#define MP16_CS 1
-#endif
-#ifndef MP16_SGB
-#define MP16_SGB 1  // 1: a k16 group's prefetches interleaved with its MFMAs (seg_main16); 0: in a clump before them
-#endif
+constexpr int kQ16Cs = 1;
 
 struct AFrag {
   h8 hi, lo;
@@ -101,12 +91,6 @@ __device__ __forceinline__ void split4(const f32x4 &v, h4 &hi, h4 &lo) {
 // TERMS selects the arithmetic: 3 = hi*hi + hi*lo + lo*hi (f32-class, "f16x3"); 2 = weights
 // rounded to f16, activations still split (hi*hi + hi*lo, "f16w"); 1 = plain f16 operands ("f16").
 __device__ __forceinline__ h8 hload(const WStream &w, int idx16) {
-#if defined(MP16_ABLATE) && (MP16_ABLATE == 11 || MP16_ABLATE == 14)  // timing experiment: no weight loads
-  h8 r;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) r[e] = (_Float16)(float)(idx16 & 3);
-  return r;
-#endif
   return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.lane16, idx16 * 16, 0));
 }
 
@@ -164,19 +148,9 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
       h8 nh[NR], nl[NR];
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
-#if defined(MP16_ABLATE) && (MP16_ABLATE == 13 || MP16_ABLATE == 14)  // timing experiment: no LDS reads
-        nh[n] = bh[n];
-        nl[n] = bl[n];
-        (void)boff;
-        (void)boff_lo;
-        continue;
-#endif
         nh[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + boff);
         if (TERMS >= 2) nl[n] = *reinterpret_cast<const h8 *>(b + n * 32 * ROWB + boff_lo);
       }
-#if !MP16_SGB
-      __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above the MFMAs (see query.hip)
-#endif
       // term-major order: consecutive MFMAs hit different accumulators
 #pragma unroll
       for (int m = 0; m < MR; ++m)
@@ -202,7 +176,6 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
         bh[n] = nh[n];
         if (TERMS >= 2) bl[n] = nl[n];
       }
-#if MP16_SGB
       // One wave per SIMD: whatever the wave issues between two runs of MFMAs is time the matrix
       // pipe idles (nobody else feeds it).  So the prefetches of this group -- NV weight fragments,
       // ND LDS reads -- go INTO the run, one behind each MFMA (32 cycles of shadow each).
@@ -220,7 +193,6 @@ __device__ __forceinline__ void seg_main16(f32x16 (&acc)[MR][NR], AFrag (&ring)[
         }
         if (NM > NV + ND) __builtin_amdgcn_sched_group_barrier(0x008, NM - NV - ND, 0);
       }
-#endif
       if (r == RS - 1) hook(g);
     }
   }
@@ -300,10 +272,6 @@ __device__ __forceinline__ void store_hidden16(unsigned char *hb, const f32x16 &
 constexpr int kHRow128 = 512;
 __device__ __forceinline__ void convert_store_q128(unsigned char *hb, const f32x16 &v, int q, int rb_local,
                                                    int cb, int j, int hh, float inv_scale) {
-#if defined(MP16_ABLATE) && (MP16_ABLATE == 10 || MP16_ABLATE == 14)  // timing experiment: no conversion
-  if (v[4 * q] == 12345.0f) hb[0] = 1;
-  return;
-#endif
   const int p = 32 * cb + j;
   f32x4 f;
 #pragma unroll
@@ -470,12 +438,6 @@ __global__ __launch_bounds__(kThreads16 * CS, NB >= 3 ? CS : 2) void pifu_query1
     }
     __syncthreads();
 
-#ifdef MP16_ABLATE
-    if (MP16_ABLATE == 1) {  // timing experiment only: gather alone
-      if (zc[0].hi == (_Float16)123.0f) out[0] = 1.f;
-      continue;
-    }
-#endif
     const unsigned char *xrow = xs + (32 * cbase + j) * kXRow;  // this wave's first column block
     const unsigned char *hrow = hb + (32 * cbase + j) * kHRow;
     const unsigned char *xrow0 = xs + j * kXRow;                // column block 0 (layer-0 chunks)
@@ -574,18 +536,6 @@ __global__ __launch_bounds__(kThreads16 * CS, NB >= 3 ? CS : 2) void pifu_query1
         for (int n = 0; n < NBW; ++n) finish16(acc1[m][n], inv1);
     }
 
-#ifdef MP16_ABLATE
-    if (MP16_ABLATE == 2) {  // timing experiment only: stop after layers 0+1
-      float sink = 0.f;
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) sink += acc1[m][n][0];
-      if (sink == 12345.678f) out[0] = sink;
-      __syncthreads();
-      continue;
-    }
-#endif
     // ---------------- layer 2: rows [64 wv, +64) x 128 points ----------------
     f32x16 acc2[2][NBW];
 #pragma unroll
@@ -619,18 +569,6 @@ __global__ __launch_bounds__(kThreads16 * CS, NB >= 3 ? CS : 2) void pifu_query1
         for (int n = 0; n < NBW; ++n) finish16(acc2[m][n], inv2);
     }
 
-#ifdef MP16_ABLATE
-    if (MP16_ABLATE == 3) {  // timing experiment only: stop after layer 2
-      float sink = 0.f;
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) sink += acc2[m][n][0];
-      if (sink == 12345.678f) out[0] = sink;
-      __syncthreads();
-      continue;
-    }
-#endif
     // ---------------- layer 3: rows [32 wv, +32) x 128 points ----------------
     f32x16 acc3[1][NBW];
     init_from_bias16(acc3[0][0], w32, mlp32.bias[3] + 32 * wv, mlp.scale[3]);
@@ -1137,7 +1075,7 @@ int launch_query16(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w,
   const char *t16 = getenv("MONOPORT_TAB16");
   const bool want_tab = t16 && t16[0] == 'a' ? true : t16 && t16[0] == 'o' ? false : m.precision == MP_PREC_F16X3;
   QuerySet tset;
-  if (want_tab && MP16_NB == 3 && MP16_CS == 1 && find_skip_tables(ctx, m, set, h, w, tset)) {
+  if (want_tab && kQ16Nb == 3 && kQ16Cs == 1 && find_skip_tables(ctx, m, set, h, w, tset)) {
     if ((long long)h * w * kTableRows * 4 >= (1LL << 31))
       return fail(ctx, MP_ERR_UNSUPPORTED, "table query: %dx%d map is too large for 32-bit table offsets", h, w);
 #define MP_Q16TCASE(CO, PREC, TERMS) \
@@ -1153,7 +1091,7 @@ int launch_query16(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w,
   }
 #define MP_Q16CASE(CO, PREC, TERMS)                                                         \
   if (m.cout == CO && m.precision == PREC)                                                 \
-    return launch_query16_t<CO, TERMS, MP16_NB, MP16_CS>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
+    return launch_query16_t<CO, TERMS, kQ16Nb, kQ16Cs>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
   MP_Q16CASE(1, MP_PREC_F16X3, 3)
   MP_Q16CASE(3, MP_PREC_F16X3, 3)
   MP_Q16CASE(1, MP_PREC_F16W, 2)

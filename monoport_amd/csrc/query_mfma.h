@@ -14,22 +14,10 @@
 //   MP32_NOBAR   drop the chunk-loop barriers (wrong results)   -> cost of the barriers
 //   MP32_AHOT    every A fragment read hits one cached line     -> cost of weight streaming
 //   MP32_GATHER_ONLY  stop after the gather                     -> the sampling stage on its own
-#ifdef MP32_NOBAR
-#define MP_CHUNK_SYNC() __builtin_amdgcn_sched_barrier(0)
-#else
 #define MP_CHUNK_SYNC() __syncthreads()
-#endif
-#ifndef MP32_PF1
-#define MP32_PF1 1  // A-fragment prefetch distance (k-groups) of the MR = 4 / MR = 2 segments
-#endif
-#ifndef MP32_PF0
-#define MP32_PF0 3  // same for layer 0's MR = 1 segment
-#endif
-#ifdef MP32_AHOT  // bit 0: layer 0's segment, bit 1: layer-1 hidden, bit 2: everything else
-constexpr int kAHot = MP32_AHOT;
-#else
+constexpr int kPrefetch1 = 1;  // A-fragment prefetch distance (k-groups) of the MR = 4 / MR = 2 segments
+constexpr int kPrefetch0 = 3;  // same for layer 0's MR = 1 segment
 constexpr int kAHot = 0;
-#endif
 #define MP_AG(g) (HOT ? 0 : (g))
 
 namespace mp {

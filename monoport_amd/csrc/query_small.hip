@@ -36,13 +36,11 @@
 namespace mp {
 
 constexpr int kSmallPts = 32;
-#ifndef MP32_T32_WPS
-#define MP32_T32_WPS 3  // workgroups per CU the register allocator is held to (tools/ablate.py A/B)
-#endif
+constexpr int kT32Wps = 3;  // workgroups per CU the register allocator is held to
 constexpr int kSmallHbRow = 128 * 4;  // bytes per point of a 128-row hidden chunk
 
 template <int COUT>
-__global__ __launch_bounds__(kQueryThreads, MP32_T32_WPS) void pifu_query_t32_kernel(
+__global__ __launch_bounds__(kQueryThreads, kT32Wps) void pifu_query_t32_kernel(
     MlpPack mlp, int fh, int fw, float z_scale, int act, QuerySetDev set, int gate_tiles64) {
   constexpr int C = 256;
   constexpr int P = kSmallPts;
@@ -148,37 +146,37 @@ __global__ __launch_bounds__(kQueryThreads, MP32_T32_WPS) void pifu_query_t32_ke
       const int a0 = mlp.ax[0] / 4;
       const int rs1 = (kHidden[0] / 8) * 64;
       const int a1 = mlp.ah[1] / 4 + (4 * wv) * rs1;
-      f32x4 ring0[MP32_PF0 + 1][1];
+      f32x4 ring0[kPrefetch0 + 1][1];
       f32x16 acc0[1][1];
       float az0[1];
-      seg_prefetch<1, MP32_PF0>(ring0, ws, a0 + wv * NGX * 64, 0, NGX);
+      seg_prefetch<1, kPrefetch0>(ring0, ws, a0 + wv * NGX * 64, 0, NGX);
       init_from_bias(acc0[0][0], ws, mlp.bias[0] + 32 * wv);
       az0[0] = wload32(ws, mlp.az[0] + wv * 64);
 #pragma unroll 1
       for (int ck = 0; ck < kHidden[0] / 128; ++ck) {
         const int rb = 4 * ck + wv;  // layer-0 rows [32 rb, +32) x the 32 points
-        seg_main<1, 1, MP32_PF0, ROWB>(acc0, ring0, ws, a0 + rb * NGX * 64, 0, NGX, xrow, swz);
-        f32x4 ring1[MP32_PF1 + 1][4];
-        seg_prefetch<4, MP32_PF1>(ring1, ws, a1 + ck * 16 * 64, rs1, 16);
+        seg_main<1, 1, kPrefetch0, ROWB>(acc0, ring0, ws, a0 + rb * NGX * 64, 0, NGX, xrow, swz);
+        f32x4 ring1[kPrefetch1 + 1][4];
+        seg_prefetch<4, kPrefetch1>(ring1, ws, a1 + ck * 16 * 64, rs1, 16);
         gemm_z<1, 1>(acc0, az0, zb);
         lrelu(acc0[0][0]);
         store_hidden<kSmallHbRow>(hb, acc0[0][0], wv, 0, j, h);
         const int rbn = min(rb + 4, kHidden[0] / 32 - 4 + wv);
-        seg_prefetch<1, MP32_PF0>(ring0, ws, a0 + rbn * NGX * 64, 0, NGX);
+        seg_prefetch<1, kPrefetch0>(ring0, ws, a0 + rbn * NGX * 64, 0, NGX);
         init_from_bias(acc0[0][0], ws, mlp.bias[0] + 32 * rbn);
         az0[0] = wload32(ws, mlp.az[0] + rbn * 64);
         __syncthreads();
         // layer-1 rows [128 wv, +128) += W1[:, 128 ck .. +128) * chunk
-        seg_main<4, 1, MP32_PF1, kSmallHbRow>(acc1, ring1, ws, a1 + ck * 16 * 64, rs1, 16, hrow1, swz);
+        seg_main<4, 1, kPrefetch1, kSmallHbRow>(acc1, ring1, ws, a1 + ck * 16 * 64, rs1, 16, hrow1, swz);
         __syncthreads();
       }
       const int a1x = mlp.ax[1] / 4 + (4 * wv) * NGX * 64;
-      f32x4 ring1[MP32_PF1 + 1][4];
+      f32x4 ring1[kPrefetch1 + 1][4];
       float az1[4];
-      seg_prefetch<4, MP32_PF1>(ring1, ws, a1x, NGX * 64, NGX);
+      seg_prefetch<4, kPrefetch1>(ring1, ws, a1x, NGX * 64, NGX);
 #pragma unroll
       for (int m = 0; m < 4; ++m) az1[m] = wload32(ws, mlp.az[1] + (4 * wv + m) * 64);
-      seg_main<4, 1, MP32_PF1, ROWB>(acc1, ring1, ws, a1x, NGX * 64, NGX, xrow, swz);
+      seg_main<4, 1, kPrefetch1, ROWB>(acc1, ring1, ws, a1x, NGX * 64, NGX, xrow, swz);
       gemm_z<4, 1>(acc1, az1, zb);
 #pragma unroll
       for (int m = 0; m < 4; ++m) lrelu(acc1[m][0]);
@@ -330,7 +328,7 @@ int launch_query32_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int 
   }
   if (max_points <= 0) return MP_OK;
   const long long tiles = (max_points + kSmallPts - 1) / kSmallPts + (set.n - 1);
-  const long long resident = (long long)ctx->n_cu * MP32_T32_WPS;
+  const long long resident = (long long)ctx->n_cu * kT32Wps;
   // device-side counts: launch the resident grid and let it stride; host-side counts: one
   // workgroup per tile up to a few waves of the machine
   long long grid = device_counts ? (tiles < resident ? tiles : resident)

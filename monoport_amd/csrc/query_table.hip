@@ -19,19 +19,11 @@
 // test_skip_table_*); the bar is 1e-4.  The plain kernels stay the default of the C-ABI: a launch
 // comes here only if every one of its feature maps has a registered table (mp_skip_table).
 //
-// TWO query kernels live here: pifu_query_tabws_kernel (round 4, the one that ships: the waves of a
-// workgroup specialised into MFMA-only consumers and table-blending producers, further down) and
-// pifu_query_tab_kernel (round 3, every wave does everything; kept for A/B, MONOPORT_TAB_KERNEL=v1).
-//
-// Decomposition of the round-3 kernel (32-point tiles, as query_small.hip; two workgroups per CU):
-//   * a lane owns ONE point (p = lane & 31) and the rows its MFMA accumulator registers stand for
-//     (C layout: rows 8 q + 4 h + i of a 32-row block), so a blend lands exactly where the MFMA
-//     path would have left the product and everything downstream (z column, leaky ReLU, the
-//     point-major hidden chunk) is shared with the plain kernels (query_mfma.h);
-//   * layer 0 in 128-row chunks: the 16 table loads of chunk ck + 1 are in flight under layer 1's
-//     MFMAs of chunk ck (64 registers);  layer 0's bias sits in LDS;
-//   * the skip rows of layers 1-3 are blended into the accumulators when those are initialised,
-//     layer 4's in the final reduction.
+// The query kernel that ships is pifu_query_tabws_kernel (round 4: the waves of a workgroup specialised into
+// MFMA-only consumers and table-blending producers, below).  Round 3's kernel, in which every wave did
+// everything (0.72 of the roof: two workgroups sharing a SIMD's matrix pipe drift into phase), and the
+// timing-experiment builds of both are in the history (last present at commit 78cb450; DESIGN.md 4.1c / 4.1d
+// record their measurements).
 #include <cstdlib>
 #include <cstring>
 
@@ -44,281 +36,13 @@
 namespace mp {
 
 constexpr int kTabPts = 32;
-// A/B hooks (tools/ablate.py): workgroups per CU the register allocator is held to, and how many
-// of a 32-row block's four row groups one round of table loads fetches (4: 16 loads = 64 registers
-// per lane; 2: 8 loads = 32 registers)
-#ifndef MPT_WPS
-#define MPT_WPS 2
-#endif
-#ifndef MPT_QROUND
-#define MPT_QROUND 4
-#endif
-constexpr int kTabQ = MPT_QROUND;
+constexpr int kTabQ = 4;             // row groups of a 32-row block fetched per round of table loads (16 loads = 64 registers per lane)
 constexpr int kTabHbRow = 128 * 4;  // bytes per point of a 128-row hidden chunk
 
 typedef f32x4 TabRows[kTabQ][4];  // [q][tap]: rows 8 (q0 + q) + 4 h .. + 3 of a 32-row block, four texels
 
-// grid_sample's chain (query_common.h: blend) on table rows, added to row groups q0 .. q0 + kTabQ - 1
-// of an accumulator tile
-__device__ __forceinline__ void blend_add(f32x16 &acc, const TabRows &tp, const float (&w)[4], int q0) {
-#pragma unroll
-  for (int q = 0; q < kTabQ; ++q)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      acc[4 * (q0 + q) + i] =
-          acc[4 * (q0 + q) + i] +
-          fmaf(tp[q][3][i], w[3], fmaf(tp[q][2][i], w[2], fmaf(tp[q][1][i], w[1], __fmul_rn(tp[q][0][i], w[0]))));
-}
-
-template <int COUT>
-__global__ __launch_bounds__(kQueryThreads, MPT_WPS) void pifu_query_tab_kernel(MlpPack mlp, int fh, int fw, float z_scale,
-                                                                          int act, QuerySetDev set) {
-  constexpr int P = kTabPts;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *hb = smem;  // hidden chunk: [32][128 rows] (layer 0 -> 1) or [32][64 rows]; `red` at the end
-  float *bias0 = reinterpret_cast<float *>(smem + P * kTabHbRow);  // layer 0's bias, for the whole launch
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  const int swz = h ^ (j & 15);
-  const WStream ws = make_wstream(mlp.base, mlp.n_floats, lane);
-  for (int i = tid; i < kHidden[0]; i += kQueryThreads) bias0[i] = (mlp.base + mlp.bias[0])[i];
-  __syncthreads();
-
-  for (long long gtile = blockIdx.x;; gtile += gridDim.x) {
-    int fi = -1;
-    long long tile0 = 0;
-    {
-      long long acc = 0;
-      // groups of 8 frames: the 8 count loads of a group are in flight together, and the dynamic group offset
-      // keeps the compiler from hoisting all kMaxFrames kernel-argument loads into SGPRs (spills)
-      for (int f0 = 0; f0 < set.n; f0 += 8)
-#pragma unroll
-      for (int fk = 0; fk < 8; ++fk) {
-        const int f = f0 + fk;
-        if (f < set.n) {
-          const long long nf = set.count(f);
-          const long long t = (nf + P - 1) / P;
-          if (fi < 0 && gtile < acc + t) {
-            fi = f;
-            tile0 = acc;
-          }
-          acc += t;
-        }
-      }
-    }
-    if (fi < 0) break;
-    const QueryItem item = set.item(fi);
-    const float *__restrict__ calib = item.calib;
-    float *__restrict__ out = item.out;
-    const PointSrc &src = item.src;
-    const long long n_pts = src.n_dev ? (long long)*src.n_dev : src.n;
-    const long long n0 = (gtile - tile0) * P;
-    const __amdgpu_buffer_rsrc_t prs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(item.l0), 0, fh * fw * kTableRows * 4, 0x00020000);
-
-    // ---------------- this lane's point: projection, the four texels, z ----------------
-    float zb[1];
-    int to[4];    // byte offsets of the point's four table rows, + this lane's half of a row group
-    float tw[4];  // grid_sample weights (0 for taps outside the map and for dead points)
-    {
-      float cal[12];
-#pragma unroll
-      for (int i = 0; i < 12; ++i) cal[i] = calib[i];
-      const long long n = n0 + j;
-      float px = 0, py = 0, pz = 0, x, y, z;
-      uint32_t code;
-      if (n < n_pts) load_point(src, n, px, py, pz, code);
-      project(cal, px, py, pz, x, y, z);
-      zb[0] = (h == 0 && n < n_pts) ? __fmul_rn(z, z_scale) : 0.0f;
-      const Taps t = make_taps(x, y, fh, fw, kTableRows, n < n_pts && in_image(x, y));
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-#ifdef MPT_FAKE_GATHER  // timing experiment (wrong results): every point reads texel k -> the gather's cost
-        to[k] = k * kTableRows * 4 + 16 * h;
-#else
-        to[k] = (int)t.o[k] * 4 + 16 * h;
-#endif
-        tw[k] = t.w[k];
-      }
-    }
-    // acc += blend of rows row0 .. row0 + 31 (this lane: 8 q + 4 h .. + 3) of the point's four texels,
-    // kTabQ row groups per round of loads.  The loads are requested where they are used: the
-    // second workgroup of the CU covers their latency, and a lane keeps 64 (32) registers less
-    // alive across the MFMA phases than with a one-phase-ahead prefetch (measured: 9.72 against
-    // 10.17 ms per 885 k lattice points, profiles/r03af_skip_table_variants.txt)
-    auto rows_blend = [&](f32x16 &acc, int row0) {
-#pragma unroll
-      for (int q0 = 0; q0 < 4; q0 += kTabQ) {
-        TabRows tp;
-#pragma unroll
-        for (int q = 0; q < kTabQ; ++q)
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            tp[q][k] = __builtin_bit_cast(
-                f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, to[k], (row0 + 8 * (q0 + q)) * 4, 0));
-        blend_add(acc, tp, tw, q0);
-        __builtin_amdgcn_sched_barrier(0);  // one round at a time (hipcc would hoist them all and spill)
-      }
-    };
-
-    const unsigned char *hrow = hb + j * kHbRowBytes;  // 64-row chunks (layers 2, 3)
-    const unsigned char *hrow1 = hb + j * kTabHbRow;   // 128-row chunks (layer 0 -> 1)
-
-    // ---------------- layer 1 accumulators: bias + skip rows ----------------
-    f32x16 acc1[4][1];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      init_from_bias(acc1[m][0], ws, mlp.bias[1] + 32 * (4 * wv + m));
-      rows_blend(acc1[m][0], kTableL[1] + 32 * (4 * wv + m));
-    }
-
-    // ---------------- layers 0 + 1, fused over 128-row chunks of layer 0 ----------------
-    {
-      const int rs1 = (kHidden[0] / 8) * 64;
-      const int a1 = mlp.ah[1] / 4 + (4 * wv) * rs1;
-      f32x16 acc0[1][1];
-      float az0[1];
-      az0[0] = wload32(ws, mlp.az[0] + wv * 64);
-#pragma unroll 1
-      for (int ck = 0; ck < kHidden[0] / 128; ++ck) {
-        const int rb = 4 * ck + wv;  // layer-0 rows [32 rb, +32) x the 32 points
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 bq = *reinterpret_cast<const f32x4 *>(bias0 + 32 * rb + 8 * q + 4 * h);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc0[0][0][4 * q + i] = bq[i];
-        }
-        rows_blend(acc0[0][0], kTableL[0] + 32 * rb);
-        f32x4 ring1[MP32_PF1 + 1][4];
-        seg_prefetch<4, MP32_PF1>(ring1, ws, a1 + ck * 16 * 64, rs1, 16);
-        gemm_z<1, 1>(acc0, az0, zb);
-        lrelu(acc0[0][0]);
-        store_hidden<kTabHbRow>(hb, acc0[0][0], wv, 0, j, h);
-        const int rbn = min(rb + 4, kHidden[0] / 32 - 4 + wv);
-        az0[0] = wload32(ws, mlp.az[0] + rbn * 64);
-        __syncthreads();
-        // layer-1 rows [128 wv, +128) += W1[:, 128 ck .. +128) * chunk
-        seg_main<4, 1, MP32_PF1, kTabHbRow>(acc1, ring1, ws, a1 + ck * 16 * 64, rs1, 16, hrow1, swz);
-        __syncthreads();
-      }
-      float az1[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) az1[m] = wload32(ws, mlp.az[1] + (4 * wv + m) * 64);
-      gemm_z<4, 1>(acc1, az1, zb);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) lrelu(acc1[m][0]);
-    }
-
-    // ---------------- layer 2: rows [64 wv, +64): bias + skip rows, K = 512 hidden (8 chunks of 64) ----------------
-    f32x16 acc2[2][1];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) init_from_bias(acc2[m][0], ws, mlp.bias[2] + 32 * (2 * wv + m));
-#pragma unroll
-    for (int m = 0; m < 2; ++m) rows_blend(acc2[m][0], kTableL[2] + 32 * (2 * wv + m));
-    {
-      const int rs2 = (kHidden[1] / 8) * 64;
-      const int a2 = mlp.ah[2] / 4 + (2 * wv) * rs2;
-      f32x4 ring2[2][2];
-      seg_prefetch<2, 1>(ring2, ws, a2, rs2, 8);
-#pragma unroll
-      for (int ck = 0; ck < 8; ++ck) {
-        if (wv == (ck >> 1)) {  // owner of hidden rows [64 ck, +64): row blocks 2 (ck & 1), + 1
-#pragma unroll
-          for (int mm = 0; mm < 2; ++mm) store_hidden(hb, acc1[2 * (ck & 1) + mm][0], mm, 0, j, h);
-        }
-        __syncthreads();
-        seg_main<2, 1, 1, kHbRowBytes>(acc2, ring2, ws, a2 + ck * 8 * 64, rs2, 8, hrow, swz);
-        if (ck < 7) seg_prefetch<2, 1>(ring2, ws, a2 + (ck + 1) * 8 * 64, rs2, 8);
-        __syncthreads();
-      }
-      float az2[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) az2[m] = wload32(ws, mlp.az[2] + (2 * wv + m) * 64);
-      gemm_z<2, 1>(acc2, az2, zb);
-#pragma unroll
-      for (int m = 0; m < 2; ++m) lrelu(acc2[m][0]);
-    }
-
-    // ---------------- layer 3: rows [32 wv, +32): bias + skip rows, K = 256 hidden (4 chunks) ----------------
-    f32x16 acc3[1][1];
-    init_from_bias(acc3[0][0], ws, mlp.bias[3] + 32 * wv);
-    rows_blend(acc3[0][0], kTableL[3] + 32 * wv);
-    {
-      const int a3 = mlp.ah[3] / 4 + wv * (kHidden[2] / 8) * 64;
-      f32x4 ring3[4][1];
-      seg_prefetch<1, 3>(ring3, ws, a3, 0, 8);
-#pragma unroll
-      for (int ck = 0; ck < 4; ++ck) {
-        if (wv == ck) {
-#pragma unroll
-          for (int mm = 0; mm < 2; ++mm) store_hidden(hb, acc2[mm][0], mm, 0, j, h);
-        }
-        __syncthreads();
-        seg_main<1, 1, 3, kHbRowBytes>(acc3, ring3, ws, a3 + ck * 8 * 64, 0, 8, hrow, swz);
-        if (ck < 3) seg_prefetch<1, 3>(ring3, ws, a3 + (ck + 1) * 8 * 64, 0, 8);
-        __syncthreads();
-      }
-      float az3[1];
-      az3[0] = wload32(ws, mlp.az[3] + wv * 64);
-      gemm_z<1, 1>(acc3, az3, zb);
-      lrelu(acc3[0][0]);
-    }
-
-    // ---------------- layer 4 on the VALU: hidden part per wave, skip rows + z in the reduction ----------------
-    float *red = reinterpret_cast<float *>(hb);  // red[wave][o][p]
-    constexpr int K4 = (kHidden[3] + 256 + 1 + 3) & ~3;
-#pragma unroll
-    for (int o = 0; o < COUT; ++o) {
-      const float *w4 = (mlp.base + mlp.w4) + o * K4 + 32 * wv + 4 * h;
-      float s0 = 0.0f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 wq = *reinterpret_cast<const f32x4 *>(w4 + 8 * q);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s0 = fmaf(wq[i], acc3[0][0][4 * q + i], s0);
-      }
-      s0 += __shfl_xor(s0, 32);
-      if (h == 0) red[(wv * COUT + o) * P + j] = s0;
-    }
-    __syncthreads();
-    if (tid < COUT * P) {
-      const int o = tid / P, p = tid % P;
-      const long long n = n0 + p;
-      if (n < n_pts) {
-        float v = (mlp.base + mlp.bias[4])[o];
-#pragma unroll
-        for (int part = 0; part < 4; ++part) v += red[(part * COUT + o) * P + p];
-        const float wz = (mlp.base + mlp.w4)[o * K4 + kHidden[3] + 256];
-        float cal[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) cal[i] = calib[i];
-        float px, py, pz, x, y, z;
-        uint32_t code;
-        load_point(src, n, px, py, pz, code);
-        project(cal, px, py, pz, x, y, z);
-        const bool inside = in_image(x, y);
-        const Taps t = make_taps(x, y, fh, fw, kTableRows, inside);
-        const float *row = item.l0 + kTableL[4] + o;
-        v += fmaf(row[t.o[3]], t.w[3], fmaf(row[t.o[2]], t.w[2], fmaf(row[t.o[1]], t.w[1], __fmul_rn(row[t.o[0]], t.w[0]))));
-        v = fmaf(wz, __fmul_rn(z, z_scale), v);
-        v = inside ? activate(v, act) : 0.0f;  // MonoPortNet.py:89
-        if (src.packed) {
-          const int ix = code & 1023u, iy = (code >> 10) & 1023u, iz = code >> 20;
-          out[((long long)iz * src.level_res + iy) * src.level_res + ix] = v;
-        } else {
-          out[o * src.out_stride + n] = v;
-        }
-      }
-    }
-    __syncthreads();  // red / hb are rewritten by the next tile
-  }
-}
-
-// ---- round 4: the same query with the waves of a workgroup SPECIALISED --------------------------------
-// In pifu_query_tab_kernel every wave alternates between MFMA phases (the K loops) and phases that
+// ---- the query with the waves of a workgroup SPECIALISED ------------------------------------------------
+// In round 3's kernel every wave alternated between MFMA phases (the K loops) and phases that
 // keep the matrix pipe idle for that wave: table-row loads, blends, bias / z / leaky ReLU, LDS stores.
 // The second workgroup of the CU is supposed to fill them, but two workgroups that share a SIMD's
 // matrix pipe drift into phase (both slow down while both want the pipe, both leave it together):
@@ -373,70 +97,20 @@ static_assert(sizeof(WsFrame) == 80 && sizeof(WsShared) == 72, "two workgroups p
 constexpr int kWsFrames = kWsTend + kMaxFrames * 4;
 constexpr int kWsShared = kWsFrames + kMaxFrames * (int)sizeof(WsFrame);
 constexpr int kWsLds = kWsShared + (int)sizeof(WsShared);
-#ifdef MPT_WS_STAMP  // the stamp build adds 288 bytes of static LDS: build it with -DMP_MAX_FRAMES=16
-static_assert(2 * (kWsLds + 320) <= 160 * 1024, "two workgroups per CU (+ the 288 bytes of static LDS of the stamp build)");
-#else
 static_assert(2 * kWsLds <= 160 * 1024, "two workgroups per CU");
-#endif
 
 // timing experiments (tools/ablate.py; wrong results): the producers do no work / no barriers;
-// MPT_WS_PRIO: s_setprio of the consumer waves
-#ifdef MPT_WS_NOBAR
-#define WS_SYNC() __builtin_amdgcn_sched_barrier(0)
-#elif defined(MPT_WS_STAMP)
-// side build (tools/tab_ws_stamp_probe.py): per barrier of the tile schedule and per role, the cycles wave 0 / 4 of
-// workgroup 0 spent WORKING before it arrived and WAITING at it; the sums replace the first outputs of frame 0
-#define WS_SYNC()                                                                        \
-  do {                                                                                   \
-    const long long t0_ = __builtin_amdgcn_s_memtime();                                  \
-    __syncthreads();                                                                     \
-    const long long t1_ = __builtin_amdgcn_s_memtime();                                  \
-    if (lane == 0 && (wv & 3) == 0) {                                                    \
-      atomicAdd(&ws_stamp[((wv >> 2) * 16 + (ws_sidx & 15)) * 2], (unsigned)(t0_ - ws_leave)); \
-      atomicAdd(&ws_stamp[((wv >> 2) * 16 + (ws_sidx & 15)) * 2 + 1], (unsigned)(t1_ - t0_));   \
-    }                                                                                    \
-    ws_leave = t1_;                                                                      \
-    ++ws_sidx;                                                                           \
-  } while (0)
-#else
+// kWsConsumerPrio: s_setprio of the consumer waves
 #define WS_SYNC() __syncthreads()
-#endif
-#ifdef MPT_WS_STAMP  // ticks since the last barrier at a point inside an interval (all loads drained first), summed in slot i
-#define WS_MARK(i)                                                                              \
-  do {                                                                                          \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
-    if (lane == 0 && wv == 4) atomicAdd(&ws_mark[i], (unsigned)(__builtin_amdgcn_s_memtime() - ws_leave)); \
-  } while (0)
-#else
 #define WS_MARK(i)
-#endif
-#ifndef MPT_TAB_AUX
-#define MPT_TAB_AUX 0  // cache policy of the table-row loads (2 = nt: stream past the L2-resident weights)
-#endif
-#ifndef MPT_WS_PIECE_AHEAD
-#define MPT_WS_PIECE_AHEAD 0  // (measured: no gain) 1: the loads of a layer-1 piece are issued one interval before the piece is written
-#endif
-#ifndef MPT_WS_FINISH_AT
-#define MPT_WS_FINISH_AT 8  // the interval (8 = T0) in which the producers store the previous tile's outputs
-#endif
-#ifndef MPT_WS_SETUP_AT
-#define MPT_WS_SETUP_AT 7  // ... and in which they project the next tile's points
-#endif
-#ifndef MPT_WS_P4_FIRST
-#define MPT_WS_P4_FIRST 1  // S7: the rows of piece 4 requested before (1) or after (0) the next tile's points are set up
-#endif
-#ifndef MPT_WS_R4_LATE
-#define MPT_WS_R4_LATE 1  // layer 4's skip row of the next tile's points: in T3 (0: with the projection)
-#endif
-#ifndef MPT_WS_SPRIO
-#define MPT_WS_SPRIO 3  // s_setprio of the producers while they set up the next tile's points / store the outputs
-#endif
-#ifndef MPT_WS_PPRIO
-#define MPT_WS_PPRIO 0  // s_setprio of the producer waves
-#endif
-#ifndef MPT_WS_PRIO
-#define MPT_WS_PRIO 1  // measured: 0.819 -> 0.830 of the roof on 885 k points (3 = the same)
-#endif
+constexpr int kWsTabAux = 0;  // cache policy of the table-row loads (2 = nt: stream past the L2-resident weights)
+constexpr int kWsFinishAt = 8;  // the interval (8 = T0) in which the producers store the previous tile's outputs
+constexpr int kWsSetupAt = 7;  // ... and in which they project the next tile's points
+constexpr int kWsP4First = 1;  // S7: the rows of piece 4 requested before (1) or after (0) the next tile's points are set up
+constexpr int kWsR4Late = 1;  // layer 4's skip row of the next tile's points: in T3 (0: with the projection)
+constexpr int kWsSetupPrio = 3;  // s_setprio of the producers while they set up the next tile's points / store the outputs
+constexpr int kWsProducerPrio = 0;  // s_setprio of the producer waves
+constexpr int kWsConsumerPrio = 1;  // measured: 0.819 -> 0.830 of the roof on 885 k points (3 = the same)
 
 struct TileLoc {
   int fi;  // frame of the tile, -1: past the end
@@ -535,33 +209,19 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
       fr.npts = mine;
     }
   }
-#ifdef MPT_WS_STAMP
-  __shared__ unsigned ws_stamp[64];
-  __shared__ unsigned ws_mark[8];
-  if (tid < 64) ws_stamp[tid] = 0;
-  if (tid < 8) ws_mark[tid] = 0;
-  int ws_sidx = 15;  // the barrier before the first tile; the one behind the last tile lands in slot 14
-#endif
   __syncthreads();
-#ifdef MPT_WS_STAMP
-  long long ws_leave = __builtin_amdgcn_s_memtime();
-#endif
   const long long n_tiles = __builtin_amdgcn_readfirstlane(tend[kMaxFrames - 1]);
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own
   // L2.  Tiles that are neighbours in the list share texels (table rows) and frames, so XCD x takes the
   // CONTIGUOUS eighth [x T / 8, (x + 1) T / 8) of the tile list and its workgroups walk through it side
   // by side: a table row fetched into an L2 is reused there instead of being fetched by all eight.
-#ifdef MPT_WS_FLAT_ORDER  // A/B: the plain grid-stride order
-  const long long tile_first = blockIdx.x, tile_step = gridDim.x, tile_end = n_tiles;
-#else
   const int xcd = blockIdx.x & 7, n_xcd = gridDim.x < 8 ? (int)gridDim.x : 8;  // XCDs this launch reaches
   const long long tile_step = ((int)gridDim.x - xcd + 7) >> 3;                   // its workgroups on this XCD
   const long long tile_first = n_tiles * xcd / n_xcd + (blockIdx.x >> 3), tile_end = n_tiles * (xcd + 1) / n_xcd;
-#endif
 
   if (wv < 4) {
     // =============================== consumers: the K loops ===============================
-    if (MPT_WS_PRIO) __builtin_amdgcn_s_setprio(MPT_WS_PRIO);
+    if (kWsConsumerPrio) __builtin_amdgcn_s_setprio(kWsConsumerPrio);
     const int rs1 = (kHidden[0] / 8) * 64, rs2 = (kHidden[1] / 8) * 64;
     const int a1 = mlp.ah[1] / 4 + (4 * wv) * rs1;
     const int a2 = mlp.ah[2] / 4 + (2 * wv) * rs2;
@@ -602,9 +262,6 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     int par = 0;
     for (long long gtile = tile_first;; gtile += tile_step, par ^= 1) {
       if (gtile >= tile_end) break;
-#ifdef MPT_WS_STAMP
-      ws_sidx = 0;
-#endif
       asm volatile("" : "+v"(st0));
       zb[0] = h == 0 ? zvec[par * P + j] : 0.0f;
       // ---------------- S0-S7: layer 1 += W1[:, chunk k] * (layer-0 chunk k in X[k & 1]); piece k / 2 added on odd k ----------------
@@ -614,12 +271,12 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc1[m][0][t] = 0.0f;
       {
-        f32x4 ring1[MP32_PF1 + 1][4];
-        seg_prefetch<4, MP32_PF1>(ring1, ws, a1, rs1, 16);
+        f32x4 ring1[kPrefetch1 + 1][4];
+        seg_prefetch<4, kPrefetch1>(ring1, ws, a1, rs1, 16);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          seg_main<4, 1, MP32_PF1, kTabHbRow>(acc1, ring1, ws, a1 + k * 16 * 64, rs1, 16, xrow + (k & 1) * kWsXBytes, swz);
-          if (k < 7) seg_prefetch<4, MP32_PF1>(ring1, ws, a1 + (k + 1) * 16 * 64, rs1, 16);
+          seg_main<4, 1, kPrefetch1, kTabHbRow>(acc1, ring1, ws, a1 + k * 16 * 64, rs1, 16, xrow + (k & 1) * kWsXBytes, swz);
+          if (k < 7) seg_prefetch<4, kPrefetch1>(ring1, ws, a1 + (k + 1) * 16 * 64, rs1, 16);
           if (k & 1) add_piece(*reinterpret_cast<f32x16(*)[1][1]>(&acc1[k >> 1]), mlp.az[1] + (4 * wv + (k >> 1)) * 64, 3);
           if (k == 7) {
 #pragma unroll
@@ -650,9 +307,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
           const int buf = pr == 0 ? 2 : pr == 1 ? 0 : pr == 2 ? 1 : 3;
-#ifndef MPT_WS_SONLY  // timing experiment: layer 1 only
           seg_main<2, 1, 1, kTabHbRow>(acc2, ring2, ws, a2 + pr * 16 * 64, rs2, 16, xrow + buf * kWsXBytes, swz);
-#endif
           if (pr < 3) seg_prefetch<2, 1>(ring2, ws, a2 + (pr + 1) * 16 * 64, rs2, 16);
           if (pr == 2) add_piece(*reinterpret_cast<f32x16(*)[1][1]>(&acc2[0]), mlp.az[2] + (2 * wv) * 64, 2);  // piece 4: written to X[2] in T1
           if (pr == 3) {
@@ -680,9 +335,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #pragma unroll
             for (int m = 0; m < 2; ++m) store_k(1, acc2[m][0], 2 * (wv - 2) + m);
           }
-#ifndef MPT_WS_SONLY
           seg_main<1, 1, 3, kTabHbRow>(acc3, ring3, ws, a3 + pr * 16 * 64, 0, 16, xrow + (pr ? 1 : 2) * kWsXBytes, swz);
-#endif
           if (pr == 0) seg_prefetch<1, 3>(ring3, ws, a3 + 16 * 64, 0, 16);
           if (pr == 1) {
             add_piece(acc3, mlp.az[3] + wv * 64, 3);  // piece 6: written to PB in U0
@@ -712,7 +365,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
   } else {
     // =============================== producers: everything per point ===============================
     const int pw = wv - 4;  // partner of consumer wave pw
-    if (MPT_WS_PPRIO) __builtin_amdgcn_s_setprio(MPT_WS_PPRIO);
+    if (kWsProducerPrio) __builtin_amdgcn_s_setprio(kWsProducerPrio);
     unsigned char *h0 = smem + kWsX;
     int st1 = (j * kTabHbRow | (swz << 4)) ^ (pw << 7);  // see the consumers' store_k
     f32x4 *piece0 = reinterpret_cast<f32x4 *>(smem + kWsX) + (pw * 4) * 64 + lane;  // + region * 16 KB (3 = PB)
@@ -783,11 +436,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
       pt.r4 = 0.0f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-#ifdef MPT_FAKE_GATHER
-        pt.to[k] = k * kTableRows * 4 + 16 * h;
-#else
         pt.to[k] = (int)t.o[k] * 4 + 16 * h;
-#endif
         pt.tw[k >> 1][k & 1] = t.w[k];
       }
     };
@@ -818,22 +467,14 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-#ifdef MPT_WS_NOLOAD  // timing experiment: the blends without the table loads
-          const f32x4 fake = {pt.tw[k >> 1][k & 1], pt.tw[q >> 1][q & 1], pt.zf, (float)row0};
-          tp[q][k] = fake;
-#else
           tp[q][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, pt.to[k], (row0 + 8 * q) * 4,
-                                                                                     MPT_TAB_AUX));
-#endif
+                                                                                     kWsTabAux));
         }
     };
     // grid_sample's chain on four rows at once, started from `v0` (the bias, or bias + z column): whole
     // f32x4 fused multiply-adds -- v_pk_fma_f32, half the VALU issue slots of scalar code, and every
     // VALU instruction of a producer costs the consumer on its SIMD matrix-pipe time
     auto blend4 = [&](const f32x4 (&t)[4], const WsPoint &pt, f32x4 v0) {
-#ifdef MPT_WS_NOVALU  // timing experiment: the table loads without the blends
-      return (f32x4)__builtin_elementwise_max(__builtin_elementwise_max(t[0], t[1]), __builtin_elementwise_max(t[2], t[3]));
-#else
       f32x4 v = v0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {  // weights kept as register PAIRS: v_pk_fma_f32 takes them without a v_mov per use
@@ -841,7 +482,6 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         v = __builtin_elementwise_fma(t[k], w, v);
       }
       return v;
-#endif
     };
     // layer-0 chunk ck of this lane's point -> X[buf]: this wave's row block 4 ck + pw;
     // lrelu(b0 + z w0z + blend) with bias and z weights from LDS
@@ -898,9 +538,6 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
       setup_point(loc.fi, loc.n0, cur, 0);
       job_issue(tp, prs_cur, cur, kTableL[0] + 32 * pw);
       chunk_finish(tp, cur, 0, 0);
-#if MPT_WS_PIECE_AHEAD
-      job_issue(tp, prs_cur, cur, kTableL[1] + 32 * (4 * pw));  // piece 0 in flight
-#endif
     }
     prs_nxt = prs_cur;
     nxt = cur;
@@ -909,9 +546,6 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
     long long prev_n0 = 0;
     for (long long gtile = tile_first;; gtile += tile_step, par ^= 1) {
       if (loc.fi < 0) break;
-#ifdef MPT_WS_STAMP
-      ws_sidx = 0;
-#endif
       const TileLoc loc_n = loc_ahead;  // located in the previous tile's T0: S0 is the producers' longest interval
       // ---------------- S0-S7 ----------------
       // Even k: piece k / 2 (row block 4 pw + k / 2 of layer 1) -> PB, read in S(k + 1) -- its loads were issued at
@@ -919,25 +553,19 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
       // S7, where the producers have next to nothing to do: the previous tile's outputs, the next tile's points.
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-#ifndef MPT_WS_NOPROD
-        if (k == MPT_WS_FINISH_AT && k < 7 && prev_fi >= 0) finish_tile(prev, prev_fi, prev_n0);
-        if (k == MPT_WS_SETUP_AT && k < 7 && loc_n.fi >= 0) {
+        if (k == kWsFinishAt && k < 7 && prev_fi >= 0) finish_tile(prev, prev_fi, prev_n0);
+        if (k == kWsSetupAt && k < 7 && loc_n.fi >= 0) {
           setup_point(loc_n.fi, loc_n.n0, nxt, par ^ 1);
           prs_nxt = table_rsrc(loc_n.fi);
         }
         if (k == 0) asm volatile("" : "+v"(st1));
         if (!(k & 1)) {
-#if !MPT_WS_PIECE_AHEAD
           job_issue(tp, prs_cur, cur, kTableL[1] + 32 * (4 * pw + (k >> 1)));
-#endif
           piece_finish(tp, cur, 32 * (4 * pw + (k >> 1)), 3);
         }
         if (k < 7) {  // chunk k + 1 -> X[(k + 1) & 1] (read in S(k + 1); last read in S(k - 1) / U1)
           job_issue(tp, prs_cur, cur, kTableL[0] + 32 * (4 * (k + 1) + pw));
           chunk_finish(tp, cur, k + 1, (k + 1) & 1);
-#if MPT_WS_PIECE_AHEAD
-          if ((k & 1) && k < 7) job_issue(tp, prs_cur, cur, kTableL[1] + 32 * (4 * pw + ((k + 1) >> 1)));  // piece (k + 1) / 2 in flight
-#endif
         } else {
           // S7, where the producers have the least to do: the next tile's points (needed in U0) and the
           // previous tile's outputs.  Nothing is in flight at its top, so the outputs (which wait for a few
@@ -946,62 +574,46 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
           // the next tile's points are a chain of dependent steps (count, load, divide, project, texels) on the
           // critical path of the interval: they run at raised priority -- at the consumers' priority or below, a
           // producer instruction waits ~100 cycles for an issue slot between the MFMAs
-          if (MPT_WS_SPRIO) __builtin_amdgcn_s_setprio(MPT_WS_SPRIO);
+          if (kWsSetupPrio) __builtin_amdgcn_s_setprio(kWsSetupPrio);
           RawPoint raw_n = {};
-          if (MPT_WS_SETUP_AT == 7 && loc_n.fi >= 0) point_load(loc_n.fi, loc_n.n0, raw_n);
+          if (kWsSetupAt == 7 && loc_n.fi >= 0) point_load(loc_n.fi, loc_n.n0, raw_n);
           WS_MARK(1);
-          if (MPT_WS_FINISH_AT == 7 && prev_fi >= 0) finish_tile(prev, prev_fi, prev_n0);
-          if (MPT_WS_P4_FIRST) job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw));  // piece 4 (layer 2, row block 2 pw) in flight
+          if (kWsFinishAt == 7 && prev_fi >= 0) finish_tile(prev, prev_fi, prev_n0);
+          if (kWsP4First) job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw));  // piece 4 (layer 2, row block 2 pw) in flight
           WS_MARK(2);
-          if (MPT_WS_SETUP_AT == 7 && loc_n.fi >= 0) {
+          if (kWsSetupAt == 7 && loc_n.fi >= 0) {
             point_setup(loc_n.fi, raw_n, nxt, par ^ 1);
-            if (!MPT_WS_R4_LATE) point_r4(loc_n.fi, nxt);
+            if (!kWsR4Late) point_r4(loc_n.fi, nxt);
             prs_nxt = table_rsrc(loc_n.fi);
           }
-          if (MPT_WS_SPRIO) __builtin_amdgcn_s_setprio(MPT_WS_PPRIO);
+          if (kWsSetupPrio) __builtin_amdgcn_s_setprio(kWsProducerPrio);
           WS_MARK(3);
-          if (!MPT_WS_P4_FIRST) job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw));  // with all 64 row registers free until here
+          if (!kWsP4First) job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw));  // with all 64 row registers free until here
         }
-#endif
         WS_SYNC();
       }
       // ---------------- T0-T3, U0-U1: split jobs -- loads in one interval, blend + write in a later one ----------------
-#ifndef MPT_WS_NOPROD
-      if (MPT_WS_FINISH_AT == 8 && prev_fi >= 0) {  // T0: nothing else to do
-        if (MPT_WS_SPRIO) __builtin_amdgcn_s_setprio(MPT_WS_SPRIO);
+      if (kWsFinishAt == 8 && prev_fi >= 0) {  // T0: nothing else to do
+        if (kWsSetupPrio) __builtin_amdgcn_s_setprio(kWsSetupPrio);
         finish_tile(prev, prev_fi, prev_n0);
-        if (MPT_WS_SPRIO) __builtin_amdgcn_s_setprio(MPT_WS_PPRIO);
+        if (kWsSetupPrio) __builtin_amdgcn_s_setprio(kWsProducerPrio);
       }
-#endif
       loc_ahead = gtile + 2 * tile_step < tile_end ? locate_tile(tend, gtile + 2 * tile_step, lane) : no_tile;
       WS_SYNC();  // T0: every region holds a K pair of layer 2 or is being filled with one
-#ifndef MPT_WS_NOPROD
       piece_finish(tp, cur, kHidden[1] + 32 * (2 * pw), 2);         // T1: piece 4 -> X[2] (pair 0 was read in T0; read in T2)
       job_issue(tp, prs_cur, cur, kTableL[2] + 32 * (2 * pw + 1));  //     piece 5 in flight
-#endif
       WS_SYNC();
-#ifndef MPT_WS_NOPROD
       piece_finish(tp, cur, kHidden[1] + 32 * (2 * pw + 1), 0);  // T2: piece 5 -> X[0] (pair 1 was read in T1; read in T3)
       job_issue(tp, prs_cur, cur, kTableL[3] + 32 * pw);         //     piece 6 in flight
-#endif
       WS_SYNC();
-#ifndef MPT_WS_NOPROD
-      if (MPT_WS_SETUP_AT == 7 && MPT_WS_R4_LATE && loc_n.fi >= 0) point_r4(loc_n.fi, nxt);  // T3: nothing else to do
-#endif
+      if (kWsSetupAt == 7 && kWsR4Late && loc_n.fi >= 0) point_r4(loc_n.fi, nxt);  // T3: nothing else to do
       WS_SYNC();  // T3: the consumers read pair 3 in PB and piece 5
-#ifndef MPT_WS_NOPROD
       piece_finish(tp, cur, kHidden[1] + kHidden[2] + 32 * pw, 3);            // U0: piece 6 -> PB (read in U1)
       if (loc_n.fi >= 0) job_issue(tp, prs_nxt, nxt, kTableL[0] + 32 * pw);  //     the next tile's chunk 0 in flight
-#endif
       WS_SYNC();
-#ifndef MPT_WS_NOPROD
       if (loc_n.fi >= 0) {
         chunk_finish(tp, nxt, 0, 0);  // U1: -> X[0] (piece 5 was read in T3)
-#if MPT_WS_PIECE_AHEAD
-        job_issue(tp, prs_nxt, nxt, kTableL[1] + 32 * (4 * pw));  // the next tile's piece 0 in flight
-#endif
       }
-#endif
       WS_SYNC();
       prev_fi = loc.fi;
       prev_n0 = loc.n0;
@@ -1011,22 +623,8 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
       prs_cur = prs_nxt;
     }
     WS_SYNC();
-#ifndef MPT_WS_NOPROD
     if (prev_fi >= 0) finish_tile(prev, prev_fi, prev_n0);
-#endif
   }
-#ifdef MPT_WS_STAMP
-  __syncthreads();
-  if (blockIdx.x == 0 && tid < 64) set.it[0].out[tid] = (float)ws_stamp[tid];
-  if (blockIdx.x == 0 && tid < 8) set.it[0].out[64 + tid] = (float)ws_mark[tid];
-#endif
-}
-
-// MONOPORT_TAB_KERNEL=v1 selects round 3's kernel (every wave does everything) for A/B measurements;
-// read at every launch, so a probe can flip it inside one process
-static bool tab_kernel_v1() {
-  const char *e = getenv("MONOPORT_TAB_KERNEL");
-  return e && e[0] == 'v' && e[1] == '1';
 }
 
 template <int COUT>
@@ -1054,35 +652,12 @@ static int launch_query_tabws_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, 
   return MP_OK;
 }
 
-template <int COUT>
-static int launch_query_tab_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
-                              long long max_points, bool device_counts, hipStream_t st) {
-  if (!tab_kernel_v1()) return launch_query_tabws_t<COUT>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
-  constexpr int lds = kTabPts * kTabHbRow + kHidden[0] * 4;
-  if (max_points <= 0) return MP_OK;
-  const long long tiles = (max_points + kTabPts - 1) / kTabPts + (set.n - 1);
-  const long long resident = (long long)ctx->n_cu * MPT_WPS;
-  // device-side counts: launch the resident grid and let it stride; host-side counts: one
-  // workgroup per tile up to a few waves of the machine
-  const long long grid = device_counts ? (tiles < resident ? tiles : resident)
-                                       : (tiles < 8 * resident ? tiles : 8 * resident);
-  QuerySetDev dset;
-  {
-    const int rc_set = compact_query_set(ctx, set, dset);
-    if (rc_set != MP_OK) return rc_set;
-  }
-  hipLaunchKernelGGL(pifu_query_tab_kernel<COUT>, dim3((unsigned)grid), dim3(kQueryThreads), lds, st, m.pack(), h, w,
-                     z_scale, m.act, dset);
-  MP_HIP(ctx, hipGetLastError());
-  return MP_OK;
-}
-
 int launch_query_tab(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int w, float z_scale,
                      long long max_points, bool device_counts, hipStream_t st) {
   if ((long long)h * w * kTableRows * 4 >= (1LL << 31))
     return fail(ctx, MP_ERR_UNSUPPORTED, "table query: %dx%d map is too large for 32-bit table offsets", h, w);
-  if (m.cout == 1) return launch_query_tab_t<1>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
-  if (m.cout == 3) return launch_query_tab_t<3>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
+  if (m.cout == 1) return launch_query_tabws_t<1>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
+  if (m.cout == 3) return launch_query_tabws_t<3>(ctx, m, set, h, w, z_scale, max_points, device_counts, st);
   return fail(ctx, MP_ERR_UNSUPPORTED, "table query: Cout in {1,3}");
 }
 

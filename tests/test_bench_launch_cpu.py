@@ -76,7 +76,8 @@ def test_in_flight_layout():
     assert bench.in_flight_layout(8, 2) == (2, 2)
     assert bench.in_flight_layout(8, 1) == (2, 4)
     assert bench.pick_batch(20, 10) == 10 and bench.pick_batch(7, 10) == 7 and bench.pick_batch(22, 10) == 2
-    assert bench.pick_batch(20, None) == 20 and bench.pick_batch(48, None) == 16 and bench.pick_batch(25, None) == 5
+    assert bench.pick_batch(20, None) == 20 and bench.pick_batch(48, None) == 24 and bench.pick_batch(25, None) == 25
+    assert bench.pick_batch(96, None) == 32 and bench.pick_batch(48, 16) == 16  # one policy: largest divisor <= kMaxFrames
     try:
         bench.in_flight_layout(8, 3)
     except SystemExit:

@@ -18,15 +18,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-# frames per slot submission / launch: bench.py's default (16; round 2: 10) or MONOPORT_TRAFFIC_BATCH
+# frames per slot submission / launch: MONOPORT_TRAFFIC_BATCH (bench.py: 24 by default, 20 at the driver's --steps 20)
 BATCH, LEVELS = int(os.environ.get("MONOPORT_TRAFFIC_BATCH", "16")), 5
 
 
 def run():
     import torch
-    from monoport_amd import _lib
-    if os.environ.get("MONOPORT_ABLATE"):  # a side library of tools/ablate.py
-        _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmp_ablate%s.so" % os.environ["MONOPORT_ABLATE"])
     import bench
     from monoport_amd import synthetic as syn
     from monoport_amd.recon import pifu_calib
@@ -51,10 +48,10 @@ def counter_rows(directory, counter):
                                                      or "pifu_query_kernel" in name):
                     rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), "t32" in name or "tab" in name))
     rows.sort()
-    # with the skip tables (default) every level is ONE dispatch of the table kernel per chunk of <= 16 frames
-    # (a slot batch of 20 = chunks of 16 + 4: the chunks of a level are added up); on the plain path
+    # with the skip tables (default) every level is ONE dispatch of the table kernel per chunk of <= 32 frames
+    # (kMaxFrames; the chunks of a level are added up); on the plain path
     # (MONOPORT_SKIP_TABLE=off) levels 1-4 are a gated pair
-    chunks = (BATCH + 15) // 16
+    chunks = (BATCH + 31) // 32
     if not any(not t32 for _, _, t32 in rows[-2 * LEVELS * chunks:]):
         rows = rows[-2 * LEVELS * chunks:]
         assert len(rows) == 2 * LEVELS * chunks, len(rows)
@@ -99,8 +96,8 @@ def parse(fetch_dir, write_dir, out_path):
         "correction": "FETCH_SIZE doubled (128-B requests tallied at 64 B for 16 B/lane coalesced "
                       "reads on gfx950), WRITE_SIZE as is",
         "slot_batch": BATCH,
-        "launches_per_level": (BATCH + 15) // 16,
-        "bytes_per_launch_avg": sum(bytes_level) / (LEVELS * ((BATCH + 15) // 16)),
+        "launches_per_level": (BATCH + 31) // 32,
+        "bytes_per_launch_avg": sum(bytes_level) / (LEVELS * ((BATCH + 31) // 32)),
         "bytes_per_level_launch": bytes_level,
     }
     with open(out_path, "w") as f:
