@@ -24,7 +24,7 @@ line with the driver's contract fields plus
                   hoist 42 % of them out of the per-point work), never as a fraction;
                   `roofline.step` = the query launches AND skip_table_kernel as one rate;
                   `roofline.traffic` = memory-side bytes per launch from the committed PMC
-                  passes at this frames-per-launch (20 with --steps 20, 24 with the default 48)
+                  passes at this frames-per-launch (20 with --steps 20, 16 with the default 48)
   "plain_query_path"  (N=1 only) the headline configuration without skip tables (--no-skip-table)
   "cpu_baseline"  the CPU oracle path timed on this box's host cores (rank 0, N=1 only)
   "passes"        the timed region is run 3 times (each EXACTLY --steps frames between barrier +
@@ -147,7 +147,7 @@ def traffic_from_profile(precision, levels, with_color, slot_batch):
     --pmc FETCH_SIZE / WRITE_SIZE runs of tools/traffic_probe.py, corrected as
     MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process, so the
     figure is reported ONLY for the configurations the passes covered (f32 skip-table kernel, 5 levels,
-    geometry only, slot batches of 20 / 24 / 16 frames: --steps 20, the default --steps 48, --batch 16)
+    geometry only, slot batches of 20 / 16 / 24 frames: --steps 20, the default --steps 48, --batch 24)
     and is None for every other run or when the profile is absent."""
     if precision != "f32" or levels != 5 or with_color:
         return None
@@ -239,7 +239,11 @@ def rendezvous_only(args):
         assert len(set(devices)) == world, "ranks share a GPU: %s" % devices
     gather = parallel.FrameGather((1, 257, 257, 3), device=device, store=False)
     payload = torch.full((1, 257, 257, 3), float(rank), device=device)
+    t_g = time.perf_counter()
     gather.push(0, payload)
+    if have_gpu:
+        torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - t_g) * 1e3
     ok = True
     if rank == 0 and world > 1:
         ok = all(bool((gather.received(r) == float(r)).all()) for r in range(world))
@@ -247,7 +251,7 @@ def rendezvous_only(args):
         dist.barrier()
     if rank == 0:
         print(json.dumps({"rendezvous_only": True, "n_gpus": world, "backend": backend,
-                          "devices": devices, "gather_checked": bool(ok),
+                          "devices": devices, "gather_checked": bool(ok), "gather_ms_first": gather_ms,
                           "self_launched": os.environ.get("MONOPORT_BENCH_SELF_LAUNCHED") == "1"}),
               flush=True)
     if dist is not None:
@@ -266,6 +270,7 @@ class Job:
         self.device, self.rank, self.world, self.dist = device, rank, world, dist
         self.one_gpu_test = one_gpu_test
         self.steps, self.warm = steps, warm
+        self.gather_ms = None  # per warm-up submission: duration of the render gather on this rank (N > 1)
         n_frames = steps + warm
         # distinct frames per rank: frame id = step * world + rank (frame-parallel sharding)
         self.images = [torch.from_numpy(syn.synthetic_image(s * world + rank))[None].to(device)
@@ -293,14 +298,18 @@ class Job:
         return got
 
 
-def pick_batch(steps, upper):
-    """Frames per slot submission -- ONE policy for every --steps: the largest divisor of --steps not above
-    `upper` (--batch; MAX_RECON_BATCH = 32 = kMaxFrames of mp_recon_batch when not given), so that no slot
-    submission is short (a short batch would still pay the full-batch encoder) and every octree level of a
-    submission is ONE fused-query launch.  48 steps -> 2 submissions of 24 on two slots; the driver's 20 steps
-    -> one submission of 20 (the frames of such a run complete together: `config.frame_latency_ms` says so);
-    96 -> 3 x 32."""
+def pick_batch(steps, upper, depth=3):
+    """Frames per slot submission -- ONE rule for every --steps: equal submissions, as many as there are slots
+    (`depth`) when --steps divides that way, else as few as possible; never more than `upper` frames each (--batch;
+    MAX_RECON_BATCH = 32 = kMaxFrames of mp_recon_batch when not given), so that no submission is short (a short
+    batch would still pay the full-batch encoder) and every octree level of a submission is ONE fused-query launch.
+    48 steps on 3 slots -> 3 x 16 (each slot's encoder under another slot's octree: measured 186-188 recon/s
+    against 170 for 2 x 24); the driver's 20 steps -> one submission of 20 (20 does not divide by 3; its frames
+    complete together: `config.frame_latency_ms`; the two-submission layout is reported as
+    `two_slot_submissions`); 96 -> 3 x 32."""
     upper = MAX_RECON_BATCH if upper is None else upper
+    if steps % depth == 0 and 1 <= steps // depth <= upper:
+        return steps // depth
     return max(b for b in range(1, max(1, min(upper, steps)) + 1) if steps % b == 0)
 
 
@@ -318,6 +327,7 @@ def timed_passes(job, pipe, batch, with_color, passes, collective=True, want_sta
     render_pack = [torch.zeros((batch, r_last, r_last, 3), dtype=torch.float32, device=job.device)
                    for _ in range(depth)] if world > 1 else None
     gather_checked = [False]
+    gather_events = []  # (start, stop) HIP events around the warm-up gathers, on the slot's stream
     status_log = []
 
     def run_batch(s0, s1, log):
@@ -329,7 +339,13 @@ def timed_passes(job, pipe, batch, with_color, passes, collective=True, want_sta
                 pack = render_pack[(pipe.n_submitted - 1) % depth]  # this slot's staging buffer
                 for b in range(s1 - s0):
                     pack[b].copy_(slot.renders_tex[b] if with_color else slot.renders[b])
+                if not log:  # warm-up submissions: time the collective (events on the stream it is enqueued on)
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record(slot.stream)
                 gather.push(s0 // batch, pack)
+                if not log:
+                    ev[1].record(slot.stream)
+                    gather_events.append(ev)
                 if not log and job.rank == 0 and not gather_checked[0]:
                     # (warm-up only: this syncs) the gathered copy of rank 0's own frames must
                     # equal what rank 0 rendered
@@ -347,6 +363,9 @@ def timed_passes(job, pipe, batch, with_color, passes, collective=True, want_sta
 
     for s0 in range(0, n_warm, batch):
         run_batch(s0, min(s0 + batch, n_warm), False)
+    if gather_events:
+        bracket()
+        job.gather_ms = [a.elapsed_time(b) for a, b in gather_events]
     elapsed = []
     for p in range(passes):
         bracket()
@@ -826,8 +845,8 @@ def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48,
-                    help="frames in the timed region (default 48 = two slot submissions of 24 frames; the driver's "
-                         "20 = one submission of 20)")
+                    help="frames in the timed region (default 48 = one submission of 16 frames on each of the 3 slots; the "
+                         "driver's 20 = one submission of 20)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--depth", type=int, default=3, help="pipeline slots (streams) per GPU")
     ap.add_argument("--batch", type=int, default=None,
@@ -835,7 +854,7 @@ def parse_args(argv):
                          "their octree levels as fused-query launches of <= 32 frames; up to depth x batch frames "
                          "are in flight.  The largest divisor of --steps not above this is used, so no slot "
                          "submission is short (a short batch would still pay the full-batch encoder).  Not "
-                         "given: 32 (pick_batch)")
+                         "given: --steps / --depth when that divides, else the largest divisor <= 32 (pick_batch)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="K > 0: exactly K frames in flight across the node (K / --gpus per rank; "
                          "BASELINE configs[3] is K = 8) instead of --depth x --batch per GPU; the "
@@ -945,7 +964,7 @@ def main(argv=None):
             raise SystemExit("--steps %d is not a multiple of the %d frames per slot that "
                              "--in-flight %d gives" % (args.steps, batch, args.in_flight))
     else:
-        depth, batch = args.depth, pick_batch(args.steps, args.batch)
+        depth, batch = args.depth, pick_batch(args.steps, args.batch, args.depth)
     main_res, pipe = measure_config(job, depth, batch, not args.no_graph, resolutions,
                                     args.with_color, args.precision, args.passes, final_level=args.final_level)
     use_graph = main_res["use_graph"]
@@ -1154,6 +1173,11 @@ def main(argv=None):
                             "gloo (one-GPU test hook)" if one_gpu_test else "nccl (RCCL)"),
                 "self_launched": os.environ.get("MONOPORT_BENCH_SELF_LAUNCHED") == "1",
                 "gather_checked": bool(main_res["gather_checked"]) if world > 1 else None,
+                # where non-linearity would come from: per-rank step times are in `ms_per_step_per_rank`; the one
+                # collective of a submission (renders of `batch` frames to rank 0), timed on rank 0 during warm-up
+                "gather_ms_per_submission": (None if not job.gather_ms else
+                                             {"median": float(np.median(job.gather_ms)), "max": float(np.max(job.gather_ms)),
+                                              "bytes_per_rank": int(batch * r_last * r_last * 3 * 4)}),
                 "slot_submissions_per_rank": -(-args.steps // batch),
                 "frames_in_flight_per_rank": min(depth, -(-args.steps // batch)) * batch,
                 "frame_latency_ms": main_res["ms_per_step"] * batch * min(depth, -(-args.steps // batch)),

@@ -191,6 +191,14 @@ def test_marching_cubes_257_identical_connectivity(oracle):
     assert len(np.unique(key)) == len(key) and np.array_equal(np.sort(key), np.sort(rev))
 
 
+# A vertex of OUR reconstruction sits within 2e-3 voxels of the reference's in Z (the occupancies differ by <= 7e-6
+# with both encoders in the loop); under the rotated camera that moves the colour sample by ~1e-3 texel, and the
+# encoder features vary by O(1) per texel: the colour of such a vertex may differ by a few 1e-4 although the colour
+# CHAIN is exact to fp32 noise.  So: whole-pipeline colours within COLOR_TOL_PIPELINE, and the colour chain itself
+# -- netC.filter(feat_prior) + vertex mapping + netC.query, on the REFERENCE's vertices -- within TOL_REF.
+COLOR_TOL_PIPELINE = 2e-3
+
+
 def _color257_frame_checks(g, tag, vol, stats, X, Y, Z, tex):
     """One reconstructed frame of the configs[2] scene against the reference-driven fixture: octree
     nodes / values (modulo nodes within COLOR257_AMBIGUOUS of the threshold), the visible vertices,
@@ -206,10 +214,9 @@ def _color257_frame_checks(g, tag, vol, stats, X, Y, Z, tex):
     bg[X, Y] = False
     print("%s: %.5f of the reference's %d vertices (%d columns differ), max|colour - reference| = %.3g"
           % (tag, same, len(ref_cols), len(ref_cols ^ cols), err))
-    assert same >= 0.995 and len(ref_cols ^ cols) <= 0.005 * len(ref_cols)  # measured: see the printed line
+    assert same >= 0.995 and len(ref_cols ^ cols) <= 0.005 * len(ref_cols)  # measured: 0.99993, 0 columns
     assert (tex[bg] == 1.0).all()  # the canvas of ones (RTL/main.py:201-203) wherever no vertex landed
-    # a vertex whose Z moved by 1e-3 voxels samples the same texel neighbourhood: colours within 1e-4
-    assert err <= TOL_REF
+    assert err <= COLOR_TOL_PIPELINE  # measured 2.2e-4 (see COLOR_TOL_PIPELINE)
     return err
 
 
@@ -286,5 +293,26 @@ def test_pipeline257_color_vs_reference_batched_pipeline(batch):
                                    slot.volumes[b].cpu().numpy(), slot.status[b, 1:].cpu().numpy(),
                                    x[:c].cpu().numpy(), y[:c].cpu().numpy(), z[:c].cpu().numpy(),
                                    slot.renders_tex[b].cpu().numpy())
+        # the colour chain of the batched path alone -- the slot's packed cat([feat_G, feat_C]) maps, the vertex
+        # mapping and ONE mp_query_counted_batch launch for all frames -- on the REFERENCE's vertices
+        from monoport_amd import ops
+        n_ref = g["X"].shape[0]
+        cap = 257 * 257
+        rx = torch.zeros(cap, dtype=torch.int64, device=DEV)
+        ry = torch.zeros(cap, dtype=torch.int64, device=DEV)
+        rz = torch.zeros(cap, dtype=torch.float32, device=DEV)
+        rx[:n_ref] = torch.from_numpy(g["X"].astype(np.int64)).to(DEV)
+        ry[:n_ref] = torch.from_numpy(g["Y"].astype(np.int64)).to(DEV)
+        rz[:n_ref] = torch.from_numpy(g["Z"]).to(DEV)
+        cnt = torch.tensor([n_ref], dtype=torch.int32, device=DEV)
+        pts = ops.vertex_points(rx, ry, rz, cnt, 257, slot.mat_color)
+        preds = ops.query_counted_batch(netC.surface_classifier.packed(), slot.feats_hwc_c[:batch], [pts] * batch,
+                                        [cnt] * batch, slot.calib[:batch], syn.Z_SCALE)
+        for b in range(batch):
+            col = (preds[b][:, :n_ref] * 0.5 + 0.5).t().cpu().numpy()
+            e2 = float(np.abs(col - g["color"]).max())
+            print("configs[2] batch %d frame %d: colour chain on the reference's vertices: max|colour - reference| = %.3g"
+                  % (batch, b, e2))
+            assert e2 <= TOL_REF
     finally:
         pipe.close()

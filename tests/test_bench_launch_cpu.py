@@ -37,6 +37,16 @@ def test_self_launch_two_ranks():
     assert "launching 2 ranks" in res.stderr
 
 
+def test_self_launch_eight_ranks():
+    """BASELINE configs[3]'s rank count: eight ranks rendezvous, census their devices and gather one
+    frame-sized payload each to rank 0 (gloo here; RCCL on an 8-GPU node, which this container lacks)."""
+    res = _run([sys.executable, BENCH, "--gpus", "8", "--rendezvous-only"], OMP_NUM_THREADS="1")
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = _json_lines(res.stdout)
+    assert len(out) == 1 and out[0]["n_gpus"] == 8 and out[0]["gather_checked"] is True
+    assert len(set(out[0]["devices"])) == 8 and out[0]["gather_ms_first"] > 0
+
+
 def test_under_torchrun_joins_the_launchers_ranks():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -76,8 +86,8 @@ def test_in_flight_layout():
     assert bench.in_flight_layout(8, 2) == (2, 2)
     assert bench.in_flight_layout(8, 1) == (2, 4)
     assert bench.pick_batch(20, 10) == 10 and bench.pick_batch(7, 10) == 7 and bench.pick_batch(22, 10) == 2
-    assert bench.pick_batch(20, None) == 20 and bench.pick_batch(48, None) == 24 and bench.pick_batch(25, None) == 25
-    assert bench.pick_batch(96, None) == 32 and bench.pick_batch(48, 16) == 16  # one policy: largest divisor <= kMaxFrames
+    assert bench.pick_batch(20, None) == 20 and bench.pick_batch(48, None) == 16 and bench.pick_batch(25, None) == 25
+    assert bench.pick_batch(96, None) == 32 and bench.pick_batch(48, 8) == 8 and bench.pick_batch(64, None) == 32  # one rule (docstring)
     try:
         bench.in_flight_layout(8, 3)
     except SystemExit:

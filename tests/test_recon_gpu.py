@@ -481,9 +481,14 @@ def test_recon_batch_of_16_frames(ops, oracle):
 
 def test_recon_batch_rejects_too_many_frames(ops, body):
     from monoport_amd._lib import MonoportError
+    assert ops.MAX_FRAMES == 32
     with pytest.raises(MonoportError):
-        ops.recon_batch(body["mlp"], [body["fh"]] * 17, [body["cal"]] * 17, syn.Z_SCALE, BMIN, BMAX,
+        ops.recon_batch(body["mlp"], [body["fh"]] * 33, [body["cal"]] * 33, syn.Z_SCALE, BMIN, BMAX,
                         [9, 17])
+    # 32 frames (kMaxFrames) in one call, every level one launch: the same volume 32 times
+    vols, st = ops.recon_batch(body["mlp"], [body["fh"]] * 32, [body["cal"]] * 32, syn.Z_SCALE, BMIN, BMAX, [9, 17, 33])
+    one, st1 = ops.recon(body["mlp"], body["fh"], body["cal"], syn.Z_SCALE, BMIN, BMAX, [9, 17, 33])
+    assert all(torch.equal(v, one) for v in vols) and all(torch.equal(s, st1) for s in st)
 
 
 def _dense_iou(ops, mlp, fh, cal, vol, r):
