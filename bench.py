@@ -632,7 +632,7 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
         def vertices_one(d):
             return {**d, **dict(zip(["X", "Y", "Z", "norm"], forward_vertices(d["sdf"], direction="front")))}
 
-        wrap = ((lambda one, many, name: Coalesced(logged(name, one), logged(name, many), max_batch=8)) if coalesce
+        wrap = ((lambda one, many, name: Coalesced(logged(name, one), logged(name, many), max_batch=CO_BATCH)) if coalesce
                 else (lambda one, many, name: logged(name, one)))
         return [
             lambda data: {"input": data.to(device, non_blocking=True)},                    # main.py:327
@@ -648,6 +648,8 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
                                                         resolution=r_last)},              # :418-428
         ]
 
+    # coalescing stages: frames served per call at most / frames in flight (MONOPORT_DROPIN_COALESCE="batch,in_flight")
+    CO_BATCH, CO_IN_FLIGHT = (int(v) for v in os.environ.get("MONOPORT_DROPIN_COALESCE", "16,48").split(","))
     frames = []
     for i in range(N_IMAGES):
         img = torch.from_numpy(syn.synthetic_image(i))
@@ -711,7 +713,7 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
             # pass on a cold pool costs 1.5-1.8 s of hipMalloc (profiles/r04g_dropin_passes.txt)
             from monoport_amd.stage_pipeline import stage_stream
             with torch.no_grad(), torch.cuda.stream(stage_stream(device, 4)):
-                for b in range(1, 9):
+                for b in range(1, CO_BATCH + 1):
                     netG.filter(torch.zeros((b, 3, 512, 512), device=device))
             torch.cuda.synchronize()
         one_pass(coalesce, in_flight, validate)  # untimed
@@ -724,11 +726,11 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
 
     per_frame = mode(False, 8, "always")
     per_frame_trusted = mode(False, 8, "first")
-    co = mode(True, 16)
+    co = mode(True, CO_IN_FLIGHT)
     return {
         "surface": "RTL/main.py processors list on StagePipeline: Seg3dLossless(query_func) + forward_vertices + "
                    "colorization, eager encoder; netG.filter / reconEngine / forward_vertices as Coalesced stages "
-                   "(up to 8 queued frames per call), 16 frames in flight",
+                   "(up to %d queued frames per call), %d frames in flight" % (CO_BATCH, CO_IN_FLIGHT),
         **co,
         "per_frame_stages": {**per_frame,
                              "surface": "the same list, one frame per stage call (the reference's structure), batch 1, "

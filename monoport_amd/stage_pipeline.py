@@ -29,7 +29,12 @@ Additions:
   host sync for all their vertex counts -- instead of ``len(list)`` calls of ``fn``.  Per-frame
   semantics and FIFO order are unchanged (results leave in submission order; with an empty queue a
   frame is served alone, by ``fn``); an exception inside ``fn_many`` is re-tried frame by frame so
-  that it lands on the frame that caused it.  The reference's stages are one Python thread per
+  that it lands on the frame that caused it -- which RE-RUNS ``fn`` on frames ``fn_many`` may already
+  have worked on: the processors of a Coalesced stage must be idempotent per frame (no counters
+  advanced per call, no state that a second evaluation of the same frame would corrupt; the
+  reference's stateful camera step, RTL/main.py:330-336, is NOT a candidate).  A ``fn_many`` that finds
+  it cannot batch raises ``Coalesced.CannotBatch`` BEFORE touching any state: the frames are then
+  served by ``fn`` one by one without an error being recorded.  The reference's stages are one Python thread per
   frame step on a host that spends most of its time in the GIL; this is what the drop-in surface
   needs to reach the batched kernels.
 """
@@ -91,6 +96,9 @@ class StageError:
 class Coalesced:
     """A stage processor that can serve several queued frames in one call (see the module
     docstring): ``fn(item) -> item`` and ``fn_many([item, ...]) -> [item, ...]`` (same order)."""
+
+    class CannotBatch(Exception):
+        """Raised by ``fn_many`` before any side effect: serve these frames one by one through ``fn``."""
 
     def __init__(self, fn, fn_many, max_batch=8):
         self.fn, self.fn_many, self.max_batch = fn, fn_many, max(1, int(max_batch))
