@@ -328,6 +328,7 @@ def timed_passes(job, pipe, batch, with_color, passes, collective=True, want_sta
                    for _ in range(depth)] if world > 1 else None
     gather_checked = [False]
     gather_events = []  # (start, stop) HIP events around the warm-up gathers, on the slot's stream
+    warming = [True]
     status_log = []
 
     def run_batch(s0, s1, log):
@@ -339,11 +340,12 @@ def timed_passes(job, pipe, batch, with_color, passes, collective=True, want_sta
                 pack = render_pack[(pipe.n_submitted - 1) % depth]  # this slot's staging buffer
                 for b in range(s1 - s0):
                     pack[b].copy_(slot.renders_tex[b] if with_color else slot.renders[b])
-                if not log:  # warm-up submissions: time the collective (events on the stream it is enqueued on)
+                ev = None
+                if warming[0]:  # warm-up submissions: time the collective (events on the stream it is enqueued on)
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record(slot.stream)
                 gather.push(s0 // batch, pack)
-                if not log:
+                if ev is not None:
                     ev[1].record(slot.stream)
                     gather_events.append(ev)
                 if not log and job.rank == 0 and not gather_checked[0]:
@@ -363,6 +365,7 @@ def timed_passes(job, pipe, batch, with_color, passes, collective=True, want_sta
 
     for s0 in range(0, n_warm, batch):
         run_batch(s0, min(s0 + batch, n_warm), False)
+    warming[0] = False
     if gather_events:
         bracket()
         job.gather_ms = [a.elapsed_time(b) for a, b in gather_events]
