@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 4 gpurun command lines, one script: tools/r04_run.sh STEP [OUTDIR]
+# Round 4 gpurun command lines (HISTORICAL: the ws / wsab / wspmc / order / abtraffic steps need the side builds and
+# MONOPORT_TAB_KERNEL=v1 of commit 78cb450; round 5 is tools/r05_run.sh): tools/r04_run.sh STEP [OUTDIR]
 #   ws      quick hang check + A/B probe of the wave-specialised table kernel, full GPU suite, bench A/B
 #   tests   full GPU suite only
 #   bench   default bench line        bench20  the driver's invocation        benchq  headline only

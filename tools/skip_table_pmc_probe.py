@@ -7,8 +7,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from monoport_amd import _lib  # noqa: E402
-if os.environ.get("MONOPORT_ABLATE"):  # a side library of tools/ablate.py
-    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmp_ablate%s.so" % os.environ["MONOPORT_ABLATE"])
 from monoport_amd import ops, synthetic as syn  # noqa: E402
 from monoport_amd.recon import pifu_calib  # noqa: E402
 from skip_table_probe import lattice_points  # noqa: E402

@@ -12,8 +12,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from monoport_amd import _lib  # noqa: E402
-if os.environ.get("MONOPORT_ABLATE"):  # a side library of tools/ablate.py (kernel A/B)
-    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmp_ablate%s.so" % os.environ["MONOPORT_ABLATE"])
 from monoport_amd import ops, synthetic as syn  # noqa: E402
 from monoport_amd.recon import pifu_calib  # noqa: E402
 
@@ -57,7 +55,7 @@ def main():
     n = pts.shape[1]
     res = [17, 33, 65, 129, 257]
     rows = {}
-    for gate, name in (() if os.environ.get("MONOPORT_ABLATE") else ((0, "64-point tiles"), (1, "32-point tiles"))):
+    for gate, name in ((0, "64-point tiles"), (1, "32-point tiles")):
         lib.mp_query_tune(gate)
         rows[name] = (timed(lambda: ops.query(mlp, feats[0], p, cal, syn.Z_SCALE)),
                       timed(lambda: ops.recon_batch(mlp, feats, [cal] * frames, syn.Z_SCALE, [-1] * 3, [1] * 3, res), reps=5))
