@@ -139,6 +139,7 @@ def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, 
     return pipe
 
 
+TRAFFIC_PROFILE_513_F16W = "r05_query_traffic_513_f16w.json"  # configs[4]: tools/r05_run.sh traffic16
 TRAFFIC_PROFILE = "r05_query_traffic.json"  # PMC passes at slot batches of 16, 20 and 24 frames (tools/r05_run.sh traffic)
 
 
@@ -149,6 +150,13 @@ def traffic_from_profile(precision, levels, with_color, slot_batch):
     figure is reported ONLY for the configurations the passes covered (f32 skip-table kernel, 5 levels,
     geometry only, slot batches of 20 / 16 / 24 frames: --steps 20, the default --steps 48, --batch 24)
     and is None for every other run or when the profile is absent."""
+    if precision == "f16w" and levels == 6 and not with_color:  # configs[4]: its own passes (16 frames per launch)
+        try:
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE_513_F16W)) as f:
+                prof = json.load(f)
+            return prof["bytes_per_launch_avg"] if int(slot_batch) == int(prof["slot_batch"]) else None
+        except (OSError, KeyError, ValueError):
+            return None
     if precision != "f32" or levels != 5 or with_color:
         return None
     path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
@@ -1137,6 +1145,10 @@ def main(argv=None):
             "value": r6["value"], "unit": "recon/s", "ms_per_step": r6["ms_per_step"],
             "passes": r6["passes"], "points_per_recon": r6["points"] / args.steps,
             "roofline_frac": r6["roof"]["achieved"] / (2500.0 / 2), "roofline_peak_tflops": 2500.0 / 2,
+            "roofline_frac_of_f16_dense_peak": r6["roof"]["achieved"] / 2500.0,
+            "roofline_traffic": traffic_from_profile("f16w", 6, False, pick_batch(args.steps, args.batch or 16)),
+            "roofline_traffic_source": "profiles/%s (memory side; the same file holds the L1 -> L2 request counts: the "
+                                       "kernel is bound by the weight stream out of L2, 26 KB per point)" % TRAFFIC_PROFILE_513_F16W,
             "iou_vs_f32_volume": inter / max(union, 1),
             "max_abs_diff_vs_f32_volume": (vol32 - v16).abs().max().item(),
             "same_points_per_level": bool(torch.equal(st32.cpu(), s6.status[0].cpu()))}

@@ -102,6 +102,20 @@ for b,d in by.items():
     print(b,"frames/launch: avg %.3f GB per launch; per level (GB):"%(d["bytes_per_launch_avg"]/1e9),[round(x/1e9,3) for x in d["bytes_per_level_launch"]], "WRITE KB", [round(x) for x in d["WRITE_SIZE_per_level"]])
 PY
   ;;
+traffic16)  # configs[4] (513^3, fp16 weights): memory-side bytes and L1 -> L2 requests of pifu_query16_kernel per level
+  cd /tmp && export TMPDIR=/tmp MONOPORT_TRAFFIC_BATCH=16 MONOPORT_TRAFFIC_LEVELS=6 MONOPORT_TRAFFIC_PRECISION=f16w
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python $R/tools/traffic_probe.py run > $out/pmc_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python $R/tools/traffic_probe.py run > $out/pmc_write.log 2>&1
+  rocprofv3 --pmc TCP_TCC_READ_REQ_sum --output-format csv -d $out/pmc_l2req -- python $R/tools/traffic_probe.py run > $out/pmc_l2req.log 2>&1
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_l2hit -- python $R/tools/traffic_probe.py run > $out/pmc_l2hit.log 2>&1
+  cd $R
+  python tools/traffic_probe.py parse $out/pmc_fetch $out/pmc_write $out/r05_query_traffic_513_f16w.json > $out/parse.log 2>&1; tail -3 $out/parse.log
+  python tools/traffic_probe.py counter $out/pmc_l2req TCP_TCC_READ_REQ_sum $out/l2req.json
+  python tools/traffic_probe.py counter $out/pmc_l2hit TCC_HIT_sum $out/l2hit.json
+  python tools/traffic_probe.py counter $out/pmc_l2hit TCC_MISS_sum $out/l2miss.json
+  tail -2 $out/pmc_fetch.log | cut -c1-200
+  rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_l2req $out/pmc_l2hit
+  ;;
 dropin)
   timeout 900 python bench.py --mode dropin > $out/dropin.json 2> $out/dropin.err; tail -c 300 $out/dropin.err
   python - $out/dropin.json <<'PY'

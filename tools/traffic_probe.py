@@ -19,7 +19,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # frames per slot submission / launch: MONOPORT_TRAFFIC_BATCH (bench.py: 16 by default, 20 at the driver's --steps 20)
-BATCH, LEVELS = int(os.environ.get("MONOPORT_TRAFFIC_BATCH", "16")), 5
+BATCH = int(os.environ.get("MONOPORT_TRAFFIC_BATCH", "16"))
+# MONOPORT_TRAFFIC_LEVELS=6 MONOPORT_TRAFFIC_PRECISION=f16w: BASELINE configs[4] (513^3, fp16 weights: pifu_query16_kernel)
+LEVELS = int(os.environ.get("MONOPORT_TRAFFIC_LEVELS", "5"))
+PRECISION = os.environ.get("MONOPORT_TRAFFIC_PRECISION", "f32")
 
 
 def run():
@@ -28,7 +31,8 @@ def run():
     from monoport_amd import synthetic as syn
     from monoport_amd.recon import pifu_calib
     dev = torch.device("cuda", 0)
-    pipe = bench.make_pipeline(dev, 1, False, None, False, "f32", BATCH)
+    res = bench.RESOLUTIONS + ([513] if LEVELS == 6 else [])
+    pipe = bench.make_pipeline(dev, 1, False, res, False, PRECISION, BATCH)
     images = [torch.from_numpy(syn.synthetic_image(s))[None].to(dev) for s in range(BATCH)]
     for k in range(2):
         calibs = [pifu_calib(*syn.scene_camera(3 * (BATCH * k + b)), device=dev) for b in range(BATCH)]
@@ -45,8 +49,9 @@ def counter_rows(directory, counter):
             for r in csv.DictReader(f):
                 name = r["Kernel_Name"]
                 if r["Counter_Name"] == counter and ("pifu_query_tab" in name or "pifu_query_t32_kernel" in name
-                                                     or "pifu_query_kernel" in name):
-                    rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), "t32" in name or "tab" in name))
+                                                     or "pifu_query_kernel" in name or "pifu_query16" in name):
+                    rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]),
+                                 "t32" in name or "tab" in name or "pifu_query16" in name))
     rows.sort()
     # with the skip tables (default) every level is ONE dispatch of the table kernel per chunk of <= 32 frames
     # (kMaxFrames; the chunks of a level are added up); on the plain path
@@ -77,6 +82,17 @@ def counter_rows(directory, counter):
     return out
 
 
+def parse_counter(directory, counter, out_path):
+    """Any other per-launch counter of the same workload (e.g. TCP_TCC_READ_REQ_sum: the requests the L1s send to
+    the L2s -- the weight stream of the f16 kernels): per-level mean of the last two batches, raw counts."""
+    vals = counter_rows(directory, counter)
+    per_level = [(vals[l] + vals[LEVELS + l]) / 2 for l in range(LEVELS)]
+    out = {"counter": counter, "slot_batch": BATCH, "levels": LEVELS, "precision": PRECISION, "per_level": per_level}
+    with open(out_path, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+
+
 def parse(fetch_dir, write_dir, out_path):
     fetch = counter_rows(fetch_dir, "FETCH_SIZE")
     write = counter_rows(write_dir, "WRITE_SIZE")
@@ -95,7 +111,7 @@ def parse(fetch_dir, write_dir, out_path):
         "WRITE_SIZE_per_level": per_level_write,
         "correction": "FETCH_SIZE doubled (128-B requests tallied at 64 B for 16 B/lane coalesced "
                       "reads on gfx950), WRITE_SIZE as is",
-        "slot_batch": BATCH,
+        "slot_batch": BATCH, "levels": LEVELS, "precision": PRECISION,
         "launches_per_level": (BATCH + 31) // 32,
         "bytes_per_launch_avg": sum(bytes_level) / (LEVELS * ((BATCH + 31) // 32)),
         "bytes_per_level_launch": bytes_level,
@@ -108,5 +124,7 @@ def parse(fetch_dir, write_dir, out_path):
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run()
+    elif sys.argv[1] == "counter":
+        parse_counter(*sys.argv[2:5])
     else:
         parse(*sys.argv[2:5])
