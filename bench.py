@@ -643,7 +643,7 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
         def vertices_one(d):
             return {**d, **dict(zip(["X", "Y", "Z", "norm"], forward_vertices(d["sdf"], direction="front")))}
 
-        wrap = ((lambda one, many, name: Coalesced(logged(name, one), logged(name, many), max_batch=CO_BATCH)) if coalesce
+        wrap = ((lambda one, many, name: Coalesced(logged(name, one), logged(name, many), max_batch=CO_BATCH, max_pending=CO_PENDING)) if coalesce
                 else (lambda one, many, name: logged(name, one)))
         return [
             lambda data: {"input": data.to(device, non_blocking=True)},                    # main.py:327
@@ -660,7 +660,8 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
         ]
 
     # coalescing stages: frames served per call at most / frames in flight (MONOPORT_DROPIN_COALESCE="batch,in_flight")
-    CO_BATCH, CO_IN_FLIGHT = (int(v) for v in os.environ.get("MONOPORT_DROPIN_COALESCE", "16,48").split(","))
+    # + batches of a stage in flight on the GPU at once (Coalesced(max_pending=...), 0 = unthrottled)
+    CO_BATCH, CO_IN_FLIGHT, CO_PENDING = (int(v) for v in (os.environ.get("MONOPORT_DROPIN_COALESCE", "16,48,1") + ",1").split(",")[:3])
     frames = []
     for i in range(N_IMAGES):
         img = torch.from_numpy(syn.synthetic_image(i))

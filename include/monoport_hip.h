@@ -506,6 +506,63 @@ int mp_upsample_bicubic2x_gn(mp_ctx *ctx, const float *x, int n, int c, int h, i
 int mp_gn_apply(mp_ctx *ctx, const float *x, const mp_gn_in *gn, int relu, int n, int c, int64_t hw,
                 const float *res, float *y, const mp_gn_out *fin, mp_stream stream);
 
+/* ---- recorded launch sequences ------------------------------------------------------------------
+ * The reference calls netG.filter once per frame from a stage thread (RTL/main.py:366-370): here that is ~137
+ * launches of the entry points above.  A PLAN is that sequence recorded once -- the same argument structs, in
+ * order, each with the stream slot it ran on -- and replayed by ONE call: no host interpreter between the
+ * launches.  The recorder owns every buffer (inputs, intermediates, outputs: static for the life of the plan,
+ * copy in and out around mp_plan_run); the plan stores pointers only.  Slot 0 is the stream passed to
+ * mp_plan_run; slots 1..n_side_streams are streams the plan creates (the hourglass's skip branches run on side
+ * streams at batch <= 2); MP_PLAN_WAIT makes one slot wait for the work enqueued so far on another.  Replays of
+ * one plan must be ordered on one stream (its buffers are static).  mp_plan_run returns the first failing
+ * command's status (mp_last_error). */
+typedef struct mp_plan mp_plan;
+enum {
+  MP_PLAN_CONVK = 1,      /* args: mp_convk_args            -> mp_convk */
+  MP_PLAN_GN_APPLY = 2,   /* args: mp_plan_gn_apply_args    -> mp_gn_apply */
+  MP_PLAN_CONV3X3 = 3,    /* args: mp_conv3x3_args          -> mp_conv3x3_ex */
+  MP_PLAN_CONV1X1 = 4,    /* args: mp_conv1x1_args          -> mp_conv1x1_ex */
+  MP_PLAN_AVGPOOL2 = 5,   /* args: mp_plan_pool_args        -> mp_avgpool2_gn */
+  MP_PLAN_UPSAMPLE2X = 6, /* args: mp_plan_upsample_args    -> mp_upsample_bicubic2x_gn */
+  MP_PLAN_MEMSET = 7,     /* args: mp_plan_memset_args      -> hipMemsetAsync (the GroupNorm accumulator arena) */
+  MP_PLAN_WAIT = 8        /* args: mp_plan_wait_args        -> event record on one slot, wait on another */
+};
+typedef struct mp_plan_gn_apply_args {
+  const float *x;
+  mp_gn_in gn;
+  int relu, n, c;
+  int64_t hw;
+  const float *res;
+  float *y;
+  mp_gn_out fin;
+} mp_plan_gn_apply_args;
+typedef struct mp_plan_pool_args {
+  const float *x;
+  int n, c, h, w;
+  float *y;
+  mp_gn_out fin;
+} mp_plan_pool_args;
+typedef struct mp_plan_upsample_args {
+  const float *x;
+  int n, c, h, w;
+  const float *add;
+  float *y;
+  mp_gn_out fin;
+} mp_plan_upsample_args;
+typedef struct mp_plan_memset_args {
+  void *ptr;
+  int64_t bytes;
+  int value;
+} mp_plan_memset_args;
+typedef struct mp_plan_wait_args {
+  int waiter_slot, signaller_slot;
+} mp_plan_wait_args;
+int mp_plan_create(mp_ctx *ctx, int n_side_streams, mp_plan **out);
+int mp_plan_add(mp_plan *plan, int kind, const void *args, int64_t bytes, int stream_slot);
+int mp_plan_size(mp_plan *plan);
+int mp_plan_run(mp_plan *plan, mp_stream stream);
+void mp_plan_destroy(mp_plan *plan); /* drains and destroys the plan's side streams */
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Brackets every fused-query kernel launch made through this context with a pair of HIP events
  * recorded on the launch stream (bench.py's roofline leg).  mp_profile_end waits for the last

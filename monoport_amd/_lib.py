@@ -51,6 +51,36 @@ class ConvKArgs(ctypes.Structure):
                 ("ks", c_int), ("stride", c_int), ("y", c_vp), ("fin", GnOut)]
 
 
+class PlanGnApplyArgs(ctypes.Structure):
+    """mp_plan_gn_apply_args"""
+    _fields_ = [("x", c_vp), ("gn", GnIn), ("relu", c_int), ("n", c_int), ("c", c_int), ("hw", c_i64),
+                ("res", c_vp), ("y", c_vp), ("fin", GnOut)]
+
+
+class PlanPoolArgs(ctypes.Structure):
+    """mp_plan_pool_args"""
+    _fields_ = [("x", c_vp), ("n", c_int), ("c", c_int), ("h", c_int), ("w", c_int), ("y", c_vp), ("fin", GnOut)]
+
+
+class PlanUpsampleArgs(ctypes.Structure):
+    """mp_plan_upsample_args"""
+    _fields_ = [("x", c_vp), ("n", c_int), ("c", c_int), ("h", c_int), ("w", c_int), ("add", c_vp), ("y", c_vp),
+                ("fin", GnOut)]
+
+
+class PlanMemsetArgs(ctypes.Structure):
+    """mp_plan_memset_args"""
+    _fields_ = [("ptr", c_vp), ("bytes", c_i64), ("value", c_int)]
+
+
+class PlanWaitArgs(ctypes.Structure):
+    """mp_plan_wait_args"""
+    _fields_ = [("waiter_slot", c_int), ("signaller_slot", c_int)]
+
+
+# MP_PLAN_* command kinds (include/monoport_hip.h)
+PLAN_CONVK, PLAN_GN_APPLY, PLAN_CONV3X3, PLAN_CONV1X1, PLAN_AVGPOOL2, PLAN_UPSAMPLE2X, PLAN_MEMSET, PLAN_WAIT = range(1, 9)
+
 # name -> (restype, argtypes); kept in one table so tests can check the exported surface against
 # the header (tests/test_abi.py)
 SIGNATURES = {
@@ -134,6 +164,11 @@ SIGNATURES = {
                                          ctypes.POINTER(GnOut), c_vp]),
     "mp_gn_apply": (c_int, [c_vp, c_vp, ctypes.POINTER(GnIn), c_int, c_int, c_int, c_i64, c_vp, c_vp,
                             ctypes.POINTER(GnOut), c_vp]),
+    "mp_plan_create": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp)]),
+    "mp_plan_add": (c_int, [c_vp, c_int, c_vp, c_i64, c_int]),
+    "mp_plan_size": (c_int, [c_vp]),
+    "mp_plan_run": (c_int, [c_vp, c_vp]),
+    "mp_plan_destroy": (None, [c_vp]),
     "mp_profile_begin": (c_int, [c_vp, c_int]),
     "mp_profile_end": (c_int, [c_vp, _pf32, c_int, _pint]),
 }

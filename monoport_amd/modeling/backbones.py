@@ -140,6 +140,21 @@ ENCODER_GRAPH = os.environ.get("MONOPORT_ENCODER_GRAPH", "off")
 # "on" (default): at small batches (latency mode: a drop-in netG.filter(image) call) the skip branch of
 # every hourglass level runs on a side stream next to the low-resolution chain; larger batches and
 # hipGraph captures stay on one stream (the chip is full, and parallel graph branches measured slower)
+# A drop-in encoder call at batch <= ENCODER_PLAN_MAX_BATCH can record its launches once per (shape, flags,
+# stream) into an mp_plan (csrc/plan.hip: the same C-ABI calls with the same argument structs, side streams and
+# joins included) and replay them with ONE foreign call per frame: 0.7-1.0 ms of host time instead of 2.5-3.4 ms,
+# and the interpreter re-acquires its global lock once instead of 137 times.  Outputs are copied out of the plan's
+# static buffers (ordinary tensors that outlive the call, RTL/dataloader.py:1048-1054).  Measured (round 5,
+# tools/enc_plan_probe.py, profiles/r05d_encoder_plan.txt): the GPU is no faster for it -- 3.2-3.4 ms per call back
+# to back either way, and a lone call even 0.1-0.4 ms SLOWER (with every launch queued at once the skip branch's
+# large convolutions compete with the long chain of small ones on the critical path) -- so it pays exactly where the
+# host is the bottleneck: in a per-frame stage thread of a StagePipeline, next to seven other threads that want the
+# interpreter (118-125 -> 130-133 recon/s).  A coalescing stage wants the opposite (its batches form while the
+# stage is busy: 158 -> 146 with plans), and a caller that runs the stages one after the other in one thread has
+# no contention to remove.  Hence the default "auto": plans only in per-frame StagePipeline stage threads;
+# "on": every call at the batch bound; "off": never.
+ENCODER_PLAN = os.environ.get("MONOPORT_ENCODER_PLAN", "auto")
+ENCODER_PLAN_MAX_BATCH = int(os.environ.get("MONOPORT_ENCODER_PLAN_MAX_BATCH", "2"))
 ENCODER_BRANCHES = os.environ.get("MONOPORT_ENCODER_BRANCHES", "on")
 ENCODER_BRANCH_MAX_BATCH = int(os.environ.get("MONOPORT_ENCODER_BRANCH_MAX_BATCH", "2"))
 ENCODER_GRAPH_MAX_BATCH = int(os.environ.get("MONOPORT_ENCODER_GRAPH_MAX_BATCH", "4"))
@@ -195,6 +210,70 @@ class _GraphedForward:
             x_static.copy_(x)
             graph.replay()
             return tuple(None if o is None else o.clone() for o in outs)
+
+
+# "on" (default): the pass a plan is recorded from allocates out of a PRIVATE allocator pool (torch.cuda.MemPool)
+# and keeps no reference to its intermediates, so the caching allocator recycles blocks inside the pass exactly
+# as it does launch by launch (~200 MB per image instead of ~1 GB of separately-held intermediates) and nobody
+# else is ever handed those blocks.  "off": every intermediate stays alive on its own.  Speed is the same either
+# way (measured: single-frame latency 8.15 / 8.19 ms): the pool is about memory, not about cache locality.
+ENCODER_PLAN_POOL = os.environ.get("MONOPORT_ENCODER_PLAN_POOL", "on")
+
+
+class _PlannedForward:
+    """Per-module cache of recorded forwards: key -> (plan, static input, static outputs)."""
+
+    MAX_ENTRIES = 6  # (shape, flags, stream) combinations kept
+
+    def __init__(self):
+        self.entries = {}
+        self.lock = threading.Lock()
+
+    @staticmethod
+    def _record(x, fn):
+        use_pool = ENCODER_PLAN_POOL == "on" and hasattr(torch.cuda, "MemPool")
+        if not use_pool:
+            x_static = x.clone()
+            with ops.record_plan(x.device, keep_alive=True) as rec:
+                outs = fn(x_static)
+            return rec.finish(), x_static, outs, None
+        fn(x)  # launch by launch once, OUTSIDE the pool: weight packs, scratch arenas, side streams
+        pool = torch.cuda.MemPool()
+        with torch.cuda.use_mem_pool(pool, device=x.device):
+            x_static = x.clone()
+            # Recycling inside the pass is safe under replay: a block is handed out again on the stream it was
+            # allocated on, behind its last use in that stream's order; a use on another stream is followed by
+            # a join (ops.plan_wait) before the owner stream runs on -- and a replay keeps both orders.
+            with ops.record_plan(x.device, keep_alive=False) as rec:
+                outs = fn(x_static)
+        return rec.finish(), x_static, outs, pool
+
+    def run(self, key, x, fn):
+        """fn(x_static) -> flat tuple of tensors / None.  Returns fresh copies of the outputs."""
+        with self.lock:
+            entry = self.entries.get(key)
+            if entry is None:
+                plan, x_static, outs, pool = self._record(x, fn)  # a real pass: its results are this call's results
+                while len(self.entries) >= self.MAX_ENTRIES:
+                    self.entries.pop(next(iter(self.entries)))
+                self.entries[key] = (plan, x_static, outs, pool)
+            else:
+                self.entries[key] = self.entries.pop(key)  # most recently used last
+                plan, x_static, outs, _ = entry
+                x_static.copy_(x)
+                plan.run(x.device)
+            return tuple(None if o is None else o.clone() for o in outs)
+
+
+def _plan_wanted(x):
+    if ENCODER_PLAN == "auto":
+        from ..stage_pipeline import stage_kind
+        if stage_kind() != "stage":
+            return False
+    elif ENCODER_PLAN != "on":
+        return False
+    return (x.shape[0] <= ENCODER_PLAN_MAX_BATCH and not torch.cuda.is_current_stream_capturing()
+            and ops._recording() is None)
 
 
 def _graph_wanted(x, graphed):
@@ -362,12 +441,12 @@ class HourGlass(nn.Module):
             # high-priority side stream, skip filling in -- measured no gain (3.97 vs 3.84 ms at batch
             # 1): the host needs ~1 ms to enqueue the chain before the skip branch would even start
             cur = torch.cuda.current_stream(x.device)
-            side.wait_stream(cur)  # x and its statistics are complete on cur's timeline
+            ops.plan_wait(side, cur)  # side.wait_stream(cur): x and its statistics are complete on cur's timeline
             with torch.cuda.stream(side):
                 skip, _ = _block_dataflow(b1, x, acc_x, arena)
             x.record_stream(side)
             y, acc_u = self._low_chain(level, x, arena, sides)
-            cur.wait_stream(side)
+            ops.plan_wait(cur, side)
             skip.record_stream(cur)
         return ops.upsample_add_gn(y, skip, acc_u), acc_u
 
@@ -523,11 +602,15 @@ class HGFilter(nn.Module):
         ``graphed``: replay the kernel chain as one hipGraph (None = the ENCODER_GRAPH policy)."""
         if self._dataflow_ok(x):
             x = x.contiguous()
-            if not _graph_wanted(x, graphed):
+            planned = graphed is None and _plan_wanted(x) and not _graph_wanted(x, None)
+            if not planned and not _graph_wanted(x, graphed):
                 return self._forward_dataflow(x, last_only, hwc_out, keep_nchw)
-            cache = self.__dict__.setdefault("_graphs", _GraphedForward())
+            cache = (self.__dict__.setdefault("_plans", _PlannedForward()) if planned
+                     else self.__dict__.setdefault("_graphs", _GraphedForward()))
             key = (tuple(x.shape), str(x.device), bool(last_only), hwc_out is not None, bool(keep_nchw),
                    ENCODER_CONV_PRECISION, _GraphedForward.fingerprint(self))
+            if planned:  # a plan's buffers are static: one plan per stream that replays it, and per branch policy
+                key += (torch.cuda.current_stream(x.device).cuda_stream, ENCODER_BRANCHES, ENCODER_BRANCH_MAX_BATCH)
 
             def run(xs):
                 hwc = torch.empty((xs.shape[0], xs.shape[2] // 4, xs.shape[3] // 4, 256), dtype=torch.float32,

@@ -560,6 +560,91 @@ def stream_release(stream):
               "mp_stream_release")
 
 
+# ---- recorded launch sequences (mp_plan_*, csrc/plan.hip) --------------------------------------------
+_plan_tls = threading.local()
+
+
+class Plan:
+    """A recorded sequence of encoder launches (mp_plan): ``run()`` replays it on the current stream with ONE
+    foreign call.  Keeps every tensor the commands point at alive."""
+
+    def __init__(self, ctx, handle, keep, n_cmds):
+        self.ctx, self.handle, self.keep, self.n_cmds = ctx, handle, keep, n_cmds
+
+    def run(self, device):
+        st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        self.ctx.check(self.ctx.lib.mp_plan_run(self.handle, st), "mp_plan_run")
+
+    def __del__(self):
+        try:
+            self.ctx.lib.mp_plan_destroy(self.handle)
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class record_plan:
+    """Context manager (per host thread): the encoder wrappers below (convk, gn_apply, conv3x3_fused,
+    conv1x1_fused, avgpool2_gn, upsample_add_gn, GnArena, plan_wait) run normally AND append what they
+    launched to a plan; ``.finish()`` builds it.  The stream that is current on entry is slot 0, other
+    streams get slots in order of first use."""
+
+    def __init__(self, device, keep_alive=True):
+        """``keep_alive=False``: the caller guarantees the lifetime of every buffer itself (a private
+        allocator pool that outlives the plan); the plan then holds no tensor references, so the pass it is
+        recorded from recycles its intermediates as a launch-by-launch pass does."""
+        self.ctx = get_context(device)
+        self.device = torch.device(device)
+        self.keep_alive = bool(keep_alive)
+        self.cmds, self.keep = [], []
+        self.slots = {torch.cuda.current_stream(self.device).cuda_stream: 0}
+
+    def __enter__(self):
+        if getattr(_plan_tls, "rec", None) is not None:
+            raise RuntimeError("record_plan does not nest")
+        _plan_tls.rec = self
+        return self
+
+    def __exit__(self, *exc):
+        _plan_tls.rec = None
+        return False
+
+    def slot(self, stream=None):
+        h = (stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
+        if h not in self.slots:
+            self.slots[h] = len(self.slots)
+        return self.slots[h]
+
+    def add(self, kind, struct, tensors=()):
+        self.cmds.append((kind, bytes(struct), self.slot()))
+        if self.keep_alive:
+            self.keep.extend(t for t in tensors if t is not None)
+
+    def finish(self):
+        ctx = self.ctx
+        handle = ctypes.c_void_p()
+        ctx.check(ctx.lib.mp_plan_create(ctx.handle, len(self.slots) - 1, ctypes.byref(handle)), "mp_plan_create")
+        plan = Plan(ctx, handle, self.keep, len(self.cmds))
+        for kind, blob, slot in self.cmds:
+            buf = ctypes.create_string_buffer(blob, len(blob))
+            ctx.check(ctx.lib.mp_plan_add(handle, kind, ctypes.cast(buf, ctypes.c_void_p), len(blob), slot),
+                      "mp_plan_add")
+        return plan
+
+
+def _recording():
+    return getattr(_plan_tls, "rec", None)
+
+
+def plan_wait(waiter, signaller):
+    """``waiter.wait_stream(signaller)`` (torch streams) that a plan being recorded remembers."""
+    waiter.wait_stream(signaller)
+    rec = _recording()
+    if rec is not None:
+        w = _lib.PlanWaitArgs()
+        w.waiter_slot, w.signaller_slot = rec.slot(waiter), rec.slot(signaller)
+        rec.cmds.append((_lib.PLAN_WAIT, bytes(w), 0))
+
+
 def forward_vertices_raw(volume, direction="front"):
     """mp_forward_vertices: returns capacity-sized (X, Y, Z, norm, count) device tensors."""
     vol = volume
@@ -888,6 +973,11 @@ class GnArena:
     def __init__(self, device, n, slots):
         self.buf = gn_acc_zeros(device, n, slots)
         self.used = 0
+        rec = _recording()
+        if rec is not None:  # a replay clears the same arena again
+            m = _lib.PlanMemsetArgs()
+            m.ptr, m.bytes, m.value = self.buf.data_ptr(), self.buf.numel() * 8, 0
+            rec.add(_lib.PLAN_MEMSET, m, [self.buf])
 
     def take(self):
         if self.used >= self.buf.shape[0]:
@@ -932,6 +1022,15 @@ def _gn_in(dst, gn, c):
     dst.eps = float(mod.eps)
 
 
+def _gn_keep(gn):
+    """Tensors a recorded command's GroupNorm input points at (accumulator; the module owns gamma / beta)."""
+    if gn is None:
+        return []
+    if torch.is_tensor(gn):
+        return [gn]
+    return [gn[0], gn[1].weight, gn[1].bias]
+
+
 def _gn_out(dst, acc):
     if acc is not None:
         assert acc.dtype == torch.int64 and acc.is_contiguous()
@@ -968,6 +1067,9 @@ def conv3x3_fused(x, gn, packed, relu=True, reflect=False, want_y=True, stats=No
     a.cout = packed.cout
     a.y = y.data_ptr() if y is not None else None
     ctx.check(ctx.lib.mp_conv3x3_ex(ctx.handle, ctypes.byref(a), _stream(x)), "mp_conv3x3_ex")
+    rec = _recording()
+    if rec is not None:
+        rec.add(_lib.PLAN_CONV3X3, a, [x, packed.data, packed.wmax, y, out, res, stats, out_stats] + _gn_keep(gn))
     return y
 
 
@@ -1002,6 +1104,9 @@ def conv1x1_fused(x1, gn1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=No
     a.y = y.data_ptr() if y is not None else None
     a.y_hwc = y_hwc.data_ptr() if y_hwc is not None else None
     ctx.check(ctx.lib.mp_conv1x1_ex(ctx.handle, ctypes.byref(a), _stream(x1)), "mp_conv1x1_ex")
+    rec = _recording()
+    if rec is not None:
+        rec.add(_lib.PLAN_CONV1X1, a, [x1, x2, res, packed.data, packed.wmax, packed.bias, y, y_hwc, stats] + _gn_keep(gn1))
     return y
 
 
@@ -1044,6 +1149,9 @@ def convk(x, gn, relu, packed, stride, reflect=False, stats=None):
     a.cout, a.ks, a.stride = packed.cout, packed.ks, int(stride)
     a.y = y.data_ptr()
     ctx.check(ctx.lib.mp_convk(ctx.handle, ctypes.byref(a), _stream(x)), "mp_convk")
+    rec = _recording()
+    if rec is not None:
+        rec.add(_lib.PLAN_CONVK, a, [x, packed.data, packed.bias, y, stats] + _gn_keep(gn))
     return y
 
 
@@ -1057,6 +1165,11 @@ def avgpool2_gn(x, stats=None):
     _gn_out(fin, stats)
     ctx.check(ctx.lib.mp_avgpool2_gn(ctx.handle, _ptr(x), n, c, h, w, _ptr(y), ctypes.byref(fin), _stream(x)),
               "mp_avgpool2_gn")
+    rec = _recording()
+    if rec is not None:
+        a = _lib.PlanPoolArgs()
+        a.x, a.n, a.c, a.h, a.w, a.y, a.fin = x.data_ptr(), n, c, h, w, y.data_ptr(), fin
+        rec.add(_lib.PLAN_AVGPOOL2, a, [x, y, stats])
     return y
 
 
@@ -1073,6 +1186,12 @@ def upsample_add_gn(x, add, stats=None):
     ctx.check(ctx.lib.mp_upsample_bicubic2x_gn(ctx.handle, _ptr(x), n, c, h, w,
                                                _ptr(add) if add is not None else None, _ptr(y),
                                                ctypes.byref(fin), _stream(x)), "mp_upsample_bicubic2x_gn")
+    rec = _recording()
+    if rec is not None:
+        a = _lib.PlanUpsampleArgs()
+        a.x, a.n, a.c, a.h, a.w, a.y, a.fin = x.data_ptr(), n, c, h, w, y.data_ptr(), fin
+        a.add = add.data_ptr() if add is not None else None
+        rec.add(_lib.PLAN_UPSAMPLE2X, a, [x, add, y, stats])
     return y
 
 
@@ -1093,6 +1212,12 @@ def gn_apply(x, gn, relu=True, res=None, stats=None):
     ctx.check(ctx.lib.mp_gn_apply(ctx.handle, _ptr(x), ctypes.byref(g), int(bool(relu)), n, c, hw,
                                   _ptr(res) if res is not None else None, _ptr(y), ctypes.byref(fin),
                                   _stream(x)), "mp_gn_apply")
+    rec = _recording()
+    if rec is not None:
+        a = _lib.PlanGnApplyArgs()
+        a.x, a.gn, a.relu, a.n, a.c, a.hw, a.y, a.fin = x.data_ptr(), g, int(bool(relu)), n, c, hw, y.data_ptr(), fin
+        a.res = res.data_ptr() if res is not None else None
+        rec.add(_lib.PLAN_GN_APPLY, a, [x, res, y, stats] + _gn_keep(gn))
     return y
 
 

@@ -45,6 +45,14 @@ import threading
 import torch
 
 _END = object()
+_tls = threading.local()
+
+
+def stage_kind():
+    """What the calling host thread is: None (not a stage thread), "stage" (a per-frame stage of a StagePipeline)
+    or "coalesced" (a stage whose processor is a ``Coalesced``).  The encoders use it to decide whether a call is
+    worth replaying as a recorded plan (modeling/backbones.py: ENCODER_PLAN)."""
+    return getattr(_tls, "kind", None)
 # Stage streams are kept for the life of the process, one per (device, stage index): torch's caching
 # allocator pools memory PER STREAM, so a pipeline that made fresh streams every time it is iterated
 # would find none of the blocks its predecessor cached and go back to hipMalloc for every activation
@@ -100,8 +108,16 @@ class Coalesced:
     class CannotBatch(Exception):
         """Raised by ``fn_many`` before any side effect: serve these frames one by one through ``fn``."""
 
-    def __init__(self, fn, fn_many, max_batch=8):
+    def __init__(self, fn, fn_many, max_batch=8, max_pending=1):
+        """``max_pending``: batches of this stage that may be in flight on the GPU at once.  Before it takes
+        frames off its queue the stage waits until at most ``max_pending - 1`` of its earlier batches are
+        still running -- so batches are formed at the pace of the GPU, not of the host: a stage whose host
+        side is fast (a recorded encoder plan returns in under a millisecond) would otherwise pick every
+        frame up the moment it arrives and never see two of them together.  0 = no throttle.  Measured on the
+        reference's processors list (bench.py --mode dropin, 16 frames per call, 48 in flight): 0 / 1 / 2 / 3 ->
+        154 / 159 / 153 / 158 recon/s, +- 4 between runs; 1 ships."""
         self.fn, self.fn_many, self.max_batch = fn, fn_many, max(1, int(max_batch))
+        self.max_pending = max(0, int(max_pending))
 
     def __call__(self, item):
         return self.fn(item)
@@ -128,12 +144,14 @@ class StagePipeline:
         # pipeline would not reach the stage threads, and netG.filter -- which RTL/main.py:367-370 calls
         # undecorated -- would stay on the differentiable (MIOpen) path instead of the inference kernels
         torch.set_grad_enabled(self._grad_enabled)
+        _tls.kind = "coalesced" if isinstance(fn, Coalesced) else "stage"
         stream = None
         if self.device is not None and self.device.type == "cuda":
             torch.cuda.set_device(self.device)
             if self.use_streams:
                 stream = stage_stream(self.device, idx)
         held = None  # an item taken off the queue while coalescing that has to wait for its turn
+        pending = []  # completion events of this stage's batches that may still be running (Coalesced stages)
         while True:
             item = held if held is not None else q_in.get()
             held = None
@@ -146,6 +164,10 @@ class StagePipeline:
                 continue
             batch = [item]
             if isinstance(fn, Coalesced):  # whatever else is ALREADY waiting, up to max_batch frames
+                if fn.max_pending and stream is not None:  # ... once the GPU has room for another batch of this stage
+                    pending = [ev for ev in pending if not ev.query()]
+                    while len(pending) >= fn.max_pending:
+                        pending.pop(0).synchronize()
                 while len(batch) < fn.max_batch:
                     try:
                         nxt = q_in.get_nowait()
@@ -185,6 +207,8 @@ class StagePipeline:
                         outs.extend(run([one]))
                     except Exception:  # noqa: BLE001
                         outs.append((StageError(idx, sys.exc_info()), None))
+            if isinstance(fn, Coalesced) and outs and outs[-1][1] is not None:
+                pending.append(outs[-1][1])
             for o in outs:
                 q_out.put(o)
 

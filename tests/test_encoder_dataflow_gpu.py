@@ -338,6 +338,112 @@ def test_encoder_graph_replay_equals_eager():
         assert not torch.equal(changed[3][0], keep)
 
 
+@pytest.mark.parametrize("pool", ["on", "off"])
+@pytest.mark.parametrize("batch", [1, 2])
+def test_encoder_plan_replay_equals_eager(batch, pool, monkeypatch):
+    """The default of a drop-in netG.filter call at batch <= 2: its ~137 launches recorded once into an mp_plan
+    (csrc/plan.hip; at these batches the hourglass's skip branches run on side streams, joined by events) and
+    replayed by ONE C-ABI call.  Same bits as launch by launch, on the recording call and on every replay; the
+    returned tensors survive later calls; other images give other results; a weight update records a new plan;
+    MONOPORT_ENCODER_PLAN=off / larger batches run launch by launch."""
+    from monoport_amd.modeling import backbones
+    assert backbones.ENCODER_PLAN == "auto" and backbones.ENCODER_PLAN_MAX_BATCH >= 2 and backbones.ENCODER_PLAN_POOL == "on"
+    monkeypatch.setattr(backbones, "ENCODER_PLAN", "on")  # "auto" = only inside per-frame StagePipeline stage threads (below)
+    monkeypatch.setattr(backbones, "ENCODER_PLAN_POOL", pool)  # "on": intermediates recycled inside a private pool
+    net = _netg()
+    imgs = [torch.stack([torch.from_numpy(syn.synthetic_image(s + b)) for b in range(batch)]).to(DEV) for s in (73, 83, 93)]
+    enc = net.image_filter
+    with torch.no_grad():
+        eager = [enc(im, graphed=False) for im in imgs]
+        first = enc(imgs[0])                       # records
+        plans = enc.__dict__["_plans"].entries
+        assert len(plans) == 1
+        plan = next(iter(plans.values()))[0]
+        assert plan.n_cmds > 130
+        keep = [o[0].clone() for o in first]
+        # memory that is allocated, written and freed between replays must never be the plan's
+        junk = [torch.full((1, 256, 128, 128), float(i), device=DEV) for i in range(24)]
+        del junk
+        second = enc(imgs[1])                      # replays on another image
+        third = enc(imgs[2])
+        again = enc(imgs[0])
+        assert len(plans) == 1
+        for got, ref in ((first, eager[0]), (second, eager[1]), (third, eager[2]), (again, eager[0])):
+            assert len(got) == 4 and all(torch.equal(a[0], b[0]) for a, b in zip(got, ref))
+        assert all(torch.equal(o[0], k) for o, k in zip(first, keep))   # outputs are not the plan's buffers
+        assert not torch.equal(second[3][0], keep[3])
+        # the channels-last output and last_only through a plan of their own
+        hwc = torch.empty((batch, 128, 128, 256), device=DEV)
+        only = enc(imgs[1], last_only=True, hwc_out=hwc)
+        only2 = enc(imgs[2], last_only=True, hwc_out=hwc)
+        assert only[-1][0] is None and only2[-1][0] is None and len(plans) == 2
+        assert torch.equal(hwc, eager[2][3][0].permute(0, 2, 3, 1))
+        # the whole module API: netG.filter -> list of 4 stages
+        feats = net.filter(imgs[1])
+        assert len(feats) == 4 and torch.equal(feats[-1][0], eager[1][3][0])
+        enc.conv1.bias.add_(0.25)                  # in-place update: the fingerprint changes -> a new plan
+        changed = enc(imgs[0])
+        assert torch.equal(changed[3][0], enc(imgs[0], graphed=False)[3][0]) and not torch.equal(changed[3][0], keep[3])
+        monkeypatch.setattr(backbones, "ENCODER_PLAN", "off")
+        n = len(plans)
+        off = enc(imgs[0])
+        assert len(plans) == n and torch.equal(off[3][0], changed[3][0])
+        monkeypatch.setattr(backbones, "ENCODER_PLAN", "on")
+        big = torch.cat([imgs[0], imgs[1], imgs[2]])[:3]
+        enc(big)                                   # batch 3 > ENCODER_PLAN_MAX_BATCH: no plan
+        assert len(plans) == n
+        # the default policy: a plan in a per-frame stage thread of a StagePipeline, none in the calling thread,
+        # none in a coalescing stage
+        monkeypatch.setattr(backbones, "ENCODER_PLAN", "auto")
+        from monoport_amd.stage_pipeline import Coalesced, StagePipeline
+        enc(imgs[0])
+        assert len(plans) == n
+        seen = []
+
+        def stage(im):
+            out = enc(im)
+            seen.append(len(plans))
+            return out[3][0]
+
+        got = list(StagePipeline([imgs[0], imgs[1]], [stage], device=DEV, max_in_flight=1))
+        assert seen[-1] == n + 1 and torch.equal(got[1], enc(imgs[1], graphed=False)[3][0])
+        got = list(StagePipeline([imgs[0], imgs[1]], [Coalesced(stage, lambda ims: [stage(im) for im in ims])], device=DEV,
+                                 max_in_flight=1))
+        assert seen[-1] == n + 1 and torch.equal(got[0], enc(imgs[0], graphed=False)[3][0])
+
+
+def test_plan_api_rejects_bad_commands():
+    """mp_plan_add checks the size of every command's argument block and its stream slot."""
+    import ctypes
+    from monoport_amd import _lib, ops
+    ctx = ops.get_context(DEV)
+    handle = ctypes.c_void_p()
+    ctx.check(ctx.lib.mp_plan_create(ctx.handle, 1, ctypes.byref(handle)), "mp_plan_create")
+    try:
+        m = _lib.PlanMemsetArgs()
+        buf = torch.zeros(16, device=DEV)
+        m.ptr, m.bytes, m.value = buf.data_ptr(), 64, 0
+        blob = ctypes.create_string_buffer(bytes(m), ctypes.sizeof(m))
+        assert ctx.lib.mp_plan_add(handle, _lib.PLAN_MEMSET, ctypes.cast(blob, ctypes.c_void_p), ctypes.sizeof(m), 0) == 0
+        assert ctx.lib.mp_plan_add(handle, _lib.PLAN_MEMSET, ctypes.cast(blob, ctypes.c_void_p), 8, 0) != 0      # wrong size
+        assert ctx.lib.mp_plan_add(handle, _lib.PLAN_MEMSET, ctypes.cast(blob, ctypes.c_void_p), ctypes.sizeof(m), 5) != 0  # no such slot
+        assert ctx.lib.mp_plan_add(handle, 99, ctypes.cast(blob, ctypes.c_void_p), ctypes.sizeof(m), 0) != 0     # no such command
+        w = _lib.PlanWaitArgs()
+        w.waiter_slot, w.signaller_slot = 1, 1
+        wb = ctypes.create_string_buffer(bytes(w), ctypes.sizeof(w))
+        assert ctx.lib.mp_plan_add(handle, _lib.PLAN_WAIT, ctypes.cast(wb, ctypes.c_void_p), ctypes.sizeof(w), 0) != 0  # waits for itself
+        w.waiter_slot, w.signaller_slot = 1, 0
+        wb = ctypes.create_string_buffer(bytes(w), ctypes.sizeof(w))
+        assert ctx.lib.mp_plan_add(handle, _lib.PLAN_WAIT, ctypes.cast(wb, ctypes.c_void_p), ctypes.sizeof(w), 0) == 0
+        assert ctx.lib.mp_plan_size(handle) == 2
+        buf.fill_(1.0)
+        ctx.check(ctx.lib.mp_plan_run(handle, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "mp_plan_run")
+        torch.cuda.synchronize()
+        assert float(buf.sum()) == 0.0
+    finally:
+        ctx.lib.mp_plan_destroy(handle)
+
+
 def test_hwc_out_without_a_producing_kernel(monkeypatch):
     """hwc_out on a path that has no kernel to write it (stock convolutions): packed from the NCHW
     result instead of raising."""
