@@ -440,6 +440,113 @@ def gen_pipeline257_color(name="pipeline257_color"):
           % (margin, r[inside].mean(), r[~inside].mean(), r0, thick, float(color.min()), float(color.max()), times))
 
 
+def main_py_namespace(device="cpu"):
+    """RTL/main.py cannot be imported (cv2, flask, GL, streamer, human_inst_seg, implicit_seg at module scope), but
+    its hot-path code is plain torch: this EXECUTES the reference's own source for those pieces -- nothing is
+    restated -- by parsing the file and compiling, unchanged, the module-level statements that set up the colour
+    variables (:185-210, minus the Seg3dLossless construction), the functions ``colorization`` (:212-249) and
+    ``visulization`` (:252-281), and the two "update input by removing bg" lambdas of the processors list
+    (:352-364, found by the dict key they produce).  Returns the namespace; ``ns["lambda_input_netG"]`` /
+    ``ns["lambda_input_netC"]`` are the lambdas."""
+    import ast
+    import torch.nn.functional as F
+    from monoport.lib.modeling.geometry import orthogonal
+    path = os.path.join(REF, "RTL", "main.py")
+    src = open(path).read()
+    tree = ast.parse(src, path)
+    want_funcs = {"colorization", "visulization"}
+    want_names = {"b_min", "b_max", "resolutions", "canvas", "mat", "length", "mat_color"}
+    body = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in want_funcs:
+            body.append(node)
+        elif isinstance(node, ast.Assign):
+            t = node.targets[0]
+            name = t.id if isinstance(t, ast.Name) else t.value.id if isinstance(t, ast.Subscript) and isinstance(t.value, ast.Name) else None
+            if name in want_names:
+                body.append(node)
+    assert sum(isinstance(n, ast.FunctionDef) for n in body) == 2 and len(body) >= 2 + 9, len(body)
+    ns = {"torch": torch, "np": np, "F": F, "orthogonal": orthogonal, "cuda_color": device,
+          "mean": torch.tensor([0.5, 0.5, 0.5]).view(1, 3, 1, 1),   # cfg.netG.mean / .std (config.py:30-31), main.py:288-289
+          "std": torch.tensor([0.5, 0.5, 0.5]).view(1, 3, 1, 1)}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    found = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Lambda) and isinstance(node.body, ast.Dict):
+            for k in node.body.keys:
+                if isinstance(k, ast.Constant) and k.value in ("input_netG", "input_netC"):
+                    found[k.value] = node
+    assert set(found) == {"input_netG", "input_netC"}
+    for key, node in found.items():
+        ns["lambda_" + key] = eval(compile(ast.Expression(body=node), path, "eval"), ns)
+    return ns
+
+
+@torch.no_grad()
+def gen_main_py():
+    """SURVEY 8f row N3 and the colour closure pinned to the reference's OWN SOURCE (main_py_namespace): the two
+    input-preparation lambdas on a seeded segmentation output, ``visulization`` on the two 257^2 renders of the
+    configs[2] scene and on a seeded 129^2 render, and ``colorization`` (normal and texture branch, its own canvas
+    / mat_color globals) on that scene's vertices -- which must reproduce the renders gen_pipeline257_color built
+    from the same pieces by hand."""
+    ns = main_py_namespace()
+    store = {}
+    # --- RTL/main.py:352-364
+    rs = np.random.RandomState(101)
+    segm = rs.uniform(-1, 1, size=(1, 4, 64, 64)).astype(np.float32)
+    soft = rs.uniform(0, 1, size=(64, 64)).astype(np.float32)
+    segm[0, 3] = np.where(rs.uniform(size=(64, 64)) > 0.4, soft, 0).astype(np.float32)
+    segm[0, 3, :8] = 1.0
+    d = {"segm": torch.from_numpy(segm)}
+    for tag, (m, sd) in {"cfg": ([0.5, 0.5, 0.5], [0.5, 0.5, 0.5]), "imagenet": ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])}.items():
+        ns["mean"] = torch.tensor(m).view(1, 3, 1, 1)
+        ns["std"] = torch.tensor(sd).view(1, 3, 1, 1)
+        store["input_netG_" + tag] = ns["lambda_input_netG"](d)["input_netG"].numpy()
+    store["input_netC"] = ns["lambda_input_netC"](d)["input_netC"].numpy()
+    # --- RTL/main.py:212-249 on the configs[2] scene (needs tests/golden/pipeline257_color.npz)
+    g = np.load(os.path.join(OUT, "pipeline257_color.npz"))
+    cfg = COLOR257
+    netg, netc = ref_net("G"), ref_net("C")
+    for net, seed in ((netg, cfg["enc_g"]), (netc, cfg["enc_c"])):
+        shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
+        net.image_filter.load_state_dict(
+            {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(shapes, seed).items()})
+    load_mlp(netc, syn.rand_mlp("C", cfg["head_c"][1], cfg["head_c"][2]))
+    img_g = torch.from_numpy(syn.synthetic_image(cfg["img_g"]))[None]
+    img_c = torch.from_numpy(syn.synthetic_image(cfg["img_c"]))[None]
+    feats_c = netc.filter(img_c, feat_prior=netg.filter(img_g)[-1][-1])
+    X = torch.from_numpy(g["X"].astype(np.int64))
+    Y = torch.from_numpy(g["Y"].astype(np.int64))
+    Z, norm, calib = torch.from_numpy(g["Z"]), torch.from_numpy(g["norm"]), torch.from_numpy(g["calib"])
+    assert ns["resolutions"][-1] == 257 and tuple(ns["canvas"].shape) == (257, 257, 3)
+    render_norm = ns["colorization"](netc, None, X, Y, Z, calib, norm)
+    render_tex = ns["colorization"](netc, feats_c, X, Y, Z, calib, None)
+    assert ns["colorization"](netc, feats_c, None, None, None, calib) is None
+    same_n = bool(np.array_equal(render_norm.numpy(), g["norm_image"]))
+    same_t = float(np.abs(render_tex.numpy() - g["tex_image"]).max())
+    assert same_n and same_t == 0.0, (same_n, same_t)  # the hand-assembled renders of the fixture ARE the closure's
+    # --- RTL/main.py:252-281
+    vn, vt, vm = ns["visulization"](render_norm, render_tex)
+    store["vis_norm"], store["vis_tex"], store["vis_mask"] = vn, vt, vm
+    n2, t2, m2 = ns["visulization"](render_norm, None)
+    assert t2 is None and np.array_equal(n2, vn)
+    assert ns["visulization"](None, None) == (None, None, None)
+    small = np.ones((129, 129, 3), np.float32)
+    idx = rs.randint(0, 129, size=(3000, 2))
+    small[idx[:, 0], idx[:, 1]] = rs.rand(3000, 3).astype(np.float32)
+    s_n, _, s_m = ns["visulization"](torch.from_numpy(small), None)
+    store["vis129_in"], store["vis129_norm"], store["vis129_mask"] = small, s_n, s_m
+    store["meta"] = np.array(["RTL/main.py executed from source (oracle/gen_golden.py: main_py_namespace): lambdas "
+                              ":352-364 on segm = RandomState(101) [1,4,64,64]; colorization :212-249 on the vertices of "
+                              "pipeline257_color.npz reproduces its norm_image / tex_image exactly; visulization :252-281 of "
+                              "those two renders and of a seeded 129^2 render"])
+    np.savez_compressed(os.path.join(OUT, "main_py.npz"), segm=segm, **store)
+    print("main_py: lambdas", store["input_netG_cfg"].shape, "visulization", vn.shape, vt.shape, int(vm.sum()),
+          "foreground pixels; colorization == fixture renders:", same_n, same_t)
+
+
+
+
 def gen_obj():
     """The reference's OBJ writers (monoport/lib/mesh_util.py:223-242) on the seeded mesh: the files'
     sha256 + sizes + first lines are the fixture."""
@@ -464,7 +571,7 @@ def gen_obj():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["query", "misc", "vertices", "color", "encoders", "pipeline",
-                             "dense64", "obj", "pipeline257_color"] + sorted(PIPE257_SCENES)
+                             "dense64", "obj", "pipeline257_color", "main_py"] + sorted(PIPE257_SCENES)
     if "obj" in which:
         gen_obj()
     if "query" in which:
@@ -486,3 +593,5 @@ if __name__ == "__main__":
             gen_pipeline257(name)
     if "pipeline257_color" in which:
         gen_pipeline257_color()
+    if "main_py" in which:
+        gen_main_py()

@@ -404,6 +404,31 @@ def test_prepare_inputs_bit_exact_vs_reference_expressions():
     assert none_c is None and torch.equal(only_g, want_g)
 
 
+def test_pre_and_post_steps_vs_the_references_own_source():
+    """SURVEY 8f row N3 against REFERENCE OUTPUT: tests/golden/main_py.npz holds what RTL/main.py's own source
+    produces -- its two input-preparation lambdas (:352-364), ``visulization`` (:252-281) and ``colorization``
+    (:212-249), compiled unchanged out of the file by oracle/gen_golden.py: main_py_namespace (the module itself
+    cannot be imported) -- for a seeded segmentation output and for the renders of the configs[2] scene."""
+    from monoport_amd.recon import colorization, prepare_inputs, visulization
+    g = load_golden("main_py")
+    c = load_golden("pipeline257_color")
+    segm = torch.from_numpy(g["segm"]).to(DEV)
+    for tag, (m, sd) in {"cfg": ([0.5, 0.5, 0.5], [0.5, 0.5, 0.5]), "imagenet": ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])}.items():
+        got_g, got_c = prepare_inputs(segm, m, sd)
+        assert np.array_equal(got_g.cpu().numpy(), g["input_netG_" + tag]), tag   # bit for bit
+        assert np.array_equal(got_c.cpu().numpy(), g["input_netC"])
+    # the normal branch of colorization on the reference's vertices = the reference closure's render, bit for bit
+    X = torch.from_numpy(c["X"].astype(np.int64)).to(DEV)
+    Y = torch.from_numpy(c["Y"].astype(np.int64)).to(DEV)
+    norm = torch.from_numpy(c["norm"]).to(DEV)
+    rn = colorization(None, None, X, Y, torch.from_numpy(c["Z"]).to(DEV), torch.from_numpy(c["calib"]).to(DEV), norm)
+    assert np.array_equal(rn.cpu().numpy(), c["norm_image"])
+    vn, vt, vm = visulization(rn, torch.from_numpy(c["tex_image"]).to(DEV))
+    assert np.array_equal(vn, g["vis_norm"]) and np.array_equal(vt, g["vis_tex"]) and np.array_equal(vm, g["vis_mask"])
+    n2, t2, m2 = visulization(torch.from_numpy(g["vis129_in"]).to(DEV), None)
+    assert t2 is None and np.array_equal(n2, g["vis129_norm"]) and np.array_equal(m2, g["vis129_mask"])
+
+
 def test_bench_two_ranks_on_one_gpu():
     """bench.py's N > 1 path (rank-sharded frames, barriers, gather to rank 0, MAX-over-ranks
     timing) with two processes on this box's single GPU, launched the way the driver launched its
