@@ -394,10 +394,12 @@ def gen_pipeline257_color(name="pipeline257_color"):
     rf = res[-1]
     queried = np.zeros((rf, rf, rf), bool)
 
-    def query_func(points):  # RTL/main.py:169-183 on [3,N] numpy
-        pt = torch.from_numpy(points.T.copy())[None]
-        samples = pt.repeat(1, 1, 1).permute(0, 2, 1)
-        return netg.query(feats_g, points=samples, calibs=calib)[0][0, 0].numpy()
+    ns = main_py_namespace()
+    ns["netG"] = netg
+
+    def query_func(points):  # the reference's OWN query_func (RTL/main.py:169-183, compiled from the file) on [3,N] numpy
+        pt = torch.from_numpy(points.T.copy())[None]          # [1,N,3], what Seg3dLossless hands it
+        return ns["query_func"](pt, feats_g, calib)[0, 0].numpy()
 
     stats = []
     t3 = time.perf_counter()
@@ -444,7 +446,8 @@ def main_py_namespace(device="cpu"):
     """RTL/main.py cannot be imported (cv2, flask, GL, streamer, human_inst_seg, implicit_seg at module scope), but
     its hot-path code is plain torch: this EXECUTES the reference's own source for those pieces -- nothing is
     restated -- by parsing the file and compiling, unchanged, the module-level statements that set up the colour
-    variables (:185-210, minus the Seg3dLossless construction), the functions ``colorization`` (:212-249) and
+    variables (:185-210, minus the Seg3dLossless construction), the functions ``query_func`` (:169-183; it reads
+    the global ``netG``: set ``ns["netG"]``), ``colorization`` (:212-249) and
     ``visulization`` (:252-281), and the two "update input by removing bg" lambdas of the processors list
     (:352-364, found by the dict key they produce).  Returns the namespace; ``ns["lambda_input_netG"]`` /
     ``ns["lambda_input_netC"]`` are the lambdas."""
@@ -454,7 +457,7 @@ def main_py_namespace(device="cpu"):
     path = os.path.join(REF, "RTL", "main.py")
     src = open(path).read()
     tree = ast.parse(src, path)
-    want_funcs = {"colorization", "visulization"}
+    want_funcs = {"colorization", "visulization", "query_func"}
     want_names = {"b_min", "b_max", "resolutions", "canvas", "mat", "length", "mat_color"}
     body = []
     for node in tree.body:
@@ -465,7 +468,7 @@ def main_py_namespace(device="cpu"):
             name = t.id if isinstance(t, ast.Name) else t.value.id if isinstance(t, ast.Subscript) and isinstance(t.value, ast.Name) else None
             if name in want_names:
                 body.append(node)
-    assert sum(isinstance(n, ast.FunctionDef) for n in body) == 2 and len(body) >= 2 + 9, len(body)
+    assert sum(isinstance(n, ast.FunctionDef) for n in body) == 3 and len(body) >= 3 + 9, len(body)
     ns = {"torch": torch, "np": np, "F": F, "orthogonal": orthogonal, "cuda_color": device,
           "mean": torch.tensor([0.5, 0.5, 0.5]).view(1, 3, 1, 1),   # cfg.netG.mean / .std (config.py:30-31), main.py:288-289
           "std": torch.tensor([0.5, 0.5, 0.5]).view(1, 3, 1, 1)}
