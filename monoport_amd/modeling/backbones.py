@@ -155,6 +155,10 @@ ENCODER_GRAPH = os.environ.get("MONOPORT_ENCODER_GRAPH", "off")
 # "on": every call at the batch bound; "off": never.
 ENCODER_PLAN = os.environ.get("MONOPORT_ENCODER_PLAN", "auto")
 ENCODER_PLAN_MAX_BATCH = int(os.environ.get("MONOPORT_ENCODER_PLAN_MAX_BATCH", "2"))
+# "on" (default): with last_only (the stacks' own outputs are not asked for) stacks 0-2 hand over to the next
+# stack with ONE folded 1x1 GEMM instead of l, then [bl | al] (HGFilter._tail_packed); "off": always the reference's
+# three GEMMs
+ENCODER_FOLD_TAIL = os.environ.get("MONOPORT_ENCODER_FOLD_TAIL", "on")
 ENCODER_BRANCHES = os.environ.get("MONOPORT_ENCODER_BRANCHES", "on")
 ENCODER_BRANCH_MAX_BATCH = int(os.environ.get("MONOPORT_ENCODER_BRANCH_MAX_BATCH", "2"))
 ENCODER_GRAPH_MAX_BATCH = int(os.environ.get("MONOPORT_ENCODER_GRAPH_MAX_BATCH", "4"))
@@ -502,6 +506,19 @@ class HGFilter(nn.Module):
             if len(mods) == 4:
                 packs.append(ops.PackedConv1x1(mods[2].weight, mods[2].bias, mods[3].weight, mods[3].bias,
                                                precision=pr))
+                # bl and l read the SAME tensor y = relu(bn_end(conv_last(.))) (HGFilters.py:187-204), so when a
+                # stack's own output l(y) is not asked for (last_only: MonoPortNet.query keeps feats_stages[-1]
+                # only, MonoPortNet.py:63-64) the stack's hand-over  x + bl(y) + al(l(y))  is ONE 256 x 256 GEMM:
+                #     x + (W_bl + W_al W_l) y + (b_bl + W_al b_l + b_al)
+                # -- the l GEMM and half of the [bl | al] GEMM (4.3 of a stack's 8.6 GFLOP of 1x1 work) are gone.
+                # Folded in float64, rounded once; the result differs from the two-GEMM form by f32 rounding only
+                # (another association of the same sums: tests/test_encoder_dataflow_gpu.py::test_folded_tail_*).
+                w_l, b_l = mods[1].weight.detach().double().flatten(1), mods[1].bias.detach().double()
+                w_bl, b_bl = mods[2].weight.detach().double().flatten(1), mods[2].bias.detach().double()
+                w_al, b_al = mods[3].weight.detach().double().flatten(1), mods[3].bias.detach().double()
+                w_f = (w_bl + w_al @ w_l).float().contiguous()
+                b_f = (b_bl + w_al @ b_l + b_al).float().contiguous()
+                packs.append(ops.PackedConv1x1(w_f, b_f, precision=pr))
             hit = (key, packs)
             cache[i] = hit
         return hit[1]
@@ -584,6 +601,12 @@ class HGFilter(nn.Module):
             acc_t = arena.take()
             t = ops.conv1x1_fused(y, None, False, None, packs[0], stats=acc_t)
             bn_end = (acc_t, getattr(self, "bn_end%d" % i))
+            if not last and last_only and ENCODER_FOLD_TAIL == "on":
+                # nobody reads this stack's l(y): x + bl(y) + al(l(y)) as one folded GEMM (_tail_packed)
+                outputs.append((None,))
+                acc_x = arena.take()
+                x = ops.conv1x1_fused(t, bn_end, True, None, packs[3], res=x, stats=acc_x)
+                continue
             want_nchw = not last or keep_nchw or not (last_only and hwc_out is not None)
             out = ops.conv1x1_fused(t, bn_end, True, None, packs[1], want_nchw=want_nchw,
                                     y_hwc=hwc_out if last else None)

@@ -301,6 +301,40 @@ def test_hgfilter_dataflow_vs_reference_and_round2_path(monkeypatch, precision):
     print("HGFilter dataflow %s: full-coverage G3 block-mean error %.3g, pixel-mean error %.3g" % (precision, eb, ep))
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_folded_tail_of_unused_stacks(monkeypatch, precision):
+    """last_only (what FramePipeline asks for: MonoPortNet.query keeps feats_stages[-1] only): stacks 0-2 hand
+    over with ONE folded 1x1 GEMM, x + (W_bl + W_al W_l) y + b, instead of l and [bl | al] (HGFilters.py:187-204;
+    HGFilter._tail_packed).  The last stack's features against the REFERENCE's (every element, through the
+    8 x 8 block / pixel means of the fixture), against the three-GEMM form (another association of the same sums:
+    f32 rounding only), batch 1 and 3, channels-last output included; MONOPORT_ENCODER_FOLD_TAIL=off = the
+    three-GEMM form bit for bit."""
+    from monoport_amd.modeling import backbones
+    monkeypatch.setattr(backbones, "ENCODER_CONV_PRECISION", precision)
+    assert backbones.ENCODER_FOLD_TAIL == "on"
+    gold = load_golden("encoders")
+    net = _netg()
+    enc = net.image_filter
+    imgs = torch.stack([torch.from_numpy(syn.synthetic_image(s)) for s in (73, 74, 75)]).to(DEV)
+    with torch.no_grad():
+        full1, full3 = enc(imgs[:1], graphed=False), enc(imgs, graphed=False)      # all four outputs: nothing folded
+        fold1, fold3 = enc(imgs[:1], last_only=True, graphed=False), enc(imgs, last_only=True, graphed=False)
+        hwc = torch.empty((3, 128, 128, 256), device=DEV)
+        only = enc(imgs, last_only=True, hwc_out=hwc, graphed=False)
+        monkeypatch.setattr(backbones, "ENCODER_FOLD_TAIL", "off")
+        plain3 = enc(imgs, last_only=True, graphed=False)
+    assert len(fold1) == len(fold3) == 1 and only[-1][0] is None
+    assert torch.equal(plain3[-1][0], full3[3][0])
+    d1 = (fold1[-1][0] - full1[3][0]).abs().max().item()
+    d3 = (fold3[-1][0] - full3[3][0]).abs().max().item()
+    assert torch.equal(hwc, fold3[-1][0].permute(0, 2, 3, 1))
+    err = float(np.abs(fold1[-1][0][0, ::8, ::8, ::8].cpu().numpy() - gold["G3"]).max())
+    eb, ep = check_full_coverage(gold, "G3", fold1[-1][0][0].cpu().numpy())
+    print("folded tail %s: vs the three-GEMM form %.3g (batch 1) / %.3g (batch 3); vs the reference's G3 %.3g, "
+          "block means %.3g, pixel means %.3g" % (precision, d1, d3, err, eb, ep))
+    assert 0 < d1 <= 2e-5 and 0 < d3 <= 2e-5 and err <= 1e-4
+
+
 def test_hgfilter_dataflow_hwc_and_last_only():
     from monoport_amd import ops
     net = _netg()
