@@ -155,9 +155,9 @@ ENCODER_GRAPH = os.environ.get("MONOPORT_ENCODER_GRAPH", "off")
 # "on": every call at the batch bound; "off": never.
 ENCODER_PLAN = os.environ.get("MONOPORT_ENCODER_PLAN", "auto")
 ENCODER_PLAN_MAX_BATCH = int(os.environ.get("MONOPORT_ENCODER_PLAN_MAX_BATCH", "2"))
-# "on" (default): with last_only (the stacks' own outputs are not asked for) stacks 0-2 hand over to the next
-# stack with ONE folded 1x1 GEMM instead of l, then [bl | al] (HGFilter._tail_packed); "off": always the reference's
-# three GEMMs
+# "on" (default): stacks 0-2 hand over to the next stack with ONE folded 1x1 GEMM over y = relu(bn_end(conv_last(.)))
+# instead of [bl | al] over (y, l(y)) (HGFilter._tail_packed), and with last_only -- the stacks' own outputs are
+# not asked for -- their l GEMM is skipped altogether; "off": always the reference's three GEMMs
 ENCODER_FOLD_TAIL = os.environ.get("MONOPORT_ENCODER_FOLD_TAIL", "on")
 ENCODER_BRANCHES = os.environ.get("MONOPORT_ENCODER_BRANCHES", "on")
 ENCODER_BRANCH_MAX_BATCH = int(os.environ.get("MONOPORT_ENCODER_BRANCH_MAX_BATCH", "2"))
@@ -601,19 +601,20 @@ class HGFilter(nn.Module):
             acc_t = arena.take()
             t = ops.conv1x1_fused(y, None, False, None, packs[0], stats=acc_t)
             bn_end = (acc_t, getattr(self, "bn_end%d" % i))
-            if not last and last_only and ENCODER_FOLD_TAIL == "on":
-                # nobody reads this stack's l(y): x + bl(y) + al(l(y)) as one folded GEMM (_tail_packed)
+            fold = not last and ENCODER_FOLD_TAIL == "on"
+            if fold and last_only:  # nobody reads this stack's l(y)
                 outputs.append((None,))
-                acc_x = arena.take()
-                x = ops.conv1x1_fused(t, bn_end, True, None, packs[3], res=x, stats=acc_x)
-                continue
-            want_nchw = not last or keep_nchw or not (last_only and hwc_out is not None)
-            out = ops.conv1x1_fused(t, bn_end, True, None, packs[1], want_nchw=want_nchw,
-                                    y_hwc=hwc_out if last else None)
-            outputs.append((out,))
+            else:
+                want_nchw = not last or keep_nchw or not (last_only and hwc_out is not None)
+                out = ops.conv1x1_fused(t, bn_end, True, None, packs[1], want_nchw=want_nchw,
+                                        y_hwc=hwc_out if last else None)
+                outputs.append((out,))
             if not last:
                 acc_x = arena.take()
-                x = ops.conv1x1_fused(t, bn_end, True, out, packs[2], res=x, stats=acc_x)
+                if fold:  # x + bl(y) + al(l(y)) as ONE folded GEMM over y (_tail_packed)
+                    x = ops.conv1x1_fused(t, bn_end, True, None, packs[3], res=x, stats=acc_x)
+                else:
+                    x = ops.conv1x1_fused(t, bn_end, True, out, packs[2], res=x, stats=acc_x)
         return outputs[-1:] if last_only else outputs
 
     def forward(self, x, last_only=False, hwc_out=None, keep_nchw=False, graphed=None):

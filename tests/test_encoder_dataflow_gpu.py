@@ -317,14 +317,18 @@ def test_folded_tail_of_unused_stacks(monkeypatch, precision):
     enc = net.image_filter
     imgs = torch.stack([torch.from_numpy(syn.synthetic_image(s)) for s in (73, 74, 75)]).to(DEV)
     with torch.no_grad():
-        full1, full3 = enc(imgs[:1], graphed=False), enc(imgs, graphed=False)      # all four outputs: nothing folded
+        all3 = enc(imgs, graphed=False)            # all four outputs asked for: l computed, hand-over folded
         fold1, fold3 = enc(imgs[:1], last_only=True, graphed=False), enc(imgs, last_only=True, graphed=False)
         hwc = torch.empty((3, 128, 128, 256), device=DEV)
         only = enc(imgs, last_only=True, hwc_out=hwc, graphed=False)
         monkeypatch.setattr(backbones, "ENCODER_FOLD_TAIL", "off")
+        full1, full3 = enc(imgs[:1], graphed=False), enc(imgs, graphed=False)      # the reference's three GEMMs
         plain3 = enc(imgs, last_only=True, graphed=False)
     assert len(fold1) == len(fold3) == 1 and only[-1][0] is None
     assert torch.equal(plain3[-1][0], full3[3][0])
+    assert torch.equal(all3[3][0], fold3[-1][0]) and torch.equal(all3[0][0], full3[0][0])  # same hand-over; stack 0's l(y) untouched
+    for i in range(1, 4):
+        assert 0 < (all3[i][0] - full3[i][0]).abs().max().item() <= 2e-5
     d1 = (fold1[-1][0] - full1[3][0]).abs().max().item()
     d3 = (fold3[-1][0] - full3[3][0]).abs().max().item()
     assert torch.equal(hwc, fold3[-1][0].permute(0, 2, 3, 1))
