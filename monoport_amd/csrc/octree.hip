@@ -51,9 +51,26 @@ size_t recon_scratch_bytes(const int *res, int n_levels) {
   return total + 4096;
 }
 
+// The housekeeping kernels of a level serve ALL frames of a batch in one launch (blockIdx.z = frame; round 5: per
+// frame they were 40-odd launches of 3-25 us between two query launches, each too small to fill the chip): the
+// per-frame pointers travel by value.
+struct FrameBufs {
+  const float *prev[kMaxFrames];   // previous level's volume
+  float *cur[kMaxFrames];          // this level's volume
+  u64 *bnd[kMaxFrames];            // boundary flags of this level
+  const u64 *ev_prev[kMaxFrames];  // evaluated bits of the previous level
+  u64 *ev[kMaxFrames];             // evaluated bits of this level
+  uint32_t *packed[kMaxFrames];    // point list
+  int32_t *count[kMaxFrames];      // its length (device side)
+  int32_t *flag[kMaxFrames];       // level 0: "anything above the threshold" (status[0])
+};
+static_assert(sizeof(FrameBufs) <= 2048 + 64, "kernel argument");
+
 // ---- level 0 ---------------------------------------------------------------------------------
-__global__ void iota_nodes_kernel(int r, uint32_t *__restrict__ packed, u64 *__restrict__ ev,
-                                  int w64, int32_t *__restrict__ count, int y_major) {
+__global__ void iota_nodes_kernel(int r, FrameBufs fb, int w64, int y_major) {
+  uint32_t *__restrict__ packed = fb.packed[blockIdx.z];
+  u64 *__restrict__ ev = fb.ev[blockIdx.z];
+  int32_t *__restrict__ count = fb.count[blockIdx.z];
   const int total = r * r * r;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t == 0) *count = total;
@@ -69,8 +86,9 @@ __global__ void iota_nodes_kernel(int r, uint32_t *__restrict__ packed, u64 *__r
   }
 }
 
-__global__ void any_above_kernel(const float *__restrict__ occ, int n, float balance,
-                                 int32_t *__restrict__ flag) {
+__global__ void any_above_kernel(FrameBufs fb, int n, float balance) {
+  const float *__restrict__ occ = fb.cur[blockIdx.z];
+  int32_t *__restrict__ flag = fb.flag[blockIdx.z];
   int hit = 0;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
     hit |= occ[t] > balance;
@@ -101,10 +119,11 @@ __device__ __forceinline__ bool boundary_flag(int in, int all, int rule) {
   return rule == 0 ? (in > 0 && in < all) : rule == 1 ? (2 * in == all) : false;
 }
 
-__global__ __launch_bounds__(256) void upsample_classify_kernel(const float *__restrict__ prev,
-                                                                int rp, float *__restrict__ cur,
-                                                                int r, float balance,
-                                                                u64 *__restrict__ bnd, int w64, int rule) {
+__global__ __launch_bounds__(256) void upsample_classify_kernel(FrameBufs fb, int rp, int r, float balance,
+                                                                int w64, int rule) {
+  const float *__restrict__ prev = fb.prev[blockIdx.z];
+  float *__restrict__ cur = fb.cur[blockIdx.z];
+  u64 *__restrict__ bnd = fb.bnd[blockIdx.z];
   const int lane = threadIdx.x & 63;
   const int wpx = (rp + 63) >> 6;  // waves per parent row
   const unsigned plane_item = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -196,10 +215,12 @@ static bool octree_y_major() {
 }
 
 template <int D, bool YMAJOR>
-__global__ __launch_bounds__(256) void select_compact_kernel(
-    const u64 *__restrict__ bnd, const u64 *__restrict__ ev_prev, int rp, int w64p,
-    u64 *__restrict__ ev, int r, int w64, uint32_t *__restrict__ packed,
-    int32_t *__restrict__ count) {
+__global__ __launch_bounds__(256) void select_compact_kernel(FrameBufs fb, int rp, int w64p, int r, int w64) {
+  const u64 *__restrict__ bnd = fb.bnd[blockIdx.z];
+  const u64 *__restrict__ ev_prev = fb.ev_prev[blockIdx.z];
+  u64 *__restrict__ ev = fb.ev[blockIdx.z];
+  uint32_t *__restrict__ packed = fb.packed[blockIdx.z];
+  int32_t *__restrict__ count = fb.count[blockIdx.z];
   // items: z-major r * r * w64; slab order ceil(r / kYSlab) * kYSlab * r * w64 (rows past r are empty)
   const unsigned n_items = (unsigned)((YMAJOR ? (r + kYSlab - 1) / kYSlab * kYSlab : r) * r * w64);  // <= 1024 * 1023 * 16
   const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,18 +302,17 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
 
 // 9^3, 7^3, 3^3 boxes at levels 1, 2, 3+ (the upstream engine's "faster" schedule)
 
-static void launch_select(int box, hipStream_t st, const u64 *bnd, const u64 *ev_prev, int rp, int w64p, u64 *ev,
-                          int r, int w64, uint32_t *packed, int32_t *count) {
+static void launch_select(int box, hipStream_t st, const FrameBufs &fb, int n_frames, int rp, int w64p, int r, int w64) {
   const bool ym = octree_y_major();
   const long long items = (long long)(ym ? (r + kYSlab - 1) / kYSlab * kYSlab : r) * r * w64;
   const unsigned blocks = (unsigned)((items + 255) / 256);
-#define MP_SELECT(D)                                                                                              \
-  if (ym)                                                                                                         \
-    hipLaunchKernelGGL((select_compact_kernel<D, true>), dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp, w64p, \
-                       ev, r, w64, packed, count);                                                                \
-  else                                                                                                            \
-    hipLaunchKernelGGL((select_compact_kernel<D, false>), dim3(blocks), dim3(256), 0, st, bnd, ev_prev, rp, w64p, \
-                       ev, r, w64, packed, count)
+#define MP_SELECT(D)                                                                                           \
+  if (ym)                                                                                                      \
+    hipLaunchKernelGGL((select_compact_kernel<D, true>), dim3(blocks, 1, n_frames), dim3(256), 0, st, fb, rp, \
+                       w64p, r, w64);                                                                          \
+  else                                                                                                         \
+    hipLaunchKernelGGL((select_compact_kernel<D, false>), dim3(blocks, 1, n_frames), dim3(256), 0, st, fb, rp, \
+                       w64p, r, w64)
   if (box == 9) {
     MP_SELECT(4);
   } else if (box == 7) {
@@ -382,18 +402,26 @@ int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int
                          const u64 *ev_prev, u64 *ev_cur, u64 *bnd, int box, float balance,
                          uint32_t *packed, int32_t *count, hipStream_t st) {
   const int w64 = words64(r);
+  FrameBufs fb;
+  std::memset(&fb, 0, sizeof(fb));
+  fb.prev[0] = prev;
+  fb.cur[0] = cur;
+  fb.bnd[0] = bnd;
+  fb.ev_prev[0] = ev_prev;
+  fb.ev[0] = ev_cur;
+  fb.packed[0] = packed;
+  fb.count[0] = count;
   if (!prev) {
     const int total = r * r * r;
-    hipLaunchKernelGGL(iota_nodes_kernel, dim3((total + 255) / 256), dim3(256), 0, st, r, packed,
-                       ev_cur, w64, count, (int)octree_y_major());
+    hipLaunchKernelGGL(iota_nodes_kernel, dim3((total + 255) / 256), dim3(256), 0, st, r, fb, w64, (int)octree_y_major());
   } else {
     MP_HIP(ctx, hipMemsetAsync(count, 0, sizeof(int32_t), st));
     // box 1: the undilated "upsampled mask == 0.5" rule; box 0: upsample only (nothing selected)
     hipLaunchKernelGGL(upsample_classify_kernel,
                        dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp), dim3(256), 0,
-                       st, prev, rp, cur, r, balance, bnd, w64,
+                       st, fb, rp, r, balance, w64,
                        box == 1 ? MP_FINAL_UPSTREAM : box == 0 ? MP_FINAL_INTERPOLATE : MP_FINAL_DILATE3);
-    launch_select(box, st, bnd, ev_prev, rp, words64(rp), ev_cur, r, w64, packed, count);
+    launch_select(box, st, fb, 1, rp, words64(rp), r, w64);
   }
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
@@ -470,12 +498,17 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
     MP_HIP(ctx, hipMemsetAsync(status[f], 0, sizeof(int32_t) * (1 + n_levels), st));
   }
 
+  FrameBufs fb;
+  std::memset(&fb, 0, sizeof(fb));
   // level 0: every node of every frame, one query launch for the whole set
   {
     const int r = res[0], total = r * r * r;
     for (int f = 0; f < n_frames; ++f) {
-      hipLaunchKernelGGL(iota_nodes_kernel, dim3((total + 255) / 256), dim3(256), 0, st, r,
-                         packed[f], lv[f][0].ev, words64(r), status[f] + 1, (int)octree_y_major());
+      fb.cur[f] = lv[f][0].occ;
+      fb.ev[f] = lv[f][0].ev;
+      fb.packed[f] = packed[f];
+      fb.count[f] = status[f] + 1;
+      fb.flag[f] = status[f];
       QueryItem &q = set.it[f];
       q.out = lv[f][0].occ;
       q.src.stride = (rf - 1) / (r - 1);
@@ -483,11 +516,12 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
       q.src.n_dev = nullptr;
       q.src.n = total;
     }
+    hipLaunchKernelGGL(iota_nodes_kernel, dim3((total + 255) / 256, 1, n_frames), dim3(256), 0, st, r, fb, words64(r),
+                       (int)octree_y_major());
     int rc = launch_query_set(ctx, m, set, h, w, z_scale, (long long)total * n_frames, false, st);
     if (rc != MP_OK) return rc;
-    for (int f = 0; f < n_frames; ++f)
-      hipLaunchKernelGGL(any_above_kernel, dim3(min((total + 255) / 256, 256)), dim3(256), 0, st,
-                         lv[f][0].occ, total, balance, status[f]);
+    hipLaunchKernelGGL(any_above_kernel, dim3(min((total + 255) / 256, 256), 1, n_frames), dim3(256), 0, st, fb, total,
+                       balance);
   }
   for (int l = 1; l < n_levels; ++l) {
     const int r = res[l], rp = res[l - 1], w64 = words64(r);
@@ -495,12 +529,12 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
     // too; "upstream" evaluates only the nodes whose upsampled mask is exactly 0.5; "interpolate" none
     const int rule = l == n_levels - 1 ? final_level : MP_FINAL_DILATE3;
     for (int f = 0; f < n_frames; ++f) {
-      hipLaunchKernelGGL(upsample_classify_kernel,
-                         dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp), dim3(256),
-                         0, st, lv[f][l - 1].occ, rp, lv[f][l].occ, r, balance, lv[f][l].bnd, w64, rule);
-      if (rule == MP_FINAL_INTERPOLATE) continue;  // status[1 + l] stays 0
-      launch_select(rule == MP_FINAL_UPSTREAM ? 1 : octree_box_of_level(l), st, lv[f][l].bnd, lv[f][l - 1].ev, rp,
-                    words64(rp), lv[f][l].ev, r, w64, packed[f], status[f] + 1 + l);
+      fb.prev[f] = lv[f][l - 1].occ;
+      fb.cur[f] = lv[f][l].occ;
+      fb.bnd[f] = lv[f][l].bnd;
+      fb.ev_prev[f] = lv[f][l - 1].ev;
+      fb.ev[f] = lv[f][l].ev;
+      fb.count[f] = status[f] + 1 + l;
       QueryItem &q = set.it[f];
       q.out = lv[f][l].occ;
       q.src.stride = (rf - 1) / (r - 1);
@@ -508,7 +542,11 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
       q.src.n_dev = status[f] + 1 + l;
       q.src.n = 0;
     }
-    if (rule == MP_FINAL_INTERPOLATE) continue;
+    hipLaunchKernelGGL(upsample_classify_kernel,
+                       dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp, (unsigned)n_frames), dim3(256),
+                       0, st, fb, rp, r, balance, w64, rule);
+    if (rule == MP_FINAL_INTERPOLATE) continue;  // status[1 + l] stays 0, no query
+    launch_select(rule == MP_FINAL_UPSTREAM ? 1 : octree_box_of_level(l), st, fb, n_frames, rp, words64(rp), r, w64);
     int rc = launch_query_set(ctx, m, set, h, w, z_scale, (long long)r * r * r * n_frames, true, st);
     if (rc != MP_OK) return rc;
   }
