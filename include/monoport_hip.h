@@ -253,6 +253,13 @@ int mp_scatter_nodes(mp_ctx *ctx, const uint32_t *packed, const int32_t *count, 
 int mp_forward_vertices(mp_ctx *ctx, const float *volume, int r, int direction, int64_t *x,
                         int64_t *y, float *z, float *norm, int32_t *count, mp_stream stream);
 
+/* mp_forward_vertices over n_frames (1..32) volumes of one size in ONE set of launches (the vertex extraction of a
+ * single 257^3 volume is three launches of 65-2300 workgroups: launch-bound).  volume / x / y / z / norm / count are
+ * HOST arrays of n_frames device pointers, each as in mp_forward_vertices; results are identical to n_frames calls. */
+int mp_forward_vertices_batch(mp_ctx *ctx, int n_frames, const float *const *volume, int r, int direction,
+                              int64_t *const *x, int64_t *const *y, float *const *z, float *const *norm,
+                              int32_t *const *count, mp_stream stream);
+
 /* ---- colorization (RTL/main.py:212-249) ---------------------------------------------------- */
 /* verts = (X, Y, res - Z) mapped through the voxel->world matrix `mat` (host, row-major 4x4,
  * RTL/main.py:204-210, :231-237) -> points [3,N] for netC.query.  `count` (device int32) gives N
@@ -266,6 +273,12 @@ int mp_vertex_points(mp_ctx *ctx, const int64_t *x, const int64_t *y, const floa
 int mp_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *values,
              int channel_major, const int32_t *count, int64_t capacity, int res, float scale,
              float bias, float lo, float hi, float *image, mp_stream stream);
+
+/* mp_paint over n_frames (1..32) renders of one size in two launches; x / y / values / count / image are HOST arrays
+ * of n_frames device pointers, each as in mp_paint (one `capacity` for all). */
+int mp_paint_batch(mp_ctx *ctx, int n_frames, const int64_t *const *x, const int64_t *const *y,
+                   const float *const *values, int channel_major, const int32_t *const *count, int64_t capacity,
+                   int res, float scale, float bias, float lo, float hi, float *const *image, mp_stream stream);
 
 /* visulization (sic, RTL/main.py:252-281) for one render: out[i,j,:] = 255 * image[rot90, nearest
  * resized res -> size]; image [res,res,3] f32 in [0,1], out [size,size,3] f32, mask [size,size]

@@ -123,6 +123,9 @@ SIGNATURES = {
     "mp_lattice_points": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, _pf32, _pf32, c_vp, c_vp]),
     "mp_scatter_nodes": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "mp_forward_vertices": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mp_forward_vertices_batch": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mp_paint_batch": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_f32, c_f32, c_f32, c_f32,
+                               c_vp, c_vp]),
     "mp_vertex_points": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, _pf32, c_vp, c_vp]),
     "mp_paint": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_f32, c_f32, c_f32,
                          c_f32, c_vp, c_vp]),

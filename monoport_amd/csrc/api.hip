@@ -685,10 +685,31 @@ int mp_forward_vertices(mp_ctx *ctx, const float *volume, int r, int direction, 
     return fail(ctx, MP_ERR_ARG, "mp_forward_vertices: bad argument");
   DeviceGuard g(ctx->device);
   void *scratch = nullptr;
-  int rc = ensure_scratch(ctx, (hipStream_t)stream, (size_t)r * r * sizeof(int32_t) + ((size_t)r * r / 1024 + 2) * sizeof(int32_t) + 4096, &scratch);
+  int rc = ensure_scratch(ctx, (hipStream_t)stream, forward_vertices_scratch_bytes(r) + 4096, &scratch);
   if (rc != MP_OK) return rc;
   return launch_forward_vertices(ctx, scratch, volume, r, direction, x, y, z, norm, count,
                                  (hipStream_t)stream);
+}
+
+int mp_forward_vertices_batch(mp_ctx *ctx, int n_frames, const float *const *volume, int r, int direction,
+                              int64_t *const *x, int64_t *const *y, float *const *z, float *const *norm,
+                              int32_t *const *count, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n_frames < 1 || n_frames > kMaxFrames)
+    return fail(ctx, MP_ERR_ARG, "mp_forward_vertices_batch: 1..%d frames per call, got %d", kMaxFrames, n_frames);
+  if (!volume || !x || !y || !z || !norm || !count || r < 1 || r > 4096 || direction < MP_DIR_FRONT ||
+      direction > MP_DIR_RIGHT)
+    return fail(ctx, MP_ERR_ARG, "mp_forward_vertices_batch: bad argument");
+  for (int f = 0; f < n_frames; ++f)
+    if (!volume[f] || !x[f] || !y[f] || !z[f] || !norm[f] || !count[f])
+      return fail(ctx, MP_ERR_ARG, "mp_forward_vertices_batch: null buffer for frame %d", f);
+  DeviceGuard g(ctx->device);
+  void *scratch = nullptr;
+  int rc = ensure_scratch(ctx, (hipStream_t)stream, (size_t)n_frames * forward_vertices_scratch_bytes(r) + 4096, &scratch);
+  if (rc != MP_OK) return rc;
+  return launch_forward_vertices_batch(ctx, scratch, n_frames, volume, r, direction, x, y, z, norm, count,
+                                       (hipStream_t)stream);
 }
 
 int mp_vertex_points(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *z,
@@ -712,6 +733,23 @@ int mp_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *value
   DeviceGuard g(ctx->device);
   return launch_paint(ctx, x, y, values, channel_major, count, capacity, res, scale, bias, lo, hi,
                       image, (hipStream_t)stream);
+}
+
+int mp_paint_batch(mp_ctx *ctx, int n_frames, const int64_t *const *x, const int64_t *const *y,
+                   const float *const *values, int channel_major, const int32_t *const *count, int64_t capacity,
+                   int res, float scale, float bias, float lo, float hi, float *const *image, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n_frames < 1 || n_frames > kMaxFrames)
+    return fail(ctx, MP_ERR_ARG, "mp_paint_batch: 1..%d frames per call, got %d", kMaxFrames, n_frames);
+  if (!x || !y || !values || !count || !image || capacity < 0 || res < 1)
+    return fail(ctx, MP_ERR_ARG, "mp_paint_batch: bad argument");
+  for (int f = 0; f < n_frames; ++f)
+    if (!x[f] || !y[f] || !values[f] || !count[f] || !image[f])
+      return fail(ctx, MP_ERR_ARG, "mp_paint_batch: null buffer for frame %d", f);
+  DeviceGuard g(ctx->device);
+  return launch_paint_batch(ctx, n_frames, x, y, values, channel_major, count, capacity, res, scale, bias, lo, hi,
+                            image, (hipStream_t)stream);
 }
 
 int mp_visualize(mp_ctx *ctx, const float *image, int res, int size, float *out, uint8_t *mask,

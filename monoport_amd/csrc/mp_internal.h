@@ -269,6 +269,13 @@ int launch_scatter_nodes(mp_ctx *ctx, const uint32_t *packed, const int32_t *cou
 // vertices.hip
 int launch_forward_vertices(mp_ctx *ctx, void *scratch, const float *vol, int r, int dir, int64_t *x, int64_t *y,
                             float *z, float *norm, int32_t *count, hipStream_t st);
+size_t forward_vertices_scratch_bytes(int r);
+int launch_forward_vertices_batch(mp_ctx *ctx, void *scratch, int n_frames, const float *const *vol, int r, int dir,
+                                  int64_t *const *x, int64_t *const *y, float *const *z, float *const *norm,
+                                  int32_t *const *count, hipStream_t st);
+int launch_paint_batch(mp_ctx *ctx, int n_frames, const int64_t *const *x, const int64_t *const *y,
+                       const float *const *vals, int ch_major, const int32_t *const *count, long long cap, int res,
+                       float scale, float bias, float lo, float hi, float *const *image, hipStream_t st);
 int launch_vertex_points(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *z,
                          const int32_t *count, long long cap, int res, const float *mat16,
                          float *pts, hipStream_t st);

@@ -4,6 +4,8 @@
 // The reference materialises ten full-volume temporaries (flip, permute, ramp, max, nonzero ...);
 // here one pass walks each (x, y) column until its first occupied voxel and a single workgroup
 // turns the R*R hit map into the reference's x-major row order with a block scan.
+#include <cstring>
+
 #include "mp_internal.h"
 
 // Reference parity is op-order parity: keep every a*b+c exactly as written (the HIP headers
@@ -40,8 +42,19 @@ __device__ __forceinline__ float view_sample(const float *__restrict__ v, int r,
 constexpr int kNoHit = 0x7f7f7f7f;  // what hipMemsetAsync(0x7f) leaves behind
 constexpr int kSeg = 32;
 
-__global__ __launch_bounds__(256) void first_hit_kernel(const float *__restrict__ v, int r, int dir,
-                                                        int n_seg, int32_t *__restrict__ hit) {
+// The kernels below serve up to kMaxFrames volumes per launch (blockIdx.y = frame: mp_forward_vertices_batch; a
+// single 257^3 volume gives first_hit 2.3 k workgroups and the other two 65 each -- launch-bound).
+struct VertFrames {
+  const float *vol[kMaxFrames];
+  int64_t *x[kMaxFrames], *y[kMaxFrames];
+  float *z[kMaxFrames], *n[kMaxFrames];
+  int32_t *count[kMaxFrames];
+};
+
+__global__ __launch_bounds__(256) void first_hit_kernel(VertFrames fr, int r, int dir, int n_seg,
+                                                        int32_t *__restrict__ hit_all, long long hit_stride) {
+  const float *__restrict__ v = fr.vol[blockIdx.y];
+  int32_t *__restrict__ hit = hit_all + blockIdx.y * hit_stride;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long cols = (long long)r * r;
   if (t >= cols * n_seg) return;
@@ -76,9 +89,10 @@ __global__ __launch_bounds__(256) void first_hit_kernel(const float *__restrict_
 // block sums the counts of the blocks before it and emits its rows (recon.py:63-87).
 constexpr int kEmitBlock = 1024;
 
-__global__ __launch_bounds__(kEmitBlock) void count_hits_kernel(const int32_t *__restrict__ hit,
-                                                                int total,
-                                                                int32_t *__restrict__ blk) {
+__global__ __launch_bounds__(kEmitBlock) void count_hits_kernel(int32_t *__restrict__ hit_all,
+                                                                int total, long long hit_stride) {
+  const int32_t *__restrict__ hit = hit_all + blockIdx.y * hit_stride;
+  int32_t *__restrict__ blk = hit_all + blockIdx.y * hit_stride + total;
   __shared__ int wave_tot[kEmitBlock / 64];
   const int idx = blockIdx.x * kEmitBlock + threadIdx.x;
   const int flag = idx < total && hit[idx] != kNoHit;
@@ -92,10 +106,17 @@ __global__ __launch_bounds__(kEmitBlock) void count_hits_kernel(const int32_t *_
   }
 }
 
-__global__ __launch_bounds__(kEmitBlock) void emit_vertices_kernel(
-    const float *__restrict__ v, int r, int dir, const int32_t *__restrict__ hit,
-    const int32_t *__restrict__ blk, int64_t *__restrict__ xo, int64_t *__restrict__ yo,
-    float *__restrict__ zo, float *__restrict__ no, int32_t *__restrict__ count) {
+__global__ __launch_bounds__(kEmitBlock) void emit_vertices_kernel(VertFrames fr, int r, int dir,
+                                                                   const int32_t *__restrict__ hit_all,
+                                                                   long long hit_stride) {
+  const float *__restrict__ v = fr.vol[blockIdx.y];
+  const int32_t *__restrict__ hit = hit_all + blockIdx.y * hit_stride;
+  const int32_t *__restrict__ blk = hit + r * r;
+  int64_t *__restrict__ xo = fr.x[blockIdx.y];
+  int64_t *__restrict__ yo = fr.y[blockIdx.y];
+  float *__restrict__ zo = fr.z[blockIdx.y];
+  float *__restrict__ no = fr.n[blockIdx.y];
+  int32_t *__restrict__ count = fr.count[blockIdx.y];
   __shared__ int wave_tot[kEmitBlock / 64];
   __shared__ int base_s;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -140,22 +161,42 @@ __global__ __launch_bounds__(kEmitBlock) void emit_vertices_kernel(
   no[3 * row + 2] = __fdiv_rn(nz, len);
 }
 
-int launch_forward_vertices(mp_ctx *ctx, void *scratch, const float *vol, int r, int dir, int64_t *x,
-                            int64_t *y, float *z, float *norm, int32_t *count, hipStream_t st) {
+size_t forward_vertices_scratch_bytes(int r) {  // per frame: hit [r * r] + per-block counts
+  const size_t total = (size_t)r * r;
+  return ((total + (total + kEmitBlock - 1) / kEmitBlock + 2) * sizeof(int32_t) + 255) & ~size_t(255);
+}
+
+int launch_forward_vertices_batch(mp_ctx *ctx, void *scratch, int n_frames, const float *const *vol, int r, int dir,
+                                  int64_t *const *x, int64_t *const *y, float *const *z, float *const *norm,
+                                  int32_t *const *count, hipStream_t st) {
+  VertFrames fr;
+  std::memset(&fr, 0, sizeof(fr));
+  for (int f = 0; f < n_frames; ++f) {
+    fr.vol[f] = vol[f];
+    fr.x[f] = x[f];
+    fr.y[f] = y[f];
+    fr.z[f] = z[f];
+    fr.n[f] = norm[f];
+    fr.count[f] = count[f];
+  }
   int32_t *hit = static_cast<int32_t *>(scratch);
+  const long long stride = (long long)(forward_vertices_scratch_bytes(r) / sizeof(int32_t));
   const int total = r * r;
   const int n_blk = (total + kEmitBlock - 1) / kEmitBlock;
-  int32_t *blk = hit + total;
   const int n_seg = (r + kSeg - 1) / kSeg;
-  MP_HIP(ctx, hipMemsetAsync(hit, 0x7f, sizeof(int32_t) * (size_t)total, st));
+  MP_HIP(ctx, hipMemsetAsync(hit, 0x7f, sizeof(int32_t) * (size_t)stride * n_frames, st));
   const long long threads = (long long)total * n_seg;
-  hipLaunchKernelGGL(first_hit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
-                     vol, r, dir, n_seg, hit);
-  hipLaunchKernelGGL(count_hits_kernel, dim3(n_blk), dim3(kEmitBlock), 0, st, hit, total, blk);
-  hipLaunchKernelGGL(emit_vertices_kernel, dim3(n_blk), dim3(kEmitBlock), 0, st, vol, r, dir, hit,
-                     blk, x, y, z, norm, count);
+  hipLaunchKernelGGL(first_hit_kernel, dim3((unsigned)((threads + 255) / 256), (unsigned)n_frames), dim3(256), 0, st, fr,
+                     r, dir, n_seg, hit, stride);
+  hipLaunchKernelGGL(count_hits_kernel, dim3(n_blk, n_frames), dim3(kEmitBlock), 0, st, hit, total, stride);
+  hipLaunchKernelGGL(emit_vertices_kernel, dim3(n_blk, n_frames), dim3(kEmitBlock), 0, st, fr, r, dir, hit, stride);
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
+}
+
+int launch_forward_vertices(mp_ctx *ctx, void *scratch, const float *vol, int r, int dir, int64_t *x,
+                            int64_t *y, float *z, float *norm, int32_t *count, hipStream_t st) {
+  return launch_forward_vertices_batch(ctx, scratch, 1, &vol, r, dir, &x, &y, &z, &norm, &count, st);
 }
 
 // verts = (X, Y, res - Z) (main.py:231-233) through orthogonal(., mat_color) (main.py:237).
@@ -193,17 +234,27 @@ int launch_vertex_points(mp_ctx *ctx, const int64_t *x, const int64_t *y, const 
   return MP_OK;
 }
 
-__global__ void fill_kernel(float *__restrict__ p, long long n, float v) {
+struct PaintFrames {
+  const int64_t *x[kMaxFrames], *y[kMaxFrames];
+  const float *vals[kMaxFrames];
+  const int32_t *count[kMaxFrames];
+  float *image[kMaxFrames];
+};
+
+__global__ void fill_kernel(PaintFrames fr, long long n, float v) {
+  float *__restrict__ p = fr.image[blockIdx.y];
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)
     p[i] = v;
 }
 
-__global__ void paint_kernel(const int64_t *__restrict__ x, const int64_t *__restrict__ y,
-                             const float *__restrict__ vals, int ch_major,
-                             const int32_t *__restrict__ count, long long cap, int res, float scale,
-                             float bias, float lo, float hi, float *__restrict__ image) {
-  const long long n = min((long long)*count, cap);
+__global__ void paint_kernel(PaintFrames fr, int ch_major, long long cap, int res, float scale,
+                             float bias, float lo, float hi) {
+  const int64_t *__restrict__ x = fr.x[blockIdx.y];
+  const int64_t *__restrict__ y = fr.y[blockIdx.y];
+  const float *__restrict__ vals = fr.vals[blockIdx.y];
+  float *__restrict__ image = fr.image[blockIdx.y];
+  const long long n = min((long long)*fr.count[blockIdx.y], cap);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     const long long px = x[i], py = y[i];
@@ -218,20 +269,35 @@ __global__ void paint_kernel(const int64_t *__restrict__ x, const int64_t *__res
   }
 }
 
-int launch_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *vals, int ch_major,
-                 const int32_t *count, long long cap, int res, float scale, float bias, float lo,
-                 float hi, float *image, hipStream_t st) {
+int launch_paint_batch(mp_ctx *ctx, int n_frames, const int64_t *const *x, const int64_t *const *y,
+                       const float *const *vals, int ch_major, const int32_t *const *count, long long cap, int res,
+                       float scale, float bias, float lo, float hi, float *const *image, hipStream_t st) {
+  PaintFrames fr;
+  std::memset(&fr, 0, sizeof(fr));
+  for (int f = 0; f < n_frames; ++f) {
+    fr.x[f] = x[f];
+    fr.y[f] = y[f];
+    fr.vals[f] = vals[f];
+    fr.count[f] = count[f];
+    fr.image[f] = image[f];
+  }
   const long long n_img = (long long)res * res * 3;
-  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n_img + 255) / 256 > 1024 ? 1024 : (n_img + 255) / 256)),
-                     dim3(256), 0, st, image, n_img, 1.0f);  // canvas of ones, main.py:201-203
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n_img + 255) / 256 > 1024 ? 1024 : (n_img + 255) / 256), n_frames),
+                     dim3(256), 0, st, fr, n_img, 1.0f);  // canvas of ones, main.py:201-203
   if (cap > 0) {
     long long blocks = (cap + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(paint_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, vals, ch_major,
-                       count, cap, res, scale, bias, lo, hi, image);
+    hipLaunchKernelGGL(paint_kernel, dim3((unsigned)blocks, n_frames), dim3(256), 0, st, fr, ch_major, cap, res, scale,
+                       bias, lo, hi);
   }
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
+}
+
+int launch_paint(mp_ctx *ctx, const int64_t *x, const int64_t *y, const float *vals, int ch_major,
+                 const int32_t *count, long long cap, int res, float scale, float bias, float lo,
+                 float hi, float *image, hipStream_t st) {
+  return launch_paint_batch(ctx, 1, &x, &y, &vals, ch_major, &count, cap, res, scale, bias, lo, hi, &image, st);
 }
 
 // RTL/main.py:259-281: *255, torch.rot90(k=1, dims [0,1]) (out[i][j] = in[j][res-1-i]), nearest

@@ -668,6 +668,67 @@ def forward_vertices_raw(volume, direction="front"):
     return x, y, z, nrm, count
 
 
+def forward_vertices_raw_batch(volumes, direction="front"):
+    """mp_forward_vertices_batch: ``[forward_vertices_raw(v, direction) for v in volumes]`` (up to MAX_FRAMES cubic
+    volumes of one size) in one set of launches; every frame's (X, Y, Z, norm, count) are views of five tensors."""
+    vols = []
+    for v in volumes:
+        while v.dim() > 3:
+            v = v[0]
+        vols.append(_f32c(v))
+    n = len(vols)
+    r = vols[0].shape[2]
+    if any(tuple(v.shape) != (r, r, r) for v in vols):
+        raise ValueError("forward_vertices_raw_batch wants cubic volumes of one size")
+    dev = vols[0].device
+    ctx = get_context(dev)
+    cap = r * r
+    x = torch.empty((n, cap), dtype=torch.int64, device=dev)
+    y = torch.empty((n, cap), dtype=torch.int64, device=dev)
+    z = torch.empty((n, cap), dtype=torch.float32, device=dev)
+    nrm = torch.empty((n, cap, 3), dtype=torch.float32, device=dev)
+    count = torch.empty((n, 1), dtype=torch.int32, device=dev)
+    out = []
+    for f0 in range(0, n, MAX_FRAMES):
+        f1 = min(f0 + MAX_FRAMES, n)
+        ptrs = ctypes.c_void_p * (f1 - f0)
+        ctx.check(ctx.lib.mp_forward_vertices_batch(
+            ctx.handle, f1 - f0, ptrs(*[vols[f].data_ptr() for f in range(f0, f1)]), r, DIRECTIONS[direction],
+            ptrs(*[x[f].data_ptr() for f in range(f0, f1)]), ptrs(*[y[f].data_ptr() for f in range(f0, f1)]),
+            ptrs(*[z[f].data_ptr() for f in range(f0, f1)]), ptrs(*[nrm[f].data_ptr() for f in range(f0, f1)]),
+            ptrs(*[count[f].data_ptr() for f in range(f0, f1)]), _stream(x)), "mp_forward_vertices_batch")
+    stream = torch.cuda.current_stream(dev)
+    for v in vols:
+        v.record_stream(stream)
+    for f in range(n):
+        out.append((x[f], y[f], z[f], nrm[f], count[f]))
+    return out
+
+
+def paint_batch(xs, ys, values, channel_major, counts, res, scale, bias, lo, hi):
+    """mp_paint_batch: ``[paint(x, y, v, channel_major, c, res, ...) for ...]`` (up to MAX_FRAMES renders of one size,
+    one capacity) in two launches; the images are views of one [n, res, res, 3] tensor."""
+    n = len(xs)
+    dev = xs[0].device
+    ctx = get_context(dev)
+    cap = xs[0].shape[0]
+    vals = [_f32c(v) for v in values]
+    images = torch.empty((n, res, res, 3), dtype=torch.float32, device=dev)
+    for f0 in range(0, n, MAX_FRAMES):
+        f1 = min(f0 + MAX_FRAMES, n)
+        ptrs = ctypes.c_void_p * (f1 - f0)
+        ctx.check(ctx.lib.mp_paint_batch(
+            ctx.handle, f1 - f0, ptrs(*[xs[f].data_ptr() for f in range(f0, f1)]),
+            ptrs(*[ys[f].data_ptr() for f in range(f0, f1)]), ptrs(*[vals[f].data_ptr() for f in range(f0, f1)]),
+            int(channel_major), ptrs(*[counts[f].data_ptr() for f in range(f0, f1)]), cap, int(res), float(scale),
+            float(bias), float(lo), float(hi), ptrs(*[images[f].data_ptr() for f in range(f0, f1)]), _stream(images)),
+            "mp_paint_batch")
+    stream = torch.cuda.current_stream(dev)
+    for v in vals:
+        v.record_stream(stream)
+    return [images[f] for f in range(n)]
+
+
 def vertex_points(x, y, z, count, res, mat):
     """(X, Y, res - Z) through the voxel->world matrix (RTL/main.py:231-237) -> [3,cap]."""
     ctx = get_context(x.device)

@@ -146,10 +146,15 @@ class FrameSlot:
                             self.b_max, self.res, self.balance, volumes=self.volumes[b0:b1],
                             status=self.status[b0:b1], final_level=self.final_level)
         pts_all = []
+        # forward_vertices and the normal renders of all frames of the slot: one set of launches each
+        # (mp_forward_vertices_batch, mp_paint_batch), results identical to the per-frame calls
+        raws = ops.forward_vertices_raw_batch(self.volumes[:n], "front")
+        renders = ops.paint_batch([v[0] for v in raws], [v[1] for v in raws], [v[3] for v in raws], 0,
+                                  [v[4] for v in raws], r, 0.5, 0.5, 0.0, 1.0)
         for b in range(n):
-            x, y, z, nrm, count = ops.forward_vertices_raw(self.volumes[b], "front")
-            self.vertices[b] = (x, y, z, nrm, count)
-            self.renders[b] = ops.paint(x, y, nrm, 0, count, r, 0.5, 0.5, 0.0, 1.0)
+            x, y, z, nrm, count = raws[b]
+            self.vertices[b] = raws[b]
+            self.renders[b] = renders[b]
             if self.netC is not None:
                 # netC.filter(image_c, feat_prior=featG_last) -> cat([prior, featC])
                 # (MonoPortNet.py:41-45) packed straight into one channels-last map per frame
@@ -164,10 +169,10 @@ class FrameSlot:
                 preds = ops.query_counted_batch(
                     mlp_c, self.feats_hwc_c[b0:b1], pts_all[b0:b1],
                     [self.vertices[b][4] for b in range(b0, b1)], self.calib[b0:b1], Z_SCALE)
+                tex = ops.paint_batch([self.vertices[b][0] for b in range(b0, b1)], [self.vertices[b][1] for b in range(b0, b1)],
+                                      preds, 1, [self.vertices[b][4] for b in range(b0, b1)], r, 0.5, 0.5, -np.inf, np.inf)
                 for b in range(b0, b1):
-                    x, y, _, _, count = self.vertices[b]
-                    self.renders_tex[b] = ops.paint(x, y, preds[b - b0], 1, count, r, 0.5, 0.5,
-                                                    -np.inf, np.inf)
+                    self.renders_tex[b] = tex[b - b0]
 
     def prepare(self, warmup=2):
         """Warm up (scratch arenas, GroupNorm accumulator arena); with ``use_graph`` capture the ENCODER into a

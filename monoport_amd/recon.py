@@ -39,7 +39,14 @@ def forward_vertices(sdf, direction="front"):
 def forward_vertices_many(sdfs, direction="front"):
     """``[forward_vertices(s, direction) for s in sdfs]`` with ONE host sync for all the vertex
     counts (monoport_amd extension; the hook of a coalescing stage, stage_pipeline.Coalesced)."""
-    raws = [None if s is None else ops.forward_vertices_raw(s, direction) for s in sdfs]
+    idx = [i for i, s in enumerate(sdfs) if s is not None]
+    raws = [None] * len(sdfs)
+    if idx and len({tuple(sdfs[i].shape[-3:]) for i in idx}) == 1:  # one size: one set of launches for all of them
+        for i, r in zip(idx, ops.forward_vertices_raw_batch([sdfs[i] for i in idx], direction)):
+            raws[i] = r
+    else:
+        for i in idx:
+            raws[i] = ops.forward_vertices_raw(sdfs[i], direction)
     live = [r for r in raws if r is not None]
     counts = torch.cat([r[4] for r in live]).cpu().tolist() if live else []
     out, k = [], 0

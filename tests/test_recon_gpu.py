@@ -93,6 +93,27 @@ def test_forward_vertices_vs_reference(ops, res, seed, direction):
     assert np.abs(n[:c].cpu().numpy() - g[key + "norm"]).max() <= 1e-5
 
 
+@pytest.mark.parametrize("direction", ["front", "left"])
+def test_forward_vertices_and_paint_batches_equal_single_calls(ops, direction):
+    """mp_forward_vertices_batch / mp_paint_batch (all frames of a pipeline slot in one set of launches) give,
+    frame by frame, the bits of the per-frame calls -- volumes with different surfaces, an EMPTY one included."""
+    vols = [torch.from_numpy(syn.blob_volume(65, 60 + i)).to(DEV) for i in range(5)]
+    vols[3] = torch.zeros_like(vols[3])
+    single = [ops.forward_vertices_raw(v, direction) for v in vols]
+    batch = ops.forward_vertices_raw_batch(vols, direction)
+    for (x, y, z, n, c), (bx, by, bz, bn, bc) in zip(single, batch):
+        k = int(c.item())
+        assert k == int(bc.item())
+        assert torch.equal(x[:k], bx[:k]) and torch.equal(y[:k], by[:k])
+        assert torch.equal(z[:k], bz[:k]) and torch.equal(n[:k], bn[:k])
+    assert int(batch[3][4].item()) == 0 and int(batch[0][4].item()) > 50
+    one = [ops.paint(x, y, n, 0, c, 65, 0.5, 0.5, 0.0, 1.0) for x, y, z, n, c in single]
+    many = ops.paint_batch([b[0] for b in batch], [b[1] for b in batch], [b[3] for b in batch], 0, [b[4] for b in batch],
+                           65, 0.5, 0.5, 0.0, 1.0)
+    assert all(torch.equal(a, b) for a, b in zip(one, many))
+    assert bool((many[3] == 1.0).all())
+
+
 def test_forward_vertices_nan_at_front_face(ops, oracle):
     """A hit at z'=0 divides 0/0 in the reference: compare NaN for NaN."""
     vol = syn.blob_volume(33, 77)
