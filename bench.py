@@ -27,7 +27,7 @@ line with the driver's contract fields plus
                   passes at this frames-per-launch (20 with --steps 20, 16 with the default 48)
   "plain_query_path"  (N=1 only) the headline configuration without skip tables (--no-skip-table)
   "cpu_baseline"  the CPU oracle path timed on this box's host cores (rank 0, N=1 only)
-  "passes"        the timed region is run 3 times (each EXACTLY --steps frames between barrier +
+  "passes"        the timed region is run 5 times (each EXACTLY --steps frames between barrier +
                   synchronize pairs); `value` is the median pass, min / max are listed
   "in_flight_8"   BASELINE configs[3]: 8 frames in flight across the node (8/N per rank)
   "with_color" / "levels6_f16w" / "mesh" / "dropin" / "alt_precision"   (N=1 only) the other
@@ -504,9 +504,9 @@ def breakdown_leg(job, pipe, batch, resolutions):
         nb = min(batch, MAX_RECON_BATCH)
         ops.recon_batch(mlp, slot.feats_hwc[:nb], slot.calib[:nb], syn.Z_SCALE, B_MIN, B_MAX,
                         resolutions, 0.5, volumes=slot.volumes[:nb], status=slot.status[:nb])
-        for b in range(nb):
-            x, y, z, nrm, count = ops.forward_vertices_raw(slot.volumes[b], "front")
-            ops.paint(x, y, nrm, 0, count, r_last, 0.5, 0.5, 0.0, 1.0)
+        raws = ops.forward_vertices_raw_batch(slot.volumes[:nb], "front")
+        ops.paint_batch([v[0] for v in raws], [v[1] for v in raws], [v[3] for v in raws], 0, [v[4] for v in raws],
+                        r_last, 0.5, 0.5, 0.0, 1.0)
 
     with torch.no_grad():
         # the last submission may have been a short batch: refill the slot so every entry is live
@@ -873,8 +873,10 @@ def parse_args(argv):
                     help="K > 0: exactly K frames in flight across the node (K / --gpus per rank; "
                          "BASELINE configs[3] is K = 8) instead of --depth x --batch per GPU; the "
                          "default run reports this configuration as `in_flight_8` next to `value`")
-    ap.add_argument("--passes", type=int, default=3,
-                    help="timed regions of exactly --steps frames each; `value` is the median")
+    ap.add_argument("--passes", type=int, default=5,
+                    help="timed regions of exactly --steps frames each; `value` is the median (5: with three slots "
+                         "overlapping, single passes of the default run differ by +- 4 %%; the driver's one-submission "
+                         "run repeats to 0.1 %%)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the encoder eagerly instead of replaying it as a hipGraph")
     ap.add_argument("--with-color", action="store_true",

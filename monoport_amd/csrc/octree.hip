@@ -65,6 +65,7 @@ struct FrameBufs {
   int32_t *flag[kMaxFrames];       // level 0: "anything above the threshold" (status[0])
 };
 static_assert(sizeof(FrameBufs) <= 2048 + 64, "kernel argument");
+constexpr int kHouseChunk = kMaxFrames;  // frames per housekeeping launch (see launch_recon)
 
 // ---- level 0 ---------------------------------------------------------------------------------
 __global__ void iota_nodes_kernel(int r, FrameBufs fb, int w64, int y_major) {
@@ -500,6 +501,28 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
 
   FrameBufs fb;
   std::memset(&fb, 0, sizeof(fb));
+  // frames per housekeeping launch (MONOPORT_OCTREE_CHUNK, measurement switch; results do not depend on it)
+  static const int chunk_env = [] {
+    const char *e = getenv("MONOPORT_OCTREE_CHUNK");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : kHouseChunk;
+  }();
+  const int chunk = chunk_env < n_frames ? chunk_env : n_frames;
+  auto sub = [&](int f0, int nf) {  // the descriptors of frames f0 .. f0 + nf - 1 as frames 0 .. nf - 1
+    FrameBufs c;
+    std::memset(&c, 0, sizeof(c));
+    for (int f = 0; f < nf; ++f) {
+      c.prev[f] = fb.prev[f0 + f];
+      c.cur[f] = fb.cur[f0 + f];
+      c.bnd[f] = fb.bnd[f0 + f];
+      c.ev_prev[f] = fb.ev_prev[f0 + f];
+      c.ev[f] = fb.ev[f0 + f];
+      c.packed[f] = fb.packed[f0 + f];
+      c.count[f] = fb.count[f0 + f];
+      c.flag[f] = fb.flag[f0 + f];
+    }
+    return c;
+  };
   // level 0: every node of every frame, one query launch for the whole set
   {
     const int r = res[0], total = r * r * r;
@@ -516,12 +539,18 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
       q.src.n_dev = nullptr;
       q.src.n = total;
     }
-    hipLaunchKernelGGL(iota_nodes_kernel, dim3((total + 255) / 256, 1, n_frames), dim3(256), 0, st, r, fb, words64(r),
-                       (int)octree_y_major());
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+      const int nf = min(chunk, n_frames - f0);
+      hipLaunchKernelGGL(iota_nodes_kernel, dim3((total + 255) / 256, 1, nf), dim3(256), 0, st, r, sub(f0, nf), words64(r),
+                         (int)octree_y_major());
+    }
     int rc = launch_query_set(ctx, m, set, h, w, z_scale, (long long)total * n_frames, false, st);
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(any_above_kernel, dim3(min((total + 255) / 256, 256), 1, n_frames), dim3(256), 0, st, fb, total,
-                       balance);
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+      const int nf = min(chunk, n_frames - f0);
+      hipLaunchKernelGGL(any_above_kernel, dim3(min((total + 255) / 256, 256), 1, nf), dim3(256), 0, st, sub(f0, nf), total,
+                         balance);
+    }
   }
   for (int l = 1; l < n_levels; ++l) {
     const int r = res[l], rp = res[l - 1], w64 = words64(r);
@@ -542,11 +571,16 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
       q.src.n_dev = status[f] + 1 + l;
       q.src.n = 0;
     }
-    hipLaunchKernelGGL(upsample_classify_kernel,
-                       dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp, (unsigned)n_frames), dim3(256),
-                       0, st, fb, rp, r, balance, w64, rule);
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+      const int nf = min(chunk, n_frames - f0);
+      const FrameBufs c = sub(f0, nf);
+      hipLaunchKernelGGL(upsample_classify_kernel,
+                         dim3((unsigned)((rp * ((rp + 63) / 64) + 3) / 4), (unsigned)rp, (unsigned)nf), dim3(256), 0, st,
+                         c, rp, r, balance, w64, rule);
+      if (rule != MP_FINAL_INTERPOLATE)
+        launch_select(rule == MP_FINAL_UPSTREAM ? 1 : octree_box_of_level(l), st, c, nf, rp, words64(rp), r, w64);
+    }
     if (rule == MP_FINAL_INTERPOLATE) continue;  // status[1 + l] stays 0, no query
-    launch_select(rule == MP_FINAL_UPSTREAM ? 1 : octree_box_of_level(l), st, fb, n_frames, rp, words64(rp), r, w64);
     int rc = launch_query_set(ctx, m, set, h, w, z_scale, (long long)r * r * r * n_frames, true, st);
     if (rc != MP_OK) return rc;
   }

@@ -26,7 +26,13 @@ import torch
 from . import ops
 from .synthetic import Z_SCALE
 
+import os
+
 RESOLUTIONS = (17, 33, 65, 129, 257)  # RTL/main.py:187
+# frames per forward_vertices / paint launch set (measurement switch; results are identical): "on" = all frames of the
+# slot, "off" = one, or a number
+_vb = os.environ.get("MONOPORT_VERTEX_BATCH", "on")
+VERTEX_BATCH = 0 if _vb == "off" else (int(_vb) if _vb.isdigit() else 10 ** 6)
 MAX_RECON_BATCH = ops.MAX_FRAMES  # kMaxFrames of the C-ABI (include/monoport_hip.h, mp_recon_batch): 32
 
 
@@ -148,9 +154,16 @@ class FrameSlot:
         pts_all = []
         # forward_vertices and the normal renders of all frames of the slot: one set of launches each
         # (mp_forward_vertices_batch, mp_paint_batch), results identical to the per-frame calls
-        raws = ops.forward_vertices_raw_batch(self.volumes[:n], "front")
-        renders = ops.paint_batch([v[0] for v in raws], [v[1] for v in raws], [v[3] for v in raws], 0,
-                                  [v[4] for v in raws], r, 0.5, 0.5, 0.0, 1.0)
+        if VERTEX_BATCH:
+            raws, renders = [], []
+            for b0 in range(0, n, VERTEX_BATCH):
+                rw = ops.forward_vertices_raw_batch(self.volumes[b0:min(b0 + VERTEX_BATCH, n)], "front")
+                raws += rw
+                renders += ops.paint_batch([v[0] for v in rw], [v[1] for v in rw], [v[3] for v in rw], 0,
+                                           [v[4] for v in rw], r, 0.5, 0.5, 0.0, 1.0)
+        else:  # A/B: one set of launches per frame
+            raws = [ops.forward_vertices_raw(self.volumes[b], "front") for b in range(n)]
+            renders = [ops.paint(v[0], v[1], v[3], 0, v[4], r, 0.5, 0.5, 0.0, 1.0) for v in raws]
         for b in range(n):
             x, y, z, nrm, count = raws[b]
             self.vertices[b] = raws[b]
