@@ -29,9 +29,11 @@ from .synthetic import Z_SCALE
 import os
 
 RESOLUTIONS = (17, 33, 65, 129, 257)  # RTL/main.py:187
-# frames per forward_vertices / paint launch set (measurement switch; results are identical): "on" = all frames of the
-# slot, "off" = one, or a number
-_vb = os.environ.get("MONOPORT_VERTEX_BATCH", "on")
+# frames per forward_vertices / paint launch set (results are identical): "on" = all frames of the slot, "off" = one,
+# or a number.  4: measured on 20-frame single submissions 185.8 (1) / 189.2 (4) / 189.8 (all) recon/s -- and with three
+# slots overlapping, launches over all 16 frames of a slot (first_hit: 37 k workgroups) hold up the other slots'
+# chains of small dependent kernels: passes of 5.4-5.6 ms per frame against 5.2-5.4 with 1 or 4 frames per launch
+_vb = os.environ.get("MONOPORT_VERTEX_BATCH", "4")
 VERTEX_BATCH = 0 if _vb == "off" else (int(_vb) if _vb.isdigit() else 10 ** 6)
 MAX_RECON_BATCH = ops.MAX_FRAMES  # kMaxFrames of the C-ABI (include/monoport_hip.h, mp_recon_batch): 32
 
