@@ -24,7 +24,7 @@ line with the driver's contract fields plus
                   hoist 42 % of them out of the per-point work), never as a fraction;
                   `roofline.step` = the query launches AND skip_table_kernel as one rate;
                   `roofline.traffic` = memory-side bytes per launch from the committed PMC
-                  passes at this frames-per-launch (20 with --steps 20, 16 with the default 48)
+                  passes at this frames-per-launch (20 with --steps 20, 32 with the default 32)
   "plain_query_path"  (N=1 only) the headline configuration without skip tables (--no-skip-table)
   "cpu_baseline"  the CPU oracle path timed on this box's host cores (rank 0, N=1 only)
   "passes"        the timed region is run 5 times (each EXACTLY --steps frames between barrier +
@@ -140,7 +140,7 @@ def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, 
 
 
 TRAFFIC_PROFILE_513_F16W = "r05_query_traffic_513_f16w.json"  # configs[4]: tools/r05_run.sh traffic16
-TRAFFIC_PROFILE = "r05_query_traffic.json"  # PMC passes at slot batches of 16, 20 and 24 frames (tools/r05_run.sh traffic)
+TRAFFIC_PROFILE = "r05_query_traffic.json"  # PMC passes at slot batches of 16, 20, 24 and 32 frames (tools/r05_run.sh traffic)
 
 
 def traffic_from_profile(precision, levels, with_color, slot_batch):
@@ -148,7 +148,7 @@ def traffic_from_profile(precision, levels, with_color, slot_batch):
     --pmc FETCH_SIZE / WRITE_SIZE runs of tools/traffic_probe.py, corrected as
     MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process, so the
     figure is reported ONLY for the configurations the passes covered (f32 skip-table kernel, 5 levels,
-    geometry only, slot batches of 20 / 16 / 24 frames: --steps 20, the default --steps 48, --batch 24)
+    geometry only, slot batches of 20 / 32 / 16 / 24 frames: --steps 20, the default --steps 32, --steps 48, --batch 24)
     and is None for every other run or when the profile is absent."""
     if precision == "f16w" and levels == 6 and not with_color:  # configs[4]: its own passes (16 frames per launch)
         try:
@@ -311,10 +311,10 @@ def pick_batch(steps, upper, depth=3):
     (`depth`) when --steps divides that way, else as few as possible; never more than `upper` frames each (--batch;
     MAX_RECON_BATCH = 32 = kMaxFrames of mp_recon_batch when not given), so that no submission is short (a short
     batch would still pay the full-batch encoder) and every octree level of a submission is ONE fused-query launch.
-    48 steps on 3 slots -> 3 x 16 (each slot's encoder under another slot's octree: measured 186-188 recon/s
-    against 170 for 2 x 24); the driver's 20 steps -> one submission of 20 (20 does not divide by 3; its frames
-    complete together: `config.frame_latency_ms`; the two-submission layout is reported as
-    `two_slot_submissions`); 96 -> 3 x 32."""
+    The default 32 steps -> one submission of 32 (194-195 recon/s); the driver's 20 steps -> one submission of
+    20 (190; its frames complete together: `config.frame_latency_ms`; the two-submission layout is reported as
+    `two_slot_submissions`); 48 steps on 3 slots -> 3 x 16 (183-190, passes scatter: which slot's encoder meets
+    which slot's octree is a matter of timing); 96 -> 3 x 32."""
     upper = MAX_RECON_BATCH if upper is None else upper
     if steps % depth == 0 and 1 <= steps // depth <= upper:
         return steps // depth
@@ -858,9 +858,11 @@ def measure_config(job, depth, batch, use_graph, resolutions, with_color, precis
 def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48,
-                    help="frames in the timed region (default 48 = one submission of 16 frames on each of the 3 slots; the "
-                         "driver's 20 = one submission of 20)")
+    ap.add_argument("--steps", type=int, default=32,
+                    help="frames in the timed region (default 32 = ONE slot submission of 32 frames, every octree level one "
+                         "launch of kMaxFrames frames: 194-195 recon/s, passes within 0.5 %%; the driver's 20 = one "
+                         "submission of 20: 190; several overlapping submissions -- 48 = 3 x 16, 64 = 2 x 32 -- are no "
+                         "faster since round 5 and their passes scatter by +- 4 %%)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--depth", type=int, default=3, help="pipeline slots (streams) per GPU")
     ap.add_argument("--batch", type=int, default=None,

@@ -55,7 +55,7 @@ first)
   timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench20.json 2> $out/bench20.err; tail -c 300 $out/bench20.err
   bench_line $out/bench20.json steps20
   levels s20 --steps 20 --warmup 5
-  levels s48
+  levels s32
   ;;
 tests) run_tests ;;
 bench)
@@ -67,7 +67,7 @@ bench20)
 benchq)
   timeout 600 python bench.py --no-extras --no-cpu-baseline $FLAGS > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.err
   bench_line $out/bench.json "quick $FLAGS" ;;
-levels) levels s48 ;;
+levels) levels s32 ;;
 levels20) levels s20 --steps 20 --warmup 5 ;;
 prof20)  # kernel trace + stats of the driver's invocation with the per-launch point counts of the roofline leg
   cd /tmp && export TMPDIR=/tmp
@@ -80,7 +80,7 @@ prof20)  # kernel trace + stats of the driver's invocation with the per-launch p
   ;;
 traffic)
   cd /tmp && export TMPDIR=/tmp
-  for b in 16 20 24; do
+  for b in 16 20 24 32; do
     export MONOPORT_TRAFFIC_BATCH=$b
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$b -- python $R/tools/traffic_probe.py run > $out/pmc_fetch_$b.log 2>&1
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$b -- python $R/tools/traffic_probe.py run > $out/pmc_write_$b.log 2>&1
@@ -94,9 +94,9 @@ traffic)
 import json,sys,os
 out=sys.argv[1]
 by={}
-for b in (16,20,24):
+for b in (16,20,24,32):
     by[str(b)]=json.load(open(os.path.join(out,"traffic_%d.json"%b)))
-merged={"source":"tools/r05_run.sh traffic: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/traffic_probe.py run at slot batches of 16, 20 and 24 frames (bench.py --batch 16 / the driver's --steps 20 / the default --steps 48): one fused-query launch per octree level","by_slot_batch":by}
+merged={"source":"tools/r05_run.sh traffic: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/traffic_probe.py run at slot batches of 16, 20, 24 and 32 frames (bench.py --steps 48 / the driver's --steps 20 / --batch 24 / the default --steps 32): one fused-query launch per octree level","by_slot_batch":by}
 json.dump(merged,open(os.path.join(out,"r05_query_traffic.json"),"w"),indent=1)
 for b,d in by.items():
     print(b,"frames/launch: avg %.3f GB per launch; per level (GB):"%(d["bytes_per_launch_avg"]/1e9),[round(x/1e9,3) for x in d["bytes_per_level_launch"]], "WRITE KB", [round(x) for x in d["WRITE_SIZE_per_level"]])

@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-# frames per slot submission / launch: MONOPORT_TRAFFIC_BATCH (bench.py: 16 by default, 20 at the driver's --steps 20)
+# frames per slot submission / launch: MONOPORT_TRAFFIC_BATCH (bench.py: 32 by default, 20 at the driver's --steps 20)
 BATCH = int(os.environ.get("MONOPORT_TRAFFIC_BATCH", "16"))
 # MONOPORT_TRAFFIC_LEVELS=6 MONOPORT_TRAFFIC_PRECISION=f16w: BASELINE configs[4] (513^3, fp16 weights: pifu_query16_kernel)
 LEVELS = int(os.environ.get("MONOPORT_TRAFFIC_LEVELS", "5"))
