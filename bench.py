@@ -29,9 +29,14 @@ line with the driver's contract fields plus
   "cpu_baseline"  the CPU oracle path timed on this box's host cores (rank 0, N=1 only)
   "passes"        the timed region is run 5 times (each EXACTLY --steps frames between barrier +
                   synchronize pairs); `value` is the median pass, min / max are listed
+  "scaling_vs_single_rank"  (N > 1) rank 0 alone on the same frames while the others wait: efficiency inside ONE run
   "in_flight_8"   BASELINE configs[3]: 8 frames in flight across the node (8/N per rank)
   "with_color" / "levels6_f16w" / "mesh" / "dropin" / "alt_precision"   (N=1 only) the other
                   BASELINE configs and surfaces, each with its own timing and parity deltas
+
+Test hooks for the N > 1 code on a ONE-GPU box (tests/test_dropin_gpu.py): MONOPORT_BENCH_ONE_GPU_TEST=1 (--gpus 2,
+both ranks on device 0, collectives over gloo) and MONOPORT_BENCH_FORCE_GROUP=1 (--gpus 1 inside a one-rank RCCL
+group: the same collective calls on the real backend).
 """
 import argparse
 import json
@@ -326,14 +331,14 @@ def timed_passes(job, pipe, batch, with_color, passes, collective=True, want_sta
     barrier + synchronize pairs; returns (per-pass seconds of THIS rank, status rows of the first
     pass, gather_checked).  `collective=False` runs the same frames without the render gather and
     the barriers (the single-rank leg of an N > 1 run)."""
-    world = job.world if collective else 1
+    gathering = collective and job.dist is not None  # N > 1 (or the forced one-rank group of the test hook)
     depth = len(pipe.slots)
     r_last = pipe.slots[0].res[-1]
     n_warm, n_frames = job.warm, job.steps + job.warm
     gather = parallel.FrameGather((batch, r_last, r_last, 3), device=job.device, store=False) \
-        if world > 1 else None
+        if gathering else None
     render_pack = [torch.zeros((batch, r_last, r_last, 3), dtype=torch.float32, device=job.device)
-                   for _ in range(depth)] if world > 1 else None
+                   for _ in range(depth)] if gathering else None
     gather_checked = [False]
     gather_events = []  # (start, stop) HIP events around the warm-up gathers, on the slot's stream
     warming = [True]
@@ -344,7 +349,7 @@ def timed_passes(job, pipe, batch, with_color, passes, collective=True, want_sta
         slot = pipe.submit([job.images[s % len(job.images)] for s in range(s0, s1)],
                            [job.calibs[s] for s in range(s0, s1)])
         with torch.cuda.stream(slot.stream):
-            if world > 1:
+            if gathering:
                 pack = render_pack[(pipe.n_submitted - 1) % depth]  # this slot's staging buffer
                 for b in range(s1 - s0):
                     pack[b].copy_(slot.renders_tex[b] if with_color else slot.renders[b])
@@ -950,9 +955,12 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     backend = "gloo" if one_gpu_test else "nccl"  # nccl = RCCL on ROCm
-    rank, world = parallel.init_from_env(backend=backend, device=device)
+    # second test hook: a ONE-rank RCCL group, so that a one-GPU box runs every collective call of the N > 1
+    # path (barrier, all_reduce, all_gather_object, the render gather) on the real backend
+    force_group = os.environ.get("MONOPORT_BENCH_FORCE_GROUP") == "1" and args.gpus == 1
+    rank, world = parallel.init_from_env(backend=backend, device=device, force=force_group)
     dist = None
-    if world > 1:
+    if world > 1 or force_group:
         import torch.distributed as dist
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     # every rank on its own GPU: (device index, PCI bus id) must be N distinct values (the one-GPU
@@ -992,7 +1000,7 @@ def main(argv=None):
 
     # single-rank leg of an N > 1 run: rank 0 repeats the passes alone (no gather, no barriers)
     # while the other ranks wait -> scaling efficiency against a line measured in THIS run
-    if world > 1:
+    if dist is not None:
         job.barrier()
         if rank == 0:
             el, _, _ = timed_passes(job, pipe, batch, args.with_color, args.passes, collective=False,
@@ -1191,10 +1199,11 @@ def main(argv=None):
                 "frames_per_rank": args.steps,
                 "distinct_images": len(job.images),
                 "devices": devices,
-                "backend": ("none (single process)" if world == 1 else
+                "backend": ("nccl (RCCL), one-rank group (test hook)" if force_group else
+                            "none (single process)" if world == 1 else
                             "gloo (one-GPU test hook)" if one_gpu_test else "nccl (RCCL)"),
                 "self_launched": os.environ.get("MONOPORT_BENCH_SELF_LAUNCHED") == "1",
-                "gather_checked": bool(main_res["gather_checked"]) if world > 1 else None,
+                "gather_checked": bool(main_res["gather_checked"]) if dist is not None else None,
                 # where non-linearity would come from: per-rank step times are in `ms_per_step_per_rank`; the one
                 # collective of a submission (renders of `batch` frames to rank 0), timed on rank 0 during warm-up
                 "gather_ms_per_submission": (None if not job.gather_ms else

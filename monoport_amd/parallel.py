@@ -13,13 +13,20 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None, device=None):
+def init_from_env(backend=None, device=None, force=False):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun sets them).
-    Returns (rank, world).  A single process needs no group."""
+    Returns (rank, world).  A single process needs no group; ``force`` makes one anyway (a
+    ONE-rank RCCL communicator: how a one-GPU box exercises the collective calls of the N > 1
+    path on the real backend, tests/test_dropin_gpu.py)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # only a forced single-process group gets here without one
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kwargs = {}
@@ -50,7 +57,7 @@ class FrameGather:
         self.dtype = dtype
         # gloo has no gather for device tensors: stage through the host (CPU tests and the
         # one-GPU test hook of bench.py only; the GPU path is RCCL on device buffers)
-        self._stage = (self.world > 1 and dist.get_backend() == "gloo"
+        self._stage = (dist.is_initialized() and dist.get_backend() == "gloo"
                        and torch.device(device).type != "cpu")
         self.device = device
         if self._stage:
@@ -59,13 +66,15 @@ class FrameGather:
                        for _ in range(self.world)] if self.rank == dst else None)
         self._pad = torch.zeros(self.shape, dtype=dtype, device=device)
         self.store = store  # False: only the newest round stays in the receive buffers
+        # a process group of ONE rank still gathers through its backend (bench.py's forced RCCL group)
+        self._collective = dist.is_initialized()
         self.results = {}  # frame id -> tensor (rank dst only)
 
     def push(self, round_idx, result):
         """Every rank calls this once per round with its frame's result (or None past the end).
         Frame id of rank r in round k is k*world + r."""
         payload = self._pad if result is None else result.to(self.dtype).contiguous()
-        if self.world == 1:
+        if self.world == 1 and not self._collective:
             if result is not None and self.store:
                 self.results[round_idx] = payload.clone()
             return

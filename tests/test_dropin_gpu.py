@@ -459,6 +459,33 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["in_flight_8"]["value"] > 0 and "2 slot(s) x 2 frame(s)" in out["in_flight_8"]["config"]
 
 
+def test_bench_collectives_on_rccl_one_rank_group():
+    """The same collective calls on the REAL backend: `MONOPORT_BENCH_FORCE_GROUP=1` makes bench.py join a
+    one-rank RCCL ("nccl") group and run the N > 1 code with it -- communicator creation with `device_id`,
+    barrier, all_reduce on device tensors, all_gather_object, the gather of the renders on the slot's stream
+    next to the encoder's hipGraph, the single-rank leg.  (Two ranks need two GPUs; this box has one.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MONOPORT_BENCH_FORCE_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+           "--passes", "2", "--no-extras"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 1 and out["value"] > 0 and 0 < out["roofline"]["frac"] < 1
+    assert "RCCL" in cfg["backend"] and cfg["gather_checked"] is True
+    assert cfg["gather_ms_per_submission"]["median"] > 0
+    assert 0.5 < out["scaling_vs_single_rank"]["efficiency"] < 1.5
+
+
 def test_netg_query_uses_the_skip_table_by_default(monkeypatch):
     """MonoPortNet.bind makes and registers the skip table of a newly bound feature map
     (ops.SKIP_TABLE, default on): netG.query and the fused octree engine then blend table rows.  The

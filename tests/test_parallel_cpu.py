@@ -57,3 +57,26 @@ def test_single_process_path():
     g.push(0, torch.ones(2, 2))
     g.push(1, 2 * torch.ones(2, 2))
     assert torch.equal(g.ordered(2), torch.stack([torch.ones(2, 2), 2 * torch.ones(2, 2)]))
+
+
+def _one_rank_worker(rank, port, out_path):
+    import torch.distributed as dist
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from monoport_amd import parallel
+    r, w = parallel.init_from_env(backend="gloo", force=True)
+    assert (r, w) == (0, 1) and dist.is_initialized() and dist.get_world_size() == 1
+    g = parallel.FrameGather((2, 2))
+    assert g._collective  # the gather goes through the backend, not the single-process shortcut
+    g.push(0, torch.ones(2, 2))
+    g.push(1, 2 * torch.ones(2, 2))
+    assert torch.equal(g.received(0), 2 * torch.ones(2, 2))
+    torch.save(g.ordered(2), out_path)
+    dist.destroy_process_group()
+
+
+def test_forced_one_rank_group_gathers_through_the_backend(tmp_path):
+    """bench.py's MONOPORT_BENCH_FORCE_GROUP hook (a one-GPU box running the N > 1 collectives on RCCL): a group
+    of ONE rank is a real group -- init_from_env(force=True) makes it, FrameGather gathers through it."""
+    out = str(tmp_path / "one.pt")
+    mp.spawn(_one_rank_worker, args=(_free_port(), out), nprocs=1, join=True)
+    assert torch.equal(torch.load(out), torch.stack([torch.ones(2, 2), 2 * torch.ones(2, 2)]))
