@@ -486,6 +486,48 @@ def test_recon_batch_equals_single_frames(ops, oracle, precision):
     assert len({tuple(r) for r in st[:, 2:].tolist()}) > 1  # the frames really differ
 
 
+_CHUNK_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from monoport_amd import ops, synthetic as syn
+from monoport_amd.recon import pifu_calib
+mlp = ops.PackedMLP.from_layers("cuda:0", syn.body_mlp("G", noise=0.05, seed=1), 1)
+feats, cals = [], []
+for i in range(5):
+    feats.append(ops.pack_features(torch.from_numpy(syn.body_feat(256, 128, 128, 2 + i))[None].to("cuda:0")))
+    cals.append(pifu_calib(*syn.scene_camera(25 * i), device="cuda:0"))
+vols, status = ops.recon_batch(mlp, feats, cals, syn.Z_SCALE, [-1.0] * 3, [1.0] * 3, [17, 33, 65, 129])
+np.savez(sys.argv[2], status=status.cpu().numpy(), vols=torch.stack(vols).cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize("chunk", ["1", "2"])
+def test_recon_batch_same_bits_for_any_housekeeping_chunk(ops, oracle, tmp_path, chunk):
+    """The octree's housekeeping kernels take all frames of a call per launch (blockIdx.z = frame);
+    MONOPORT_OCTREE_CHUNK (read once per process) cuts them into launches of that many frames -- frames
+    f0 .. f0 + n of the call as frames 0 .. n of a launch.  Status rows and volumes do not depend on it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "chunk.py"
+    script.write_text(_CHUNK_SCRIPT)
+    got = {}
+    for c in (chunk, None):
+        env = dict(os.environ)
+        env.pop("MONOPORT_OCTREE_CHUNK", None)
+        if c is not None:
+            env["MONOPORT_OCTREE_CHUNK"] = c
+        out = str(tmp_path / ("out_%s.npz" % c))
+        res = subprocess.run([sys.executable, str(script), root, out], env=env, capture_output=True, text=True,
+                             timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        got[c] = np.load(out)
+    assert (got[None]["status"][:, 0] == 1).all()
+    assert np.array_equal(got[chunk]["status"], got[None]["status"])
+    assert np.array_equal(got[chunk]["vols"], got[None]["vols"])
+
+
 def test_recon_batch_of_16_frames(ops, oracle):
     """The full frame set of one launch (kMaxFrames = 16), every frame with its own camera."""
     mlp = ops.PackedMLP.from_layers(DEV, syn.body_mlp("G", noise=0.05, seed=1), 1)
