@@ -427,7 +427,7 @@ def roofline_leg(job, pipe, batch, resolutions, with_color):
                 prof_vcount.append(torch.cat([slot.vertices[b][4].reshape(1) for b in range(s1 - s0)]))
     slot.wait()
     all_ms = ops.profile_end(job.device, capacity=cap)
-    # launch order per submission of n frames: for every chunk of <= 16 frames one launch per level
+    # launch order per submission of n frames: for every chunk of <= MAX_RECON_BATCH (32) frames one launch per level
     # (its points = that level's nodes summed over the chunk, pipeline.py / mp_recon_batch); with
     # colour one netC launch per chunk follows the octree launches of the whole submission
     launch_ms, launch_pts, c_ms, c_pts, cursor = [], [], [], [], 0

@@ -528,16 +528,16 @@ def test_recon_batch_same_bits_for_any_housekeeping_chunk(ops, oracle, tmp_path,
     assert np.array_equal(got[chunk]["vols"], got[None]["vols"])
 
 
-def test_recon_batch_of_16_frames(ops, oracle):
-    """The full frame set of one launch (kMaxFrames = 16), every frame with its own camera."""
+def test_recon_batch_of_32_frames(ops, oracle):
+    """The full frame set of one launch (kMaxFrames = 32), every frame with its own camera."""
     mlp = ops.PackedMLP.from_layers(DEV, syn.body_mlp("G", noise=0.05, seed=1), 1)
     fh = ops.pack_features(torch.from_numpy(syn.body_feat(256, 128, 128, 2))[None].to(DEV))
     res = [9, 17, 33, 65]
-    cals = [torch.from_numpy(oracle.pifu_calib(*syn.scene_camera(11 * i))).to(DEV) for i in range(16)]
-    vols, status = ops.recon_batch(mlp, [fh] * 16, cals, syn.Z_SCALE, BMIN, BMAX, res)
+    cals = [torch.from_numpy(oracle.pifu_calib(*syn.scene_camera(11 * i))).to(DEV) for i in range(32)]
+    vols, status = ops.recon_batch(mlp, [fh] * 32, cals, syn.Z_SCALE, BMIN, BMAX, res)
     st = status.cpu().numpy()
-    assert (st[:, 0] == 1).all() and len({tuple(r) for r in st[:, 2:].tolist()}) > 8
-    for i in (0, 7, 8, 15):
+    assert (st[:, 0] == 1).all() and len({tuple(r) for r in st[:, 2:].tolist()}) > 16
+    for i in (0, 7, 8, 15, 16, 23, 31):
         v1, s1 = ops.recon(mlp, fh, cals[i], syn.Z_SCALE, BMIN, BMAX, res)
         assert np.array_equal(s1.cpu().numpy(), st[i]) and torch.equal(v1, vols[i]), i
 
