@@ -518,16 +518,21 @@ def breakdown_leg(job, pipe, batch, resolutions):
         slot.submit([job.images[s % len(job.images)] for s in range(batch)], job.calibs[:batch])
         slot.wait()
         enc_ms = timed(lambda: slot.net.image_filter(slot.image, last_only=True), 10) / batch
+        # ... and as the timed region runs it: the slot's captured hipGraph (static buffers; the eager figure moves
+        # with the state of torch's caching allocator this late in the process: 1.77 or 1.87 ms on the same code)
+        enc_graph_ms = timed(slot.graph.replay, 10) / batch if slot.graph is not None else None
         enc1_ms = timed(lambda: slot.net.image_filter(slot.image[:1], last_only=True), 10)
         rec_ms = timed(recon_only, 10)
         rec_batched_ms = timed(recon_batched, 5) / min(batch, MAX_RECON_BATCH)
     return {
         "encoder_ms_per_frame": enc_ms, "encoder_ms_batch1": enc1_ms,
+        "encoder_ms_per_frame_as_run": enc_graph_ms,
         "recon_vertices_render_ms": rec_ms,
         "recon_vertices_render_ms_per_frame_batched": rec_batched_ms,
         "recon_per_s_encoder_excluded": 1e3 / rec_batched_ms,
         "recon_per_s_encoder_excluded_single_frame": 1e3 / rec_ms,
-        "note": "single stream, no overlap; encoder eager at the bench batch size (and at batch 1); "
+        "note": "single stream, no overlap; encoder eager at the bench batch size (and at batch 1), `as_run` = the hipGraph of "
+                "the slot (with --with-color: both encoders); "
                 "batched = mp_recon_batch over the slot's frames, as the pipeline runs it",
     }
 
