@@ -241,9 +241,13 @@ class FrameSlot:
             dst[:n].copy_(src.reshape(dst[:n].shape), non_blocking=True)
             srcs = [src]
         else:
-            for b, s in enumerate(src):
-                dst[b].copy_(s.reshape(dst[b].shape), non_blocking=True)
             srcs = list(src)
+            if len(srcs) > 1 and all(s.is_cuda and s.device == dst.device and s.dtype == dst.dtype for s in srcs):
+                # one gather launch for the frames of a submission instead of one copy per frame
+                torch.cat([s.reshape(dst[:1].shape) for s in srcs], out=dst[:len(srcs)])
+            else:
+                for b, s in enumerate(srcs):
+                    dst[b].copy_(s.reshape(dst[b].shape), non_blocking=True)
         for s in srcs:
             if s.is_cuda:  # the caching allocator must not recycle a source the copy still reads
                 s.record_stream(self.stream)
