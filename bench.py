@@ -24,7 +24,9 @@ line with the driver's contract fields plus
                   hoist 42 % of them out of the per-point work), never as a fraction;
                   `roofline.step` = the query launches AND skip_table_kernel as one rate;
                   `roofline.traffic` = memory-side bytes per launch from the committed PMC
-                  passes at this frames-per-launch (20 with --steps 20, 32 with the default 32)
+                  passes at this frames-per-launch (20 with --steps 20, 32 with the default 32);
+                  `roofline.sustained` = what a register-only loop of the same MFMA instruction delivers on this
+                  box right after the timed launches, with the shader clock it ran at (`peak` stays nominal)
   "plain_query_path"  (N=1 only) the headline configuration without skip tables (--no-skip-table)
   "cpu_baseline"  the CPU oracle path timed on this box's host cores (rank 0, N=1 only)
   "passes"        the timed region is run 5 times (each EXACTLY --steps frames between barrier +
@@ -1000,6 +1002,12 @@ def main(argv=None):
                                     args.with_color, args.precision, args.passes, final_level=args.final_level)
     use_graph = main_res["use_graph"]
     roof = main_res["roof"]
+    # what the f32 matrix pipe of THIS box holds right now, and at which clock (mp_mfma_clock_probe, a 30-50 ms
+    # register-only MFMA loop straight after the roofline leg): boxes of one pool differ by a few per cent
+    sustained = None
+    if (rank == 0 or world == 1) and args.precision == "f32":
+        torch.cuda.synchronize()
+        sustained = ops.mfma_clock_probe(device, 50.0)
     r_last = resolutions[-1]
     extras = {}
 
@@ -1278,6 +1286,16 @@ def main(argv=None):
                              "every FLOP per point" % FLOP_SKIP_TABLE_PER_FRAME)
                     if skip_on else "equal to the executed FLOPs"},
                 "step": roofline_step(roof, skip_on, peak_tflops),
+                # `peak` stays the nominal figure of MI355X_MICROARCH.md; this is what the box delivered to a
+                # register-only loop of the same instruction right after the timed launches
+                "sustained": None if sustained is None else {
+                    "mfma_f32_tflops": sustained["tflops"], "shader_clock_mhz": sustained["shader_clock_mhz"],
+                    "probe_ms": sustained["ms"],
+                    "frac_of_sustained": (roof["achieved"] * (FLOP_PER_POINT_SKIP_TABLE / FLOP_PER_POINT if skip_on else 1.0)
+                                          / sustained["tflops"]),
+                    "note": "mp_mfma_clock_probe (csrc/clock_probe.hip): v_mfma_f32_32x32x2_f32 back to back on random "
+                            "mantissas, two 4-wave workgroups per CU, no memory; shader clock = s_memtime cycles per "
+                            "100 MHz s_memrealtime tick averaged over the workgroups"},
             },
         }
         out.update(extras)

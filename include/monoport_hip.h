@@ -584,6 +584,14 @@ void mp_plan_destroy(mp_plan *plan); /* drains and destroys the plan's side stre
 int mp_profile_begin(mp_ctx *ctx, int max_records);
 int mp_profile_end(mp_ctx *ctx, float *ms_out /*host*/, int capacity, int *n_out /*host*/);
 
+/* What the f32 matrix pipe of this device sustains right now and at which shader clock: a register-only loop of
+ * v_mfma_f32_32x32x2_f32 on random mantissas, two 4-wave workgroups per CU, about ms_target (1..2000) milliseconds,
+ * timed with HIP events; every workgroup reads the shader clock counter and the 100 MHz reference around its loop.
+ * out4 (host): [0] TFLOP/s, [1] average shader clock in MHz during the launch, [2] the launch's ms, [3] workgroups.
+ * Synchronises the stream.  bench.py reports it as `roofline.sustained` next to the nominal peak (boxes of one pool
+ * hold clocks a few per cent apart under a matrix load).  No counterpart in the reference. */
+int mp_mfma_clock_probe(mp_ctx *ctx, float ms_target, double *out4 /*host*/, mp_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -172,6 +172,7 @@ SIGNATURES = {
     "mp_plan_size": (c_int, [c_vp]),
     "mp_plan_run": (c_int, [c_vp, c_vp]),
     "mp_plan_destroy": (None, [c_vp]),
+    "mp_mfma_clock_probe": (c_int, [c_vp, ctypes.c_float, ctypes.POINTER(ctypes.c_double), c_vp]),
     "mp_profile_begin": (c_int, [c_vp, c_int]),
     "mp_profile_end": (c_int, [c_vp, _pf32, c_int, _pint]),
 }

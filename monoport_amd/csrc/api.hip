@@ -1132,6 +1132,15 @@ int mp_gn_apply(mp_ctx *ctx, const float *x, const mp_gn_in *gn, int relu, int n
   return launch_gn_apply_gn(ctx, x, to_in(gn), relu, n, c, hw, res, y, to_out(fin), out_cap(fin), (hipStream_t)stream);
 }
 
+int mp_mfma_clock_probe(mp_ctx *ctx, float ms_target, double *out4, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!out4 || !(ms_target >= 1.0f) || ms_target > 2000.0f)
+    return fail(ctx, MP_ERR_ARG, "mp_mfma_clock_probe: out4 must be given, 1 <= ms_target <= 2000");
+  DeviceGuard g(ctx->device);
+  return launch_mfma_clock_probe(ctx, ms_target, out4, (hipStream_t)stream);
+}
+
 int mp_profile_begin(mp_ctx *ctx, int max_records) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);

@@ -204,6 +204,9 @@ int ensure_scratch(mp_ctx *ctx, hipStream_t st, size_t bytes, void **out);
                       __FILE__, __LINE__);                                           \
   } while (0)
 
+// clock_probe.hip
+int launch_mfma_clock_probe(mp_ctx *ctx, float ms_target, double *out, hipStream_t st);
+
 // query.hip
 int launch_query(mp_ctx *ctx, const Mlp &m, const float *feat_hwc, int h, int w,
                  const float *calib, float z_scale, const PointSrc &src, float *out,

@@ -1282,6 +1282,17 @@ def gn_apply(x, gn, relu=True, res=None, stats=None):
     return y
 
 
+def mfma_clock_probe(device, ms_target=20.0, stream=None):
+    """What the f32 matrix pipe of ``device`` sustains right now (mp_mfma_clock_probe, csrc/clock_probe.hip):
+    {"tflops", "shader_clock_mhz", "ms", "workgroups"} of a register-only MFMA loop of about ``ms_target`` ms."""
+    ctx = get_context(device)
+    out = (ctypes.c_double * 4)()
+    st = stream if stream is not None else torch.cuda.current_stream(torch.device(device))
+    ctx.check(ctx.lib.mp_mfma_clock_probe(ctx.handle, float(ms_target), out, ctypes.c_void_p(st.cuda_stream)),
+              "mp_mfma_clock_probe")
+    return {"tflops": out[0], "shader_clock_mhz": out[1], "ms": out[2], "workgroups": int(out[3])}
+
+
 def profile_begin(device, max_records=4096):
     """Start bracketing fused-query launches on ``device`` with HIP events (bench.py roofline)."""
     ctx = get_context(device)

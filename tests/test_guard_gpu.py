@@ -93,3 +93,19 @@ def test_no_out_of_bounds_writes(res):
     ctx.check(lib.mp_paint(h, vp(p_x), vp(p_y), vp(p_pred), 1, vp(p_cnt), cap, r, 0.5, 0.5, -1e30, 1e30, vp(p_img2), st), "paint2")
     torch.cuda.synchronize()
     slab.check()
+
+
+def test_mfma_clock_probe_reports_a_plausible_rate_and_clock():
+    """mp_mfma_clock_probe (bench.py's `roofline.sustained`): the register-only v_mfma_f32_32x32x2_f32 loop must land
+    near the nominal 157.3 TFLOP/s at a shader clock near 2.4 GHz -- and rate / clock must be the 256 CUs x 4 SIMDs x
+    64 FLOP per cycle of the matrix pipe (the probe measures both independently: events vs in-kernel counters)."""
+    from monoport_amd import ops
+    from monoport_amd._lib import MonoportError
+    got = ops.mfma_clock_probe(DEV, 10.0)
+    print("mfma clock probe:", got)
+    assert 5.0 < got["ms"] < 40.0 and got["workgroups"] == 2 * torch.cuda.get_device_properties(0).multi_processor_count
+    assert 1500.0 < got["shader_clock_mhz"] < 2600.0 and 100.0 < got["tflops"] < 165.0
+    per_clock = got["tflops"] * 1e12 / (got["shader_clock_mhz"] * 1e6) / (got["workgroups"] // 2 * 4)
+    assert 60.0 < per_clock < 65.0, per_clock  # FLOP per SIMD and cycle: 64 when the pipe never idles
+    with pytest.raises(MonoportError):
+        ops.mfma_clock_probe(DEV, 0.0)

@@ -23,6 +23,7 @@ print("[%s]" % sys.argv[2], "value", round(d["value"],2), "ms/step", round(d["ms
       "frac", round(r["frac"],4), "like-for-like", r.get("like_for_like_frac"), "step", round(st.get("frac",0),4), "frames/launch", r.get("frames_per_launch"),
       "recon/frame", round(d["breakdown"]["recon_vertices_render_ms_per_frame_batched"],3), "enc", round(d["breakdown"]["encoder_ms_per_frame"],3),
       "enc(as run)", d["breakdown"].get("encoder_ms_per_frame_as_run"), "enc@1", round(d["breakdown"]["encoder_ms_batch1"],3))
+if r.get("sustained"): print("    sustained", {k:(round(v,4) if isinstance(v,float) else v) for k,v in r["sustained"].items() if k != "note"})
 for k in ("plain_query_path","two_slot_submissions","in_flight_8","alt_precision","with_color","levels6_f16w","mesh","cpu_baseline"):
     v=d.get(k)
     if v: print("   ", k, {kk:(round(vv,4) if isinstance(vv,float) else vv) for kk,vv in v.items() if kk in ("value","roofline_frac","roofline_frac_netG_query","roofline_frac_netC_query","ms_per_step","mesh_ms","iou_vs_f32_volume")})
