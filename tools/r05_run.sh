@@ -6,6 +6,7 @@
 #   levels / levels20   headline bench + per-level roof fractions of its roofline leg (tools/launch_levels.py)
 #   prof20   rocprofv3 --kernel-trace --stats of the driver's invocation, summarised for profiles/
 #   traffic  the --pmc FETCH_SIZE / WRITE_SIZE passes behind roofline.traffic at 16 / 20 / 24 frames per launch
+#   pmc      counters of the table query kernel (MFMA busy, INSTS_MFMA, L2 hits)
 #   dropin   bench.py --mode dropin         shapes  headline by slot layout         f16w  configs[4] alone
 R=${GRAFT_REPO_ROOT:-/root/repo}
 step=${1:-first}
@@ -70,6 +71,15 @@ benchq)
   bench_line $out/bench.json "quick $FLAGS" ;;
 levels) levels s32 ;;
 levels20) levels s20 --steps 20 --warmup 5 ;;
+pmc)  # counters of the shipped table query kernel on one 885 k-point lattice launch (counters only, separate passes)
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/pmc_a -- python $R/tools/skip_table_pmc_probe.py > $out/pmc_a.log 2>&1
+  rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum --output-format csv -d $out/pmc_c -- python $R/tools/skip_table_pmc_probe.py > $out/pmc_c.log 2>&1
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_d -- python $R/tools/skip_table_pmc_probe.py > $out/pmc_d.log 2>&1
+  for ps in a c d; do echo "== pass $ps"; python $R/tools/pmc_summary.py $out/pmc_$ps | grep -v skip_table | tail -1; done > $out/pmc_summary.txt 2>&1
+  rm -rf $out/pmc_a $out/pmc_c $out/pmc_d
+  cat $out/pmc_summary.txt
+  cd $R ;;
 prof20)  # kernel trace + stats of the driver's invocation with the per-launch point counts of the roofline leg
   cd /tmp && export TMPDIR=/tmp
   CMD="python bench.py --gpus 1 --steps 20 --warmup 5"
