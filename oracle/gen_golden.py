@@ -290,11 +290,22 @@ PIPE257_SCENES = {
     "pipeline257_b": (dict(k=40.0, c=2.0, noise=0.05, seed=195), 196, 40),
     "pipeline257_soft": (dict(k=6.0, c=2.0, noise=1.0, seed=295), 296, 250),
 }
+# BASELINE configs[4] size: the body / camera the 513^3 GPU tests reconstruct (tests/test_recon_gpu.py:
+# test_config5_513_fp16_weights), 17..513 through the reference's netG.query -- so that the config has a
+# reference-produced value behind every node it queries, f32 and f16-weight kernels alike.
+PIPE513_SCENES = {
+    "pipeline513": (dict(k=40.0, c=2.0, noise=0.05, seed=1), 2, 30),
+    # the same sharp body under a head whose seeded weights are 40x larger (noise 2.0, other seed / map /
+    # camera): rounding the weights of layers 0-3 to f16 moves the occupancy by up to ~1e-4 here (1e-7 in the
+    # scene above, whose weights that matter -- 40, 31.25, 1 -- are exact in f16), so the fp16-weight kernel
+    # of configs[4] is held to its 3e-4 on a field that notices
+    "pipeline513_w": (dict(k=40.0, c=2.0, noise=2.0, seed=501), 502, 70),
+}
 
 
 @torch.no_grad()
-def gen_pipeline257(name="pipeline257"):
-    """BASELINE configs[1] size: one frame at 17..257 with the REFERENCE netG.query as query_func
+def gen_pipeline257(name="pipeline257", res=(17, 33, 65, 129, 257)):
+    """BASELINE configs[1] size (configs[4] size with res = 17..513, gen_pipeline513): one frame with the REFERENCE netG.query as query_func
     (RTL/main.py:169-183) and the reference forward_vertices; the octree schedule is OUR
     restatement (implicit_seg is not vendored).  Stored: the set of nodes the octree queried
     (bit mask over the 257^3 lattice) with the reference's value at each of them in raster
@@ -302,14 +313,14 @@ def gen_pipeline257(name="pipeline257"):
     import time
     import recon as ref_recon
     from oracle import pifu_oracle as orc
-    head, feat_seed, step = PIPE257_SCENES[name]
+    head, feat_seed, step = {**PIPE257_SCENES, **PIPE513_SCENES}[name]
     net = ref_net("G")
     load_mlp(net, syn.body_mlp("G", **head))
     f = syn.body_feat(256, 128, 128, feat_seed)
     feats = [[torch.zeros(1, 256, 2, 2)]] * 3 + [[torch.from_numpy(f)[None]]]
     ext, intr = syn.scene_camera(step)
     calib = ref_recon.pifu_calib(ext, intr, device="cpu")
-    res = [17, 33, 65, 129, 257]
+    res = list(res)
     rf = res[-1]
     queried = np.zeros((rf, rf, rf), bool)
 
@@ -334,8 +345,8 @@ def gen_pipeline257(name="pipeline257"):
         Y=Y.numpy().astype(np.int16), Z=Z.numpy(), norm=norm.numpy(), calib=calib.numpy(),
         margin=np.float64(margin),
         meta=np.array(["mlp=body_mlp(G,%r) feat=body_feat(256,128,128,%d) scene_camera(%d) "
-                       "res=17..257; reference CPU times (%d threads): octree+query %.2fs, "
-                       "forward_vertices %.2fs" % (head, feat_seed, step, torch.get_num_threads(), t1 - t0,
+                       "res=17..%d; reference CPU times (%d threads): octree+query %.2fs, "
+                       "forward_vertices %.2fs" % (head, feat_seed, step, rf, torch.get_num_threads(), t1 - t0,
                                                    t2 - t1)]))
     sat = float(((vals == 0) | (vals >= 1)).mean())
     print(name, stats, sum(stats), int(X.shape[0]), "verts; margin %.3g; saturated values %.1f%%; "
@@ -594,6 +605,9 @@ if __name__ == "__main__":
     for name in PIPE257_SCENES:
         if name in which:
             gen_pipeline257(name)
+    for name in PIPE513_SCENES:  # not in the default list: 1.2 M points each through the reference, ~1 min
+        if name in which:
+            gen_pipeline257(name, res=(17, 33, 65, 129, 257, 513))
     if "pipeline257_color" in which:
         gen_pipeline257_color()
     if "main_py" in which:

@@ -196,7 +196,7 @@ def test_marching_cubes_257_identical_connectivity(oracle):
 # encoder features vary by O(1) per texel: the colour of such a vertex may differ by a few 1e-4 although the colour
 # CHAIN is exact to fp32 noise.  So: whole-pipeline colours within COLOR_TOL_PIPELINE, and the colour chain itself
 # -- netC.filter(feat_prior) + vertex mapping + netC.query, on the REFERENCE's vertices -- within TOL_REF.
-COLOR_TOL_PIPELINE = 2e-3
+COLOR_TOL_PIPELINE = 5e-4  # measured 2.2e-4 .. 2.6e-4 (round 5 allowed 2e-3); the vertex Z bound that explains it is asserted beside it
 
 
 def _color257_frame_checks(g, tag, vol, stats, X, Y, Z, tex):
@@ -216,6 +216,11 @@ def _color257_frame_checks(g, tag, vol, stats, X, Y, Z, tex):
           % (tag, same, len(ref_cols), len(ref_cols ^ cols), err))
     assert same >= 0.995 and len(ref_cols ^ cols) <= 0.005 * len(ref_cols)  # measured: 0.99993, 0 columns
     assert (tex[bg] == 1.0).all()  # the canvas of ones (RTL/main.py:201-203) wherever no vertex landed
+    ref_z = {(int(a), int(b)): float(c) for a, b, c in zip(g["X"], g["Y"], g["Z"])}
+    dz = np.array([abs(ref_z[(int(a), int(b))] - float(c)) for a, b, c in zip(X, Y, Z) if (int(a), int(b)) in ref_z])
+    dz_ok = float((dz <= 2e-3).mean())
+    print("%s: |dZ| <= 2e-3 voxel on %.5f of the shared columns (median %.3g)" % (tag, dz_ok, float(np.median(dz))))
+    assert dz_ok >= 0.995
     assert err <= COLOR_TOL_PIPELINE  # measured 2.2e-4 (see COLOR_TOL_PIPELINE)
     return err
 
