@@ -75,6 +75,28 @@ const char *mp_last_error(mp_ctx *ctx); /* calling thread's last error; ctx may 
  * by the owner of a pipeline slot; arenas are keyed by the stream handle).  Synchronises the
  * device.  Unknown streams are fine (MP_OK). */
 int mp_stream_release(mp_ctx *ctx, mp_stream stream);
+/* A HIP stream whose kernels run on `n_cus` of the device's compute units only (round 6).  The reference runs
+ * every pipeline stage on its own host thread (RTL/dataloader.py:1026-1053), so netG.filter of frame k+1 and
+ * reconEngine of frame k are in flight together (RTL/main.py:366-395) -- but a persistent query launch owns every
+ * CU's LDS for milliseconds and a batch-1 encoder cannot fill 256 CUs: on ordinary streams the two stages take
+ * turns.  Giving each stage a disjoint share of the CUs lets them run side by side.  Bit i of the mask =
+ * "CU i", i in [first_cu, first_cu + n_cus); the driver deals consecutive bits out round-robin over the 8 XCDs
+ * and their shader engines, so a range that is a multiple of 32 takes the same share of every XCD.  The
+ * persistent query kernels size their grids from the stream's share (launches on other streams: the whole
+ * device).  The stream is created on the context's device, non-blocking; destroy it with mp_stream_destroy
+ * (synchronises the stream, frees its arena).  MP_ERR_ARG unless 0 <= first_cu, n_cus >= 8 and first_cu +
+ * n_cus <= the device's CU count. */
+int mp_stream_create_cu_mask(mp_ctx *ctx, int first_cu, int n_cus, mp_stream *out);
+int mp_stream_destroy(mp_ctx *ctx, mp_stream stream);
+/* CUs a launch on `stream` is sized for: the share of a stream made by mp_stream_create_cu_mask on this
+ * context, else the device's count. */
+int mp_stream_cu_count(mp_ctx *ctx, mp_stream stream);
+/* Device memory the context owns right now (host array of 4): [0] scratch arenas incl. outgrown blocks still
+ * kept for captured graphs, [1] packed MLP weights (all precisions), [2] number of arenas, [3] number of
+ * skip tables registered (the tables themselves are the caller's).  Soak tests assert these stay flat. */
+int mp_memory_stats(mp_ctx *ctx, int64_t *out4);
+/* Frames one fused-query / mp_recon_batch / mp_query_counted_batch call accepts (kMaxFrames). */
+int mp_max_frames(void);
 
 /* ---- SurfaceClassifier weights ------------------------------------------------------------ */
 /* Replaces SurfaceClassifier.__init__ (heads/SurfaceClassifier.py:7-37) for the skip-concat
@@ -588,7 +610,9 @@ int mp_profile_end(mp_ctx *ctx, float *ms_out /*host*/, int capacity, int *n_out
  * v_mfma_f32_32x32x2_f32 on random mantissas, two 4-wave workgroups per CU, about ms_target (1..2000) milliseconds,
  * timed with HIP events; every workgroup reads the shader clock counter and the 100 MHz reference around its loop.
  * out4 (host): [0] TFLOP/s, [1] average shader clock in MHz during the launch, [2] the launch's ms, [3] workgroups.
- * Synchronises the stream.  bench.py reports it as `roofline.sustained` next to the nominal peak (boxes of one pool
+ * Synchronises the stream and holds the context's mutex while it runs (every other call on this context waits up
+ * to ms_target): a set-up / measurement call, not one for a running pipeline.  On a stream of
+ * mp_stream_create_cu_mask it measures that stream's share of the device.  bench.py reports it as `roofline.sustained` next to the nominal peak (boxes of one pool
  * hold clocks a few per cent apart under a matrix load).  No counterpart in the reference. */
 int mp_mfma_clock_probe(mp_ctx *ctx, float ms_target, double *out4 /*host*/, mp_stream stream);
 

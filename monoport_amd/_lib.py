@@ -89,6 +89,11 @@ SIGNATURES = {
     "mp_destroy": (None, [c_vp]),
     "mp_last_error": (ctypes.c_char_p, [c_vp]),
     "mp_stream_release": (c_int, [c_vp, c_vp]),
+    "mp_stream_create_cu_mask": (c_int, [c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),
+    "mp_stream_destroy": (c_int, [c_vp, c_vp]),
+    "mp_stream_cu_count": (c_int, [c_vp, c_vp]),
+    "mp_memory_stats": (c_int, [c_vp, ctypes.POINTER(c_i64)]),
+    "mp_max_frames": (c_int, []),
     "mp_mlp_create": (c_int, [c_vp, c_int, _pint, c_int, _pint]),
     "mp_mlp_load": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
     "mp_mlp_destroy": (c_int, [c_vp, c_int]),

@@ -42,7 +42,10 @@ int ensure_scratch(mp_ctx *ctx, hipStream_t st, size_t bytes, void **out) {
         return fail(ctx, MP_ERR_NOMEM, "scratch arena: hipMalloc(%zu) failed", want);
       }
     }
-    if (a.ptr) a.retired.push_back(a.ptr);
+    if (a.ptr) {
+      a.retired.push_back(a.ptr);
+      a.retired_bytes += a.bytes;
+    }
     a.ptr = p;
     a.bytes = want;
   }
@@ -174,6 +177,62 @@ int mp_stream_release(mp_ctx *ctx, mp_stream stream) {
   MP_HIP(ctx, first);
   return MP_OK;
 }
+
+int mp_stream_create_cu_mask(mp_ctx *ctx, int first_cu, int n_cus, mp_stream *out) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!out || first_cu < 0 || n_cus < 8 || first_cu + n_cus > ctx->n_cu)
+    return fail(ctx, MP_ERR_ARG, "mp_stream_create_cu_mask: CUs [%d, %d) of %d", first_cu, first_cu + n_cus, ctx->n_cu);
+  DeviceGuard g(ctx->device);
+  std::vector<uint32_t> mask((ctx->n_cu + 31) / 32, 0u);
+  for (int i = first_cu; i < first_cu + n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+  hipStream_t st = nullptr;
+  MP_HIP(ctx, hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+  ctx->stream_cus[(void *)st] = n_cus;
+  *out = (mp_stream)st;
+  return MP_OK;
+}
+
+int mp_stream_destroy(mp_ctx *ctx, mp_stream stream) {
+  if (!ctx || !stream) return MP_ERR_ARG;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->stream_cus.find((void *)stream);
+    if (it == ctx->stream_cus.end())
+      return fail(ctx, MP_ERR_ARG, "mp_stream_destroy: not a stream of mp_stream_create_cu_mask on this context");
+    ctx->stream_cus.erase(it);
+  }
+  const int rc = mp_stream_release(ctx, stream);  // drains the device, frees the stream's arena
+  DeviceGuard g(ctx->device);
+  MP_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
+  return rc;
+}
+
+int mp_stream_cu_count(mp_ctx *ctx, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return cus_of(ctx, (hipStream_t)stream);
+}
+
+int mp_memory_stats(mp_ctx *ctx, int64_t *out4) {
+  if (!ctx || !out4) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  int64_t arena = 0, weights = 0;
+  for (const auto &kv : ctx->arenas) arena += (int64_t)(kv.second.bytes + kv.second.retired_bytes);
+  for (const Mlp &m : ctx->mlps) {
+    if (!m.used) continue;
+    if (m.buf) weights += (int64_t)m.total * 4;
+    if (m.raw) weights += (int64_t)(m.off_raw[3] + (size_t)kHidden[3] * (kHidden[2] + m.c + 1)) * 4;
+    if (m.buf16) weights += (int64_t)m.total16 * 16;
+  }
+  out4[0] = arena;
+  out4[1] = weights;
+  out4[2] = (int64_t)ctx->arenas.size();
+  out4[3] = (int64_t)ctx->skip_tables.size();
+  return MP_OK;
+}
+
+int mp_max_frames(void) { return kMaxFrames; }
 
 int mp_mlp_create(mp_ctx *ctx, int n_layers, const int *channels, int last_op, int *mlp_out) {
   if (!ctx) return MP_ERR_ARG;

@@ -55,20 +55,20 @@ __global__ __launch_bounds__(256) void mfma_clock_probe_kernel(int iters, unsign
 // out[0] = TFLOP/s of the timed launch, out[1] = shader clock in MHz (cycles per 100 MHz reference tick, averaged
 // over the workgroups), out[2] = its duration in ms, out[3] = workgroups.  Synchronises `st`.
 int launch_mfma_clock_probe(mp_ctx *ctx, float ms_target, double *out, hipStream_t st) {
-  const int grid = 2 * ctx->n_cu;  // two 4-wave workgroups per CU = two waves per SIMD, as the query kernels run
+  const int grid = 2 * cus_of(ctx, st);  // two 4-wave workgroups per CU = two waves per SIMD, as the query kernels run
   unsigned long long *clocks = nullptr;
   float *sink = nullptr;
-  MP_HIP(ctx, hipMalloc(&clocks, (size_t)grid * 16));
-  MP_HIP(ctx, hipMalloc(&sink, 1024));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = MP_OK;
   auto done = [&](int code) {
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    (void)hipFree(clocks);
-    (void)hipFree(sink);
+    if (clocks) (void)hipFree(clocks);
+    if (sink) (void)hipFree(sink);
     return code;
   };
+  if (hipMalloc(&clocks, (size_t)grid * 16) != hipSuccess || hipMalloc(&sink, 1024) != hipSuccess)
+    return done(fail(ctx, MP_ERR_NOMEM, "mp_mfma_clock_probe: hipMalloc failed"));
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
     return done(fail(ctx, MP_ERR_HIP, "mp_mfma_clock_probe: hipEventCreate failed"));
   int iters = 600;  // ~1 ms: calibrates the timed launch (and wakes the clocks up)

@@ -174,8 +174,11 @@ struct mp_ctx {
     void *ptr = nullptr;  // current block
     size_t bytes = 0;
     std::vector<void *> retired;  // outgrown blocks, kept until mp_stream_release / mp_destroy
+    size_t retired_bytes = 0;
   };
   std::unordered_map<void *, Arena> arenas;
+  // streams made by mp_stream_create_cu_mask -> compute units in their mask (guarded by mu)
+  std::unordered_map<void *, int> stream_cus;
   // kernels whose dynamic-LDS limit has been raised on this context's device (guarded by mu)
   std::unordered_set<const void *> lds_attr_done;
   // skip tables registered for feature maps (mp_skip_table): feat pointer -> table + the packed
@@ -194,6 +197,14 @@ struct mp_ctx {
 namespace mp {
 
 int fail(mp_ctx *ctx, int code, const char *fmt, ...);
+// compute units a launch on `st` may use: the share of a CU-masked stream, else the whole device
+inline int cus_of(const mp_ctx *ctx, hipStream_t st) {
+  if (!ctx->stream_cus.empty()) {
+    auto it = ctx->stream_cus.find((void *)st);
+    if (it != ctx->stream_cus.end()) return it->second;
+  }
+  return ctx->n_cu;
+}
 int ensure_scratch(mp_ctx *ctx, hipStream_t st, size_t bytes, void **out);
 
 #define MP_HIP(ctx, expr)                                                            \

@@ -433,7 +433,7 @@ static int launch_query_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h,
   if (max_points <= 0) return MP_OK;
   // every frame of the set rounds its own tail tile up
   const long long tiles = (max_points + kTilePts - 1) / kTilePts + (set.n - 1);
-  const long long resident = (long long)ctx->n_cu * WPS;
+  const long long resident = (long long)cus_of(ctx, st) * WPS;
   // device-side counts: launch the resident grid and let it stride; host-side counts: one
   // workgroup per tile up to a few waves of the machine
   long long grid = device_counts ? (tiles < resident ? tiles : resident)

@@ -1010,7 +1010,7 @@ static int launch_query16_tab_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, 
   }
   if (max_points <= 0) return MP_OK;
   const long long tiles = (max_points + P - 1) / P + (set.n - 1);
-  const long long resident = (long long)ctx->n_cu;
+  const long long resident = (long long)cus_of(ctx, st);
   const long long grid = device_counts ? (tiles < resident ? tiles : resident)
                                        : (tiles < 8 * resident ? tiles : 8 * resident);
   QuerySetDev dset;
@@ -1044,7 +1044,7 @@ static int launch_query16_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int 
   }
   if (max_points <= 0) return MP_OK;
   const long long tiles = (max_points + P - 1) / P + (set.n - 1);
-  const long long resident = (long long)ctx->n_cu * (NB >= 3 ? 1 : 2);  // 160 / 144 / 80 KB of LDS each
+  const long long resident = (long long)cus_of(ctx, st) * (NB >= 3 ? 1 : 2);  // 160 / 144 / 80 KB of LDS each
   const long long grid = device_counts ? (tiles < resident ? tiles : resident)
                                        : (tiles < 8 * resident ? tiles : 8 * resident);
   QuerySetDev dset;

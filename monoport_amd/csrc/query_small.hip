@@ -328,7 +328,7 @@ int launch_query32_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, int h, int 
   }
   if (max_points <= 0) return MP_OK;
   const long long tiles = (max_points + kSmallPts - 1) / kSmallPts + (set.n - 1);
-  const long long resident = (long long)ctx->n_cu * kT32Wps;
+  const long long resident = (long long)cus_of(ctx, st) * kT32Wps;
   // device-side counts: launch the resident grid and let it stride; host-side counts: one
   // workgroup per tile up to a few waves of the machine
   long long grid = device_counts ? (tiles < resident ? tiles : resident)

@@ -638,7 +638,7 @@ static int launch_query_tabws_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, 
     ctx->lds_attr_done.insert(kern_id);
   }
   const long long tiles = (max_points + kTabPts - 1) / kTabPts + (set.n - 1);
-  const long long resident = (long long)ctx->n_cu * 2;
+  const long long resident = (long long)cus_of(ctx, st) * 2;
   // persistent: a workgroup's producers run one chunk ahead of its consumers ACROSS tiles, so a
   // workgroup should see several tiles; never more workgroups than are resident at once
   const long long grid = tiles < resident ? tiles : resident;
@@ -748,7 +748,7 @@ int launch_skip_table(mp_ctx *ctx, const Mlp &m, const float *feat_hwc, int h, i
     MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     ctx->lds_attr_done.insert(kern_id);
   }
-  const long long tiles = texels / 64, resident = (long long)ctx->n_cu * 2;
+  const long long tiles = texels / 64, resident = (long long)cus_of(ctx, st) * 2;
   const dim3 grid((unsigned)(tiles < resident ? tiles : resident));
   if (m.cout == 1)
     hipLaunchKernelGGL(skip_table_kernel<1>, grid, dim3(kQueryThreads), lds, st, m.pack(), feat_hwc, texels, table);

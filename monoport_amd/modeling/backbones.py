@@ -235,7 +235,13 @@ class _PlannedForward:
 
     @staticmethod
     def _record(x, fn):
-        use_pool = ENCODER_PLAN_POOL == "on" and hasattr(torch.cuda, "MemPool")
+        # The private pool is only private if torch routes THIS THREAD's allocations into it: torch >= 2.7
+        # (torch._C._cuda_beginAllocateCurrentThreadToPool; the installed 2.10 has it).  Older versions route
+        # every thread's allocations on the device into the pool while the context is open, so a neighbouring
+        # stage thread's tensor could land in a block the plan later overwrites on replay: keep the
+        # intermediates alive there instead (keep_alive=True, no recycling to get wrong).
+        use_pool = (ENCODER_PLAN_POOL == "on" and hasattr(torch.cuda, "MemPool")
+                    and hasattr(torch._C, "_cuda_beginAllocateCurrentThreadToPool"))
         if not use_pool:
             x_static = x.clone()
             with ops.record_plan(x.device, keep_alive=True) as rec:
