@@ -234,6 +234,29 @@ int mp_recon_batch_ex(mp_ctx *ctx, int mlp, int n_frames, const float *const *fe
                       const float *b_max, const int *resolutions, int n_levels, float balance,
                       int final_level, float *const *volume, int32_t *const *status, mp_stream stream);
 
+/* mp_recon_batch_ex with an EARLY hand-over (round 6).  The reference's engine returns None for a frame whose
+ * coarsest level is empty (RTL/recon.py:32-33) and our drop-in class must know whether the caller's query_func is
+ * the plain netG.query the fused kernels implement -- both facts are known after the coarsest level, ~0.1 ms into
+ * a ~3.5 ms call.  With `early`, right after that level the call
+ *   - compares frame f's coarsest-level values with expect_level0[f] (device, res[0]^3 floats in (z,y,x) order:
+ *     what query_func returned for those nodes; NULL entry or NULL array = no comparison),
+ *   - writes flags_dev[2f] = status[f][0] and flags_dev[2f+1] = 1 if any value differs (bitwise float !=),
+ *   - copies the 2*n_frames flags to flags_host (PINNED host memory) and records `event` (a hipEvent_t, may be
+ *     NULL) on `stream`, then enqueues the remaining levels.
+ * A stage thread waits for `event`, reads two integers and hands the volume on while the GPU is still refining
+ * it; the per-level counts in `status` are complete when the stream is.  Results are those of mp_recon_batch_ex. */
+typedef struct mp_recon_early {
+  const float *const *expect_level0;
+  int32_t *flags_dev;  /* device int32[2 * n_frames] */
+  int32_t *flags_host; /* pinned host int32[2 * n_frames] */
+  void *event;
+} mp_recon_early;
+int mp_recon_batch_early(mp_ctx *ctx, int mlp, int n_frames, const float *const *feat_hwc, int c, int h,
+                         int w, const float *const *calib, float z_scale, const float *b_min,
+                         const float *b_max, const int *resolutions, int n_levels, float balance,
+                         int final_level, float *const *volume, int32_t *const *status,
+                         const mp_recon_early *early, mp_stream stream);
+
 /* The same engine one level at a time, for an arbitrary Python ``query_func`` (the general
  * Seg3dLossless contract, RTL/main.py:169-195): the caller evaluates the selected nodes itself.
  *   mp_octree_select: level 0 (prev == NULL) selects every node; otherwise upsamples prev [rp^3]

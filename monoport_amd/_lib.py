@@ -73,6 +73,11 @@ class PlanMemsetArgs(ctypes.Structure):
     _fields_ = [("ptr", c_vp), ("bytes", c_i64), ("value", c_int)]
 
 
+class ReconEarly(ctypes.Structure):
+    """mp_recon_early"""
+    _fields_ = [("expect_level0", c_vp), ("flags_dev", c_vp), ("flags_host", c_vp), ("event", c_vp)]
+
+
 class PlanWaitArgs(ctypes.Structure):
     """mp_plan_wait_args"""
     _fields_ = [("waiter_slot", c_int), ("signaller_slot", c_int)]
@@ -117,6 +122,8 @@ SIGNATURES = {
                                _pint, c_int, c_f32, c_vp, c_vp, c_vp]),
     "mp_recon_batch_ex": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_f32, _pf32, _pf32,
                                   _pint, c_int, c_f32, c_int, c_vp, c_vp, c_vp]),
+    "mp_recon_batch_early": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_f32, _pf32, _pf32,
+                                     _pint, c_int, c_f32, c_int, c_vp, c_vp, ctypes.POINTER(ReconEarly), c_vp]),
     "mp_concat3_add": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_vp]),
     "mp_prepare_inputs": (c_int, [c_vp, c_vp, c_i64, _pf32, _pf32, c_vp, c_vp, c_vp]),
     "mp_octree_select": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_f32, c_vp,

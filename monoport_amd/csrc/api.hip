@@ -626,6 +626,15 @@ int mp_recon_batch_ex(mp_ctx *ctx, int mlp, int n_frames, const float *const *fe
                       int w, const float *const *calib, float z_scale, const float *b_min,
                       const float *b_max, const int *resolutions, int n_levels, float balance,
                       int final_level, float *const *volume, int32_t *const *status, mp_stream stream) {
+  return mp_recon_batch_early(ctx, mlp, n_frames, feat_hwc, c, h, w, calib, z_scale, b_min, b_max, resolutions,
+                              n_levels, balance, final_level, volume, status, nullptr, stream);
+}
+
+int mp_recon_batch_early(mp_ctx *ctx, int mlp, int n_frames, const float *const *feat_hwc, int c, int h,
+                         int w, const float *const *calib, float z_scale, const float *b_min,
+                         const float *b_max, const int *resolutions, int n_levels, float balance,
+                         int final_level, float *const *volume, int32_t *const *status,
+                         const mp_recon_early *early, mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   const Mlp *m = get_mlp(ctx, mlp);
@@ -648,13 +657,15 @@ int mp_recon_batch_ex(mp_ctx *ctx, int mlp, int n_frames, const float *const *fe
                 final_level);
   rc = check_resolutions(ctx, "mp_recon", resolutions, n_levels);
   if (rc != MP_OK) return rc;
+  if (early && (!early->flags_dev || !early->flags_host))
+    return fail(ctx, MP_ERR_ARG, "mp_recon_batch_early: flags_dev and flags_host are required");
   DeviceGuard g(ctx->device);
   void *scratch = nullptr;
   rc = ensure_scratch(ctx, (hipStream_t)stream, n_frames * recon_scratch_bytes(resolutions, n_levels),
                       &scratch);
   if (rc != MP_OK) return rc;
   return launch_recon(ctx, scratch, *m, n_frames, feat_hwc, h, w, calib, z_scale, b_min, b_max,
-                      resolutions, n_levels, balance, final_level, volume, status, (hipStream_t)stream);
+                      resolutions, n_levels, balance, final_level, volume, status, early, (hipStream_t)stream);
 }
 
 int mp_recon(mp_ctx *ctx, int mlp, const float *feat_hwc, int c, int h, int w, const float *calib,

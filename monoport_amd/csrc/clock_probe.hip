@@ -71,16 +71,16 @@ int launch_mfma_clock_probe(mp_ctx *ctx, float ms_target, double *out, hipStream
     return done(fail(ctx, MP_ERR_NOMEM, "mp_mfma_clock_probe: hipMalloc failed"));
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
     return done(fail(ctx, MP_ERR_HIP, "mp_mfma_clock_probe: hipEventCreate failed"));
-  int iters = 600;  // ~1 ms: calibrates the timed launch (and wakes the clocks up)
+  int iters = 600;  // ~1 ms: wakes the clocks up (rep 0, not used), calibrates the timed launch (rep 1)
   float ms = 0.0f;
-  for (int rep = 0; rep < 2 && rc == MP_OK; ++rep) {
+  for (int rep = 0; rep < 3 && rc == MP_OK; ++rep) {
     (void)hipEventRecord(e0, st);
     hipLaunchKernelGGL(mfma_clock_probe_kernel, dim3((unsigned)grid), dim3(256), 0, st, iters, clocks, sink);
     (void)hipEventRecord(e1, st);
     if (hipGetLastError() != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
         hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
       rc = fail(ctx, MP_ERR_HIP, "mp_mfma_clock_probe: launch failed");
-    if (rep == 0 && rc == MP_OK) {
+    if (rep == 1 && rc == MP_OK) {
       const double scale = ms > 0.0f ? ms_target / ms : 1.0;
       const double want = iters * scale;
       iters = want < 1000.0 ? 1000 : want > 4.0e6 ? 4000000 : (int)want;

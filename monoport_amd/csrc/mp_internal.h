@@ -265,7 +265,8 @@ size_t recon_scratch_bytes(const int *res, int n_levels);
 int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
                  const float *const *feat_hwc, int h, int w, const float *const *calib,
                  float z_scale, const float *bmin, const float *bmax, const int *res, int n_levels,
-                 float balance, int final_level, float *const *volume, int32_t *const *status, hipStream_t st);
+                 float balance, int final_level, float *const *volume, int32_t *const *status,
+                 const mp_recon_early *early, hipStream_t st);
 int launch_octree_select(mp_ctx *ctx, const float *prev, int rp, float *cur, int r,
                          const unsigned long long *ev_prev, unsigned long long *ev_cur,
                          unsigned long long *bnd, int box, float balance, uint32_t *packed,

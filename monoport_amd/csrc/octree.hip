@@ -96,6 +96,25 @@ __global__ void any_above_kernel(FrameBufs fb, int n, float balance) {
   if (__any(hit) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// mp_recon_batch_early: per frame [2f] = the frame's non-empty flag, [2f + 1] = 1 if any of its level-0 values
+// differs from what the caller's query_func returned for the same nodes (NaN != NaN counts as a difference, as in
+// the tensor comparison this replaces).  flags must be zeroed; one block column per frame.
+struct EarlyBufs {
+  const float *occ[kMaxFrames];
+  const float *expect[kMaxFrames];
+  const int32_t *flag[kMaxFrames];
+};
+__global__ void early_flags_kernel(EarlyBufs eb, int n, int32_t *__restrict__ flags) {
+  const int f = blockIdx.z;
+  const float *__restrict__ occ = eb.occ[f];
+  const float *__restrict__ expect = eb.expect[f];
+  int hit = 0;
+  if (expect)
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) hit |= occ[t] != expect[t];
+  if (__any(hit) && (threadIdx.x & 63) == 0) atomicOr(flags + 2 * f + 1, 1);
+  if (blockIdx.x == 0 && threadIdx.x == 0) flags[2 * f] = *eb.flag[f];
+}
+
 // ---- upsample + boundary flags ---------------------------------------------------------------
 // One lane per PARENT node (z0, y0, x0): it loads the 2x2x2 parent cell once and emits the up to
 // eight fine nodes (2 z0 + oz, 2 y0 + oy, 2 x0 + ox) that interpolate inside it -- 8 loads per 8
@@ -457,7 +476,8 @@ int launch_scatter_nodes(mp_ctx *ctx, const uint32_t *packed, const int32_t *cou
 int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
                  const float *const *feat_hwc, int h, int w, const float *const *calib,
                  float z_scale, const float *bmin, const float *bmax, const int *res, int n_levels,
-                 float balance, int final_level, float *const *volume, int32_t *const *status, hipStream_t st) {
+                 float balance, int final_level, float *const *volume, int32_t *const *status,
+                 const mp_recon_early *early, hipStream_t st) {
   // carve the scratch arena: one private set of level buffers per frame
   const size_t per_frame = recon_scratch_bytes(res, n_levels);
   LevelBufs lv[kMaxFrames][8];
@@ -550,6 +570,20 @@ int launch_recon(mp_ctx *ctx, void *scratch, const Mlp &m, int n_frames,
       const int nf = min(chunk, n_frames - f0);
       hipLaunchKernelGGL(any_above_kernel, dim3(min((total + 255) / 256, 256), 1, nf), dim3(256), 0, st, sub(f0, nf), total,
                          balance);
+    }
+    if (early) {  // what the caller needs to decide "None or a volume" and "fused or not": ready after ~0.1 ms of GPU time
+      EarlyBufs eb;
+      std::memset(&eb, 0, sizeof(eb));
+      for (int f = 0; f < n_frames; ++f) {
+        eb.occ[f] = lv[f][0].occ;
+        eb.expect[f] = early->expect_level0 ? early->expect_level0[f] : nullptr;
+        eb.flag[f] = status[f];
+      }
+      MP_HIP(ctx, hipMemsetAsync(early->flags_dev, 0, sizeof(int32_t) * 2 * n_frames, st));
+      hipLaunchKernelGGL(early_flags_kernel, dim3(min((total + 255) / 256, 32), 1, n_frames), dim3(256), 0, st, eb, total,
+                         early->flags_dev);
+      MP_HIP(ctx, hipMemcpyAsync(early->flags_host, early->flags_dev, sizeof(int32_t) * 2 * n_frames, hipMemcpyDeviceToHost, st));
+      if (early->event) MP_HIP(ctx, hipEventRecord((hipEvent_t)early->event, st));
     }
   }
   for (int l = 1; l < n_levels; ++l) {

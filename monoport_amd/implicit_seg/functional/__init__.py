@@ -32,6 +32,7 @@ Constructor flags (upstream names):
   ``align_corners=True``, ``visualize=True``, ``use_shadow=True``, ``channels != 1``: not built,
                     NotImplementedError at construction.
 """
+import threading
 import warnings
 
 import numpy as np
@@ -85,7 +86,8 @@ class Seg3dLossless(nn.Module):
         self.final_level = final_level
         self.use_cuda_impl = bool(use_cuda_impl)  # same kernels either way (see module docstring)
         self.debug = bool(debug)
-        self.last_status = None
+        self._status = None    # CPU tensor, or the device tensor of a call whose refinement may still be running
+        self._early = threading.local()  # per host thread: the EarlyFlags buffers of its fused calls
         self.last_path = None  # "fused" | "generic": which engine served the last call
         # "always" (the default of this drop-in class): every call evaluates the coarsest level through
         # query_func for real and compares it with the fused kernel -- a closure whose arithmetic changes
@@ -104,6 +106,27 @@ class Seg3dLossless(nn.Module):
         # nn.Module.to(device) is called on the engine (RTL/main.py:195): carry a buffer so it
         # has a device like the upstream module does
         self.register_buffer("_device_tag", torch.zeros(1), persistent=False)
+
+    @property
+    def last_status(self):
+        """int32 [1 + levels] on the CPU: (coarsest level non-empty, points queried per level) of the last call.
+        A fused call returns as soon as its coarsest level is known (mp_recon_batch_early): reading this waits
+        for the call's stream to finish the remaining levels."""
+        st = self._status
+        if st is not None and st.is_cuda:
+            st = self._status = st.cpu()
+        return st
+
+    @last_status.setter
+    def last_status(self, value):
+        self._status = value
+
+    def _early_flags(self, dev, n=1):
+        cache = self._early.__dict__.setdefault("flags", {})
+        e = cache.get(n)
+        if e is None:
+            e = cache[n] = ops.EarlyFlags(dev, n)
+        return e
 
     def forward(self, **kwargs):
         """engine(**kwargs) -> [1,1,R,R,R] f32 occupancy volume (z,y,x) or None when the coarsest
@@ -137,20 +160,22 @@ class Seg3dLossless(nn.Module):
             occ0 = self.query_func(points=pts0[None], **kwargs)
         binding = rec.binding if rec.calls == 1 else None
         if binding is not None and self.faster:
+            eng.scatter(occ0)  # the caller's values on the coarsest lattice, [r0,r0,r0]
+            early = self._early_flags(dev)
             volume, status = ops.recon(binding.mlp, binding.feat_hwc, binding.calib, binding.z_scale,
                                        self.b_min[0], self.b_max[0], self.resolutions,
-                                       self.balance_value, final_level=self.final_level)
-            eng.scatter(occ0)  # the caller's values on the coarsest lattice, [r0,r0,r0]
-            s = (self.resolutions[-1] - 1) // (self.resolutions[0] - 1)
-            differs = (volume[::s, ::s, ::s] != eng.cur).any().to(torch.int32).reshape(1)
-            # the one host sync of a reconstruction (upstream syncs at every level)
-            st = torch.cat([status, differs]).cpu()
-            if int(st[-1]) == 0:
-                self.last_status, self.last_path = st[:-1], "fused"
+                                       self.balance_value, final_level=self.final_level, early=early,
+                                       expect_level0=eng.cur)
+            # the one host sync of a reconstruction (upstream syncs at every level) -- and it waits for the
+            # coarsest level only: "None or a volume" and "is query_func the fused kernels' function" are both
+            # known there, the finer levels go on refining `volume` on this stream after the call has returned
+            nonempty, differs = (int(v) for v in early.wait()[0])
+            if differs == 0:
+                self.last_status, self.last_path = status, "fused"
                 key = self._binding_key(binding)
                 self._agreed = self._agreed + 1 if key == self._trusted_key else 1
                 self._trusted_key = key
-                return None if int(st[0]) == 0 else volume[None, None]
+                return None if nonempty == 0 else volume[None, None]
             self._agreed, self._trusted_key = 0, None
             warnings.warn("Seg3dLossless: query_func is not a plain MonoPortNet.query call (its "
                           "values differ from the fused kernel's); using the level-at-a-time engine")
@@ -184,11 +209,12 @@ class Seg3dLossless(nn.Module):
         if b is None or rec.calls != 1 or self._binding_key(b) != self._trusted_key:
             self._agreed, self._trusted_key = 0, None
             return NotImplemented
+        early = self._early_flags(self._device_tag.device)
         volume, status = ops.recon(b.mlp, b.feat_hwc, b.calib, b.z_scale, self.b_min[0], self.b_max[0],
-                                   self.resolutions, self.balance_value, final_level=self.final_level)
-        st = status.cpu()
-        self.last_status, self.last_path = st, "fused"
-        return None if int(st[0]) == 0 else volume[None, None]
+                                   self.resolutions, self.balance_value, final_level=self.final_level, early=early)
+        nonempty = int(early.wait()[0, 0])  # waits for the coarsest level only (see forward)
+        self.last_status, self.last_path = status, "fused"
+        return None if nonempty == 0 else volume[None, None]
 
     def forward_many(self, kwargs_list):
         """``[self(**kw) for kw in kwargs_list]`` for up to ops.MAX_FRAMES frames at once (monoport_amd extension;
@@ -199,6 +225,10 @@ class Seg3dLossless(nn.Module):
         for bit.  In any other state (not yet validated, ``validate = "always"``, a re-validation
         due, a binding that changed) the frames are served one by one by ``forward``."""
         n = len(kwargs_list)
+        if n >= 2 and self.validate == "always" and not getattr(self, "_warned_many", False):
+            self._warned_many = True
+            warnings.warn("Seg3dLossless.forward_many on an engine with validate='always' (the class default) serves "
+                          "the frames one by one; construct it with validate='first' to let a coalescing stage batch them")
         if (n < 2 or n > ops.MAX_FRAMES or not self.faster or self.validate == "always" or self._agreed < self.VALIDATE_CALLS
                 or self._since_check + n >= self.REVALIDATE_EVERY):
             return [self(**kw) for kw in kwargs_list]
@@ -212,13 +242,14 @@ class Seg3dLossless(nn.Module):
                 return [self(**kw) for kw in kwargs_list]  # forward() re-validates
             bindings.append(b)
         b0 = bindings[0]
+        early = self._early_flags(self._device_tag.device, n)
         volumes, status = ops.recon_batch(b0.mlp, [b.feat_hwc for b in bindings], [b.calib for b in bindings],
                                           b0.z_scale, self.b_min[0], self.b_max[0], self.resolutions,
-                                          self.balance_value, final_level=self.final_level)
-        st = status.cpu()  # the one host sync of the whole batch
+                                          self.balance_value, final_level=self.final_level, early=early)
+        flags = early.wait().clone()  # the one host sync of the whole batch: its coarsest level (see forward)
         self._since_check += n
-        self.last_status, self.last_path = st[-1], "fused"
-        return [None if int(st[i, 0]) == 0 else volumes[i][None, None] for i in range(n)]
+        self.last_status, self.last_path = status[-1], "fused"
+        return [None if int(flags[i, 0]) == 0 else volumes[i][None, None] for i in range(n)]
 
     def forward_async(self, **kwargs):
         """Fused path only, no host sync and no validation of ``query_func`` (the caller vouches

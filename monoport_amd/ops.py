@@ -368,7 +368,33 @@ def query_counted_batch(mlp, feats_hwc, points, counts, calibs, z_scale, outs=No
 
 # Selection rule of the LAST octree level (include/monoport_hip.h, MP_FINAL_*; Seg3dLossless docstring)
 FINAL_LEVELS = {"dilate3": 0, "upstream": 1, "interpolate": 2}
-MAX_FRAMES = 32  # kMaxFrames: frames per mp_recon_batch / mp_query_counted_batch call
+MAX_FRAMES = _lib.load().mp_max_frames()  # kMaxFrames: frames per mp_recon_batch / mp_query_counted_batch call
+
+
+class EarlyFlags:
+    """Buffers of one mp_recon_batch_early hand-over for up to ``n`` frames: device flags, their pinned host copy
+    and the event recorded behind the copy.  ``wait()`` blocks until the coarsest octree level of the call is
+    done (~0.1 ms of GPU time into it) and returns [n,2] int32: (level 0 non-empty, level-0 values differ from the
+    expected ones).  One object serves one call at a time (reuse it after ``wait``)."""
+
+    def __init__(self, device, n=1):
+        self.n = int(n)
+        self.dev = torch.zeros(2 * self.n, dtype=torch.int32, device=device)
+        self.host = torch.zeros(2 * self.n, dtype=torch.int32).pin_memory()
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(device))  # materialises the hipEvent_t the C side re-records
+
+    def struct(self, expect):
+        n = self.n
+        self._expect = None
+        if expect is not None:
+            self._expect = (ctypes.c_void_p * n)(*[None if e is None else e.data_ptr() for e in expect])
+        return _lib.ReconEarly(ctypes.cast(self._expect, ctypes.c_void_p) if self._expect is not None else None,
+                               self.dev.data_ptr(), self.host.data_ptr(), self.event.cuda_event)
+
+    def wait(self):
+        self.event.synchronize()
+        return self.host.view(self.n, 2)
 
 
 def _final_level(final_level):
@@ -379,22 +405,26 @@ def _final_level(final_level):
 
 
 def recon(mlp, feat_hwc, calib, z_scale, b_min, b_max, resolutions, balance=0.5, volume=None,
-          status=None, final_level="dilate3"):
+          status=None, final_level="dilate3", early=None, expect_level0=None):
     """Coarse-to-fine occupancy volume (Seg3dLossless replacement).  Returns (volume [R,R,R]
-    f32, status int32[1+levels]) -- both on device, nothing synchronised."""
+    f32, status int32[1+levels]) -- both on device, nothing synchronised.  ``early`` / ``expect_level0``: see
+    ``recon_batch``."""
     st = None if status is None else status.reshape(1, -1)
     volumes, st = recon_batch(mlp, [feat_hwc], [calib], z_scale, b_min, b_max, resolutions, balance,
-                              None if volume is None else [volume], st, final_level)
+                              None if volume is None else [volume], st, final_level, early,
+                              None if expect_level0 is None else [expect_level0])
     return volumes[0], st[0]
 
 
 def recon_batch(mlp, feats_hwc, calibs, z_scale, b_min, b_max, resolutions, balance=0.5,
-                volumes=None, status=None, final_level="dilate3"):
+                volumes=None, status=None, final_level="dilate3", early=None, expect_level0=None):
     """``recon`` over up to MAX_FRAMES independent frames in one call: every octree level evaluates the
     selected nodes of all frames in ONE fused-query launch (the coarse levels of a single frame
     cannot fill 256 CUs).  feats_hwc: list of [H,W,C] maps; calibs: [B,4,4] (or list of [1,4,4]);
     volumes: list of [R,R,R]; status: [B, 1+levels] int32.  Results equal B separate ``recon``
-    calls bit for bit."""
+    calls bit for bit.  ``early``: an ``EarlyFlags`` for B frames -- mp_recon_batch_early: after the coarsest level
+    the call hands (non-empty, differs-from-``expect_level0[b]``) per frame to the host (``early.wait()``) and goes
+    on refining; ``expect_level0``: list of [r0,r0,r0] f32 tensors (or None entries)."""
     ctx = mlp.ctx
     n = len(feats_hwc)
     h, w, c = feats_hwc[0].shape
@@ -416,12 +446,26 @@ def recon_batch(mlp, feats_hwc, calibs, z_scale, b_min, b_max, resolutions, bala
     bmax = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(b_max, np.float32).reshape(3)])
     res_c = (ctypes.c_int * len(res))(*res)
     ptrs = ctypes.c_void_p * n
-    ctx.check(ctx.lib.mp_recon_batch_ex(
+    if early is not None:
+        if early.n != n:
+            raise ValueError("recon_batch: EarlyFlags for %d frames, call has %d" % (early.n, n))
+        if expect_level0 is not None:
+            for e in expect_level0:
+                assert e is None or (e.numel() == res[0] ** 3 and e.is_contiguous() and e.dtype == torch.float32)
+        est = early.struct(expect_level0)
+        early_arg = ctypes.byref(est)
+    else:
+        early_arg = None
+    ctx.check(ctx.lib.mp_recon_batch_early(
         ctx.handle, mlp.id, n, ptrs(*[f.data_ptr() for f in feats_hwc]), c, h, w,
         ptrs(*[cb.data_ptr() for cb in cals]), float(z_scale), bmin, bmax, res_c, len(res),
         float(balance), _final_level(final_level), ptrs(*[v.data_ptr() for v in volumes]),
-        ptrs(*[status[b].data_ptr() for b in range(n)]), _stream(volumes[0])), "mp_recon_batch_ex")
+        ptrs(*[status[b].data_ptr() for b in range(n)]), early_arg, _stream(volumes[0])), "mp_recon_batch_early")
     stream = torch.cuda.current_stream(dev)
+    if expect_level0 is not None:
+        for e in expect_level0:
+            if e is not None:
+                e.record_stream(stream)
     for t in cals:
         t.record_stream(stream)
     return volumes, status
