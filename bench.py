@@ -55,67 +55,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from monoport_amd import ops, parallel, synthetic as syn  # noqa: E402
-from monoport_amd.modeling import PIFuNetC, PIFuNetG  # noqa: E402
 from monoport_amd.pipeline import MAX_RECON_BATCH, FramePipeline  # noqa: E402
 from monoport_amd.recon import pifu_calib  # noqa: E402
 
-RESOLUTIONS = [17, 33, 65, 129, 257]  # RTL/main.py:187
-B_MIN, B_MAX = [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]  # RTL/main.py:185-186
-FLOP_PER_POINT = 2363906  # netG MLP, SURVEY.md section 8d / BASELINE.md section 2
-# with the skip tables (mp_skip_table, default): the products of weights with the sampled feature
-# (layer 0 and the skip connections: 1921 x 256 multiply-adds) leave the per-point work -- they are
-# taken once per texel and frame in skip_table_kernel (16 GFLOP per frame)
-FLOP_PER_POINT_SKIP_TABLE = FLOP_PER_POINT - 2 * 1921 * 256
-FLOP_SKIP_TABLE_PER_FRAME = 2 * 1921 * 256 * 128 * 128
-FLOP_PER_POINT_C = 3350022  # netC MLP (per-vertex colour query)
-F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak
-N_IMAGES = 8  # distinct synthetic frames cycled through the timed region
-# the reference's OWN modules timed on CPU (oracle/time_reference.py, build container: the GPU box
-# has no /root/reference) -- a constant with its provenance, next to the live "port" baseline
-CPU_BASELINE_REFERENCE = {
-    "value": 0.123, "unit": "recon/s", "cores": 8, "kind": "reference",
-    "where": "build container (no GPU), 8 threads; not re-measured on the GPU box",
-    "source": "oracle/time_reference.py -> BASELINE.md section 4",
-    "sample": "1 reconstruction = netG.filter 0.565 s + 17..257 octree through the reference's "
-              "netG.query 7.49 s (280,936 points) + forward_vertices 0.092 s = 8.15 s",
-}
-
-
-def set_precision_everywhere(head, precision):
-    """MLP arithmetic of the fused query kernel AND of the encoder's fused 3x3 convolutions:
-    "f16x3" switches both to f32 emulated on f16 MFMA (three MFMAs per product, f32 accumulate);
-    the other f16 query variants leave the encoder on exact f32."""
-    from monoport_amd.modeling import backbones
-    head.set_precision(precision)
-    backbones.set_encoder_conv_precision("f16x3" if precision == "f16x3" else "f32")
-
-
-def build_netg(device, precision="f32"):
-    """Random-init (seeded) encoder of the reference architecture + the analytic F-body head."""
-    net = PIFuNetG().eval()
-    set_precision_everywhere(net.surface_classifier, precision)
-    shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
-    sd = syn.seeded_state_dict(shapes, 71)
-    net.image_filter.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    layers = syn.body_mlp("G", noise=0.05, seed=1)
-    net.surface_classifier.load_state_dict(
-        {**{"filters.%d.weight" % i: torch.from_numpy(w)[:, :, None] for i, (w, _) in enumerate(layers)},
-         **{"filters.%d.bias" % i: torch.from_numpy(b) for i, (_, b) in enumerate(layers)}})
-    return net.to(device), layers
-
-
-def build_netc(device):
-    """netC with seeded random weights of the reference architecture (config 3)."""
-    net = PIFuNetC().eval()
-    shapes = {k: tuple(v.shape) for k, v in net.image_filter.state_dict().items()}
-    sd = syn.seeded_state_dict(shapes, 72)
-    net.image_filter.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    layers = syn.rand_mlp("C", 61, 2.0)
-    net.surface_classifier.load_state_dict(
-        {**{"filters.%d.weight" % i: torch.from_numpy(w)[:, :, None] for i, (w, _) in enumerate(layers)},
-         **{"filters.%d.bias" % i: torch.from_numpy(b) for i, (_, b) in enumerate(layers)}})
-    return net.to(device)
+from bench_common import (B_MAX, B_MIN, CPU_BASELINE_REFERENCE, F32_MFMA_PEAK_TFLOPS, FLOP_PER_POINT,  # noqa: E402,F401
+                          FLOP_PER_POINT_C, FLOP_PER_POINT_SKIP_TABLE, FLOP_SKIP_TABLE_PER_FRAME, HBM_PEAK_GBS,
+                          N_IMAGES, RESOLUTIONS, build_netc, build_netg, set_precision_everywhere)
+from bench_dropin import dropin_surface, soak  # noqa: E402
 
 
 def make_pipeline(device, depth, use_graph, resolutions=None, with_color=False, precision="f32",
@@ -573,202 +519,6 @@ def mesh_leg(job, volume, resolutions):
     }
 
 
-def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
-    """The reference's own call surface, as RTL/main.py:326-452 drives it: the processors=[...]
-    list (H2D, camera, pifu_calib, input normalisation, netG.filter, reconEngine =
-    Seg3dLossless(query_func) with its per-frame host sync, forward_vertices with its .item(),
-    colorization) on the thread-per-stage pipeline, eager encoder.  Two modes, `passes` runs each
-    (median / min / max): `per_frame_stages` = one frame per stage call, exactly the reference's
-    structure; and the headline of this leg, the same list with the three heavy stages wrapped in
-    stage_pipeline.Coalesced -- when frames queue up in front of a stage it serves up to 8 of them in
-    one call (a batched netG.filter, Seg3dLossless.forward_many = one mp_recon_batch, one host sync
-    for all vertex counts); per-frame results are unchanged.  Also the latency of a single frame run
-    stage by stage."""
-    from monoport_amd.implicit_seg.functional import Seg3dLossless
-    from monoport_amd.recon import colorization, forward_vertices, forward_vertices_many
-    from monoport_amd.stage_pipeline import Coalesced, StagePipeline
-    netG, _ = build_netg(device)
-    planes = torch.from_numpy(syn.body_feature_planes(128, 128)).to(device)
-
-    def query_func(points, im_feat_list, calib_tensor):  # RTL/main.py:169-183
-        assert len(points) == 1
-        samples = points.repeat(1, 1, 1)
-        samples = samples.permute(0, 2, 1)
-        return netG.query(im_feat_list, points=samples, calibs=calib_tensor)[0]
-
-    # two engines: the class default validates query_func on EVERY frame (one extra 17^3 query + host sync;
-    # what a maintainer gets by swapping the import); validate="first" trusts a closure after three agreeing
-    # frames (re-checked every 32nd) and is what lets a coalescing stage batch frames (forward_many)
-    engines = {v: Seg3dLossless(query_func=query_func, b_min=np.array([B_MIN], np.float32),
-                                b_max=np.array([B_MAX], np.float32), resolutions=resolutions,
-                                balance_value=0.5, use_cuda_impl=False, faster=True, validate=v).to(device)
-               for v in ("always", "first")}
-    mean, std = 0.5, 0.5
-    r_last = resolutions[-1]
-
-    def filt(d):
-        feats = netG.filter(d["input_netG"])
-        feats[-1][0][0, 0:2].copy_(planes)  # synthetic body planes, as in the headline run
-        return {**d, "feat_tensor_G": feats}
-
-    debug = os.environ.get("MONOPORT_DROPIN_DEBUG") == "1"
-    call_log = []
-
-    def logged(name, fn):
-        if not debug:
-            return fn
-
-        def wrapper(x):
-            t0 = time.perf_counter()
-            out = fn(x)
-            call_log.append((name, len(x) if isinstance(x, list) else 1, time.perf_counter() - t0))
-            return out
-        return wrapper
-
-    def filt_many(ds):
-        feats = netG.filter(torch.cat([d["input_netG"] for d in ds]))
-        out = []
-        for i, d in enumerate(ds):
-            fi = [[f[i:i + 1] for f in stage] for stage in feats]
-            fi[-1][0][0, 0:2].copy_(planes)
-            out.append({**d, "feat_tensor_G": fi})
-        return out
-
-    def recon_many(ds):
-        sdfs = engines["first"].forward_many([dict(im_feat_list=d["feat_tensor_G"], calib_tensor=d["calib_tensor"]) for d in ds])
-        return [{**d, "sdf": sdf} for d, sdf in zip(ds, sdfs)]
-
-    def vertices_many(ds):
-        vs = forward_vertices_many([d["sdf"] for d in ds], direction="front")
-        return [{**d, **dict(zip(["X", "Y", "Z", "norm"], v))} for d, v in zip(ds, vs)]
-
-    def processors(step, coalesce=False, validate="always"):
-        engine = engines["first" if coalesce else validate]
-
-        def camera(d):
-            ext, intr = syn.scene_camera(3 * step[0])
-            step[0] += 1
-            return {**d, "extrinsic": ext, "intrinsic": intr}
-        def recon_one(d):
-            return {**d, "sdf": engine(im_feat_list=d["feat_tensor_G"], calib_tensor=d["calib_tensor"])}
-
-        def vertices_one(d):
-            return {**d, **dict(zip(["X", "Y", "Z", "norm"], forward_vertices(d["sdf"], direction="front")))}
-
-        wrap = ((lambda one, many, name: Coalesced(logged(name, one), logged(name, many), max_batch=CO_BATCH, max_pending=CO_PENDING)) if coalesce
-                else (lambda one, many, name: logged(name, one)))
-        return [
-            lambda data: {"input": data.to(device, non_blocking=True)},                    # main.py:327
-            camera,                                                                       # :330-336
-            lambda d: {**d, "calib_tensor": pifu_calib(d["extrinsic"], d["intrinsic"], device=device)},
-            lambda d: {**d, "input_netG": (((d["input"][:, 0:3] * 0.5 + 0.5) - mean) / std)
-                       * d["input"][:, 3:4]},                                             # :353-357
-            wrap(filt, filt_many, "filter"),                                              # :367-370
-            wrap(recon_one, recon_many, "recon"),                                         # :390-395
-            wrap(vertices_one, vertices_many, "vertices"),                                # :401-406
-            lambda d: {**d, "render_norm": colorization(None, None, d["X"], d["Y"], d["Z"],
-                                                        d["calib_tensor"], d["norm"],
-                                                        resolution=r_last)},              # :418-428
-        ]
-
-    # coalescing stages: frames served per call at most / frames in flight (MONOPORT_DROPIN_COALESCE="batch,in_flight")
-    # + batches of a stage in flight on the GPU at once (Coalesced(max_pending=...), 0 = unthrottled)
-    CO_BATCH, CO_IN_FLIGHT, CO_PENDING = (int(v) for v in (os.environ.get("MONOPORT_DROPIN_COALESCE", "16,48,1") + ",1").split(",")[:3])
-    frames = []
-    for i in range(N_IMAGES):
-        img = torch.from_numpy(syn.synthetic_image(i))
-        mask = (img.abs().sum(0, keepdim=True) > 0).float()
-        frames.append(torch.cat([img, mask], 0)[None].pin_memory())
-
-    # single-frame latency: one frame through the stages, one after the other, nothing else on
-    # the GPU; median of 7 after a warm-up
-    procs = processors([0])
-    lat = []
-    with torch.no_grad():
-        for i in range(3 + 7):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            d = frames[i % N_IMAGES]
-            for p in procs:
-                d = p(d)
-            torch.cuda.synchronize()
-            lat.append(time.perf_counter() - t0)
-    assert d["render_norm"] is not None
-    latency_ms = float(np.median(lat[3:])) * 1e3
-
-    # throughput: the same list on the stage pipeline (thread + stream per stage, FIFO order)
-    n_frames = max(n_frames, 96)  # long against the pipeline's fill and drain, which are INSIDE the timed region
-    passes = max(passes, 5)
-
-    def one_pass(coalesce, in_flight, validate):
-        engine = engines["first" if coalesce else validate]
-
-        def source():
-            for i in range(n_frames):
-                yield frames[i % N_IMAGES]
-
-        # the clock runs from an EMPTY pipeline to an empty pipeline (fill and drain included): starting it
-        # after a few warm-up outputs would count frames that are already half way through the stages
-        out_count, last = 0, None
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            for d in StagePipeline(source(), processors([0], coalesce, validate), device=device, max_in_flight=in_flight):
-                out_count += 1
-                last = d
-            torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        assert out_count == n_frames and engine.last_path == "fused" and last["render_norm"] is not None
-        if debug:
-            st = torch.cuda.memory_stats()
-            print("dropin pass coalesce=%s: %.1f recon/s; device allocs %d frees %d retries %d, reserved %.1f GB; %d calls, "
-                  "batch sizes %s; slow calls: %s"
-                  % (coalesce, n_frames / elapsed, st.get("num_device_alloc", -1), st.get("num_device_free", -1),
-                     st.get("num_alloc_retries", -1), torch.cuda.memory_reserved() / 2 ** 30, len(call_log),
-                     sorted(set(b for _, b, _ in call_log)),
-                     " ".join("%s x%d %.0fms" % (n, b, 1e3 * t) for n, b, t in call_log if t > 0.1)), file=sys.stderr, flush=True)
-            call_log.clear()
-        return elapsed
-
-    def mode(coalesce, in_flight, validate="first"):
-        if coalesce:
-            # untimed: first use of every encoder batch size the coalescing filter stage can meet, ON THAT STAGE'S
-            # STREAM (stage 4 of the list) -- torch's allocator pools blocks per stream, and a first batched encoder
-            # pass on a cold pool costs 1.5-1.8 s of hipMalloc (profiles/r04g_dropin_passes.txt)
-            from monoport_amd.stage_pipeline import stage_stream
-            with torch.no_grad(), torch.cuda.stream(stage_stream(device, 4)):
-                for b in range(1, CO_BATCH + 1):
-                    netG.filter(torch.zeros((b, 3, 512, 512), device=device))
-            torch.cuda.synchronize()
-        one_pass(coalesce, in_flight, validate)  # untimed
-        runs = sorted(one_pass(coalesce, in_flight, validate) for _ in range(passes))
-        med = runs[len(runs) // 2]
-        return {"value": n_frames / med, "unit": "recon/s", "ms_per_step": med / n_frames * 1e3,
-                "passes": {"n": passes, "value_min": n_frames / runs[-1], "value_median": n_frames / med,
-                           "value_max": n_frames / runs[0]},
-                "frames_in_flight": in_flight, "validate": "first" if coalesce else validate}
-
-    per_frame = mode(False, 8, "always")
-    per_frame_trusted = mode(False, 8, "first")
-    co = mode(True, CO_IN_FLIGHT)
-    return {
-        "surface": "RTL/main.py processors list on StagePipeline: Seg3dLossless(query_func) + forward_vertices + "
-                   "colorization, eager encoder; netG.filter / reconEngine / forward_vertices as Coalesced stages "
-                   "(up to %d queued frames per call), %d frames in flight" % (CO_BATCH, CO_IN_FLIGHT),
-        **co,
-        "per_frame_stages": {**per_frame,
-                             "surface": "the same list, one frame per stage call (the reference's structure), batch 1, "
-                                        "8 frames in flight; Seg3dLossless as constructed by RTL/main.py:188-195 (class "
-                                        "default validate='always': query_func checked on every frame)"},
-        "per_frame_stages_trusted": {**per_frame_trusted,
-                                     "surface": "the same with Seg3dLossless(..., validate='first')"},
-        "latency_validate": "always",
-        "latency_ms_single_frame": latency_ms,
-        "latency_ms_min": float(np.min(lat[3:])) * 1e3,
-        "frames": n_frames,
-    }
-
-
 def cpu_baseline(threads):
     """One reconstruction on the host cores: encoder (torch CPU, the reference's own op set) +
     CPU oracle octree / query / forward_vertices.  Test infrastructure used as the baseline."""
@@ -906,6 +656,9 @@ def parse_args(argv):
                          "host sync; dropin: `value` is measured through the reference's call surface "
                          "(StagePipeline + Seg3dLossless + forward_vertices), as the default run's "
                          "`dropin` object")
+    ap.add_argument("--soak", type=float, default=10.0,
+                    help="seconds of the per-frame drop-in pipeline's soak leg (dropin.soak: latency distribution and "
+                         "held memory per 10-s window; `--mode dropin --soak 60` for the long form, 0 = off)")
     ap.add_argument("--final-level", default="dilate3", choices=["dilate3", "upstream", "interpolate"],
                     help="selection rule of the LAST octree level (Seg3dLossless(final_level=...)): dilate3 = the "
                          "lossless schedule (default, the headline); upstream = nodes whose upsampled mask is exactly "
@@ -961,6 +714,11 @@ def main(argv=None):
                          % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # host cores next to this rank's GPU (N > 1; MONOPORT_BENCH_PIN=1 forces it for one rank, =0 switches it off)
+    pin = os.environ.get("MONOPORT_BENCH_PIN", "auto")
+    cpu_affinity = (parallel.pin_to_gpu_numa(local_rank, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", args.gpus)))
+                    if pin == "1" or (pin == "auto" and args.gpus > 1 and not one_gpu_test) else
+                    {"source": "unchanged (single process)", "cpus": len(os.sched_getaffinity(0))})
     backend = "gloo" if one_gpu_test else "nccl"  # nccl = RCCL on ROCm
     # second test hook: a ONE-rank RCCL group, so that a one-GPU box runs every collective call of the N > 1
     # path (barrier, all_reduce, all_gather_object, the render gather) on the real backend
@@ -980,14 +738,16 @@ def main(argv=None):
     if args.mode == "dropin":
         assert world == 1, "--mode dropin is a single-GPU measurement"
         res = dropin_surface(device, args.steps, args.warmup, resolutions, args.passes)
+        if args.soak > 0:
+            res["soak"] = soak(device, args.soak, resolutions)
         print(json.dumps({
             "metric": "reconstructions/sec (512^2 in, %d^3 grid) through the drop-in surface" % (resolutions[-1] - 1),
             "value": res["value"], "unit": "recon/s", "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": res["surface"]}, "passes": res["passes"],
-            "per_frame_stages": res["per_frame_stages"],
-            "latency_ms_single_frame": res["latency_ms_single_frame"]}), flush=True)
+            "per_frame_stages": res["per_frame_stages"], "per_frame_stages_trusted": res["per_frame_stages_trusted"],
+            "latency_ms_single_frame": res["latency_ms_single_frame"], "soak": res.get("soak")}), flush=True)
         return
 
     job = Job(device, rank, world, dist, one_gpu_test, args.steps, args.warmup)
@@ -1004,10 +764,19 @@ def main(argv=None):
     roof = main_res["roof"]
     # what the f32 matrix pipe of THIS box holds right now, and at which clock (mp_mfma_clock_probe, a 30-50 ms
     # register-only MFMA loop straight after the roofline leg): boxes of one pool differ by a few per cent
-    sustained = None
-    if (rank == 0 or world == 1) and args.precision == "f32":
+    # On N > 1 EVERY rank probes its own GPU at the same time (all eight under matrix load, as in the timed region)
+    # and rank 0 prints all of them: a slow or down-clocked GPU is visible in the one line.
+    sustained = sustained_per_rank = None
+    if args.precision == "f32":
         torch.cuda.synchronize()
+        if dist is not None:
+            job.barrier()
         sustained = ops.mfma_clock_probe(device, 50.0)
+        if dist is not None:
+            got = [None] * world
+            dist.all_gather_object(got, {"rank": rank, "mfma_f32_tflops": sustained["tflops"],
+                                         "shader_clock_mhz": sustained["shader_clock_mhz"]})
+            sustained_per_rank = got
     r_last = resolutions[-1]
     extras = {}
 
@@ -1212,6 +981,11 @@ def main(argv=None):
                 "frames_per_rank": args.steps,
                 "distinct_images": len(job.images),
                 "devices": devices,
+                "cpu_affinity": cpu_affinity,
+                # what the process group reports, not what was asked for: ranks and backend of the communicator
+                "rccl_ranks": (None if dist is None else
+                               {"world_size": int(dist.get_world_size()), "backend": str(dist.get_backend()),
+                                "distinct_devices": len(set(devices))}),
                 "backend": ("nccl (RCCL), one-rank group (test hook)" if force_group else
                             "none (single process)" if world == 1 else
                             "gloo (one-GPU test hook)" if one_gpu_test else "nccl (RCCL)"),
@@ -1293,6 +1067,7 @@ def main(argv=None):
                     "probe_ms": sustained["ms"],
                     "frac_of_sustained": (roof["achieved"] * (FLOP_PER_POINT_SKIP_TABLE / FLOP_PER_POINT if skip_on else 1.0)
                                           / sustained["tflops"]),
+                    "per_rank": sustained_per_rank,
                     "note": "mp_mfma_clock_probe (csrc/clock_probe.hip): v_mfma_f32_32x32x2_f32 back to back on random "
                             "mantissas, two 4-wave workgroups per CU, no memory; shader clock = s_memtime cycles per "
                             "100 MHz s_memrealtime tick averaged over the workgroups"},
@@ -1304,6 +1079,8 @@ def main(argv=None):
         if world == 1 and not args.no_dropin and not args.with_color and args.precision == "f32":
             out["dropin"] = dropin_surface(device, args.steps, args.warmup, resolutions, args.passes)
             out["latency_ms_single_frame"] = out["dropin"]["latency_ms_single_frame"]
+            if args.soak > 0:
+                out["dropin"]["soak"] = soak(device, args.soak, resolutions)
         if world == 1 and not args.no_cpu_baseline and not args.with_color and args.levels == 5:
             # bounded thread count: torch-CPU convs at batch 1 collapse when oversubscribed
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))

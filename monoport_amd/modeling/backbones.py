@@ -678,6 +678,14 @@ class HGFilter(nn.Module):
         return outputs[-1:] if last_only else outputs
 
 
+    def plan_count(self):
+        """Recorded mp_plans (one per shape / flags / stream that replays it, at most _PlannedForward.MAX_ENTRIES)
+        plus captured hipGraphs this encoder holds right now -- each owns ~200 MB of static buffers; the soak leg
+        of bench.py asserts the count stays flat."""
+        d = self.__dict__
+        return (len(d["_plans"].entries) if "_plans" in d else 0) + (len(d["_graphs"].entries) if "_graphs" in d else 0)
+
+
 def PIFuHGFilters(*args, **kwargs):
     return HGFilter(num_stack=4, depth=2, dim=256)
 

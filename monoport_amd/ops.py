@@ -1326,6 +1326,15 @@ def gn_apply(x, gn, relu=True, res=None, stats=None):
     return y
 
 
+def memory_stats(device):
+    """mp_memory_stats: device memory the context of ``device`` owns (scratch arenas incl. outgrown blocks, packed MLP
+    weights) and how many arenas / registered skip tables it tracks."""
+    ctx = get_context(device)
+    out = (ctypes.c_int64 * 4)()
+    ctx.check(ctx.lib.mp_memory_stats(ctx.handle, out), "mp_memory_stats")
+    return {"arena_bytes": int(out[0]), "weight_bytes": int(out[1]), "arenas": int(out[2]), "skip_tables": int(out[3])}
+
+
 def mfma_clock_probe(device, ms_target=20.0, stream=None):
     """What the f32 matrix pipe of ``device`` sustains right now (mp_mfma_clock_probe, csrc/clock_probe.hip):
     {"tflops", "shader_clock_mhz", "ms", "workgroups"} of a register-only MFMA loop of about ``ms_target`` ms."""

@@ -36,6 +36,66 @@ def init_from_env(backend=None, device=None, force=False):
     return rank, world
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa(device_index, local_rank=0, local_world=1, sysfs="/sys/bus/pci/devices"):
+    """Pin the calling process (every thread it starts later inherits the mask) to the host cores next to its GPU.
+    One process per GPU: the stage threads of a rank (eight Python threads feeding one device) should not
+    migrate across sockets, nor share cores with the seven other ranks.  The cores come from the GPU's PCI device
+    (``local_cpulist`` in sysfs, i.e. the CPUs of its NUMA node), divided among the ranks that share that node; when
+    sysfs has no answer (containers, one-socket boxes) the cores the process may use are split evenly by local
+    rank.  Returns a dict for the bench line (``config.cpu_affinity``); never raises -- affinity is an
+    optimisation, not a requirement."""
+    info = {"source": "unchanged", "cpus": None, "numa_node": None}
+    try:
+        allowed = os.sched_getaffinity(0)
+    except (AttributeError, OSError):
+        return info
+    local = None
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id)
+        base = os.path.join(sysfs, bdf)
+        with open(os.path.join(base, "local_cpulist")) as f:
+            local = _parse_cpulist(f.read()) & allowed
+        with open(os.path.join(base, "numa_node")) as f:
+            info["numa_node"] = int(f.read().strip())
+    except Exception:  # noqa: BLE001 -- no GPU properties / no sysfs entry
+        local = None
+    if local and len(local) < len(allowed):
+        # ranks on the same NUMA node share its cores: give each an equal slice (ranks of one node are those whose
+        # GPUs report the same list; without a census we slice by the rank's position among `local_world` ranks
+        # assuming GPUs are spread evenly over the nodes, which is how 8-GPU MI355X hosts are built)
+        nodes = max(1, round(len(allowed) / len(local)))
+        per_node = max(1, -(-local_world // nodes))
+        cpus = sorted(local)
+        k = local_rank % per_node
+        share = cpus[k * len(cpus) // per_node:(k + 1) * len(cpus) // per_node] or cpus
+        info["source"] = "sysfs local_cpulist of the GPU's PCI device, sliced over %d rank(s) per NUMA node" % per_node
+    elif local_world > 1:
+        cpus = sorted(allowed)
+        share = cpus[local_rank * len(cpus) // local_world:(local_rank + 1) * len(cpus) // local_world] or cpus
+        info["source"] = "even split of the allowed cores over %d local ranks (no NUMA information)" % local_world
+    else:
+        info["cpus"] = len(allowed)
+        return info
+    try:
+        os.sched_setaffinity(0, share)
+        info["cpus"] = len(share)
+        info["first_cpu"], info["last_cpu"] = share[0], share[-1]
+    except OSError as e:
+        info["source"] = "unchanged (sched_setaffinity failed: %s)" % e
+    return info
+
+
 def frames_of_rank(rank, world, n_frames):
     """Frame ids handled by ``rank``: round-robin, rank r gets r, r+world, ..."""
     return list(range(rank, n_frames, world))

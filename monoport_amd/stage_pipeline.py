@@ -136,6 +136,7 @@ class StagePipeline:
                                 and self.device.type == "cuda")
         self._threads = []
         self._grad_enabled = True
+        self._stop = threading.Event()
 
     # ---- worker bodies ------------------------------------------------------------------------
     def _stage_loop(self, idx, fn, q_in, q_out):
@@ -216,6 +217,8 @@ class StagePipeline:
         try:
             for item in self.source:
                 slots.acquire()
+                if self._stop.is_set():  # the consumer went away (an error was re-raised, or it stopped iterating)
+                    break
                 q0.put((item, None))
         except Exception:  # noqa: BLE001
             q0.put((StageError(-1, sys.exc_info()), None))
@@ -231,21 +234,39 @@ class StagePipeline:
             self._threads.append(threading.Thread(target=self._stage_loop,
                                                   args=(i, fn, queues[i], queues[i + 1]),
                                                   daemon=True))
+        self._stop.clear()
         for t in self._threads:
             t.start()
-        while True:
-            item = queues[-1].get()
-            if item is _END:
-                break
-            payload, event = item
-            slots.release()
-            if isinstance(payload, StageError):
-                payload.reraise()
-            if event is not None:
-                # the consumer reads the result on its own current stream
-                cur = torch.cuda.current_stream(self.device)
-                cur.wait_event(event)
-                _record_streams(payload, cur)
-            yield payload
-        for t in self._threads:
-            t.join(timeout=5)
+        finished = False
+        try:
+            while True:
+                item = queues[-1].get()
+                if item is _END:
+                    finished = True
+                    break
+                payload, event = item
+                slots.release()
+                if isinstance(payload, StageError):
+                    payload.reraise()
+                if event is not None:
+                    # the consumer reads the result on its own current stream
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(event)
+                    _record_streams(payload, cur)
+                yield payload
+        finally:
+            if not finished:
+                # an error was re-raised above, or the consumer stopped iterating: shut the pipeline down instead of
+                # leaving its threads parked on their queues (the reference's loader dies with the process,
+                # RTL/dataloader.py:909-914).  The feeder stops admitting, the frames already inside run through and
+                # are dropped here, the end marker follows them down the stages.
+                self._stop.set()
+                for _ in range(self.max_in_flight + 1):
+                    slots.release()
+                try:
+                    while queues[-1].get(timeout=30) is not _END:
+                        slots.release()
+                except queue.Empty:
+                    pass
+            for t in self._threads:
+                t.join(timeout=5)

@@ -94,3 +94,27 @@ def test_in_flight_layout():
         pass
     else:
         raise AssertionError("8 frames over 3 ranks must be refused")
+
+
+def test_rank_cpu_affinity_helpers():
+    """parallel.pin_to_gpu_numa (bench.py: config.cpu_affinity on N > 1): the sysfs cpulist parser, and the fallback
+    when the GPU's PCI device has no NUMA answer (here: no GPU at all) -- the allowed cores split evenly by local
+    rank, disjoint between ranks, the mask applied to the process and restorable."""
+    from monoport_amd import parallel
+    assert parallel._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert parallel._parse_cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    try:
+        if len(before) >= 2:
+            a = parallel.pin_to_gpu_numa(0, 0, 2)
+            got_a = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, before)
+            b = parallel.pin_to_gpu_numa(1, 1, 2)
+            got_b = os.sched_getaffinity(0)
+            assert got_a and got_b and not (got_a & got_b) and (got_a | got_b) <= before
+            assert a["cpus"] == len(got_a) and b["cpus"] == len(got_b) and "even split" in a["source"]
+        os.sched_setaffinity(0, before)
+        one = parallel.pin_to_gpu_numa(0, 0, 1)  # a single process is left alone
+        assert os.sched_getaffinity(0) == before and one["cpus"] == len(before)
+    finally:
+        os.sched_setaffinity(0, before)

@@ -708,3 +708,26 @@ def test_coalesced_stages_give_the_per_frame_results():
         outs = list(StagePipeline(source(), stages, device=DEV, max_in_flight=8))
     assert [d["i"] for d in outs] == list(range(6)) and max(sizes) > 1
     assert all(torch.equal(d["sdf"], singles[d["i"]]) for d in outs)
+
+
+def test_soak_of_the_per_frame_pipeline_is_flat_and_surfaces_errors():
+    """The reference's steady-state mode (RTL/main.py:487: an endless loop at one frame per stage call) for ~10 s
+    on 64 rotating images / cameras with empty scenes in the mix (bench_dropin.soak, the `dropin.soak` leg of
+    bench.py): every frame comes back, empty scenes as None (RTL/recon.py:32-33), and after the first window
+    nothing the process holds grows -- torch's reserved bytes, the C side's arenas / weights / registered tables
+    (mp_memory_stats), the encoder's recorded plans.  Then the same pipeline with a failure injected in the recon
+    stage: the error reaches the consumer (RTL/dataloader.py:1042-1047) and every stage thread exits."""
+    import bench_dropin
+    res = bench_dropin.soak(DEV, 10.0, [17, 33, 65, 129, 257], window_s=2.5, empty_every=23)
+    lat = res["latency_ms"]
+    print("soak: %d frames in %.1f s = %.1f recon/s, %d None; latency p50 %.1f p99 %.1f max %.1f ms; windows %s"
+          % (res["frames"], res["seconds"], res["value"], res["none_frames"], lat["p50"], lat["p99"], lat["max"],
+             [(round(w["value"], 1), w["torch_reserved"] >> 20, w["mp_arena_bytes"] >> 20, w["encoder_plans"])
+              for w in res["windows"]]))
+    assert res["error"] is None and res["stage_threads_alive_after"] == 0
+    assert res["frames"] > 300 and res["none_frames"] == res["frames"] // 23
+    assert len(res["windows"]) >= 3 and res["flat_after_warmup"], res["windows"]
+    assert lat["p99"] < 4 * lat["p50"] and lat["max"] < 250.0  # no stall: a frame never waits for an allocation storm
+    bad = bench_dropin.soak(DEV, 3.0, [17, 33, 65, 129, 257], window_s=1.0, raise_at=40)
+    assert bad["error"] is not None and "stage 5 failed" in bad["error"] and "injected failure at frame 40" in bad["error"]
+    assert bad["frames"] == 40 and bad["stage_threads_alive_after"] == 0

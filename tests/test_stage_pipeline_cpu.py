@@ -147,3 +147,33 @@ def test_stage_threads_inherit_the_consumers_grad_mode():
     assert seen == [False] * 3
     seen.clear()
     assert list(pipe()) == [0, 1, 2] and seen == [True] * 3
+
+
+def test_pipeline_shuts_down_after_an_error_or_an_early_exit():
+    """An exception re-raised in the consumer (RTL/dataloader.py:909-914) or a consumer that stops iterating must not
+    leave the feeder and the stage threads parked on their queues: the feeder stops admitting from an ENDLESS
+    source, the frames inside run through and the end marker follows them (round 6: the soak leg's requirement)."""
+    import itertools
+    from monoport_amd.stage_pipeline import StagePipeline
+
+    def boom(x):
+        if x == 7:
+            raise ValueError("frame seven")
+        return x
+
+    pipe = StagePipeline(itertools.count(), [lambda x: x, boom, lambda x: x], device=None, max_in_flight=4)
+    got = []
+    with pytest.raises(RuntimeError, match="stage 1 failed: ValueError: frame seven"):
+        for v in pipe:
+            got.append(v)
+    assert got == list(range(7))
+    assert pipe._threads and not any(t.is_alive() for t in pipe._threads)
+
+    pipe = StagePipeline(itertools.count(), [lambda x: x + 1], device=None, max_in_flight=3)
+    for v in pipe:
+        if v == 5:
+            break
+    time.sleep(0.05)
+    for t in pipe._threads:
+        t.join(timeout=5)
+    assert not any(t.is_alive() for t in pipe._threads)
