@@ -216,7 +216,8 @@ def _percentiles(values_ms):
             "max": float(v.max()), "mean": float(v.mean()), "n": int(v.size)}
 
 
-def soak(device, seconds, resolutions, window_s=10.0, n_inputs=64, in_flight=8, empty_every=37, raise_at=None):
+def soak(device, seconds, resolutions, window_s=None, n_inputs=64, in_flight=8, empty_every=37, raise_at=None,
+         latency_sweep=(1, 2, 4), sweep_seconds=1.5):
     """The reference's steady-state operating mode -- an endless ``for data_dict in loader`` at one frame per stage
     call (RTL/main.py:487, RTL/dataloader.py:1026-1053) -- run for ``seconds``: the processors list of
     RTL/main.py:326-452 on the per-frame StagePipeline (Seg3dLossless as the reference constructs it, class default
@@ -228,11 +229,14 @@ def soak(device, seconds, resolutions, window_s=10.0, n_inputs=64, in_flight=8, 
     ``in_flight`` frames admitted at once this includes the time a frame queues behind its predecessors) overall and
     per ``window_s`` window, and per window what the process holds: torch's reserved / allocated bytes, the C side's
     scratch arenas / packed weights / arenas / registered skip tables (mp_memory_stats) and the live encoder plans.
-    ``flat``: the last window's figures equal the second window's (the first one warms up).
+    ``flat``: the last window's figures equal the second window's (the first one warms up).  ``window_s`` defaults
+    to a sixth of the run, at least 2.5 s.
+    ``latency_sweep``: after the soak, the same pipeline for ``sweep_seconds`` each at these numbers of frames in
+    flight -- by Little's law the admission-to-render latency at k frames in flight is k / throughput, so the
+    8-in-flight figure of the soak is a queueing time; the sweep shows what a caller gets who admits fewer.
     ``raise_at``: (test hook) make the recon stage raise on that frame: the error must reach the consumer."""
     from monoport_amd.implicit_seg.functional import Seg3dLossless
     from monoport_amd.recon import colorization, forward_vertices
-    from monoport_amd.stage_pipeline import StagePipeline
     netG, _ = build_netg(device)
     planes = torch.from_numpy(syn.body_feature_planes(128, 128)).to(device)
     empty_planes = torch.empty_like(planes)
@@ -254,17 +258,11 @@ def soak(device, seconds, resolutions, window_s=10.0, n_inputs=64, in_flight=8, 
         mask = (img.abs().sum(0, keepdim=True) > 0).float()
         frames.append(torch.cat([img, mask], 0)[None].pin_memory())
     cameras = [syn.scene_camera(5 * i) for i in range(n_inputs)]
-    admitted = {}
 
     def filt(d):
         feats = netG.filter(d["input_netG"])
         feats[-1][0][0, 0:2].copy_(empty_planes if d["empty"] else planes)
         return {**d, "feat_tensor_G": feats}
-
-    def recon(d):
-        if raise_at is not None and d["index"] == raise_at:
-            raise ValueError("injected failure at frame %d" % raise_at)
-        return {**d, "sdf": engine(im_feat_list=d["feat_tensor_G"], calib_tensor=d["calib_tensor"])}
 
     procs = [
         lambda item: {"index": item[0], "empty": item[2], "camera": item[3],
@@ -273,11 +271,46 @@ def soak(device, seconds, resolutions, window_s=10.0, n_inputs=64, in_flight=8, 
         lambda d: {**d, "calib_tensor": pifu_calib(d["extrinsic"], d["intrinsic"], device=device)},
         lambda d: {**d, "input_netG": (((d["input"][:, 0:3] * 0.5 + 0.5) - 0.5) / 0.5) * d["input"][:, 3:4]},
         filt,                                                                                   # :367-370
-        recon,                                                                                  # :390-395
+        None,                                                                                   # :390-395 (procs_for)
         lambda d: {**d, **dict(zip(["X", "Y", "Z", "norm"], forward_vertices(d["sdf"], direction="front")))},
         lambda d: {**d, "render_norm": colorization(None, None, d["X"], d["Y"], d["Z"], d["calib_tensor"],
                                                     d["norm"], resolution=r_last)},              # :418-428
     ]
+    if window_s is None:
+        window_s = max(2.5, float(seconds) / 6.0)
+
+    def run_once(seconds, in_flight, window_s, raise_at):
+        return _soak_run(device, procs_for(raise_at), frames, cameras, n_inputs, empty_every, seconds, in_flight, window_s,
+                         held)
+
+    def procs_for(raise_at_frame):
+        def recon_stage(d):
+            if raise_at_frame is not None and d["index"] == raise_at_frame:
+                raise ValueError("injected failure at frame %d" % raise_at_frame)
+            return {**d, "sdf": engine(im_feat_list=d["feat_tensor_G"], calib_tensor=d["calib_tensor"])}
+        return procs[:5] + [recon_stage] + procs[6:]
+
+    def held():
+        st = ops.memory_stats(device)
+        return {"torch_reserved": int(torch.cuda.memory_reserved(device)), "torch_allocated": int(torch.cuda.memory_allocated(device)),
+                "mp_arena_bytes": st["arena_bytes"], "mp_weight_bytes": st["weight_bytes"], "mp_arenas": st["arenas"],
+                "mp_skip_tables": st["skip_tables"], "encoder_plans": netG.image_filter.plan_count()}
+
+    res = run_once(seconds, in_flight, window_s, raise_at)
+    res["surface"] = ("RTL/main.py processors list on the per-frame StagePipeline (validate='always'), %d distinct images / "
+                      "cameras in rotation, every %dth frame an empty scene, %d frames in flight, renders copied to the host"
+                      % (n_inputs, empty_every, in_flight))
+    if raise_at is None and latency_sweep:
+        res["latency_by_frames_in_flight"] = {}
+        for k in latency_sweep:
+            r = run_once(sweep_seconds, k, sweep_seconds, None)
+            res["latency_by_frames_in_flight"][str(k)] = {"value": r["value"], "latency_ms": r["latency_ms"]}
+    return res
+
+
+def _soak_run(device, procs, frames, cameras, n_inputs, empty_every, seconds, in_flight, window_s, held):
+    from monoport_amd.stage_pipeline import StagePipeline
+    admitted = {}
     t_end = [None]
 
     def source():
@@ -286,12 +319,6 @@ def soak(device, seconds, resolutions, window_s=10.0, n_inputs=64, in_flight=8, 
             admitted[i] = time.perf_counter()  # the feeder blocks on the in-flight semaphore BEFORE asking for the next item
             yield (i, frames[i % n_inputs], empty_every > 0 and i % empty_every == empty_every - 1, cameras[i % n_inputs])
             i += 1
-
-    def held():
-        st = ops.memory_stats(device)
-        return {"torch_reserved": int(torch.cuda.memory_reserved(device)), "torch_allocated": int(torch.cuda.memory_allocated(device)),
-                "mp_arena_bytes": st["arena_bytes"], "mp_weight_bytes": st["weight_bytes"], "mp_arenas": st["arenas"],
-                "mp_skip_tables": st["skip_tables"], "encoder_plans": netG.image_filter.plan_count()}
 
     windows, lat_all, lat_win, none_count = [], [], [], 0
     pipe = StagePipeline(source(), procs, device=device, max_in_flight=in_flight)
@@ -327,9 +354,6 @@ def soak(device, seconds, resolutions, window_s=10.0, n_inputs=64, in_flight=8, 
     keys = ("torch_reserved", "mp_arena_bytes", "mp_weight_bytes", "mp_arenas", "mp_skip_tables", "encoder_plans")
     flat = len(windows) >= 3 and all(windows[-1][k] == windows[1][k] for k in keys)
     return {
-        "surface": "RTL/main.py processors list on the per-frame StagePipeline (validate='always'), %d distinct images / "
-                   "cameras in rotation, every %dth frame an empty scene, %d frames in flight, renders copied to the host"
-                   % (n_inputs, empty_every, in_flight),
         "seconds": elapsed, "frames": len(lat_all), "none_frames": none_count,
         "value": len(lat_all) / elapsed, "unit": "recon/s",
         "latency_ms": _percentiles(lat_all) if lat_all else None,

@@ -352,7 +352,8 @@ int mp_marching_cubes(mp_ctx *ctx, const float *volume, int r, float level,
                       int64_t max_verts, int32_t *faces, int64_t max_faces, int32_t *counts,
                       mp_stream stream);
 
-/* ---- encoder helpers (the convolutions stay in MIOpen) ------------------------- */
+/* ---- encoder helpers (stand-alone GroupNorm / upsample / concat kernels -- the
+ * convolutions are the mp_conv* entry points below, nothing of the inference path is left on MIOpen) ---------- */
 /* y = [relu](GroupNorm(groups, C)(x)): x, y [N,C,HW] f32 (contiguous NCHW), gamma/beta [C];
  * biased variance, eps inside the sqrt -- torch.nn.GroupNorm as used by
  * backbones/HGFilters.py:23-27 and ResBlkFilters.py:19.  Needs HW % 4 == 0. */

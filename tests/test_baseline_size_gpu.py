@@ -58,10 +58,10 @@ def test_dense64_vs_reference(case, path, monkeypatch):
 
 
 def test_dense64_with_gpu_encoder_in_the_loop():
-    """Same grid, but the features come from OUR encoder on the GPU (MIOpen convolutions) while
+    """Same grid, but the features come from OUR encoder on the GPU (the hand-written convolution chain) while
     the fixture used the reference's netG.filter on the CPU: the SDF error with the GPU encoder in
     the loop, on the random-weight head (gain 2: every feature channel matters).  Measured on the
-    MI355X: features within 5.7e-6 of the reference's, SDF within 1.6e-6 (MIOpen's fp32
+    MI355X: features within 5.7e-6 of the reference's, SDF within 1.6e-6 (our fp32
     convolution algorithms differ from the CPU's in the last bits only)."""
     from monoport_amd.modeling import PIFuNetG
     g = load_golden("dense64")
