@@ -722,8 +722,8 @@ def test_soak_of_the_per_frame_pipeline_is_flat_and_surfaces_errors():
     lat = res["latency_ms"]
     print("soak: %d frames in %.1f s = %.1f recon/s, %d None; latency p50 %.1f p99 %.1f max %.1f ms; windows %s"
           % (res["frames"], res["seconds"], res["value"], res["none_frames"], lat["p50"], lat["p99"], lat["max"],
-             [(round(w["value"], 1), w["torch_reserved"] >> 20, w["mp_arena_bytes"] >> 20, w["encoder_plans"])
-              for w in res["windows"]]))
+             [(round(w["value"], 1), w["torch_reserved"] >> 20, w["mp_arena_bytes"] >> 20, w["mp_arenas"],
+               w["mp_skip_tables"], w["encoder_plans"]) for w in res["windows"]]))
     assert res["error"] is None and res["stage_threads_alive_after"] == 0
     assert res["frames"] > 300 and res["none_frames"] == res["frames"] // 23
     assert len(res["windows"]) >= 3 and res["flat_after_warmup"], res["windows"]
