@@ -21,7 +21,7 @@ _contexts_lock = threading.Lock()
 
 
 class Context:
-    """One mp_ctx per HIP device, shared by all host threads (calls are serialised inside)."""
+    """One mp_ctx (calls on it are serialised inside); ``get_context`` keeps two per HIP device, by role."""
 
     def __init__(self, device_index):
         self.lib = _lib.load()
@@ -38,18 +38,30 @@ class Context:
         _lib.check(self.handle, rc, what)
 
 
-def get_context(device):
-    """Context for a torch device (``cuda:N``).  Raises on CPU tensors: no CPU fallback."""
+def get_context(device, role="query"):
+    """Context for a torch device (``cuda:N``).  Raises on CPU tensors: no CPU fallback.
+
+    Two contexts per device (include/monoport_hip.h: "calls on ONE context are serialised by an internal mutex ...
+    give each stage its own context"): ``role="query"`` owns the packed heads, the skip-table registry and the
+    reconstruction / vertex / render calls; ``role="encoder"`` serves the stateless encoder launches (and the plans
+    recorded from them).  The reference runs netG.filter and reconEngine on different host threads
+    (RTL/dataloader.py:1026-1053): with one context the filter stage's 137 launches per frame and the recon stage's
+    multi-launch mp_recon_batch_early would take turns on one mutex."""
     device = torch.device(device)
     if device.type != "cuda":
         raise _lib.MonoportError(
             "monoport_amd runs on MI355X only (got device %s); there is no CPU path" % device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = idx if role == "query" else (idx, role)
     with _contexts_lock:
-        ctx = _contexts.get(idx)
+        ctx = _contexts.get(key)
         if ctx is None:
-            ctx = _contexts[idx] = Context(idx)
+            ctx = _contexts[key] = Context(idx)
     return ctx
+
+
+def get_encoder_context(device):
+    return get_context(device, "encoder")
 
 
 def _stream(t):
@@ -599,9 +611,9 @@ def recon_generic(query_func, kwargs, device, b_min, b_max, resolutions, balance
 def stream_release(stream):
     """Free the scratch arena the context keeps for ``stream`` (a torch.cuda.Stream); call it when
     a stream that made C-ABI calls is retired.  Synchronises the device."""
-    ctx = get_context(stream.device)
-    ctx.check(ctx.lib.mp_stream_release(ctx.handle, ctypes.c_void_p(stream.cuda_stream)),
-              "mp_stream_release")
+    for ctx in (get_context(stream.device), get_encoder_context(stream.device)):
+        ctx.check(ctx.lib.mp_stream_release(ctx.handle, ctypes.c_void_p(stream.cuda_stream)),
+                  "mp_stream_release")
 
 
 # ---- recorded launch sequences (mp_plan_*, csrc/plan.hip) --------------------------------------------
@@ -636,7 +648,7 @@ class record_plan:
         """``keep_alive=False``: the caller guarantees the lifetime of every buffer itself (a private
         allocator pool that outlives the plan); the plan then holds no tensor references, so the pass it is
         recorded from recycles its intermediates as a launch-by-launch pass does."""
-        self.ctx = get_context(device)
+        self.ctx = get_encoder_context(device)
         self.device = torch.device(device)
         self.keep_alive = bool(keep_alive)
         self.cmds, self.keep = [], []
@@ -855,7 +867,7 @@ def marching_cubes_raw(volume, level=0.5, b_min=(-1, -1, -1), b_max=(1, 1, 1), m
 
 def group_norm(x, groups, weight, bias, eps=1e-5, relu=False):
     """[relu](GroupNorm(x)) for x [N,C,H,W] f32 contiguous on the GPU (mp_group_norm)."""
-    ctx = get_context(x.device)
+    ctx = get_encoder_context(x.device)
     n, c = x.shape[0], x.shape[1]
     hw = x.shape[2] * x.shape[3]
     y = torch.empty_like(x)
@@ -873,7 +885,7 @@ def group_norm_supported(x):
 def upsample_bicubic2x(x, add=None):
     """[add +] F.interpolate(x, scale_factor=2, mode='bicubic', align_corners=True), x [N,C,H,W]
     (the batch is folded into the channel axis: every plane is resampled independently)."""
-    ctx = get_context(x.device)
+    ctx = get_encoder_context(x.device)
     n, c, h, w = x.shape
     y = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
     ctx.check(ctx.lib.mp_upsample_bicubic2x(ctx.handle, _ptr(x), n * c, h, w,
@@ -892,7 +904,7 @@ def concat3_add_supported(a, b, c, shortcut):
 def concat3_add(a, b, c, shortcut):
     """torch.cat((a, b, c), 1) + shortcut in one pass (the tail of the encoders' ConvBlock)."""
     a, b, c, shortcut = _f32c(a), _f32c(b), _f32c(c), _f32c(shortcut)
-    ctx = get_context(a.device)
+    ctx = get_encoder_context(a.device)
     n, ca, h, w = a.shape
     y = torch.empty_like(shortcut)
     ctx.check(ctx.lib.mp_concat3_add(ctx.handle, _ptr(a), ca, _ptr(b), b.shape[1], _ptr(c),
@@ -914,7 +926,7 @@ class PackedConv3x3:
         if precision not in ("f32", "f16x3"):
             raise ValueError("conv precision must be 'f32' or 'f16x3'")
         self.precision = precision
-        ctx = get_context(w.device)
+        ctx = get_encoder_context(w.device)
         self.data = torch.empty((w.numel(),), dtype=torch.float32, device=w.device)  # same bytes either way
         self.wmax = None
         if precision == "f32":
@@ -934,7 +946,7 @@ def conv3x3_supported(cin, cout, h, w):
 
 def scale_shift_add(t, ss, res):
     """res + (t * scale + shift): x + GroupNorm(t) with (scale, shift) from ``gn_finalize``."""
-    ctx = get_context(t.device)
+    ctx = get_encoder_context(t.device)
     t, res = t.contiguous(), res.contiguous()
     n, c = t.shape[0], t.shape[1]
     y = torch.empty_like(t)
@@ -948,7 +960,7 @@ def conv3x3_gn(x, ss, packed, relu=True, want_stats=False, reflect=False):
     ``reflect`` -- no bias) as one MFMA kernel; ``ss`` [N,Cin,2] from ``gn_finalize`` or None (plain
     x).  Returns (y, stats) where
     stats = (partial sums double [N,32,S,2], S) of GroupNorm(32, Cout) over y, or None."""
-    ctx = get_context(x.device)
+    ctx = get_encoder_context(x.device)
     n, cin, h, w = x.shape
     if cin != packed.cin:
         raise ValueError("conv3x3_gn: input has %d channels, weights expect %d" % (cin, packed.cin))
@@ -987,7 +999,7 @@ class PackedConv1x1:
             w2 = _f32c(w2.detach().reshape(w2.shape[0], -1))
             self.c2 = int(w2.shape[1])
         self.precision = precision
-        ctx = get_context(w1.device)
+        ctx = get_encoder_context(w1.device)
         self.data = torch.empty((self.cout * (self.c1 + self.c2),), dtype=torch.float32, device=w1.device)
         self.wmax = torch.zeros((1,), dtype=torch.float32, device=w1.device)
         bias = None if b1 is None else b1.detach().float()
@@ -1011,7 +1023,7 @@ def conv1x1_supported(x):
 def conv1x1(x1, ss1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=None, want_stats=False):
     """y = W [relu?(x1 * scale + shift) ; x2] + bias (+ res) as one fused GEMM (mp_conv1x1).
     Returns (y [N,Cout,H,W] or None, stats or None); ``y_hwc`` [N,H,W,256] is filled when given."""
-    ctx = get_context(x1.device)
+    ctx = get_encoder_context(x1.device)
     x1 = x1.contiguous()
     n, c1, h, w = x1.shape
     hw = h * w
@@ -1041,7 +1053,7 @@ def conv1x1(x1, ss1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=None, wa
 
 def gn_stats(x, groups):
     """One read pass over x [N,C,H,W]: (partial sums double [N*groups, S, 2], S)."""
-    ctx = get_context(x.device)
+    ctx = get_encoder_context(x.device)
     n, c = x.shape[0], x.shape[1]
     hw = x.shape[2] * x.shape[3]
     s = ctx.lib.mp_gn_stat_slices()
@@ -1054,7 +1066,7 @@ def gn_stats(x, groups):
 def gn_finalize(stats, n, c, groups, count, weight, bias, eps):
     """Partial sums -> ss [N,C,2] = (gamma rstd, beta - mean gamma rstd) of GroupNorm(groups, C)."""
     partial, slices = stats
-    ctx = get_context(partial.device)
+    ctx = get_encoder_context(partial.device)
     ss = torch.empty((n, c, 2), dtype=torch.float32, device=partial.device)
     ctx.check(ctx.lib.mp_gn_finalize(ctx.handle, _ptr(partial), n, c, int(groups), int(slices),
                                      int(count), _ptr(weight), _ptr(bias), float(eps), _ptr(ss),
@@ -1151,7 +1163,7 @@ def conv3x3_fused(x, gn, packed, relu=True, reflect=False, want_y=True, stats=No
       out, res   [N,Ctot,H,W]: out[:, out_off:out_off+Cout] = y + res[:, same]  (cat + residual)
       out_stats  accumulator for GroupNorm(32, Ctot) over ``out`` (shared by the launches filling it)
     Returns y (or None with want_y=False)."""
-    ctx = get_context(x.device)
+    ctx = get_encoder_context(x.device)
     n, cin, h, w = x.shape
     if cin != packed.cin:
         raise ValueError("conv3x3: input has %d channels, weights expect %d" % (cin, packed.cin))
@@ -1181,7 +1193,7 @@ def conv3x3_fused(x, gn, packed, relu=True, reflect=False, want_y=True, stats=No
 def conv1x1_fused(x1, gn1, relu1, x2, packed, res=None, want_nchw=True, y_hwc=None, stats=None):
     """mp_conv1x1_ex: ``conv1x1`` with the GroupNorm hand-over (gn1 / stats as in conv3x3_fused).
     Returns y (or None)."""
-    ctx = get_context(x1.device)
+    ctx = get_encoder_context(x1.device)
     x1 = x1.contiguous()
     n, c1, h, w = x1.shape
     hw = h * w
@@ -1222,7 +1234,7 @@ class PackedConvK:
     def __init__(self, weight, bias=None):
         w = _f32c(weight.detach())
         self.cout, self.cin, self.ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
-        ctx = get_context(w.device)
+        ctx = get_encoder_context(w.device)
         n = ctx.lib.mp_convk_packed_floats(self.cin, self.cout, self.ks)
         if n <= 0 or w.shape[2] != w.shape[3]:
             raise ValueError("PackedConvK: unsupported weight %s" % (tuple(w.shape),))
@@ -1240,7 +1252,7 @@ def convk_supported(cin, cout, ks, stride, h, w):
 def convk(x, gn, relu, packed, stride, reflect=False, stats=None):
     """mp_convk: y = conv_ks(relu?(GroupNorm(x))) (+ bias), stride 1 / 2, padding ks // 2 (zero or
     reflect); gn / stats as in conv3x3_fused.  Returns y."""
-    ctx = get_context(x.device)
+    ctx = get_encoder_context(x.device)
     x = x.contiguous()
     n, cin, h, w = x.shape
     a = _lib.ConvKArgs()
@@ -1262,7 +1274,7 @@ def convk(x, gn, relu, packed, stride, reflect=False, stats=None):
 
 def avgpool2_gn(x, stats=None):
     """F.avg_pool2d(x, 2, stride=2), adding the statistics of the result into ``stats``."""
-    ctx = get_context(x.device)
+    ctx = get_encoder_context(x.device)
     x = x.contiguous()
     n, c, h, w = x.shape
     y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
@@ -1280,7 +1292,7 @@ def avgpool2_gn(x, stats=None):
 
 def upsample_add_gn(x, add, stats=None):
     """add + bicubic x2 of x (HGFilters.py:108-111), adding the statistics of the result into ``stats``."""
-    ctx = get_context(x.device)
+    ctx = get_encoder_context(x.device)
     x = x.contiguous()
     n, c, h, w = x.shape
     y = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
@@ -1303,7 +1315,7 @@ def upsample_add_gn(x, add, stats=None):
 def gn_apply(x, gn, relu=True, res=None, stats=None):
     """[res +] relu?(GroupNorm(x)) materialised (gn = (acc, module) or a legacy ss tensor), adding the
     statistics of the result into ``stats``."""
-    ctx = get_context(x.device)
+    ctx = get_encoder_context(x.device)
     x = x.contiguous()
     n, c = x.shape[0], x.shape[1]
     hw = x.shape[2] * x.shape[3]
@@ -1327,12 +1339,14 @@ def gn_apply(x, gn, relu=True, res=None, stats=None):
 
 
 def memory_stats(device):
-    """mp_memory_stats: device memory the context of ``device`` owns (scratch arenas incl. outgrown blocks, packed MLP
+    """mp_memory_stats: device memory the contexts of ``device`` own (scratch arenas incl. outgrown blocks, packed MLP
     weights) and how many arenas / registered skip tables it tracks."""
-    ctx = get_context(device)
-    out = (ctypes.c_int64 * 4)()
-    ctx.check(ctx.lib.mp_memory_stats(ctx.handle, out), "mp_memory_stats")
-    return {"arena_bytes": int(out[0]), "weight_bytes": int(out[1]), "arenas": int(out[2]), "skip_tables": int(out[3])}
+    tot = [0, 0, 0, 0]
+    for ctx in (get_context(device), get_encoder_context(device)):
+        out = (ctypes.c_int64 * 4)()
+        ctx.check(ctx.lib.mp_memory_stats(ctx.handle, out), "mp_memory_stats")
+        tot = [a + int(b) for a, b in zip(tot, out)]
+    return {"arena_bytes": tot[0], "weight_bytes": tot[1], "arenas": tot[2], "skip_tables": tot[3]}
 
 
 def mfma_clock_probe(device, ms_target=20.0, stream=None):
