@@ -316,10 +316,14 @@ def _soak_run(device, procs, frames, cameras, n_inputs, empty_every, seconds, in
     def source():
         i = 0
         while time.perf_counter() < t_end[0]:
-            admitted[i] = time.perf_counter()  # the feeder blocks on the in-flight semaphore BEFORE asking for the next item
             yield (i, frames[i % n_inputs], empty_every > 0 and i % empty_every == empty_every - 1, cameras[i % n_inputs])
             i += 1
 
+    def admit(item):  # stage 0 (the H2D copy, RTL/main.py:327): the frame has a slot and enters the pipeline NOW --
+        admitted[item[0]] = time.perf_counter()  # the feeder pulls the source one item ahead of the in-flight semaphore
+        return procs[0](item)
+
+    procs = [admit] + list(procs[1:])
     windows, lat_all, lat_win, none_count = [], [], [], 0
     pipe = StagePipeline(source(), procs, device=device, max_in_flight=in_flight)
     error = None
