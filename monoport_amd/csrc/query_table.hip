@@ -638,7 +638,15 @@ static int launch_query_tabws_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, 
     ctx->lds_attr_done.insert(kern_id);
   }
   const long long tiles = (max_points + kTabPts - 1) / kTabPts + (set.n - 1);
-  const long long resident = (long long)cus_of(ctx, st) * 2;
+  // MONOPORT_QUERY_WGS_PER_CU (measurement switch, results do not depend on it): 2 = the kernel takes both
+  // workgroup slots of every CU (all of its LDS); 1 = half of them, so that a launch of ANOTHER stream -- a second
+  // slot's query, or its encoder's convolutions -- can be resident next to it
+  static const int wgs_per_cu = [] {
+    const char *e = getenv("MONOPORT_QUERY_WGS_PER_CU");
+    const int v = e ? atoi(e) : 2;
+    return v == 1 ? 1 : 2;
+  }();
+  const long long resident = (long long)cus_of(ctx, st) * wgs_per_cu;
   // persistent: a workgroup's producers run one chunk ahead of its consumers ACROSS tiles, so a
   // workgroup should see several tiles; never more workgroups than are resident at once
   const long long grid = tiles < resident ? tiles : resident;
