@@ -209,7 +209,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        # measurement hook (tools/): MONOPORT_QUERY_SMALL_TILES moves the gate
+        # measurement hook (tools/, DESIGN_HISTORY.md section 5): MONOPORT_QUERY_SMALL_TILES moves the gate
         # between the 32- and 64-point query kernels; the results do not depend on it
         if os.environ.get("MONOPORT_QUERY_SMALL_TILES"):
             lib.mp_query_tune(int(os.environ["MONOPORT_QUERY_SMALL_TILES"]))

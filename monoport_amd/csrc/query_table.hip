@@ -22,7 +22,7 @@
 // The query kernel that ships is pifu_query_tabws_kernel (round 4: the waves of a workgroup specialised into
 // MFMA-only consumers and table-blending producers, below).  Round 3's kernel, in which every wave did
 // everything (0.72 of the roof: two workgroups sharing a SIMD's matrix pipe drift into phase), and the
-// timing-experiment builds of both are in the history (last present at commit 78cb450; DESIGN.md 4.1c / 4.1d
+// timing-experiment builds of both are in the history (last present at commit 78cb450; DESIGN_HISTORY.md 4.1c / 4.1d
 // record their measurements).
 #include <cstdlib>
 #include <cstring>
