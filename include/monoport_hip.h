@@ -574,7 +574,8 @@ int mp_gn_apply(mp_ctx *ctx, const float *x, const mp_gn_in *gn, int relu, int n
  * mp_plan_run; slots 1..n_side_streams are streams the plan creates (the hourglass's skip branches run on side
  * streams at batch <= 2); MP_PLAN_WAIT makes one slot wait for the work enqueued so far on another.  Replays of
  * one plan must be ordered on one stream (its buffers are static).  mp_plan_run returns the first failing
- * command's status (mp_last_error). */
+ * command's status (mp_last_error); the commands after it are not enqueued, and the plan's side streams are joined
+ * into `stream` before the call returns, so nothing of the partial replay runs unordered against the caller. */
 typedef struct mp_plan mp_plan;
 enum {
   MP_PLAN_CONVK = 1,      /* args: mp_convk_args            -> mp_convk */

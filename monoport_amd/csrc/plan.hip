@@ -150,6 +150,18 @@ int mp_plan_run(mp_plan *plan, mp_stream stream) {
     }
     if (rc != MP_OK) break;
   }
+  if (rc != MP_OK && !plan->side.empty()) {
+    // a command failed in the middle of the sequence: whatever the side streams were given so far must not be
+    // left running unordered against the caller's stream (the caller may free or reuse the plan's buffers as soon
+    // as ITS stream is done) -- join every side stream into slot 0 before reporting the error
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+      for (hipStream_t s : plan->side)
+        if (hipEventRecord(ev, s) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)stream, ev, 0);
+      (void)hipEventDestroy(ev);
+    }
+    (void)hipGetLastError();
+  }
   hipSetDevice(prev);
   return rc;
 }
