@@ -28,7 +28,9 @@ line with the driver's contract fields plus
                   `roofline.sustained` = what a register-only loop of the same MFMA instruction delivers on this
                   box right after the timed launches, with the shader clock it ran at (`peak` stays nominal)
   "plain_query_path"  (N=1 only) the headline configuration without skip tables (--no-skip-table)
-  "cpu_baseline"  the CPU oracle path timed on this box's host cores (rank 0, N=1 only)
+  "cpu_baseline"  the CPU oracle path timed on this box's host cores (rank 0, N=1 only); "cpu_baseline_reference_ops" =
+                  the same reconstruction with the query through the reference's own torch CPU operators, op for op
+                  (oracle/torch_ops.py: what the reference's CPU recon path costs on THIS box)
   "passes"        the timed region is run 5 times (each EXACTLY --steps frames between barrier +
                   synchronize pairs); `value` is the median pass, min / max are listed
   "scaling_vs_single_rank"  (N > 1) rank 0 alone on the same frames while the others wait: efficiency inside ONE run
@@ -541,11 +543,31 @@ def cpu_baseline(threads):
     orc.forward_vertices(vol, "front")
     t3 = time.perf_counter()
     total = t3 - t0
+    # the same reconstruction with the query through the reference's OWN torch CPU operators (oracle/torch_ops.py:
+    # baddbmm, grid_sample, the Conv1d chain, op for op -- bit-identical to the reference-generated goldens where those
+    # were made): the encoder above already is the reference's op set, so this is what "the reference CPU recon path"
+    # costs on THIS box's host cores (/root/reference itself does not exist here)
+    from oracle import torch_ops
+    stats_t = []
+    t4 = time.perf_counter()
+    vol_t = orc.seg3d_lossless(lambda p: torch_ops.query(feat, p, calib, layers, 1, syn.Z_SCALE)[0],
+                               B_MIN, B_MAX, RESOLUTIONS, stats=stats_t)
+    t5 = time.perf_counter()
+    total_t = (t1 - t0) + (t5 - t4) + (t3 - t2)
+    ref_ops = {
+        "value": 1.0 / total_t, "unit": "recon/s", "cores": threads, "kind": "port",
+        "ops": "the reference's torch CPU operators restated op for op (MonoPortNet.py:48-91 -> oracle/torch_ops.py)",
+        "sample": "1 reconstruction: encoder %.2fs (torch CPU) + octree %.2fs (%d pts through baddbmm / grid_sample / "
+                  "Conv1d, %d torch threads) + forward_vertices %.2fs" % (t1 - t0, t5 - t4, sum(stats_t), threads, t3 - t2),
+        "mpts_per_s": sum(stats_t) / (t5 - t4) / 1e6,
+        "max_abs_diff_vs_c_oracle_volume": float(np.abs(vol_t - vol).max()),
+    }
     return {
         "value": 1.0 / total, "unit": "recon/s", "cores": threads, "kind": "port",
         "sample": "1 reconstruction: encoder %.2fs (torch CPU) + octree %.2fs (%d pts, C oracle f32, "
                   "OpenMP) + forward_vertices %.2fs" % (t1 - t0, t2 - t1, sum(stats), t3 - t2),
         "mpts_per_s": sum(stats) / (t2 - t1) / 1e6,
+        "reference_ops": ref_ops,
     }
 
 
@@ -1084,6 +1106,7 @@ def main(argv=None):
         if world == 1 and not args.no_cpu_baseline and not args.with_color and args.levels == 5:
             # bounded thread count: torch-CPU convs at batch 1 collapse when oversubscribed
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))
+            out["cpu_baseline_reference_ops"] = out["cpu_baseline"].pop("reference_ops")
             out["cpu_baseline_reference"] = CPU_BASELINE_REFERENCE
         launch_log = os.environ.get("MONOPORT_BENCH_LAUNCH_LOG")
         if launch_log:  # tools/profile_summary.py: per-launch (ms, points) of the roofline leg

@@ -52,6 +52,41 @@ def test_query_matches_reference(oracle, name, precision, tol):
     assert np.abs(out - ref).max() <= tol
 
 
+@pytest.mark.parametrize("name", sorted(QUERY_CASES))
+def test_torch_ops_query_matches_reference(name):
+    """oracle/torch_ops.py restates the reference's OPERATOR SEQUENCE (baddbmm, grid_sample, Conv1d chain) so that
+    bench.py can time "the reference CPU recon path" on a box without /root/reference.  Same operators, same order:
+    in the container that generated the goldens the outputs are the reference's bits; elsewhere (other core counts:
+    oneDNN / MKL may block differently) within fp32 summation noise."""
+    from oracle import torch_ops
+    g = load_golden(name)
+    kind, layers, f, p = query_inputs(name)
+    out = torch_ops.query(f, p, g["calib"][0], layers, syn.LAST_OP[kind], syn.Z_SCALE)
+    same = np.array_equal(out, g["out"])
+    err = float(np.abs(out - g["out"]).max())
+    print("%s: torch-operator restatement vs the reference: bit-identical %s, max|d| %.3g" % (name, same, err))
+    assert out.shape == g["out"].shape and err <= 2e-6
+    assert np.array_equal(out == 0, g["out"] == 0)
+
+
+def test_torch_ops_drive_the_octree_like_the_reference(oracle):
+    """... and driving the 17..257 schedule with it reproduces the reference-driven fixture node for node: same
+    queried set, same per-level counts, values within fp32 summation noise (bit-identical where the goldens were made)."""
+    from oracle import torch_ops
+    name = "pipeline257"
+    g, queried_ref = pipeline257_golden(name)
+    layers, f, step = pipeline257_inputs(name)
+    calib = oracle.pifu_calib(*syn.scene_camera(step))
+    stats, queried = [], np.zeros_like(queried_ref)
+    vol = oracle.seg3d_lossless(lambda p: torch_ops.query(f, p, calib[0], layers, 1, syn.Z_SCALE)[0],
+                                [-1, -1, -1], [1, 1, 1], PIPE257_RES, stats=stats, evaluated_out=queried)
+    assert stats == list(g["stats"]) and np.array_equal(queried, queried_ref)
+    err = float(np.abs(vol[queried] - g["values"]).max())
+    print("octree through the torch-operator restatement: max|value - reference| %.3g over %d nodes, bit-identical %s"
+          % (err, int(queried.sum()), np.array_equal(vol[queried], g["values"])))
+    assert err <= 2e-6
+
+
 def test_index_matches_reference(oracle):
     g = load_golden("index")
     f = syn.rand_feat(256, 128, 128, 41)

@@ -25,7 +25,7 @@ print("[%s]" % sys.argv[2], "value", round(d["value"],2), "ms/step", round(d["ms
       "recon/frame", round(d["breakdown"]["recon_vertices_render_ms_per_frame_batched"],3), "enc", round(d["breakdown"]["encoder_ms_per_frame"],3),
       "enc(as run)", d["breakdown"].get("encoder_ms_per_frame_as_run"), "enc@1", round(d["breakdown"]["encoder_ms_batch1"],3))
 if r.get("sustained"): print("    sustained", {k:(round(v,4) if isinstance(v,float) else v) for k,v in r["sustained"].items() if k != "note"})
-for k in ("plain_query_path","two_slot_submissions","in_flight_8","alt_precision","with_color","levels6_f16w","mesh","cpu_baseline"):
+for k in ("plain_query_path","two_slot_submissions","in_flight_8","alt_precision","with_color","levels6_f16w","mesh","cpu_baseline","cpu_baseline_reference_ops"):
     v=d.get(k)
     if v: print("   ", k, {kk:(round(vv,4) if isinstance(vv,float) else vv) for kk,vv in v.items() if kk in ("value","roofline_frac","roofline_frac_netG_query","roofline_frac_netC_query","ms_per_step","mesh_ms","iou_vs_f32_volume")})
 f=d.get("final_level_rules")
@@ -36,6 +36,8 @@ if f:
 dr=d.get("dropin")
 if dr:
     print("    dropin: coalesced %.1f | per-frame stages (validate=always) %.1f | per-frame trusted %.1f | latency %.2f ms" % (dr["value"], dr["per_frame_stages"]["value"], dr["per_frame_stages_trusted"]["value"], dr["latency_ms_single_frame"]))
+    sk=dr.get("soak")
+    if sk: print("    soak: %.1f recon/s over %.1f s, %d frames (%d None), latency p50 %.1f p99 %.1f max %.1f ms, flat %s; by frames in flight: %s" % (sk["value"], sk["seconds"], sk["frames"], sk["none_frames"], sk["latency_ms"]["p50"], sk["latency_ms"]["p99"], sk["latency_ms"]["max"], sk["flat_after_warmup"], {k:(round(v["value"],1), round(v["latency_ms"]["p50"],1), round(v["latency_ms"]["p99"],1)) for k,v in sk.get("latency_by_frames_in_flight",{}).items()}))
 PY
 }
 run_tests() {
