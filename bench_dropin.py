@@ -321,8 +321,9 @@ def _soak_run(device, procs, frames, cameras, n_inputs, empty_every, seconds, in
 
     def admit(item):  # stage 0 (the H2D copy, RTL/main.py:327): the frame has a slot and enters the pipeline NOW --
         admitted[item[0]] = time.perf_counter()  # the feeder pulls the source one item ahead of the in-flight semaphore
-        return procs[0](item)
+        return first_stage(item)
 
+    first_stage = procs[0]
     procs = [admit] + list(procs[1:])
     windows, lat_all, lat_win, none_count = [], [], [], 0
     pipe = StagePipeline(source(), procs, device=device, max_in_flight=in_flight)
