@@ -325,7 +325,7 @@ def _soak_run(device, procs, frames, cameras, n_inputs, empty_every, seconds, in
 
     first_stage = procs[0]
     procs = [admit] + list(procs[1:])
-    windows, lat_all, lat_win, none_count = [], [], [], 0
+    windows, lat_all, lat_win, lat_steady, none_count = [], [], [], [], 0
     pipe = StagePipeline(source(), procs, device=device, max_in_flight=in_flight)
     error = None
     torch.cuda.synchronize()
@@ -345,6 +345,8 @@ def _soak_run(device, procs, frames, cameras, n_inputs, empty_every, seconds, in
                 lat = (now - admitted.pop(d["index"])) * 1e3
                 lat_all.append(lat)
                 lat_win.append(lat)
+                if windows:  # past the first window: plans recorded, allocator pools and arenas grown
+                    lat_steady.append(lat)
                 n_win += 1
                 if now - t_win >= window_s:
                     windows.append({"t_s": now - t0, "frames": n_win, "value": n_win / (now - t_win),
@@ -366,6 +368,7 @@ def _soak_run(device, procs, frames, cameras, n_inputs, empty_every, seconds, in
         "seconds": elapsed, "frames": len(lat_all), "none_frames": none_count,
         "value": len(lat_all) / elapsed, "unit": "recon/s",
         "latency_ms": _percentiles(lat_all) if lat_all else None,
+        "latency_ms_after_first_window": _percentiles(lat_steady) if lat_steady else None,
         "latency_definition": "admission to the pipeline -> render on the host, %d frames in flight" % in_flight,
         "windows": windows, "window_s": window_s,
         "flat_after_warmup": bool(flat), "flat_keys": list(keys) + ["mp_skip_tables <= frames in flight + 2"],

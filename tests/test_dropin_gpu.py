@@ -727,7 +727,9 @@ def test_soak_of_the_per_frame_pipeline_is_flat_and_surfaces_errors():
     assert res["error"] is None and res["stage_threads_alive_after"] == 0
     assert res["frames"] > 300 and res["none_frames"] == res["frames"] // 23
     assert len(res["windows"]) >= 3 and res["flat_after_warmup"], res["windows"]
-    assert lat["p99"] < 4 * lat["p50"] and lat["max"] < 250.0  # no stall: a frame never waits for an allocation storm
+    steady = res["latency_ms_after_first_window"]  # the first window records the plan and grows pools / arenas
+    print("after the first window: p50 %.1f p99 %.1f max %.1f ms" % (steady["p50"], steady["p99"], steady["max"]))
+    assert steady["p99"] < 2 * steady["p50"] and steady["max"] < 4 * steady["p50"]  # no stall once warm
     sweep = res["latency_by_frames_in_flight"]
     print("latency by frames in flight:", {k: (round(v["value"], 1), round(v["latency_ms"]["p50"], 2), round(v["latency_ms"]["p99"], 2))
                                           for k, v in sweep.items()})

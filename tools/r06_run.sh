@@ -37,7 +37,7 @@ dr=d.get("dropin")
 if dr:
     print("    dropin: coalesced %.1f | per-frame stages (validate=always) %.1f | per-frame trusted %.1f | latency %.2f ms" % (dr["value"], dr["per_frame_stages"]["value"], dr["per_frame_stages_trusted"]["value"], dr["latency_ms_single_frame"]))
     sk=dr.get("soak")
-    if sk: print("    soak: %.1f recon/s over %.1f s, %d frames (%d None), latency p50 %.1f p99 %.1f max %.1f ms, flat %s; by frames in flight: %s" % (sk["value"], sk["seconds"], sk["frames"], sk["none_frames"], sk["latency_ms"]["p50"], sk["latency_ms"]["p99"], sk["latency_ms"]["max"], sk["flat_after_warmup"], {k:(round(v["value"],1), round(v["latency_ms"]["p50"],1), round(v["latency_ms"]["p99"],1)) for k,v in sk.get("latency_by_frames_in_flight",{}).items()}))
+    if sk: print("    soak: %.1f recon/s over %.1f s, %d frames (%d None), latency p50 %.1f p99 %.1f max %.1f ms, flat %s; by frames in flight: %s" % (sk["value"], sk["seconds"], sk["frames"], sk["none_frames"], sk["latency_ms_after_first_window"]["p50"], sk["latency_ms_after_first_window"]["p99"], sk["latency_ms_after_first_window"]["max"], sk["flat_after_warmup"], {k:(round(v["value"],1), round(v["latency_ms"]["p50"],1), round(v["latency_ms"]["p99"],1)) for k,v in sk.get("latency_by_frames_in_flight",{}).items()}))
 PY
 }
 run_tests() {
