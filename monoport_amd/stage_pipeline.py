@@ -44,8 +44,11 @@ import threading
 
 import torch
 
+import os
+
 _END = object()
 _tls = threading.local()
+SWITCH_INTERVAL = float(os.environ.get("MONOPORT_STAGE_SWITCH_INTERVAL", "0"))
 
 
 def stage_kind():
@@ -235,6 +238,13 @@ class StagePipeline:
                                                   args=(i, fn, queues[i], queues[i + 1]),
                                                   daemon=True))
         self._stop.clear()
+        # CPython hands the interpreter lock to a waiting thread only when the holder blocks or after the switch
+        # interval (5 ms by default): with eight stage threads a frame's hand-over to the next stage can sit behind a
+        # neighbour stage's pure-Python stretch for that long.  A shorter interval while the pipeline runs bounds it
+        # (MONOPORT_STAGE_SWITCH_INTERVAL seconds, 0 = leave the interpreter's setting alone).
+        switch_old = sys.getswitchinterval()
+        if SWITCH_INTERVAL > 0:
+            sys.setswitchinterval(SWITCH_INTERVAL)
         for t in self._threads:
             t.start()
         finished = False
@@ -270,3 +280,5 @@ class StagePipeline:
                     pass
             for t in self._threads:
                 t.join(timeout=5)
+            if SWITCH_INTERVAL > 0:
+                sys.setswitchinterval(switch_old)
