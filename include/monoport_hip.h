@@ -84,7 +84,8 @@ int mp_stream_release(mp_ctx *ctx, mp_stream stream);
  * and their shader engines, so a range that is a multiple of 32 takes the same share of every XCD.  The
  * persistent query kernels size their grids from the stream's share (launches on other streams: the whole
  * device).  The stream is created on the context's device, non-blocking; destroy it with mp_stream_destroy
- * (synchronises the stream, frees its arena).  MP_ERR_ARG unless 0 <= first_cu, n_cus >= 8 and first_cu +
+ * (synchronises the stream, frees its arena; an allocator that pools memory per stream -- torch's -- must drop the
+ * stream's cached blocks first, `torch.cuda.empty_cache()`, or it will touch a dead stream later).  MP_ERR_ARG unless 0 <= first_cu, n_cus >= 8 and first_cu +
  * n_cus <= the device's CU count. */
 int mp_stream_create_cu_mask(mp_ctx *ctx, int first_cu, int n_cus, mp_stream *out);
 int mp_stream_destroy(mp_ctx *ctx, mp_stream stream);
