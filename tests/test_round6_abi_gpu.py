@@ -81,18 +81,24 @@ def test_cu_masked_stream_runs_the_same_bits(scene):
         assert lib.mp_stream_cu_count(ctx.handle, h) == 64
         st = torch.cuda.ExternalStream(h.value, device=DEV)
         st.wait_stream(torch.cuda.current_stream())
+        # torch's allocator notes every stream a tensor was used on (record_stream, ops.recon_batch does it for the
+        # calibration) and records an event on THAT stream when the tensor is freed: nothing that met the masked stream
+        # may outlive it -- private copies of the inputs, gone before the stream is
+        cal_m, pts_m = cal.clone(), pts.clone()
         with torch.cuda.stream(st):
-            vol_m, _ = ops.recon(mlp, fh, cal, syn.Z_SCALE, BMIN, BMAX, RES)       # table kernel, 128 workgroups
+            vol_m, _ = ops.recon(mlp, fh, cal_m, syn.Z_SCALE, BMIN, BMAX, RES)       # table kernel, 128 workgroups
             table.release()
-            vol_p, st_p = ops.recon(mlp, fh, cal, syn.Z_SCALE, BMIN, BMAX, RES)    # plain kernels
-            out_p = ops.query(mlp, fh, pts, cal, syn.Z_SCALE)
+            vol_p, st_p = ops.recon(mlp, fh, cal_m, syn.Z_SCALE, BMIN, BMAX, RES)    # plain kernels
+            out_p = ops.query(mlp, fh, pts_m, cal_m, syn.Z_SCALE)
             st.synchronize()
-        assert torch.equal(vol_m, vol_tab)
-        assert torch.equal(vol_p, vol_ref) and torch.equal(st_p, st_ref) and torch.equal(out_p, out_ref)
-        del vol_m, vol_p, st_p, out_p
+        same = (torch.equal(vol_m, vol_tab), torch.equal(vol_p, vol_ref), torch.equal(st_p, st_ref), torch.equal(out_p, out_ref))
+        del vol_m, vol_p, st_p, out_p, cal_m, pts_m
+        assert all(same), same
     finally:
+        table.release()
         torch.cuda.synchronize()
         torch.cuda.empty_cache()  # the allocator's cached blocks of this stream go before the stream does (header)
+        del st
         ctx.check(lib.mp_stream_destroy(ctx.handle, h), "mp_stream_destroy")
     assert lib.mp_stream_cu_count(ctx.handle, h) == n_cu  # forgotten: sized like any other stream
     for first, n in ((0, 4), (-1, 64), (n_cu - 32, 64)):
@@ -121,9 +127,9 @@ def test_memory_stats_and_max_frames(scene):
     with torch.cuda.stream(s):
         ops.recon(scene["mlp"], scene["fh"], scene["cal"], syn.Z_SCALE, BMIN, BMAX, [17, 33, 65, 129])
         s.synchronize()
-    grown = ops.memory_stats(DEV)
-    assert grown["arenas"] == mid["arenas"] + 1 and grown["arena_bytes"] > mid["arena_bytes"]
+    grown = ops.memory_stats(DEV)  # torch hands streams out of a pool: `s` may have met the library in an earlier test
+    assert grown["arenas"] >= mid["arenas"] and grown["arena_bytes"] >= mid["arena_bytes"] and grown["arena_bytes"] > 0
     ops.stream_release(s)
     after = ops.memory_stats(DEV)
-    assert after["arenas"] == mid["arenas"] and after["arena_bytes"] == mid["arena_bytes"]
+    assert after["arenas"] == grown["arenas"] - 1 and after["arena_bytes"] < grown["arena_bytes"]
     del extra

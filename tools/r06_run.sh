@@ -41,7 +41,7 @@ if dr:
 PY
 }
 run_tests() {
-  timeout 1800 python -m pytest tests -q -m gpu ${K:+-k "$K"} -s > $out/tests.log 2>&1
+  timeout 1800 python -X faulthandler -m pytest tests -q -m gpu ${K:+-k "$K"} -s > $out/tests.log 2>&1
   echo "pytest rc=$?" >> $out/tests.log
   grep -E "passed|failed|^FAILED|^ERROR|rc=|configs\[2\]|colour chain|final_level=|pipeline257_color|513\^3|pipeline513" $out/tests.log | tail -40
 }
