@@ -97,10 +97,20 @@ def test_cu_masked_stream_runs_the_same_bits(scene):
     finally:
         table.release()
         torch.cuda.synchronize()
-        torch.cuda.empty_cache()  # the allocator's cached blocks of this stream go before the stream does (header)
-        del st
-        ctx.check(lib.mp_stream_destroy(ctx.handle, h), "mp_stream_destroy")
-    assert lib.mp_stream_cu_count(ctx.handle, h) == n_cu  # forgotten: sized like any other stream
+    # The stream torch worked on is NOT destroyed here: torch's allocator keeps per-stream state (cached blocks, the
+    # events of record_stream'ed tensors) and would touch a dead stream later -- a caller who wants it gone must drop
+    # every tensor that met it and torch.cuda.empty_cache() first (header).  mp_stream_destroy is exercised on a
+    # stream only the library itself has used:
+    h2 = ctypes.c_void_p()
+    ctx.check(lib.mp_stream_create_cu_mask(ctx.handle, 0, 32, ctypes.byref(h2)), "mp_stream_create_cu_mask")
+    out4 = (ctypes.c_double * 4)()
+    ctx.check(lib.mp_mfma_clock_probe(ctx.handle, ctypes.c_float(5.0), out4, h2), "mp_mfma_clock_probe")
+    full = ops.mfma_clock_probe(DEV, 5.0)
+    print("clock probe on 32 of %d CUs: %.1f TFLOP/s (whole device %.1f)" % (n_cu, out4[0], full["tflops"]))
+    assert int(out4[3]) == 64 and 0.09 < out4[0] / full["tflops"] < 0.16  # 2 workgroups per masked CU; 1/8 of the rate
+    ctx.check(lib.mp_stream_destroy(ctx.handle, h2), "mp_stream_destroy")
+    assert lib.mp_stream_cu_count(ctx.handle, h2) == n_cu  # forgotten: sized like any other stream
+    h = h2
     for first, n in ((0, 4), (-1, 64), (n_cu - 32, 64)):
         with pytest.raises(MonoportError):
             ctx.check(lib.mp_stream_create_cu_mask(ctx.handle, first, n, ctypes.byref(h)), "mp_stream_create_cu_mask")
