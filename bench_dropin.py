@@ -362,8 +362,11 @@ def _soak_run(device, procs, frames, cameras, n_inputs, empty_every, seconds, in
     # what must not move after the first window: bytes held and the things that own bytes.  The registered skip tables
     # are the frames in flight between the encoder and the vertex stage (a table lives as long as its frame's feature
     # map): their number breathes with the pipeline's occupancy but is bounded by the frames in flight.
-    keys = ("torch_reserved", "mp_arena_bytes", "mp_weight_bytes", "mp_arenas", "encoder_plans")
+    # torch's caching allocator may still add a segment after the first window (which stream frees a block first is a
+    # matter of timing): its reserved bytes may grow by <= 10 % over the rest of the run, the C side's not at all.
+    keys = ("mp_arena_bytes", "mp_weight_bytes", "mp_arenas", "encoder_plans")
     flat = (len(windows) >= 3 and all(windows[-1][k] == windows[1][k] for k in keys)
+            and windows[-1]["torch_reserved"] <= 1.10 * windows[1]["torch_reserved"]
             and all(w["mp_skip_tables"] <= tables0 + in_flight + 2 for w in windows[1:]))
     return {
         "seconds": elapsed, "frames": len(lat_all), "none_frames": none_count,
@@ -372,6 +375,6 @@ def _soak_run(device, procs, frames, cameras, n_inputs, empty_every, seconds, in
         "latency_ms_after_first_window": _percentiles(lat_steady) if lat_steady else None,
         "latency_definition": "admission to the pipeline -> render on the host, %d frames in flight" % in_flight,
         "windows": windows, "window_s": window_s,
-        "flat_after_warmup": bool(flat), "flat_keys": list(keys) + ["mp_skip_tables <= those registered before the run + frames in flight + 2"],
+        "flat_after_warmup": bool(flat), "flat_keys": list(keys) + ["torch_reserved within 10 %","mp_skip_tables <= those registered before the run + frames in flight + 2"],
         "error": error, "stage_threads_alive_after": int(alive),
     }
