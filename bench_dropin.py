@@ -14,7 +14,7 @@ from monoport_amd import ops, synthetic as syn
 from monoport_amd.recon import pifu_calib
 
 
-def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
+def dropin_surface(device, n_frames, n_warm, resolutions, passes=5, legs=("per_frame", "per_frame_trusted", "coalesced")):
     """The reference's own call surface, as RTL/main.py:326-452 drives it: the processors=[...]
     list (H2D, camera, pifu_calib, input normalisation, netG.filter, reconEngine =
     Seg3dLossless(query_func) with its per-frame host sync, forward_vertices with its .item(),
@@ -190,6 +190,8 @@ def dropin_surface(device, n_frames, n_warm, resolutions, passes=5):
                 "frames_in_flight": in_flight, "validate": "first" if coalesce else validate}
 
     per_frame = mode(False, 8, "always")
+    if "coalesced" not in legs:  # probes (tools/per_frame_overlap_probe.py): the per-frame leg and the latency only
+        return {"per_frame_stages": per_frame, "latency_ms_single_frame": latency_ms, "frames": n_frames}
     per_frame_trusted = mode(False, 8, "first")
     co = mode(True, CO_IN_FLIGHT)
     return {

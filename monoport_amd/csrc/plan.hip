@@ -59,7 +59,11 @@ int mp_plan_create(mp_ctx *ctx, int n_side_streams, mp_plan **out) {
   hipSetDevice(ctx->device);
   for (int i = 0; i < n_side_streams; ++i) {
     hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    // MONOPORT_PLAN_SIDE_PRIORITY (measurement switch): HIP priority of the side streams (lower = served first)
+    static const char *prio_env = getenv("MONOPORT_PLAN_SIDE_PRIORITY");
+    const hipError_t e_create = prio_env ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, atoi(prio_env))
+                                         : hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e_create != hipSuccess) {
       for (hipStream_t t : p->side) hipStreamDestroy(t);
       delete p;
       hipSetDevice(prev);

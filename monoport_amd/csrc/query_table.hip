@@ -649,7 +649,21 @@ static int launch_query_tabws_t(mp_ctx *ctx, const Mlp &m, const QuerySet &set, 
   const long long resident = (long long)cus_of(ctx, st) * wgs_per_cu;
   // persistent: a workgroup's producers run one chunk ahead of its consumers ACROSS tiles, so a
   // workgroup should see several tiles; never more workgroups than are resident at once
-  const long long grid = tiles < resident ? tiles : resident;
+  long long grid = tiles < resident ? tiles : resident;
+  // A launch for ONE frame comes from a per-frame caller (the reference's recon stage, RTL/main.py:389-395) whose
+  // neighbour stage is running netG.filter of the next frame on another stream: it gets 8 x the resident workgroups,
+  // each with 1 / 8 of the tiles, so that the launch gives its workgroup slots back a few at a time and the encoder's
+  // chain of small convolutions gets onto the chip between them instead of waiting for the whole level.  Measured on
+  // the per-frame stage pipeline (tools/per_frame_overlap_probe.py, profiles/r06r_per_frame_grid_mult.txt): 130-131 ->
+  // 136-137 recon/s at 8 x; the query launches alone and the batched headline do not notice (x 1 .. x 16 within noise).
+  // MONOPORT_QUERY_GRID_MULT overrides the factor for every launch (measurement switch; results do not depend on it).
+  static const int grid_mult_env = [] {
+    const char *e = getenv("MONOPORT_QUERY_GRID_MULT");
+    const int v = e ? atoi(e) : 0;
+    return v < 0 ? 0 : v > 64 ? 64 : v;
+  }();
+  const int grid_mult = grid_mult_env ? grid_mult_env : set.n == 1 ? 8 : 1;
+  if (grid_mult > 1) grid = tiles < resident * grid_mult ? tiles : resident * grid_mult;
   QuerySetDev dset;
   {
     const int rc_set = compact_query_set(ctx, set, dset);

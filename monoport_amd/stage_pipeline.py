@@ -49,6 +49,8 @@ import os
 _END = object()
 _tls = threading.local()
 SWITCH_INTERVAL = float(os.environ.get("MONOPORT_STAGE_SWITCH_INTERVAL", "0"))
+# HIP stream priority per stage index ("4:-1,5:0": lower = served first by the GPU's dispatcher; default 0 for all)
+STAGE_PRIORITY = {int(k): int(v) for k, v in (kv.split(":") for kv in os.environ.get("MONOPORT_STAGE_PRIORITY", "").split(",") if kv)}
 
 
 def stage_kind():
@@ -72,7 +74,7 @@ def stage_stream(device, idx):
     with _STREAMS_LOCK:
         st = _STREAMS.get(key)
         if st is None:
-            st = _STREAMS[key] = torch.cuda.Stream(device=device)
+            st = _STREAMS[key] = torch.cuda.Stream(device=device, priority=STAGE_PRIORITY.get(idx, 0))
     return st
 
 

@@ -385,6 +385,49 @@ def test_frame_pipeline_is_deterministic_under_concurrency():
     assert (counts[:, :, 0] == 1).all() and len(set(counts[:, :, 4].flatten().tolist())) > 10
 
 
+def test_frame_pipeline_holds_a_fixed_amount_of_memory():
+    """Weak #10 of the round-5 verdict: a FramePipeline (what bench.py's headline runs) must hold what it holds after
+    its first round of submissions and not a byte more -- torch's reserved bytes, the C side's arenas / weights /
+    arena count (mp_memory_stats) and the registered skip tables (one per frame of every slot) are identical after 3 and
+    after 12 rounds over the slots (torch's allocated bytes within 1 MiB); closing the pipeline gives the tables back."""
+    import gc
+    import bench
+    from monoport_amd import ops
+    from monoport_amd.recon import pifu_calib
+    gc.collect()
+    torch.cuda.synchronize()
+    base = ops.memory_stats(DEV)
+    pipe = bench.make_pipeline(torch.device(DEV), 3, True, [17, 33, 65, 129, 257], False, "f32", 4)
+    images = [torch.from_numpy(syn.synthetic_image(i))[None].to(DEV) for i in range(4)]
+    calibs = [pifu_calib(*syn.scene_camera(7 * i), device=DEV) for i in range(12)]
+
+    def rounds(n):
+        for r in range(n):
+            for s0 in range(0, 12, 4):
+                pipe.submit([images[(s + r) % 4] for s in range(s0, s0 + 4)], calibs[s0:s0 + 4])
+        pipe.synchronize()
+        st = ops.memory_stats(DEV)
+        return (torch.cuda.memory_reserved(DEV), torch.cuda.memory_allocated(DEV), st["arena_bytes"], st["weight_bytes"],
+                st["arenas"], st["skip_tables"])
+
+    try:
+        after3 = rounds(3)
+        after12 = rounds(9)
+        print("FramePipeline 3 slots x 4 frames at 17..257: reserved %.2f GB, allocated %.2f GB, arenas %.0f MB in %d, "
+              "%d tables" % (after3[0] / 2 ** 30, after3[1] / 2 ** 30, after3[2] / 2 ** 20, after3[4], after3[5]))
+        # reserved bytes, arenas, weights and tables exactly; torch's ALLOCATED bytes within 1 MiB (whether the last
+        # submission's small status / count tensors have been released yet is a matter of timing)
+        assert after12[0] == after3[0] and after12[2:] == after3[2:]
+        assert abs(after12[1] - after3[1]) <= 2 ** 20
+        assert after3[5] - base["skip_tables"] == 12  # one table per frame of every slot
+    finally:
+        pipe.close()
+    del pipe
+    gc.collect()
+    end = ops.memory_stats(DEV)
+    assert end["skip_tables"] == base["skip_tables"] and end["arena_bytes"] <= after3[2]
+
+
 def test_prepare_inputs_bit_exact_vs_reference_expressions():
     """RTL/main.py:352-364: the two background-removal processors, fused; same bits as the
     reference's chain of torch ops on the same device."""
