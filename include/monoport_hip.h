@@ -502,8 +502,18 @@ typedef struct mp_conv3x3_args {
   const float *res;
   int y2_channels, y2_offset;
   mp_gn_out fin, fin2;
+  /* round 6: NULL, or the Winograd-domain weights of the same convolution (mp_conv3x3_pack_wino, 16 * Cout * Cin
+   * floats).  With them, launches that mp_conv3x3_wino_supported serves (zero padding, exact f32, no legacy
+   * statistics buffers) run as Winograd F(2x2, 3x3) on the same f32 MFMAs -- 4 / 9 of the multiplies of the direct
+   * form; `packed` must still be given (every other launch uses it). */
+  const float *packed_wino;
 } mp_conv3x3_args;
 int mp_conv3x3_ex(mp_ctx *ctx, const mp_conv3x3_args *args, mp_stream stream);
+/* U = G g G^T of nn.Conv2d(Cin, Cout, 3, 1, 1) weights (backbones/HGFilters.py:15-19) in the fragment order of
+ * csrc/conv_wino.hip, computed in double and rounded once; 16 * Cout * Cin floats, 16-byte aligned. */
+int mp_conv3x3_pack_wino(mp_ctx *ctx, const float *w /*[Cout,Cin,3,3]*/, int cout, int cin, float *packed_wino,
+                         mp_stream stream);
+int mp_conv3x3_wino_supported(int cin, int cout, int h, int w); /* 1 if the Winograd kernel is built for the shape */
 
 /* mp_conv1x1 with the GroupNorm hand-over: gn1 = GroupNorm(32, C1) of x1 (+ ReLU with relu1); fin =
  * GroupNorm(32, 256) over the output (res included), i.e. bn_end after conv_last and the first

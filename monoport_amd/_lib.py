@@ -34,7 +34,7 @@ class Conv3x3Args(ctypes.Structure):
     _fields_ = [("x", c_vp), ("n", c_int), ("cin", c_int), ("h", c_int), ("w", c_int), ("gn", GnIn),
                 ("relu", c_int), ("reflect", c_int), ("packed", c_vp), ("wmax", c_vp), ("cout", c_int),
                 ("y", c_vp), ("y2", c_vp), ("res", c_vp), ("y2_channels", c_int), ("y2_offset", c_int),
-                ("fin", GnOut), ("fin2", GnOut)]
+                ("fin", GnOut), ("fin2", GnOut), ("packed_wino", c_vp)]
 
 
 class Conv1x1Args(ctypes.Structure):
@@ -148,6 +148,8 @@ SIGNATURES = {
                               c_vp]),
     "mp_upsample_bicubic2x": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "mp_conv3x3_pack": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "mp_conv3x3_pack_wino": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "mp_conv3x3_wino_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "mp_conv3x3_stat_slices": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mp_conv3x3_tune": (None, [c_int]),
     "mp_query_tune": (None, [c_int]),

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libmonoport_hip.so")
 SOURCES = ["api.hip", "pack.hip", "query.hip", "query_small.hip", "query_table.hip", "query16.hip", "octree.hip", "vertices.hip", "mcubes.hip",
-           "encoder_ops.hip", "conv3x3.hip", "convim2col.hip", "plan.hip", "clock_probe.hip"]
+           "encoder_ops.hip", "conv3x3.hip", "conv_wino.hip", "convim2col.hip", "plan.hip", "clock_probe.hip"]
 HEADERS = [os.path.join(CSRC, "mp_internal.h"), os.path.join(CSRC, "query_common.h"),
            os.path.join(CSRC, "encoder_kernels.h"), os.path.join(CSRC, "gn_tail.h"),
            os.path.join(CSRC, "query_mfma.h"),

@@ -909,6 +909,19 @@ int mp_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *packe
   return launch_conv3x3_pack(ctx, w, cout, cin, packed, (hipStream_t)stream);
 }
 
+int mp_conv3x3_pack_wino(mp_ctx *ctx, const float *w, int cout, int cin, float *packed_wino, mp_stream stream) {
+  if (!ctx) return MP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!w || !packed_wino || cout <= 0 || cin <= 0) return fail(ctx, MP_ERR_ARG, "mp_conv3x3_pack_wino: bad argument");
+  if (cin % 16 || cout % 32)
+    return fail(ctx, MP_ERR_UNSUPPORTED, "mp_conv3x3_pack_wino: needs Cin %% 16 == 0 and Cout %% 32 == 0");
+  if (!aligned16(packed_wino)) return fail(ctx, MP_ERR_ARG, "mp_conv3x3_pack_wino: the output must be 16-byte aligned");
+  DeviceGuard g(ctx->device);
+  return launch_conv3x3_wino_pack(ctx, w, cout, cin, packed_wino, (hipStream_t)stream);
+}
+
+int mp_conv3x3_wino_supported(int cin, int cout, int h, int w) { return conv3x3_wino_supported(cin, cout, h, w) ? 1 : 0; }
+
 int mp_conv3x3_pack16(mp_ctx *ctx, const float *w, int cout, int cin, void *packed16, float *wmax,
                       mp_stream stream) {
   if (!ctx) return MP_ERR_ARG;
@@ -1072,6 +1085,10 @@ int mp_conv3x3_ex(mp_ctx *ctx, const mp_conv3x3_args *q, mp_stream stream) {
   a.w = q->w;
   a.relu = q->relu;
   a.reflect = q->reflect;
+  if (q->packed_wino) {
+    if (!aligned16(q->packed_wino)) return fail(ctx, MP_ERR_ARG, "mp_conv3x3_ex: packed_wino must be 16-byte aligned");
+    a.wpw = q->packed_wino;
+  }
   const long long cap[2] = {out_cap(&q->fin), out_cap(&q->fin2)};
   return launch_conv3x3(ctx, a, q->wmax, cap, (hipStream_t)stream);
 }

@@ -877,8 +877,13 @@ int launch_conv3x3_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *w
 static int g_conv_nr = 0;  // 0 = heuristic; tools/conv_probe.py overrides it for A/B runs
 static int g_conv_sk = -1; // -1 = heuristic; 0 / 1 force the large-tile / the split-K kernel
 
+static int g_conv_wino = 1;  // 0: never take the Winograd kernel (mp_conv3x3_tune(0x400 or a forced variant); A/B runs)
+static long long g_conv_wino_min_wgs = 128;  // launches with fewer Winograd workgroups stay on the direct kernels (one 88 us workgroup per CU: tools/wino_check.py)
+
 void conv3x3_set_nr(int nr) {
   g_conv_nr = nr & 0xff;
+  g_conv_wino = (nr >> 8) == 0 ? 1 : 0;  // any forced variant (| 0x100, | 0x200) or 0x400 (direct kernels, heuristic) turns Winograd off
+  nr &= ~0x400;
   g_conv_sk = (nr >> 8) == 0 ? -1 : (nr >> 8) - 1;  // mp_conv3x3_tune(nr | 0x100: large tiles, | 0x200: split-K)
 }
 
@@ -1002,7 +1007,18 @@ int launch_conv3x3(mp_ctx *ctx, ConvArgs a, const float *wmax16, const long long
   if (cin > kMaxCin)
     return fail(ctx, MP_ERR_UNSUPPORTED, "conv3x3: at most %d input channels (got %d)", kMaxCin, cin);
   a.wp_floats = cout * cin * 9;
-  const ConvPlan c = conv_plan(cout, n, h, w, wmax16 != nullptr);
+  ConvPlan c = conv_plan(cout, n, h, w, wmax16 != nullptr);
+  // Winograd F(2x2, 3x3) (conv_wino.hip) when the caller packed the weights for it: zero padding, exact-f32 products,
+  // statistics by hand-over only (the legacy partial buffers are sized from conv_plan's tiles)
+  const bool wino = a.wpw && !wmax16 && !a.reflect && !a.fin.partial && !a.fin2.partial && g_conv_wino &&
+                    conv3x3_wino_supported(cin, cout, h, w) &&
+                    (long long)conv3x3_wino_tiles(h, w) * n * (cout / 128) >= g_conv_wino_min_wgs;
+  if (wino) {
+    a.wpw_floats = 16 * cout * cin;
+    c.tiles = conv3x3_wino_tiles(h, w);
+    c.th = 8;
+    c.tw = 16;
+  }
   a.tw = c.tw;
   a.th = c.th;
   if (a.th > h)
@@ -1034,6 +1050,7 @@ int launch_conv3x3(mp_ctx *ctx, ConvArgs a, const float *wmax16, const long long
     a.gn.n = n;
     a.gn.count = (double)(cin / 32) * h * w;
   }
+  if (wino) return launch_conv3x3_wino(ctx, a, st);
   if (c.sk) return c.nr == 2 ? launch_conv_sk_t<2>(ctx, a, c.tiles, st) : launch_conv_sk_t<1>(ctx, a, c.tiles, st);
   const int rbw = c.rbw, nr = c.nr, tiles = c.tiles;
 #define MP_CONV_CASE(R, N)                                                                   \

@@ -1,0 +1,436 @@
+// 3x3 convolutions of the hourglass encoder as Winograd F(2x2, 3x3) on f32 MFMA (round 6).
+//
+// The pyramid block (backbones/HGFilters.py:40-62) is conv3x3(relu(GroupNorm(x))) three times, and the 3x3
+// convolutions are 176 of the 197 GFLOP of a netG.filter pass (RTL/main.py:366-370).  csrc/conv3x3.hip runs them as a
+// direct implicit GEMM (K = 9 Cin) at 0.85 of the f32 MFMA roof for its best shape -- the roof, not the schedule, is
+// what is left.  F(2x2, 3x3) (Lavin & Gray) computes a 2x2 output tile from a 4x4 input patch with 16 multiplies per
+// (Cin, Cout) pair instead of 36:
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A
+// so the convolution becomes 16 independent GEMMs  M[i][j] = U[i][j] (Cout x Cin) . V[i][j] (Cin x tiles)  -- 2.25x
+// fewer MFMAs -- between an input transform (adds only) and an output transform (adds only).  The transformed weights
+// U = G g G^T are computed once, in double, by conv3x3_wino_pack_kernel.  Everything around the GEMMs is what
+// conv3x3.hip does: GroupNorm + ReLU applied while the input is staged (zero padding of the NORMALISED tensor), the
+// epilogue of conv3x3.hip (raw output, pyramid-block tail, the next GroupNorms' statistics by integer atomics).
+//
+// Decomposition (one workgroup = 8 waves = 512 threads, one per CU):
+//   * workgroup = 8 x 4 Winograd tiles (16 x 8 output pixels, 18 x 10 input patch) x 128 output channels;
+//   * K loop over 16-channel chunks of the input, one barrier per chunk, three stages in flight:
+//       chunk k + 2/3: global -> registers (lane = patch pixel, wave = 2 channel planes), GroupNorm + ReLU,
+//                      -> raw[2] in LDS, pixel-major (64 B per pixel, XOR-swizzled);
+//       chunk k + 1:   input transform raw -> V[2][i][j][tile][16 ch]: thread = (tile, 4 channels, column j),
+//                      8 ds_read_b128 + 16 packed adds + 4 ds_write_b128;
+//       chunk k:       wave (j, half) multiplies frequencies (0..3, j) for its two 32-channel row blocks: A = U
+//                      fragments streamed from L2 in fragment order, B = V rows from LDS, 64 MFMAs per chunk;
+//   * output transform: rows in registers (A^T M), columns through LDS (. A); wave (j, half) then owns output row
+//     r = j & 1 of every tile for row block j >> 1 of its half and runs conv3x3.hip's epilogue on it.
+// Executed FLOPs: 2 * 16 * Cin * Cout per 2 x 2 output pixels = 4 / 9 of the direct form.  Rounding: the products are
+// exact-f32 MFMA FMA chains as before; the transforms add 2-3 roundings per side (F(2x2, 3x3) has the mildest
+// constants of the family: 0, +-1, +-1/2) -- measured against the fp64 convolution in tests/test_conv_gpu.py.
+#include "mp_internal.h"
+#include "query_common.h"
+#include "gn_tail.h"
+
+#pragma clang fp contract(off)
+
+namespace mp {
+
+constexpr int kWnThreads = 512;
+constexpr int kWnTX = 8, kWnTY = 4;              // Winograd tiles of a workgroup
+constexpr int kWnPW = 2 * kWnTX + 2;             // 18 patch columns
+constexpr int kWnPH = 2 * kWnTY + 2;             // 10 patch rows
+constexpr int kWnPix = kWnPW * kWnPH;            // 180 staged pixels
+constexpr int kWnPasses = (kWnPix + 63) / 64;    // 3 passes of 64 lanes
+constexpr int kWnRawBytes = kWnPix * 64;         // one raw buffer: [pixel][16 ch] f32
+constexpr int kWnVBytes = 16 * 32 * 64;          // one V buffer: [i][j][tile][16 ch] f32
+constexpr int kWnRaw = 0;
+constexpr int kWnV = 2 * kWnRawBytes;
+constexpr int kWnXchBytes = 8 * 2 * 2 * 4 * 64 * 16;  // output-transform exchange: [wave][r][m][q][lane] f32x4 (128 KB)
+constexpr int kWnStat = kWnXchBytes;             // wino_epilogue's statistics scratch (8 KB)
+constexpr int kWnLds = kWnStat + 8192;
+constexpr int kWnAhead = 3;                    // A fragments are requested this many steps (of 16 MRB MFMAs) ahead
+static_assert(kWnV + 2 * kWnVBytes <= kWnXchBytes, "the exchange region covers the K loop's buffers");
+static_assert(kWnLds <= 160 * 1024, "LDS");
+
+// W [Cout][Cin][3][3] -> U = G g G^T in MFMA fragment order: fragment ((((rb * 4 + j) * chunks + chunk) * 4 + i) * 2 + g)
+// holds, for lane (r = lane & 31, hh = lane >> 5), U[i][j][32 rb + r][16 chunk + 8 g + 4 hh + 0..3].  Wave (j, half) of
+// the kernel streams the fragments of (rb, j) front to back.
+__global__ void conv3x3_wino_pack_kernel(const float *__restrict__ w, int cout, int cin, float *__restrict__ up) {
+  const long long total = 16LL * cout * cin;
+  const int n_chunks = cin / 16;
+  const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int ii = (int)(t & 3), lane = (int)((t >> 2) & 63);
+    long long q = t >> 8;
+    const int g = (int)(q & 1);
+    q >>= 1;
+    const int i = (int)(q & 3);
+    q >>= 2;
+    const int chunk = (int)(q % n_chunks);
+    q /= n_chunks;
+    const int j = (int)(q & 3), rb = (int)(q >> 2);
+    const int co = 32 * rb + (lane & 31);
+    const int ci = 16 * chunk + 8 * g + 4 * (lane >> 5) + ii;
+    const float *gk = w + ((long long)co * cin + ci) * 9;
+    double s = 0.0;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) s += G[i][a] * (double)gk[3 * a + b] * G[j][b];
+    up[t] = (float)s;
+  }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// The epilogue of conv3x3.hip (conv_epilogue: raw output, pyramid-block tail y2 = conv + res, the next GroupNorms'
+// statistics through csrc/gn_tail.h) for this kernel's register layout: a wave holds, for the 32-row block `rbi` of the
+// workgroup's NCH channels, output row r_o of every Winograd tile -- lane (j = tile, h), pr[t] = the two neighbouring
+// pixels (2 tx, 2 tx + 1) of channel row (t & 3) + 8 (t >> 2) + 4 h.  The pair is 8-byte aligned: 64-bit accesses.
+// smem: 2 x [2][NCH][2] doubles of scratch.
+template <int NCH>
+__device__ __forceinline__ void wino_epilogue(const ConvArgs &p, f32x2 (&pr)[16], int img, int tile, int y0, int x0,
+                                              int rbi, int r_o, int lane, unsigned char *smem) {
+  const int j = lane & 31, h = lane >> 5;
+  const int hw = p.h * p.w;
+  const int ch0 = NCH * blockIdx.y + 32 * rbi;
+  const bool cat = p.y2 != nullptr;
+  const bool st1 = gn_wanted(p.fin), st2 = cat && gn_wanted(p.fin2);
+  const int tid = threadIdx.x;
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+      p.y ? p.y + (long long)img * p.cout * hw : const_cast<float *>(p.x), 0, p.y ? p.cout * hw * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(
+      cat ? p.y2 + (long long)img * p.y2_c * hw : const_cast<float *>(p.x), 0, cat ? p.y2_c * hw * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(cat ? p.res + (long long)img * p.y2_c * hw : p.x), 0, cat ? p.y2_c * hw * 4 : 0, 0x00020000);
+  const int vo = (4 * h * hw + (y0 + 2 * (j >> 3) + r_o) * p.w + x0 + 2 * (j & 7)) * 4;
+  auto so1 = [&](int t) { return (ch0 + (t & 3) + 8 * (t >> 2)) * hw * 4; };  // scalar
+  auto so2 = [&](int t) { return so1(t) + p.y2_off * hw * 4; };
+  double *cs1 = reinterpret_cast<double *>(smem);             // [2 rows][NCH][2] per-channel sums of y
+  double *cs2 = reinterpret_cast<double *>(smem + NCH * 32);  // ... of y2
+  auto to_lds = [&](double *cs, float (&a1)[16], float (&a2)[16]) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      a1[t] = half_wave_sum(a1[t]);
+      a2[t] = half_wave_sum(a2[t]);
+    }
+    if (j == kHalfSumLane) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int idx = r_o * NCH + 32 * rbi + (t & 3) + 8 * (t >> 2) + 4 * h;
+        cs[2 * idx] = (double)a1[t];
+        cs[2 * idx + 1] = (double)a2[t];
+      }
+    }
+  };
+  f32x2 u[16];  // the block tail: conv + res
+  if (cat) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      u[t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, vo, so2(t), 0));
+  }
+  if (st1) {
+    float s1[16], s2[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      s1[t] = pr[t].x + pr[t].y;
+      s2[t] = fmaf(pr[t].y, pr[t].y, pr[t].x * pr[t].x);
+    }
+    to_lds(cs1, s1, s2);
+  }
+  if (cat) {
+    float q1[16], q2[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      u[t] = u[t] + pr[t];
+      q1[t] = u[t].x + u[t].y;
+      q2[t] = fmaf(u[t].y, u[t].y, u[t].x * u[t].x);
+    }
+    if (st2) to_lds(cs2, q1, q2);
+  }
+  if (st1 || st2) {
+    __syncthreads();
+    if (tid < 64) {
+      auto fold = [&](const GnOut &f, const double *cs, int c_off) {
+        const int cpg = f.c / 32;  // channels per group of the normalised tensor
+        const int ng = NCH / cpg;  // groups this workgroup covers
+        double a = 0.0, b = 0.0;
+        if (tid < ng)
+          for (int r = 0; r < 2; ++r)
+            for (int ch = 0; ch < cpg; ++ch) {
+              const int idx = r * NCH + tid * cpg + ch;
+              a += cs[2 * idx];
+              b += cs[2 * idx + 1];
+            }
+        gn_emit(f, img, (c_off + NCH * (int)blockIdx.y) / cpg, ng, tile, a, b);
+      };
+      if (st1) fold(p.fin, cs1, 0);
+      if (st2) fold(p.fin2, cs2, p.y2_off);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    if (p.y) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pr[t]), rs_y, vo, so1(t), 0);
+    if (cat) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, u[t]), rs_y2, vo, so2(t), 0);
+  }
+}
+
+template <int MRB>
+__global__ __launch_bounds__(kWnThreads, 1) void conv3x3_wino_kernel(ConvArgs p) {
+  static_assert(MRB == 2, "128 output channels per workgroup");
+  constexpr int NCH = 64 * MRB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jl = lane & 31, h = lane >> 5;
+  const int jf = wv & 3, rbh = wv >> 2;
+
+  const int tiles_x = p.w / (2 * kWnTX), tiles = tiles_x * (p.h / (2 * kWnTY));
+  const int tile = blockIdx.x % tiles, img = blockIdx.x / tiles;
+  const int y0 = (tile / tiles_x) * (2 * kWnTY), x0 = (tile % tiles_x) * (2 * kWnTX);
+  const int hw = p.h * p.w;
+  const int n_chunks = p.cin / 16;
+
+  const WStream ws = make_wstream(p.wpw, p.wpw_floats, lane);
+  __shared__ float gn_stats[64];
+  __shared__ float ss_in[2 * 512];
+
+  // ---- staging plan: wave wv stages channel planes 2 wv, 2 wv + 1 of every chunk; lane = patch pixel ----
+  int goff[kWnPasses];  // byte offset inside a channel plane, -1 = outside the image (zero padding) / no pixel
+#pragma unroll
+  for (int it = 0; it < kWnPasses; ++it) {
+    const int lp = lane + 64 * it;
+    const int r = lp / kWnPW, c = lp - r * kWnPW;
+    const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+    const bool ok = lp < kWnPix && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+    goff[it] = ok ? (gy * p.w + gx) * 4 : -1;
+  }
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.x + (long long)img * p.cin * hw), 0, p.cin * hw * 4, 0x00020000);
+  float stg[kWnPasses][2];
+  int ch_staged = 0;
+  auto stage_load = [&](int chunk) {
+    const int ch = chunk * 16 + 2 * wv;
+#pragma unroll
+    for (int it = 0; it < kWnPasses; ++it) {
+      const int o = goff[it] < 0 ? 0 : goff[it];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        stg[it][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, o, (ch + k) * hw * 4, 0));
+    }
+    ch_staged = ch;
+  };
+  auto stage_store = [&](int buf) {
+    float sc[2], sh[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      sc[k] = ss_in[2 * (ch_staged + k)];
+      sh[k] = ss_in[2 * (ch_staged + k) + 1];
+    }
+    unsigned char *raw = smem + kWnRaw + buf * kWnRawBytes;
+#pragma unroll
+    for (int it = 0; it < kWnPasses; ++it) {
+      const int lp = lane + 64 * it;
+      if (lp < kWnPix) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 v;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          float t = fmaf(stg[it][k], sc[k], sh[k]);
+          if (p.relu) t = fmaxf(t, 0.0f);
+          v[k] = goff[it] < 0 ? 0.0f : t;
+        }
+        *reinterpret_cast<f32x2 *>(raw + lp * 64 + (((wv >> 1) ^ ((lp >> 2) & 3)) << 4) + (wv & 1) * 8) = v;
+      }
+    }
+  };
+
+  // ---- input transform plan: thread = (tile jl, channel quad chq, column jt) ----
+  const int jt = wv >> 1, chq = ((wv & 1) << 1) | h;
+  const int tyy = jl >> 3, txx = jl & 7;
+  // t[r] = d[r][ca] + sg * d[r][cb]   (column jt of B):  j = 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
+  const int ca = jt == 0 ? 0 : jt == 2 ? 2 : 1;
+  const int cb = jt == 0 ? 2 : jt == 1 ? 2 : jt == 2 ? 1 : 3;
+  const float sg = jt == 1 ? 1.0f : -1.0f;
+  int offa[4], offb[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int la = (2 * tyy + r) * kWnPW + 2 * txx + ca, lb = (2 * tyy + r) * kWnPW + 2 * txx + cb;
+    offa[r] = la * 64 + ((chq ^ ((la >> 2) & 3)) << 4);
+    offb[r] = lb * 64 + ((chq ^ ((lb >> 2) & 3)) << 4);
+  }
+  const int voff_w = (jt * 32 + jl) * 64 + ((chq ^ ((jl >> 2) & 3)) << 4);  // + i * 8192
+  auto transform = [&](int buf) {
+    const unsigned char *raw = smem + kWnRaw + buf * kWnRawBytes;
+    unsigned char *v = smem + kWnV + buf * kWnVBytes;
+    f32x4 t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(raw + offa[r]);
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(raw + offb[r]);
+      t[r] = a + b * sg;
+    }
+    // rows of B^T:  i = 0: t0 - t2;  1: t1 + t2;  2: t2 - t1;  3: t1 - t3
+    *reinterpret_cast<f32x4 *>(v + voff_w + 0 * 8192) = t[0] - t[2];
+    *reinterpret_cast<f32x4 *>(v + voff_w + 1 * 8192) = t[1] + t[2];
+    *reinterpret_cast<f32x4 *>(v + voff_w + 2 * 8192) = t[2] - t[1];
+    *reinterpret_cast<f32x4 *>(v + voff_w + 3 * 8192) = t[1] - t[3];
+  };
+
+  // ---- GEMM plan: wave (jf, rbh): frequencies (i, jf), row blocks rbh * MRB + m ----
+  const int boff = (jf * 32 + jl) * 64;  // + i * 8192; slot (2 g + h) ^ ((jl >> 2) & 3)
+  const int bsw = (jl >> 2) & 3;
+  int a_base[MRB];
+#pragma unroll
+  for (int m = 0; m < MRB; ++m) {
+    const int rb = (int)blockIdx.y * (2 * MRB) + rbh * MRB + m;
+    a_base[m] = ((rb * 4 + jf) * n_chunks) * 8 * 64;
+  }
+  f32x16 acc[4][MRB];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int m = 0; m < MRB; ++m)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[i][m][t] = 0.0f;
+
+  // A ring: the 2 MRB fragments of step s = 4 chunk + i in slot s & 3, loaded kWnAhead steps ahead.  Three steps: a
+  // wave's loads return in order, so the wait for a fragment also waits for every staging load issued before it -- an
+  // HBM round trip; at three steps (6 k cycles of the SIMD's MFMA work) those have landed
+  f32x4 ring[4][MRB][2];
+  auto a_load = [&](int slot, int step) {
+#pragma unroll
+    for (int m = 0; m < MRB; ++m)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) ring[slot][m][g] = wload128(ws, a_base[m] + step * 128 + g * 64);
+  };
+  const int n_steps = 4 * n_chunks;
+
+#ifdef WN_STAMP
+  long long stamp[6];
+  stamp[0] = __builtin_readcyclecounter();
+#define WN_MARK(i) stamp[i] = __builtin_readcyclecounter()
+#else
+#define WN_MARK(i)
+#endif
+  // ---- prologue ----
+  stage_load(0);
+  GnAffine affine;
+  gn_affine_load(p.gn, p.cin, affine);
+  gn_load_stats(p.gn, img, gn_stats);
+#pragma unroll
+  for (int d = 0; d < kWnAhead; ++d) a_load(d, min(d, n_steps - 1));
+  __syncthreads();
+  gn_table_fill(p.gn, img, p.cin, gn_stats, affine, ss_in);
+  __syncthreads();
+  stage_store(0);
+  if (n_chunks > 1) stage_load(1);
+  __syncthreads();
+  transform(0);
+  if (n_chunks > 1) stage_store(1);
+  if (n_chunks > 2) stage_load(2);
+  __syncthreads();
+
+  WN_MARK(1);
+#pragma unroll 1
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    const unsigned char *vb = smem + kWnV + (chunk & 1) * kWnVBytes + boff;
+    const bool more1 = chunk + 1 < n_chunks, more2 = chunk + 2 < n_chunks, more3 = chunk + 3 < n_chunks;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int step = 4 * chunk + i;
+      f32x4 b[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) b[g] = *reinterpret_cast<const f32x4 *>(vb + i * 8192 + (((2 * g + h) ^ bsw) << 4));
+      // the two waves of a SIMD (rbh = 0 / 1) transform the next chunk at opposite ends of the iteration: one of them
+      // is always in its MFMAs
+      if (i == 0 && more1 && rbh == 0) transform((chunk + 1) & 1);
+      a_load((i + kWnAhead) & 3, min(step + kWnAhead, n_steps - 1));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int m = 0; m < MRB; ++m)
+            acc[i][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[i][m][g][ii], b[g][ii], acc[i][m], 0, 0, 0);
+      if (i == 1 && more2) stage_store(chunk & 1);
+      if (i == 2 && more3) stage_load(chunk + 3);
+      if (i == 3 && more1 && rbh == 1) transform((chunk + 1) & 1);
+    }
+    __syncthreads();
+  }
+
+  WN_MARK(2);
+  // ---- output transform, rows: S[r] = (A^T M)[r] over i:  r = 0: M0 + M1 + M2;  r = 1: M1 - M2 - M3 ----
+  f32x4 *xch = reinterpret_cast<f32x4 *>(smem);
+#pragma unroll
+  for (int m = 0; m < MRB; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 s0, s1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int t = 4 * q + e;
+        s0[e] = (acc[0][m][t] + acc[1][m][t]) + acc[2][m][t];
+        s1[e] = (acc[1][m][t] - acc[2][m][t]) - acc[3][m][t];
+      }
+      xch[(((wv * 2 + 0) * MRB + m) * 4 + q) * 64 + lane] = s0;
+      xch[(((wv * 2 + 1) * MRB + m) * 4 + q) * 64 + lane] = s1;
+    }
+  __syncthreads();
+  // ---- columns: Y[r][s] = (S A)[s] over j:  s = 0: S0 + S1 + S2;  s = 1: S1 - S2 - S3.  This wave: output row
+  // r_o = jf & 1 of every tile, row block m_o = jf >> 1 of its half ----
+  const int r_o = jf & 1, m_o = jf >> 1;
+  f32x2 pr[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = xch[((((4 * rbh + j) * 2 + r_o) * MRB + m_o) * 4 + q) * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pr[4 * q + e].x = (s[0][e] + s[1][e]) + s[2][e];
+      pr[4 * q + e].y = (s[1][e] - s[2][e]) - s[3][e];
+    }
+  }
+  WN_MARK(3);
+  wino_epilogue<NCH>(p, pr, img, tile, y0, x0, rbh * MRB + m_o, r_o, lane, smem + kWnStat);
+#ifdef WN_STAMP
+  __builtin_amdgcn_s_waitcnt(0);
+  WN_MARK(4);
+  if (tid == 0 && p.y) {  // cycles of (prologue, K loop, output transform, epilogue) of this workgroup, over its first outputs
+    float *dst = p.y + ((long long)img * p.cout + NCH * blockIdx.y) * hw + (long long)y0 * p.w + x0;
+    for (int k = 0; k < 4; ++k) dst[k] = (float)(stamp[k + 1] - stamp[k]);
+  }
+#endif
+}
+
+int launch_conv3x3_wino_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *up, hipStream_t st) {
+  const long long total = 16LL * cout * cin;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv3x3_wino_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, cout, cin, up);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+bool conv3x3_wino_supported(int cin, int cout, int h, int w) {
+  return cin % 16 == 0 && cin >= 16 && cin <= 512 && cout % 128 == 0 && h % (2 * kWnTY) == 0 && w % (2 * kWnTX) == 0;
+}
+
+int conv3x3_wino_tiles(int h, int w) { return (h / (2 * kWnTY)) * (w / (2 * kWnTX)); }
+
+int launch_conv3x3_wino(mp_ctx *ctx, const ConvArgs &a, hipStream_t st) {
+  auto kern = conv3x3_wino_kernel<2>;
+  const void *kern_id = reinterpret_cast<const void *>(kern);
+  if (!ctx->lds_attr_done.count(kern_id)) {
+    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLds));
+    ctx->lds_attr_done.insert(kern_id);
+  }
+  const int tiles = conv3x3_wino_tiles(a.h, a.w);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * a.n_img), (unsigned)(a.cout / 128)), dim3(kWnThreads), kWnLds, st, a);
+  MP_HIP(ctx, hipGetLastError());
+  return MP_OK;
+}
+
+}  // namespace mp

@@ -52,6 +52,10 @@ struct ConvArgs {
   int reflect;       // 0: zero padding (HGFilters.py ConvBlock); 1: nn.ReflectionPad2d(1) in front of
                      // the convolution (ResBlkFilters.py:28-84): halo pixels mirror the interior
   int wp_floats;     // size of wp
+  // conv_wino.hip: the Winograd-domain weights U = G g G^T (mp_conv3x3_pack_wino, 16 Cout Cin floats), or nullptr:
+  // launch_conv3x3 takes the F(2x2, 3x3) kernel for the shapes it serves when they are given
+  const float *wpw = nullptr;
+  int wpw_floats = 0;
 };
 
 struct Conv1Args {
@@ -69,6 +73,11 @@ struct Conv1Args {
 };
 
 
+// conv_wino.hip: Winograd F(2x2, 3x3) for the 128-channel-block shapes
+bool conv3x3_wino_supported(int cin, int cout, int h, int w);
+int conv3x3_wino_tiles(int h, int w);
+int launch_conv3x3_wino_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *up, hipStream_t st);
+int launch_conv3x3_wino(mp_ctx *ctx, const ConvArgs &a, hipStream_t st);
 // convim2col.hip: 7x7 (3 -> 64, stride 1 / 2) and 3x3 stride-2 convolutions
 struct ConvKArgs {
   const float *x;     // [N, Cin, H, W]

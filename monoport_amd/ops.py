@@ -913,6 +913,10 @@ def concat3_add(a, b, c, shortcut):
     return y
 
 
+# MONOPORT_CONV_WINOGRAD=0: never pack Winograd-domain weights (every 3x3 convolution on the direct kernels)
+CONV_WINOGRAD = os.environ.get("MONOPORT_CONV_WINOGRAD", "1") != "0"
+
+
 class PackedConv3x3:
     """nn.Conv2d(Cin, Cout, 3, 1, 1, bias=False) weights in the MFMA fragment order of
     csrc/conv3x3.hip: exact f32 (mp_conv3x3_pack) or pre-split f16 halves for the "f16x3"
@@ -929,9 +933,14 @@ class PackedConv3x3:
         ctx = get_encoder_context(w.device)
         self.data = torch.empty((w.numel(),), dtype=torch.float32, device=w.device)  # same bytes either way
         self.wmax = None
+        self.wino = None  # Winograd-domain weights (csrc/conv_wino.hip) for the shapes that kernel serves
         if precision == "f32":
             ctx.check(ctx.lib.mp_conv3x3_pack(ctx.handle, _ptr(w), self.cout, self.cin, _ptr(self.data),
                                               _stream(w)), "mp_conv3x3_pack")
+            if CONV_WINOGRAD and self.cout % 128 == 0:
+                self.wino = torch.empty((16 * self.cout * self.cin,), dtype=torch.float32, device=w.device)
+                ctx.check(ctx.lib.mp_conv3x3_pack_wino(ctx.handle, _ptr(w), self.cout, self.cin, _ptr(self.wino),
+                                                       _stream(w)), "mp_conv3x3_pack_wino")
         else:
             self.wmax = torch.zeros((1,), dtype=torch.float32, device=w.device)
             ctx.check(ctx.lib.mp_conv3x3_pack16(ctx.handle, _ptr(w), self.cout, self.cin, _ptr(self.data),
@@ -1181,12 +1190,13 @@ def conv3x3_fused(x, gn, packed, relu=True, reflect=False, want_y=True, stats=No
     a.relu, a.reflect = int(bool(relu)), int(bool(reflect))
     a.packed = packed.data.data_ptr()
     a.wmax = packed.wmax.data_ptr() if f16 else None
+    a.packed_wino = packed.wino.data_ptr() if packed.wino is not None else None
     a.cout = packed.cout
     a.y = y.data_ptr() if y is not None else None
     ctx.check(ctx.lib.mp_conv3x3_ex(ctx.handle, ctypes.byref(a), _stream(x)), "mp_conv3x3_ex")
     rec = _recording()
     if rec is not None:
-        rec.add(_lib.PLAN_CONV3X3, a, [x, packed.data, packed.wmax, y, out, res, stats, out_stats] + _gn_keep(gn))
+        rec.add(_lib.PLAN_CONV3X3, a, [x, packed.data, packed.wmax, packed.wino, y, out, res, stats, out_stats] + _gn_keep(gn))
     return y
 
 
