@@ -881,6 +881,8 @@ static int g_conv_wino = 1;  // 0: never take the Winograd kernel (mp_conv3x3_tu
 static long long g_conv_wino_min_wgs = 128;  // launches with fewer Winograd workgroups stay on the direct kernels (one 88 us workgroup per CU: tools/wino_check.py)
 
 void conv3x3_set_nr(int nr) {
+  conv3x3_wino_set_variant((nr & 0x800) ? 64 : (nr & 0x1000) ? 128 : 0);  // | 0x800 / | 0x1000: the 64- / 128-channel Winograd kernel
+  nr &= ~0x1800;
   g_conv_nr = nr & 0xff;
   g_conv_wino = (nr >> 8) == 0 ? 1 : 0;  // any forced variant (| 0x100, | 0x200) or 0x400 (direct kernels, heuristic) turns Winograd off
   nr &= ~0x400;
@@ -1011,8 +1013,7 @@ int launch_conv3x3(mp_ctx *ctx, ConvArgs a, const float *wmax16, const long long
   // Winograd F(2x2, 3x3) (conv_wino.hip) when the caller packed the weights for it: zero padding, exact-f32 products,
   // statistics by hand-over only (the legacy partial buffers are sized from conv_plan's tiles)
   const bool wino = a.wpw && !wmax16 && !a.reflect && !a.fin.partial && !a.fin2.partial && g_conv_wino &&
-                    conv3x3_wino_supported(cin, cout, h, w) &&
-                    (long long)conv3x3_wino_tiles(h, w) * n * (cout / 128) >= g_conv_wino_min_wgs;
+                    conv3x3_wino_supported(cin, cout, h, w) && conv3x3_wino_workgroups(a) >= g_conv_wino_min_wgs;
   if (wino) {
     a.wpw_floats = 16 * cout * cin;
     c.tiles = conv3x3_wino_tiles(h, w);

@@ -86,8 +86,8 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // workgroup's NCH channels, output row r_o of every Winograd tile -- lane (j = tile, h), pr[t] = the two neighbouring
 // pixels (2 tx, 2 tx + 1) of channel row (t & 3) + 8 (t >> 2) + 4 h.  The pair is 8-byte aligned: 64-bit accesses.
 // smem: 2 x [2][NCH][2] doubles of scratch.
-template <int NCH>
-__device__ __forceinline__ void wino_epilogue(const ConvArgs &p, f32x2 (&pr)[16], int img, int tile, int y0, int x0,
+template <int NCH, int TN>
+__device__ __forceinline__ void wino_epilogue(const ConvArgs &p, f32x2 (&pr)[TN], int t0, int img, int tile, int y0, int x0,
                                               int rbi, int r_o, int lane, unsigned char *smem) {
   const int j = lane & 31, h = lane >> 5;
   const int hw = p.h * p.w;
@@ -102,44 +102,48 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &p, f32x2 (&pr)[16]
   const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(cat ? p.res + (long long)img * p.y2_c * hw : p.x), 0, cat ? p.y2_c * hw * 4 : 0, 0x00020000);
   const int vo = (4 * h * hw + (y0 + 2 * (j >> 3) + r_o) * p.w + x0 + 2 * (j & 7)) * 4;
-  auto so1 = [&](int t) { return (ch0 + (t & 3) + 8 * (t >> 2)) * hw * 4; };  // scalar
+  auto so1 = [&](int tt) {  // scalar
+    const int t = t0 + tt;
+    return (ch0 + (t & 3) + 8 * (t >> 2)) * hw * 4;
+  };
   auto so2 = [&](int t) { return so1(t) + p.y2_off * hw * 4; };
   double *cs1 = reinterpret_cast<double *>(smem);             // [2 rows][NCH][2] per-channel sums of y
   double *cs2 = reinterpret_cast<double *>(smem + NCH * 32);  // ... of y2
-  auto to_lds = [&](double *cs, float (&a1)[16], float (&a2)[16]) {
+  auto to_lds = [&](double *cs, float (&a1)[TN], float (&a2)[TN]) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < TN; ++t) {
       a1[t] = half_wave_sum(a1[t]);
       a2[t] = half_wave_sum(a2[t]);
     }
     if (j == kHalfSumLane) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int idx = r_o * NCH + 32 * rbi + (t & 3) + 8 * (t >> 2) + 4 * h;
+      for (int t = 0; t < TN; ++t) {
+        const int tr = t0 + t;
+        const int idx = r_o * NCH + 32 * rbi + (tr & 3) + 8 * (tr >> 2) + 4 * h;
         cs[2 * idx] = (double)a1[t];
         cs[2 * idx + 1] = (double)a2[t];
       }
     }
   };
-  f32x2 u[16];  // the block tail: conv + res
+  f32x2 u[TN];  // the block tail: conv + res
   if (cat) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
+    for (int t = 0; t < TN; ++t)
       u[t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, vo, so2(t), 0));
   }
   if (st1) {
-    float s1[16], s2[16];
+    float s1[TN], s2[TN];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < TN; ++t) {
       s1[t] = pr[t].x + pr[t].y;
       s2[t] = fmaf(pr[t].y, pr[t].y, pr[t].x * pr[t].x);
     }
     to_lds(cs1, s1, s2);
   }
   if (cat) {
-    float q1[16], q2[16];
+    float q1[TN], q2[TN];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < TN; ++t) {
       u[t] = u[t] + pr[t];
       q1[t] = u[t].x + u[t].y;
       q2[t] = fmaf(u[t].y, u[t].y, u[t].x * u[t].x);
@@ -167,14 +171,14 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &p, f32x2 (&pr)[16]
     }
   }
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
+  for (int t = 0; t < TN; ++t) {
     if (p.y) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pr[t]), rs_y, vo, so1(t), 0);
     if (cat) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, u[t]), rs_y2, vo, so2(t), 0);
   }
 }
 
 template <int MRB>
-__global__ __launch_bounds__(kWnThreads, 1) void conv3x3_wino_kernel(ConvArgs p) {
+__global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p) {
   static_assert(MRB == 2, "128 output channels per workgroup");
   constexpr int NCH = 64 * MRB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv3x3_wino_kernel(ConvArgs p)
     }
   }
   WN_MARK(3);
-  wino_epilogue<NCH>(p, pr, img, tile, y0, x0, rbh * MRB + m_o, r_o, lane, smem + kWnStat);
+  wino_epilogue<NCH, 16>(p, pr, 0, img, tile, y0, x0, rbh * MRB + m_o, r_o, lane, smem + kWnStat);
 #ifdef WN_STAMP
   __builtin_amdgcn_s_waitcnt(0);
   WN_MARK(4);
@@ -403,6 +407,208 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv3x3_wino_kernel(ConvArgs p)
     for (int k = 0; k < 4; ++k) dst[k] = (float)(stamp[k + 1] - stamp[k]);
   }
 #endif
+}
+
+
+// ---- 64 output channels per workgroup, two workgroups per CU --------------------------------------------------
+// The kernel above keeps a CU to itself (128 accumulator registers per wave, 139 KB of LDS): its prologue (first
+// chunks, GroupNorm table: ~10 k cycles) and epilogue (~15-25 k) run beside nothing, a fixed cost per tile block that a
+// K loop of 16 chunks (162 k cycles) carries and one of 4-8 chunks (Cin = 64 / 128) does not.  Here a workgroup takes
+// 64 output channels of the same 8 x 4 tiles -- wave (j, half) = frequencies (0..3, j) of ONE row block, 64
+// accumulator registers -- and the input in 8-channel chunks, so that two workgroups fit a CU (<= 128 registers, 70 KB):
+// one's prologue / epilogue / barriers under the other's MFMAs.  LDS rows are 48 bytes (32 used): 16 lanes of a
+// 128-bit access then fall into 16 different 16-byte bank groups.  Serves Cout = 64 (the second and third
+// convolution of every pyramid block) and, with two workgroups per tile block, Cout = 128.
+constexpr int kW8Row = 48;                        // bytes per LDS row of 8 channels (padded)
+constexpr int kW8RawBytes = kWnPix * kW8Row;      // 8640
+constexpr int kW8VBytes = 16 * 32 * kW8Row;       // 24576: [i][j][tile][8 ch]
+constexpr int kW8Raw = 0;
+constexpr int kW8V = 2 * kW8RawBytes;
+constexpr int kW8XchBytes = 8 * 2 * 4 * 64 * 16;  // [wave][r][q][lane] f32x4 (64 KB)
+constexpr int kW8Stat = kW8V + 2 * kW8VBytes > kW8XchBytes ? kW8V + 2 * kW8VBytes : kW8XchBytes;
+constexpr int kW8Lds = kW8Stat + 4096;
+static_assert(2 * (kW8Lds + 4608) <= 160 * 1024, "two workgroups per CU");
+
+__global__ __launch_bounds__(kWnThreads, 4) void conv3x3_wino64_kernel(ConvArgs p) {
+  constexpr int NCH = 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jl = lane & 31, h = lane >> 5;
+  const int jf = wv & 3, rbh = wv >> 2;
+
+  const int tiles_x = p.w / (2 * kWnTX), tiles = tiles_x * (p.h / (2 * kWnTY));
+  const int tile = blockIdx.x % tiles, img = blockIdx.x / tiles;
+  const int y0 = (tile / tiles_x) * (2 * kWnTY), x0 = (tile % tiles_x) * (2 * kWnTX);
+  const int hw = p.h * p.w;
+  const int n_chunks = p.cin / 8;
+
+  const WStream ws = make_wstream(p.wpw, p.wpw_floats, lane);
+  __shared__ float gn_stats[64];
+  __shared__ float ss_in[2 * 512];
+
+  // ---- staging: wave wv stages channel plane 8 chunk + wv; lane = patch pixel ----
+  int goff[kWnPasses];
+#pragma unroll
+  for (int it = 0; it < kWnPasses; ++it) {
+    const int lp = lane + 64 * it;
+    const int r = lp / kWnPW, c = lp - r * kWnPW;
+    const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+    const bool ok = lp < kWnPix && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+    goff[it] = ok ? (gy * p.w + gx) * 4 : -1;
+  }
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.x + (long long)img * p.cin * hw), 0, p.cin * hw * 4, 0x00020000);
+  float stg[kWnPasses];
+  int ch_staged = 0;
+  auto stage_load = [&](int chunk) {
+    const int ch = chunk * 8 + wv;
+#pragma unroll
+    for (int it = 0; it < kWnPasses; ++it)
+      stg[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, goff[it] < 0 ? 0 : goff[it], ch * hw * 4, 0));
+    ch_staged = ch;
+  };
+  auto stage_store = [&](int buf) {
+    const float sc = ss_in[2 * ch_staged], sh = ss_in[2 * ch_staged + 1];
+    unsigned char *raw = smem + kW8Raw + buf * kW8RawBytes + wv * 4;
+#pragma unroll
+    for (int it = 0; it < kWnPasses; ++it) {
+      const int lp = lane + 64 * it;
+      if (lp < kWnPix) {
+        float t = fmaf(stg[it], sc, sh);
+        if (p.relu) t = fmaxf(t, 0.0f);
+        *reinterpret_cast<float *>(raw + lp * kW8Row) = goff[it] < 0 ? 0.0f : t;
+      }
+    }
+  };
+
+  // ---- input transform: thread = (tile (txx, tyy), channel quad chq) x wave = (column jt, row pair ih) ----
+  const int txx = lane & 7, chq = (lane >> 3) & 1, tyy = lane >> 4;
+  const int jt = wv >> 1, ih = wv & 1;
+  const int ca = jt == 0 ? 0 : jt == 2 ? 2 : 1;
+  const int cb = jt == 0 ? 2 : jt == 1 ? 2 : jt == 2 ? 1 : 3;
+  const float sg = jt == 1 ? 1.0f : -1.0f;
+  // rows ih, ih + 1, ih + 2 of the patch:  ih = 0 -> V0 = t0 - t2, V1 = t1 + t2;  ih = 1 -> V2 = t2 - t1, V3 = t1 - t3
+  const int off_a = ((2 * tyy + ih) * kWnPW + 2 * txx + ca) * kW8Row + chq * 16;
+  const int off_b = ((2 * tyy + ih) * kWnPW + 2 * txx + cb) * kW8Row + chq * 16;
+  const int voff_w = (((2 * ih) * 4 + jt) * 32 + tyy * 8 + txx) * kW8Row + chq * 16;  // second row: + 4 * 32 * kW8Row
+  auto transform = [&](int buf) {
+    const unsigned char *raw = smem + kW8Raw + buf * kW8RawBytes;
+    unsigned char *v = smem + kW8V + buf * kW8VBytes + voff_w;
+    f32x4 t[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(raw + off_a + r * kWnPW * kW8Row);
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(raw + off_b + r * kWnPW * kW8Row);
+      t[r] = __builtin_elementwise_fma(b, (f32x4)sg, a);  // a +- b, exact
+    }
+    f32x4 lo, hi;
+    if (ih == 0) {
+      lo = t[0] - t[2];
+      hi = t[1] + t[2];
+    } else {
+      lo = t[1] - t[0];
+      hi = t[0] - t[2];
+    }
+    *reinterpret_cast<f32x4 *>(v) = lo;
+    *reinterpret_cast<f32x4 *>(v + 4 * 32 * kW8Row) = hi;
+  };
+
+  // ---- GEMM: wave (jf, rbh): frequencies (i, jf) of row block 2 blockIdx.y + rbh ----
+  const int boff = (jf * 32 + jl) * kW8Row + h * 16;  // + i * 4 * 32 * kW8Row
+  const int a_base = ((((int)blockIdx.y * 2 + rbh) * 4 + jf) * (p.cin / 16)) * 8 * 64;
+  // fragment of (chunk c of 8 channels, frequency row i): a_base + ((c >> 1) * 8 + i * 2 + (c & 1)) * 64
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[i][t] = 0.0f;
+  f32x4 ring[4];  // the chunk's four fragments; pair (0, 1) of the next chunk is requested while pair (2, 3) runs
+  auto a_load = [&](int i, int c) {
+    const int cc = min(c, n_chunks - 1);
+    ring[i] = wload128(ws, a_base + ((cc >> 1) * 8 + i * 2 + (cc & 1)) * 64);
+  };
+
+  // ---- prologue ----
+  stage_load(0);
+  GnAffine affine;
+  gn_affine_load(p.gn, p.cin, affine);
+  gn_load_stats(p.gn, img, gn_stats);
+  a_load(0, 0);
+  a_load(1, 0);
+  __syncthreads();
+  gn_table_fill(p.gn, img, p.cin, gn_stats, affine, ss_in);
+  __syncthreads();
+  stage_store(0);
+  if (n_chunks > 1) stage_load(1);
+  __syncthreads();
+  transform(0);
+  if (n_chunks > 1) stage_store(1);
+  if (n_chunks > 2) stage_load(2);
+  __syncthreads();
+
+#pragma unroll 1
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    const unsigned char *vb = smem + kW8V + (chunk & 1) * kW8VBytes + boff;
+    const bool more1 = chunk + 1 < n_chunks, more2 = chunk + 2 < n_chunks, more3 = chunk + 3 < n_chunks;
+    f32x4 b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i] = *reinterpret_cast<const f32x4 *>(vb + i * 4 * 32 * kW8Row);
+    a_load(2, chunk);
+    a_load(3, chunk);
+    if (more1 && rbh == 0) transform((chunk + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[i][ii], b[i][ii], acc[i], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i] = *reinterpret_cast<const f32x4 *>(vb + (i + 2) * 4 * 32 * kW8Row);
+    a_load(0, chunk + 1);
+    a_load(1, chunk + 1);
+    if (more2) stage_store(chunk & 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int i = 2; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[i][ii], b[i - 2][ii], acc[i], 0, 0, 0);
+    if (more3) stage_load(chunk + 3);
+    if (more1 && rbh == 1) transform((chunk + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- output transform, rows ----
+  f32x4 *xch = reinterpret_cast<f32x4 *>(smem);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 s0, s1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int t = 4 * q + e;
+      s0[e] = (acc[0][t] + acc[1][t]) + acc[2][t];
+      s1[e] = (acc[1][t] - acc[2][t]) - acc[3][t];
+    }
+    xch[((wv * 2 + 0) * 4 + q) * 64 + lane] = s0;
+    xch[((wv * 2 + 1) * 4 + q) * 64 + lane] = s1;
+  }
+  __syncthreads();
+  // ---- columns: this wave = output row r_o = jf & 1 of every tile, registers 8 qh .. 8 qh + 7 (qh = jf >> 1) ----
+  const int r_o = jf & 1, qh = jf >> 1;
+  f32x2 pr[8];
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) {
+    f32x4 s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = xch[(((4 * rbh + j) * 2 + r_o) * 4 + 2 * qh + qq) * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pr[4 * qq + e].x = (s[0][e] + s[1][e]) + s[2][e];
+      pr[4 * qq + e].y = (s[1][e] - s[2][e]) - s[3][e];
+    }
+  }
+  wino_epilogue<NCH, 8>(p, pr, 8 * qh, img, tile, y0, x0, rbh, r_o, lane, smem + kW8Stat);
 }
 
 int launch_conv3x3_wino_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *up, hipStream_t st) {
@@ -415,20 +621,45 @@ int launch_conv3x3_wino_pack(mp_ctx *ctx, const float *w, int cout, int cin, flo
 }
 
 bool conv3x3_wino_supported(int cin, int cout, int h, int w) {
-  return cin % 16 == 0 && cin >= 16 && cin <= 512 && cout % 128 == 0 && h % (2 * kWnTY) == 0 && w % (2 * kWnTX) == 0;
+  return cin % 16 == 0 && cin >= 16 && cin <= 512 && cout % 64 == 0 && h % (2 * kWnTY) == 0 && w % (2 * kWnTX) == 0;
 }
 
 int conv3x3_wino_tiles(int h, int w) { return (h / (2 * kWnTY)) * (w / (2 * kWnTX)); }
 
+// workgroups of the launch: 128 output channels each (one per CU) when Cout allows and variant != 64, else 64 (two per CU)
+static int g_wino_variant = 0;  // 0 = heuristic, 64 / 128 forced (measurement hook: mp_conv3x3_tune(0x800 / 0x1000))
+void conv3x3_wino_set_variant(int v) { g_wino_variant = v; }
+static bool wino_use64(const ConvArgs &a) {
+  if (a.cout % 128) return true;
+  if (g_wino_variant) return g_wino_variant == 64;
+  // 128-channel workgroups (a CU each) once they come in many rounds; below that the 64-channel kernel's two
+  // workgroups per CU win (profiles/r06s_wino_check.txt: 256 -> 128 at 64^2 x 20 = 640 workgroups: 233 vs 265 us; at
+  // 128^2 x 1 = 128: 56 vs 85 us; at 128^2 x 20 = 2560: 904 vs 871 us)
+  return (long long)conv3x3_wino_tiles(a.h, a.w) * a.n_img * (a.cout / 128) < 2048;
+}
+long long conv3x3_wino_workgroups(const ConvArgs &a) {
+  return (long long)conv3x3_wino_tiles(a.h, a.w) * a.n_img * (a.cout / (wino_use64(a) ? 64 : 128));
+}
+
 int launch_conv3x3_wino(mp_ctx *ctx, const ConvArgs &a, hipStream_t st) {
-  auto kern = conv3x3_wino_kernel<2>;
-  const void *kern_id = reinterpret_cast<const void *>(kern);
-  if (!ctx->lds_attr_done.count(kern_id)) {
-    MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLds));
-    ctx->lds_attr_done.insert(kern_id);
-  }
   const int tiles = conv3x3_wino_tiles(a.h, a.w);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * a.n_img), (unsigned)(a.cout / 128)), dim3(kWnThreads), kWnLds, st, a);
+  if (wino_use64(a)) {
+    auto kern = conv3x3_wino64_kernel;
+    const void *kern_id = reinterpret_cast<const void *>(kern);
+    if (!ctx->lds_attr_done.count(kern_id)) {
+      MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, kW8Lds));
+      ctx->lds_attr_done.insert(kern_id);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * a.n_img), (unsigned)(a.cout / 64)), dim3(kWnThreads), kW8Lds, st, a);
+  } else {
+    auto kern = conv3x3_wino_kernel<2>;
+    const void *kern_id = reinterpret_cast<const void *>(kern);
+    if (!ctx->lds_attr_done.count(kern_id)) {
+      MP_HIP(ctx, hipFuncSetAttribute(kern_id, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLds));
+      ctx->lds_attr_done.insert(kern_id);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * a.n_img), (unsigned)(a.cout / 128)), dim3(kWnThreads), kWnLds, st, a);
+  }
   MP_HIP(ctx, hipGetLastError());
   return MP_OK;
 }

@@ -937,7 +937,7 @@ class PackedConv3x3:
         if precision == "f32":
             ctx.check(ctx.lib.mp_conv3x3_pack(ctx.handle, _ptr(w), self.cout, self.cin, _ptr(self.data),
                                               _stream(w)), "mp_conv3x3_pack")
-            if CONV_WINOGRAD and self.cout % 128 == 0:
+            if CONV_WINOGRAD and self.cout % 64 == 0:
                 self.wino = torch.empty((16 * self.cout * self.cin,), dtype=torch.float32, device=w.device)
                 ctx.check(ctx.lib.mp_conv3x3_pack_wino(ctx.handle, _ptr(w), self.cout, self.cin, _ptr(self.wino),
                                                        _stream(w)), "mp_conv3x3_pack_wino")

@@ -12,7 +12,9 @@ from tools.conv_bench import graph_time
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 batches = [int(v) for v in sys.argv[1:]] or [1, 20]
-SHAPES = [(256, 128, 128, 256, 0), (256, 128, 64, 256, 0), (256, 128, 32, 256, 0), (128, 128, 128, 256, 0)]
+SHAPES = [(256, 128, 128, 256, 0), (256, 128, 64, 256, 0), (256, 128, 32, 256, 0), (128, 128, 128, 256, 0),
+          (128, 64, 128, 256, 128), (64, 64, 128, 256, 192), (128, 64, 64, 256, 128), (64, 64, 64, 256, 192),
+          (128, 64, 32, 256, 128), (64, 64, 32, 256, 192)]
 with torch.no_grad():
     for b in batches:
         for cin, cout, hw, ctot, off in SHAPES:
@@ -30,7 +32,7 @@ with torch.no_grad():
             res = torch.randn((b, ctot, hw, hw), generator=g).to(dev)
             outs = {}
             times = {}
-            for mode, tune in (("wino", 0), ("direct", 0x400)):
+            for mode, tune in (("wino", 0), ("wino64", 0x800), ("direct", 0x400)):
                 lib.mp_conv3x3_tune(tune)
                 out = torch.zeros((b, ctot, hw, hw), device=dev)
                 acc_y, acc_o = ops.gn_acc_zeros(dev, b), ops.gn_acc_zeros(dev, b)
@@ -52,7 +54,9 @@ with torch.no_grad():
             sy = (ops.gn_reference_ss(outs["wino"][2], torch.nn.GroupNorm(32, cout).to(dev), (cout // 32) * hw * hw)
                   - ops.gn_reference_ss(outs["direct"][2], torch.nn.GroupNorm(32, cout).to(dev), (cout // 32) * hw * hw)).abs().max().item()
             gf = 2.0 * 9 * cin * cout * hw * hw * b / 1e9
-            print("%3d->%3d @%3d^2 x%-2d: wino %7.1f us (%5.1f TF direct-equivalent)  direct %7.1f us (%5.1f TF) | max|d| vs fp64: wino %.2e direct %.2e "
-                  "(scale %.1f); tail wino-direct %.2e; next-GN (scale, shift) wino-direct %.2e"
-                  % (cin, cout, hw, b, times["wino"], gf / times["wino"] * 1e3, times["direct"], gf / times["direct"] * 1e3,
-                     ew, ed, scale, eo, sy), flush=True)
+            e64 = (outs["wino64"][0][:nb].double() - ref).abs().max().item()
+            eo64 = (outs["wino64"][1] - outs["direct"][1]).abs().max().item()
+            print("%3d->%3d @%3d^2 x%-2d: wino %7.1f us (%5.1f TF-eq)  wino64 %7.1f us (%5.1f)  direct %7.1f us (%5.1f) | max|d| vs fp64: %.2e / %.2e / %.2e "
+                  "(scale %.1f); tail vs direct %.2e / %.2e; next-GN ss %.2e"
+                  % (cin, cout, hw, b, times["wino"], gf / times["wino"] * 1e3, times["wino64"], gf / times["wino64"] * 1e3,
+                     times["direct"], gf / times["direct"] * 1e3, ew, e64, ed, scale, eo, eo64, sy), flush=True)
