@@ -1010,10 +1010,11 @@ int launch_conv3x3(mp_ctx *ctx, ConvArgs a, const float *wmax16, const long long
     return fail(ctx, MP_ERR_UNSUPPORTED, "conv3x3: at most %d input channels (got %d)", kMaxCin, cin);
   a.wp_floats = cout * cin * 9;
   ConvPlan c = conv_plan(cout, n, h, w, wmax16 != nullptr);
-  // Winograd F(2x2, 3x3) (conv_wino.hip) when the caller packed the weights for it: zero padding, exact-f32 products,
+  // Winograd F(2x2, 3x3) (conv_wino.hip) when the caller packed the weights for it: exact-f32 products,
   // statistics by hand-over only (the legacy partial buffers are sized from conv_plan's tiles)
-  const bool wino = a.wpw && !wmax16 && !a.reflect && !a.fin.partial && !a.fin2.partial && g_conv_wino &&
-                    conv3x3_wino_supported(cin, cout, h, w) && conv3x3_wino_workgroups(a) >= g_conv_wino_min_wgs;
+  const bool wino = a.wpw && !wmax16 && !a.fin.partial && !a.fin2.partial && g_conv_wino &&
+                    conv3x3_wino_supported(cin, cout, h, w) &&
+                    (conv3x3_wino_forced() || conv3x3_wino_workgroups(a) >= g_conv_wino_min_wgs);
   if (wino) {
     a.wpw_floats = 16 * cout * cin;
     c.tiles = conv3x3_wino_tiles(h, w);

@@ -9,7 +9,8 @@
 // so the convolution becomes 16 independent GEMMs  M[i][j] = U[i][j] (Cout x Cin) . V[i][j] (Cin x tiles)  -- 2.25x
 // fewer MFMAs -- between an input transform (adds only) and an output transform (adds only).  The transformed weights
 // U = G g G^T are computed once, in double, by conv3x3_wino_pack_kernel.  Everything around the GEMMs is what
-// conv3x3.hip does: GroupNorm + ReLU applied while the input is staged (zero padding of the NORMALISED tensor), the
+// conv3x3.hip does: GroupNorm + ReLU applied while the input is staged (zero padding of the NORMALISED tensor, or the
+// reflection padding of the ResNet encoder), the
 // epilogue of conv3x3.hip (raw output, pyramid-block tail, the next GroupNorms' statistics by integer atomics).
 //
 // Decomposition (one workgroup = 8 waves = 512 threads, one per CU):
@@ -204,8 +205,14 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
   for (int it = 0; it < kWnPasses; ++it) {
     const int lp = lane + 64 * it;
     const int r = lp / kWnPW, c = lp - r * kWnPW;
-    const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-    const bool ok = lp < kWnPix && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+    int gy = y0 - 1 + r, gx = x0 - 1 + c;
+    bool ok = lp < kWnPix;
+    if (p.reflect) {  // nn.ReflectionPad2d(1) in front of the convolution (ResBlkFilters.py:28-84): -1 -> 1, H -> H - 2
+      gy = gy < 0 ? -gy : (gy >= p.h ? 2 * p.h - 2 - gy : gy);
+      gx = gx < 0 ? -gx : (gx >= p.w ? 2 * p.w - 2 - gx : gx);
+    } else {
+      ok = ok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+    }
     goff[it] = ok ? (gy * p.w + gx) * 4 : -1;
   }
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
@@ -213,7 +220,10 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
   float stg[kWnPasses][2];
   int ch_staged = 0;
   auto stage_load = [&](int chunk) {
-    const int ch = chunk * 16 + 2 * wv;
+#ifdef WN_NO_STAGE
+    if (chunk >= 3) return;
+#endif
+    const int ch = min(chunk, n_chunks - 1) * 16 + 2 * wv;
 #pragma unroll
     for (int it = 0; it < kWnPasses; ++it) {
       const int o = goff[it] < 0 ? 0 : goff[it];
@@ -302,6 +312,9 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
   // HBM round trip; at three steps (6 k cycles of the SIMD's MFMA work) those have landed
   f32x4 ring[4][MRB][2];
   auto a_load = [&](int slot, int step) {
+#ifdef WN_NO_A  // timing experiment (wrong results): the weight stream is requested once
+    if (step >= kWnAhead) return;
+#endif
 #pragma unroll
     for (int m = 0; m < MRB; ++m)
 #pragma unroll
@@ -327,28 +340,38 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
   gn_table_fill(p.gn, img, p.cin, gn_stats, affine, ss_in);
   __syncthreads();
   stage_store(0);
-  if (n_chunks > 1) stage_load(1);
+  stage_load(1);
   __syncthreads();
   transform(0);
-  if (n_chunks > 1) stage_store(1);
-  if (n_chunks > 2) stage_load(2);
+  stage_store(1);
+  stage_load(2);
   __syncthreads();
 
   WN_MARK(1);
 #pragma unroll 1
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     const unsigned char *vb = smem + kWnV + (chunk & 1) * kWnVBytes + boff;
-    const bool more1 = chunk + 1 < n_chunks, more2 = chunk + 2 < n_chunks, more3 = chunk + 3 < n_chunks;
+    const bool more1 = chunk + 1 < n_chunks;
+    // B of step i + 1 is requested before step i's MFMAs (the two waves of a SIMD run in lock step behind the chunk
+    // barrier: an LDS round trip at the top of every step was a bubble for both); staging is unconditional and clamped
+    // so that the vector-memory waits are counted exactly
+    f32x4 b[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) b[0][g] = *reinterpret_cast<const f32x4 *>(vb + (((2 * g + h) ^ bsw) << 4));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int step = 4 * chunk + i;
-      f32x4 b[2];
+      if (i < 3) {
 #pragma unroll
-      for (int g = 0; g < 2; ++g) b[g] = *reinterpret_cast<const f32x4 *>(vb + i * 8192 + (((2 * g + h) ^ bsw) << 4));
+        for (int g = 0; g < 2; ++g)
+          b[(i + 1) & 1][g] = *reinterpret_cast<const f32x4 *>(vb + (i + 1) * 8192 + (((2 * g + h) ^ bsw) << 4));
+      }
       // the two waves of a SIMD (rbh = 0 / 1) transform the next chunk at opposite ends of the iteration: one of them
       // is always in its MFMAs
       if (i == 0 && more1 && rbh == 0) transform((chunk + 1) & 1);
       a_load((i + kWnAhead) & 3, min(step + kWnAhead, n_steps - 1));
+      if (i == 1) stage_store(chunk & 1);
+      if (i == 1) stage_load(chunk + 3);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < 2; ++g)
@@ -356,9 +379,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
           for (int m = 0; m < MRB; ++m)
-            acc[i][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[i][m][g][ii], b[g][ii], acc[i][m], 0, 0, 0);
-      if (i == 1 && more2) stage_store(chunk & 1);
-      if (i == 2 && more3) stage_load(chunk + 3);
+            acc[i][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[i][m][g][ii], b[i & 1][g][ii], acc[i][m], 0, 0, 0);
       if (i == 3 && more1 && rbh == 1) transform((chunk + 1) & 1);
     }
     __syncthreads();
@@ -454,8 +475,14 @@ __global__ __launch_bounds__(kWnThreads, 4) void conv3x3_wino64_kernel(ConvArgs 
   for (int it = 0; it < kWnPasses; ++it) {
     const int lp = lane + 64 * it;
     const int r = lp / kWnPW, c = lp - r * kWnPW;
-    const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-    const bool ok = lp < kWnPix && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+    int gy = y0 - 1 + r, gx = x0 - 1 + c;
+    bool ok = lp < kWnPix;
+    if (p.reflect) {  // nn.ReflectionPad2d(1) in front of the convolution (ResBlkFilters.py:28-84): -1 -> 1, H -> H - 2
+      gy = gy < 0 ? -gy : (gy >= p.h ? 2 * p.h - 2 - gy : gy);
+      gx = gx < 0 ? -gx : (gx >= p.w ? 2 * p.w - 2 - gx : gx);
+    } else {
+      ok = ok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+    }
     goff[it] = ok ? (gy * p.w + gx) * 4 : -1;
   }
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
@@ -463,7 +490,10 @@ __global__ __launch_bounds__(kWnThreads, 4) void conv3x3_wino64_kernel(ConvArgs 
   float stg[kWnPasses];
   int ch_staged = 0;
   auto stage_load = [&](int chunk) {
-    const int ch = chunk * 8 + wv;
+#ifdef WN_NO_STAGE
+    if (chunk >= 3) return;
+#endif
+    const int ch = min(chunk, n_chunks - 1) * 8 + wv;
 #pragma unroll
     for (int it = 0; it < kWnPasses; ++it)
       stg[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, goff[it] < 0 ? 0 : goff[it], ch * hw * 4, 0));
@@ -526,6 +556,9 @@ __global__ __launch_bounds__(kWnThreads, 4) void conv3x3_wino64_kernel(ConvArgs 
     for (int t = 0; t < 16; ++t) acc[i][t] = 0.0f;
   f32x4 ring[4];  // the chunk's four fragments; pair (0, 1) of the next chunk is requested while pair (2, 3) runs
   auto a_load = [&](int i, int c) {
+#ifdef WN_NO_A
+    if (c >= 1) return;
+#endif
     const int cc = min(c, n_chunks - 1);
     ring[i] = wload128(ws, a_base + ((cc >> 1) * 8 + i * 2 + (cc & 1)) * 64);
   };
@@ -541,17 +574,21 @@ __global__ __launch_bounds__(kWnThreads, 4) void conv3x3_wino64_kernel(ConvArgs 
   gn_table_fill(p.gn, img, p.cin, gn_stats, affine, ss_in);
   __syncthreads();
   stage_store(0);
-  if (n_chunks > 1) stage_load(1);
+  stage_load(1);
   __syncthreads();
   transform(0);
-  if (n_chunks > 1) stage_store(1);
-  if (n_chunks > 2) stage_load(2);
+  stage_store(1);
+  stage_load(2);
   __syncthreads();
 
 #pragma unroll 1
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     const unsigned char *vb = smem + kW8V + (chunk & 1) * kW8VBytes + boff;
-    const bool more1 = chunk + 1 < n_chunks, more2 = chunk + 2 < n_chunks, more3 = chunk + 3 < n_chunks;
+    const bool more1 = chunk + 1 < n_chunks;
+    // Vector-memory loads return in order, so a wait for a weight fragment also waits for every load issued before it.
+    // Per chunk: [top] fragments 2, 3 | pair 0's MFMAs | fragments 0, 1 of the next chunk, then the staging loads of
+    // chunk + 3 (unconditional and clamped: the waits are counted exactly) | pair 1's MFMAs.  The wait for fragments
+    // 0, 1 leaves the staging loads in flight; they have a whole chunk until fragments 2, 3 of the next chunk are needed.
     f32x4 b[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) b[i] = *reinterpret_cast<const f32x4 *>(vb + i * 4 * 32 * kW8Row);
@@ -568,13 +605,13 @@ __global__ __launch_bounds__(kWnThreads, 4) void conv3x3_wino64_kernel(ConvArgs 
     for (int i = 0; i < 2; ++i) b[i] = *reinterpret_cast<const f32x4 *>(vb + (i + 2) * 4 * 32 * kW8Row);
     a_load(0, chunk + 1);
     a_load(1, chunk + 1);
-    if (more2) stage_store(chunk & 1);
+    stage_store(chunk & 1);  // chunk + 2 (past the end: the clamped last chunk again, into a buffer nobody reads)
+    stage_load(chunk + 3);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
       for (int i = 2; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[i][ii], b[i - 2][ii], acc[i], 0, 0, 0);
-    if (more3) stage_load(chunk + 3);
     if (more1 && rbh == 1) transform((chunk + 1) & 1);
     __syncthreads();
   }
@@ -629,6 +666,7 @@ int conv3x3_wino_tiles(int h, int w) { return (h / (2 * kWnTY)) * (w / (2 * kWnT
 // workgroups of the launch: 128 output channels each (one per CU) when Cout allows and variant != 64, else 64 (two per CU)
 static int g_wino_variant = 0;  // 0 = heuristic, 64 / 128 forced (measurement hook: mp_conv3x3_tune(0x800 / 0x1000))
 void conv3x3_wino_set_variant(int v) { g_wino_variant = v; }
+bool conv3x3_wino_forced() { return g_wino_variant != 0; }
 static bool wino_use64(const ConvArgs &a) {
   if (a.cout % 128) return true;
   if (g_wino_variant) return g_wino_variant == 64;

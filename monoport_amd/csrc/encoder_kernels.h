@@ -78,6 +78,7 @@ bool conv3x3_wino_supported(int cin, int cout, int h, int w);
 int conv3x3_wino_tiles(int h, int w);
 long long conv3x3_wino_workgroups(const ConvArgs &a);
 void conv3x3_wino_set_variant(int v);
+bool conv3x3_wino_forced();  // a variant is forced (mp_conv3x3_tune): the size threshold does not apply
 int launch_conv3x3_wino_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *up, hipStream_t st);
 int launch_conv3x3_wino(mp_ctx *ctx, const ConvArgs &a, hipStream_t st);
 // convim2col.hip: 7x7 (3 -> 64, stride 1 / 2) and 3x3 stride-2 convolutions
