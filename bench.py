@@ -481,6 +481,9 @@ def breakdown_leg(job, pipe, batch, resolutions):
         "recon_vertices_render_ms_per_frame_batched": rec_batched_ms,
         "recon_per_s_encoder_excluded": 1e3 / rec_batched_ms,
         "recon_per_s_encoder_excluded_single_frame": 1e3 / rec_ms,
+        "encoder_conv3x3": ("Winograd F(2x2,3x3) on f32 MFMA for the launches csrc/conv_wino.hip serves (Cout % 64 == 0, >= 128 "
+                            "workgroups: 4/9 of the direct form's multiplies, exact-f32 products), direct implicit GEMM otherwise"
+                            if ops.CONV_WINOGRAD else "direct implicit GEMM on f32 MFMA (MONOPORT_CONV_WINOGRAD=0)"),
         "note": "single stream, no overlap; encoder eager at the bench batch size (and at batch 1), `as_run` = the hipGraph of "
                 "the slot (with --with-color: both encoders); "
                 "batched = mp_recon_batch over the slot's frames, as the pipeline runs it",
