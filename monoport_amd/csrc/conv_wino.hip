@@ -17,7 +17,8 @@
 //   * workgroup = 8 x 4 Winograd tiles (16 x 8 output pixels, 18 x 10 input patch) x 128 output channels;
 //   * K loop over 16-channel chunks of the input, one barrier per chunk, three stages in flight:
 //       chunk k + 2/3: global -> registers (lane = patch pixel, wave = 2 channel planes), GroupNorm + ReLU,
-//                      -> raw[2] in LDS, pixel-major (64 B per pixel, XOR-swizzled);
+//                      -> raw[2] in LDS, pixel-major (80-byte rows: 64 used, the pad keeps 128-bit accesses off each
+//                      other's banks);
 //       chunk k + 1:   input transform raw -> V[2][i][j][tile][16 ch]: thread = (tile, 4 channels, column j),
 //                      8 ds_read_b128 + 16 packed adds + 4 ds_write_b128;
 //       chunk k:       wave (j, half) multiplies frequencies (0..3, j) for its two 32-channel row blocks: A = U
@@ -41,13 +42,21 @@ constexpr int kWnPW = 2 * kWnTX + 2;             // 18 patch columns
 constexpr int kWnPH = 2 * kWnTY + 2;             // 10 patch rows
 constexpr int kWnPix = kWnPW * kWnPH;            // 180 staged pixels
 constexpr int kWnPasses = (kWnPix + 63) / 64;    // 3 passes of 64 lanes
-constexpr int kWnRawBytes = kWnPix * 64;         // one raw buffer: [pixel][16 ch] f32
-constexpr int kWnVBytes = 16 * 32 * 64;          // one V buffer: [i][j][tile][16 ch] f32
+constexpr int kWnRow = 80;                       // bytes per LDS row of 16 channels (64 used): with the pad, 16 lanes of a
+                                                 // 128-bit access fall into 16 different 16-byte bank groups -- no swizzle,
+                                                 // so every address of a thread is ONE register + an immediate offset
+constexpr int kWnRawBytes = kWnPix * kWnRow;     // one raw buffer: [pixel][16 ch] f32
+constexpr int kWnVBytes = 16 * 32 * kWnRow;      // one V buffer: [i][j][tile][16 ch] f32
 constexpr int kWnRaw = 0;
 constexpr int kWnV = 2 * kWnRawBytes;
 constexpr int kWnXchBytes = 8 * 2 * 2 * 4 * 64 * 16;  // output-transform exchange: [wave][r][m][q][lane] f32x4 (128 KB)
 constexpr int kWnStat = kWnXchBytes;             // wino_epilogue's statistics scratch (8 KB)
 constexpr int kWnLds = kWnStat + 8192;
+#ifndef WN_ABL
+#define WN_ABL 0
+#endif
+// WN_ABL (side builds of tools/wino_ablate.py, wrong results): 1 no input transform, 2 no staging stores, 4 no chunk
+// barrier, 8 no B reads in the K loop, 16 no epilogue (statistics / stores), 32 no output transform exchange
 constexpr int kWnAhead = 3;                    // A fragments are requested this many steps (of 16 MRB MFMAs) ahead
 static_assert(kWnV + 2 * kWnVBytes <= kWnXchBytes, "the exchange region covers the K loop's buffers");
 static_assert(kWnLds <= 160 * 1024, "LDS");
@@ -82,101 +91,142 @@ __global__ void conv3x3_wino_pack_kernel(const float *__restrict__ w, int cout, 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// a - b on four floats as two v_pk_add_f32 with negated second operands: hipcc has no packed subtract and emits four
+// v_sub_f32 (it also folds fma(b, -1, a) back into them), and in the K loops every VALU instruction of a wave costs the
+// other waves of its SIMD matrix-pipe time (side build without the input transform: -8.5 %)
+__device__ __forceinline__ f32x4 pk_sub4(const f32x4 &a, const f32x4 &b) {
+  f32x2 lo, hi;
+  const f32x2 alo = {a[0], a[1]}, ahi = {a[2], a[3]}, blo = {b[0], b[1]}, bhi = {b[2], b[3]};
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(alo), "v"(blo));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(ahi), "v"(bhi));
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 // The epilogue of conv3x3.hip (conv_epilogue: raw output, pyramid-block tail y2 = conv + res, the next GroupNorms'
 // statistics through csrc/gn_tail.h) for this kernel's register layout: a wave holds, for the 32-row block `rbi` of the
 // workgroup's NCH channels, output row r_o of every Winograd tile -- lane (j = tile, h), pr[t] = the two neighbouring
-// pixels (2 tx, 2 tx + 1) of channel row (t & 3) + 8 (t >> 2) + 4 h.  The pair is 8-byte aligned: 64-bit accesses.
-// smem: 2 x [2][NCH][2] doubles of scratch.
+// pixels (2 tx, 2 tx + 1) of channel row (t & 3) + 8 (t >> 2) + 4 h, t = t0 + 0 .. TN - 1.  The pair is 8-byte aligned:
+// 64-bit accesses.  Two calls: WinoTail::load_res right after the K loop (the residual's round trip to memory runs under
+// the output transform), WinoTail::finish with the outputs.  smem: 2 x [2][NCH][2] doubles of scratch.
 template <int NCH, int TN>
-__device__ __forceinline__ void wino_epilogue(const ConvArgs &p, f32x2 (&pr)[TN], int t0, int img, int tile, int y0, int x0,
-                                              int rbi, int r_o, int lane, unsigned char *smem) {
-  const int j = lane & 31, h = lane >> 5;
-  const int hw = p.h * p.w;
-  const int ch0 = NCH * blockIdx.y + 32 * rbi;
-  const bool cat = p.y2 != nullptr;
-  const bool st1 = gn_wanted(p.fin), st2 = cat && gn_wanted(p.fin2);
-  const int tid = threadIdx.x;
-  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
-      p.y ? p.y + (long long)img * p.cout * hw : const_cast<float *>(p.x), 0, p.y ? p.cout * hw * 4 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(
-      cat ? p.y2 + (long long)img * p.y2_c * hw : const_cast<float *>(p.x), 0, cat ? p.y2_c * hw * 4 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(cat ? p.res + (long long)img * p.y2_c * hw : p.x), 0, cat ? p.y2_c * hw * 4 : 0, 0x00020000);
-  const int vo = (4 * h * hw + (y0 + 2 * (j >> 3) + r_o) * p.w + x0 + 2 * (j & 7)) * 4;
-  auto so1 = [&](int tt) {  // scalar
+struct WinoTail {
+  const ConvArgs &p;
+  int t0, img, tile, rbi, r_o, j, h, hw, ch0, vo;
+  bool cat;
+  __amdgpu_buffer_rsrc_t rs_y, rs_y2, rs_res;
+  f32x2 u[TN];  // the block tail: conv + res
+
+  __device__ __forceinline__ WinoTail(const ConvArgs &p_, int t0_, int img_, int tile_, int y0, int x0, int rbi_, int r_o_, int lane)
+      : p(p_), t0(t0_), img(img_), tile(tile_), rbi(rbi_), r_o(r_o_) {
+    j = lane & 31;
+    h = lane >> 5;
+    hw = p.h * p.w;
+    ch0 = NCH * blockIdx.y + 32 * rbi;
+    cat = p.y2 != nullptr;
+    rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y ? p.y + (long long)img * p.cout * hw : const_cast<float *>(p.x), 0,
+                                             p.y ? p.cout * hw * 4 : 0, 0x00020000);
+    rs_y2 = __builtin_amdgcn_make_buffer_rsrc(cat ? p.y2 + (long long)img * p.y2_c * hw : const_cast<float *>(p.x), 0,
+                                              cat ? p.y2_c * hw * 4 : 0, 0x00020000);
+    rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cat ? p.res + (long long)img * p.y2_c * hw : p.x), 0,
+                                               cat ? p.y2_c * hw * 4 : 0, 0x00020000);
+    vo = (4 * h * hw + (y0 + 2 * (j >> 3) + r_o) * p.w + x0 + 2 * (j & 7)) * 4;
+  }
+  __device__ __forceinline__ int so1(int tt) const {  // scalar
     const int t = t0 + tt;
     return (ch0 + (t & 3) + 8 * (t >> 2)) * hw * 4;
-  };
-  auto so2 = [&](int t) { return so1(t) + p.y2_off * hw * 4; };
-  double *cs1 = reinterpret_cast<double *>(smem);             // [2 rows][NCH][2] per-channel sums of y
-  double *cs2 = reinterpret_cast<double *>(smem + NCH * 32);  // ... of y2
-  auto to_lds = [&](double *cs, float (&a1)[TN], float (&a2)[TN]) {
+  }
+  __device__ __forceinline__ int so2(int tt) const { return so1(tt) + p.y2_off * hw * 4; }
+
+  __device__ __forceinline__ void load_res() {
+    if (cat) {
 #pragma unroll
-    for (int t = 0; t < TN; ++t) {
-      a1[t] = half_wave_sum(a1[t]);
-      a2[t] = half_wave_sum(a2[t]);
+      for (int t = 0; t < TN; ++t)
+        u[t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, vo, so2(t), 0));
     }
-    if (j == kHalfSumLane) {
+  }
+
+  // per-channel (sum, sum of squares) of a wave's pixels -> LDS, the channels of one lane that share a GroupNorm group
+  // added up first: rows (t & 3) of a register quad are 4 consecutive channels, so with >= 4 channels per group one
+  // cross-lane sum serves four registers (2 with 2 channels per group): 4 (2) x fewer DPP chains
+  __device__ __forceinline__ void to_lds(double *cs, const float (&a1)[TN], const float (&a2)[TN], int cpg) const {
+    if (cpg >= 4) {
 #pragma unroll
-      for (int t = 0; t < TN; ++t) {
-        const int tr = t0 + t;
-        const int idx = r_o * NCH + 32 * rbi + (tr & 3) + 8 * (tr >> 2) + 4 * h;
-        cs[2 * idx] = (double)a1[t];
-        cs[2 * idx + 1] = (double)a2[t];
+      for (int q = 0; q < TN / 4; ++q) {
+        const float s1 = half_wave_sum((a1[4 * q] + a1[4 * q + 1]) + (a1[4 * q + 2] + a1[4 * q + 3]));
+        const float s2 = half_wave_sum((a2[4 * q] + a2[4 * q + 1]) + (a2[4 * q + 2] + a2[4 * q + 3]));
+        if (j == kHalfSumLane) {
+          const int idx = r_o * NCH + 32 * rbi + 8 * ((t0 >> 2) + q) + 4 * h;
+          cs[2 * idx] = (double)s1;
+          cs[2 * idx + 1] = (double)s2;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < TN / 2; ++q) {
+        const float s1 = half_wave_sum(a1[2 * q] + a1[2 * q + 1]);
+        const float s2 = half_wave_sum(a2[2 * q] + a2[2 * q + 1]);
+        if (j == kHalfSumLane) {
+          const int tr = t0 + 2 * q;
+          const int idx = r_o * NCH + 32 * rbi + (tr & 3) + 8 * (tr >> 2) + 4 * h;
+          cs[2 * idx] = (double)s1;
+          cs[2 * idx + 1] = (double)s2;
+        }
       }
     }
-  };
-  f32x2 u[TN];  // the block tail: conv + res
-  if (cat) {
-#pragma unroll
-    for (int t = 0; t < TN; ++t)
-      u[t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, vo, so2(t), 0));
   }
-  if (st1) {
-    float s1[TN], s2[TN];
+
+  __device__ __forceinline__ void finish(const f32x2 (&pr)[TN], unsigned char *smem) {
+    const bool st1 = gn_wanted(p.fin), st2 = cat && gn_wanted(p.fin2);
+    const int tid = threadIdx.x;
+    double *cs1 = reinterpret_cast<double *>(smem);             // [2 rows][NCH][2] sums of y (first channel of a quad / pair)
+    double *cs2 = reinterpret_cast<double *>(smem + NCH * 32);  // ... of y2
+    if (st1) {
+      float s1[TN], s2[TN];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        s1[t] = pr[t].x + pr[t].y;
+        s2[t] = fmaf(pr[t].y, pr[t].y, pr[t].x * pr[t].x);
+      }
+      to_lds(cs1, s1, s2, p.fin.c / 32);
+    }
+    if (cat) {
+      float q1[TN], q2[TN];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        u[t] = u[t] + pr[t];
+        q1[t] = u[t].x + u[t].y;
+        q2[t] = fmaf(u[t].y, u[t].y, u[t].x * u[t].x);
+      }
+      if (st2) to_lds(cs2, q1, q2, p.fin2.c / 32);
+    }
+    if (st1 || st2) {
+      __syncthreads();
+      if (tid < 64) {
+        auto fold = [&](const GnOut &f, const double *cs, int c_off) {
+          const int cpg = f.c / 32;  // channels per group of the normalised tensor
+          const int ng = NCH / cpg;  // groups this workgroup covers
+          const int pre = cpg >= 4 ? 4 : 2;
+          double a = 0.0, b = 0.0;
+          if (tid < ng)
+            for (int r = 0; r < 2; ++r)
+              for (int ch = 0; ch < cpg; ch += pre) {
+                const int idx = r * NCH + tid * cpg + ch;
+                a += cs[2 * idx];
+                b += cs[2 * idx + 1];
+              }
+          gn_emit(f, img, (c_off + NCH * (int)blockIdx.y) / cpg, ng, tile, a, b);
+        };
+        if (st1) fold(p.fin, cs1, 0);
+        if (st2) fold(p.fin2, cs2, p.y2_off);
+      }
+    }
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
-      s1[t] = pr[t].x + pr[t].y;
-      s2[t] = fmaf(pr[t].y, pr[t].y, pr[t].x * pr[t].x);
-    }
-    to_lds(cs1, s1, s2);
-  }
-  if (cat) {
-    float q1[TN], q2[TN];
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-      u[t] = u[t] + pr[t];
-      q1[t] = u[t].x + u[t].y;
-      q2[t] = fmaf(u[t].y, u[t].y, u[t].x * u[t].x);
-    }
-    if (st2) to_lds(cs2, q1, q2);
-  }
-  if (st1 || st2) {
-    __syncthreads();
-    if (tid < 64) {
-      auto fold = [&](const GnOut &f, const double *cs, int c_off) {
-        const int cpg = f.c / 32;  // channels per group of the normalised tensor
-        const int ng = NCH / cpg;  // groups this workgroup covers
-        double a = 0.0, b = 0.0;
-        if (tid < ng)
-          for (int r = 0; r < 2; ++r)
-            for (int ch = 0; ch < cpg; ++ch) {
-              const int idx = r * NCH + tid * cpg + ch;
-              a += cs[2 * idx];
-              b += cs[2 * idx + 1];
-            }
-        gn_emit(f, img, (c_off + NCH * (int)blockIdx.y) / cpg, ng, tile, a, b);
-      };
-      if (st1) fold(p.fin, cs1, 0);
-      if (st2) fold(p.fin2, cs2, p.y2_off);
+      if (p.y) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pr[t]), rs_y, vo, so1(t), 0);
+      if (cat) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, u[t]), rs_y2, vo, so2(t), 0);
     }
   }
-#pragma unroll
-  for (int t = 0; t < TN; ++t) {
-    if (p.y) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pr[t]), rs_y, vo, so1(t), 0);
-    if (cat) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, u[t]), rs_y2, vo, so2(t), 0);
-  }
-}
+};
 
 template <int MRB>
 __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p) {
@@ -245,54 +295,44 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
     for (int it = 0; it < kWnPasses; ++it) {
       const int lp = lane + 64 * it;
       if (lp < kWnPix) {
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 v;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          float t = fmaf(stg[it][k], sc[k], sh[k]);
-          if (p.relu) t = fmaxf(t, 0.0f);
-          v[k] = goff[it] < 0 ? 0.0f : t;
-        }
-        *reinterpret_cast<f32x2 *>(raw + lp * 64 + (((wv >> 1) ^ ((lp >> 2) & 3)) << 4) + (wv & 1) * 8) = v;
+        f32x2 x2 = {stg[it][0], stg[it][1]};
+        f32x2 v = __builtin_elementwise_fma(x2, (f32x2){sc[0], sc[1]}, (f32x2){sh[0], sh[1]});
+        if (p.relu) v = __builtin_elementwise_max(v, (f32x2)(0.0f));
+        if (goff[it] < 0) v = (f32x2)(0.0f);
+        *reinterpret_cast<f32x2 *>(raw + lp * kWnRow + wv * 8) = v;
       }
     }
   };
 
-  // ---- input transform plan: thread = (tile jl, channel quad chq, column jt) ----
-  const int jt = wv >> 1, chq = ((wv & 1) << 1) | h;
-  const int tyy = jl >> 3, txx = jl & 7;
+  // ---- input transform plan: thread = (tile (txx, tyy), channel quad chq, column jt); a 16-lane group = 8 txx x 2 chq ----
+  const int txx = lane & 7, tyy = lane >> 4;
+  const int jt = wv >> 1, chq = ((wv & 1) << 1) | ((lane >> 3) & 1);
   // t[r] = d[r][ca] + sg * d[r][cb]   (column jt of B):  j = 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
   const int ca = jt == 0 ? 0 : jt == 2 ? 2 : 1;
   const int cb = jt == 0 ? 2 : jt == 1 ? 2 : jt == 2 ? 1 : 3;
   const float sg = jt == 1 ? 1.0f : -1.0f;
-  int offa[4], offb[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int la = (2 * tyy + r) * kWnPW + 2 * txx + ca, lb = (2 * tyy + r) * kWnPW + 2 * txx + cb;
-    offa[r] = la * 64 + ((chq ^ ((la >> 2) & 3)) << 4);
-    offb[r] = lb * 64 + ((chq ^ ((lb >> 2) & 3)) << 4);
-  }
-  const int voff_w = (jt * 32 + jl) * 64 + ((chq ^ ((jl >> 2) & 3)) << 4);  // + i * 8192
+  const int off_a = ((2 * tyy) * kWnPW + 2 * txx + ca) * kWnRow + chq * 16;  // row r: + r * kWnPW * kWnRow
+  const int off_b = ((2 * tyy) * kWnPW + 2 * txx + cb) * kWnRow + chq * 16;
+  const int voff_w = (jt * 32 + tyy * 8 + txx) * kWnRow + chq * 16;  // + i * 4 * 32 * kWnRow
   auto transform = [&](int buf) {
     const unsigned char *raw = smem + kWnRaw + buf * kWnRawBytes;
-    unsigned char *v = smem + kWnV + buf * kWnVBytes;
+    unsigned char *v = smem + kWnV + buf * kWnVBytes + voff_w;
     f32x4 t[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const f32x4 a = *reinterpret_cast<const f32x4 *>(raw + offa[r]);
-      const f32x4 b = *reinterpret_cast<const f32x4 *>(raw + offb[r]);
-      t[r] = a + b * sg;
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(raw + off_a + r * kWnPW * kWnRow);
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(raw + off_b + r * kWnPW * kWnRow);
+      t[r] = __builtin_elementwise_fma(b, (f32x4)sg, a);  // a +- b, exact; v_pk_fma_f32
     }
     // rows of B^T:  i = 0: t0 - t2;  1: t1 + t2;  2: t2 - t1;  3: t1 - t3
-    *reinterpret_cast<f32x4 *>(v + voff_w + 0 * 8192) = t[0] - t[2];
-    *reinterpret_cast<f32x4 *>(v + voff_w + 1 * 8192) = t[1] + t[2];
-    *reinterpret_cast<f32x4 *>(v + voff_w + 2 * 8192) = t[2] - t[1];
-    *reinterpret_cast<f32x4 *>(v + voff_w + 3 * 8192) = t[1] - t[3];
+    *reinterpret_cast<f32x4 *>(v + 0 * 4 * 32 * kWnRow) = pk_sub4(t[0], t[2]);
+    *reinterpret_cast<f32x4 *>(v + 1 * 4 * 32 * kWnRow) = t[1] + t[2];
+    *reinterpret_cast<f32x4 *>(v + 2 * 4 * 32 * kWnRow) = pk_sub4(t[2], t[1]);
+    *reinterpret_cast<f32x4 *>(v + 3 * 4 * 32 * kWnRow) = pk_sub4(t[1], t[3]);
   };
 
   // ---- GEMM plan: wave (jf, rbh): frequencies (i, jf), row blocks rbh * MRB + m ----
-  const int boff = (jf * 32 + jl) * 64;  // + i * 8192; slot (2 g + h) ^ ((jl >> 2) & 3)
-  const int bsw = (jl >> 2) & 3;
+  const int boff = (jf * 32 + jl) * kWnRow + h * 16;  // + i * 4 * 32 * kWnRow + g * 32
   int a_base[MRB];
 #pragma unroll
   for (int m = 0; m < MRB; ++m) {
@@ -357,20 +397,20 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
     // so that the vector-memory waits are counted exactly
     f32x4 b[2][2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) b[0][g] = *reinterpret_cast<const f32x4 *>(vb + (((2 * g + h) ^ bsw) << 4));
+    for (int g = 0; g < 2; ++g) b[0][g] = *reinterpret_cast<const f32x4 *>(vb + g * 32);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int step = 4 * chunk + i;
-      if (i < 3) {
+      if (i < 3 && !((WN_ABL & 8) && chunk > 0)) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
-          b[(i + 1) & 1][g] = *reinterpret_cast<const f32x4 *>(vb + (i + 1) * 8192 + (((2 * g + h) ^ bsw) << 4));
+          b[(i + 1) & 1][g] = *reinterpret_cast<const f32x4 *>(vb + (i + 1) * 4 * 32 * kWnRow + g * 32);
       }
       // the two waves of a SIMD (rbh = 0 / 1) transform the next chunk at opposite ends of the iteration: one of them
       // is always in its MFMAs
-      if (i == 0 && more1 && rbh == 0) transform((chunk + 1) & 1);
+      if (!(WN_ABL & 1) && i == 0 && more1 && rbh == 0) transform((chunk + 1) & 1);
       a_load((i + kWnAhead) & 3, min(step + kWnAhead, n_steps - 1));
-      if (i == 1) stage_store(chunk & 1);
+      if (!(WN_ABL & 2) && i == 1) stage_store(chunk & 1);
       if (i == 1) stage_load(chunk + 3);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -380,9 +420,9 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
 #pragma unroll
           for (int m = 0; m < MRB; ++m)
             acc[i][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[i][m][g][ii], b[i & 1][g][ii], acc[i][m], 0, 0, 0);
-      if (i == 3 && more1 && rbh == 1) transform((chunk + 1) & 1);
+      if (!(WN_ABL & 1) && i == 3 && more1 && rbh == 1) transform((chunk + 1) & 1);
     }
-    __syncthreads();
+    if (!(WN_ABL & 4)) __syncthreads();
   }
 
   WN_MARK(2);
@@ -402,10 +442,12 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
       xch[(((wv * 2 + 0) * MRB + m) * 4 + q) * 64 + lane] = s0;
       xch[(((wv * 2 + 1) * MRB + m) * 4 + q) * 64 + lane] = s1;
     }
-  __syncthreads();
   // ---- columns: Y[r][s] = (S A)[s] over j:  s = 0: S0 + S1 + S2;  s = 1: S1 - S2 - S3.  This wave: output row
   // r_o = jf & 1 of every tile, row block m_o = jf >> 1 of its half ----
   const int r_o = jf & 1, m_o = jf >> 1;
+  WinoTail<NCH, 16> tail(p, 0, img, tile, y0, x0, rbh * MRB + m_o, r_o, lane);
+  tail.load_res();
+  __syncthreads();
   f32x2 pr[16];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -419,7 +461,8 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
     }
   }
   WN_MARK(3);
-  wino_epilogue<NCH, 16>(p, pr, 0, img, tile, y0, x0, rbh * MRB + m_o, r_o, lane, smem + kWnStat);
+  if (!(WN_ABL & 16) || p.n_img < 0) tail.finish(pr, smem + kWnStat);
+  else if (pr[0].x == 123.456f) p.y[0] = pr[5].y;
 #ifdef WN_STAMP
   __builtin_amdgcn_s_waitcnt(0);
   WN_MARK(4);
@@ -535,11 +578,11 @@ __global__ __launch_bounds__(kWnThreads, 4) void conv3x3_wino64_kernel(ConvArgs 
     }
     f32x4 lo, hi;
     if (ih == 0) {
-      lo = t[0] - t[2];
+      lo = pk_sub4(t[0], t[2]);
       hi = t[1] + t[2];
     } else {
-      lo = t[1] - t[0];
-      hi = t[0] - t[2];
+      lo = pk_sub4(t[1], t[0]);
+      hi = pk_sub4(t[0], t[2]);
     }
     *reinterpret_cast<f32x4 *>(v) = lo;
     *reinterpret_cast<f32x4 *>(v + 4 * 32 * kW8Row) = hi;
@@ -630,9 +673,11 @@ __global__ __launch_bounds__(kWnThreads, 4) void conv3x3_wino64_kernel(ConvArgs 
     xch[((wv * 2 + 0) * 4 + q) * 64 + lane] = s0;
     xch[((wv * 2 + 1) * 4 + q) * 64 + lane] = s1;
   }
-  __syncthreads();
   // ---- columns: this wave = output row r_o = jf & 1 of every tile, registers 8 qh .. 8 qh + 7 (qh = jf >> 1) ----
   const int r_o = jf & 1, qh = jf >> 1;
+  WinoTail<NCH, 8> tail(p, 8 * qh, img, tile, y0, x0, rbh, r_o, lane);
+  tail.load_res();
+  __syncthreads();
   f32x2 pr[8];
 #pragma unroll
   for (int qq = 0; qq < 2; ++qq) {
@@ -645,7 +690,7 @@ __global__ __launch_bounds__(kWnThreads, 4) void conv3x3_wino64_kernel(ConvArgs 
       pr[4 * qq + e].y = (s[1][e] - s[2][e]) - s[3][e];
     }
   }
-  wino_epilogue<NCH, 8>(p, pr, 8 * qh, img, tile, y0, x0, rbh, r_o, lane, smem + kW8Stat);
+  tail.finish(pr, smem + kW8Stat);
 }
 
 int launch_conv3x3_wino_pack(mp_ctx *ctx, const float *w, int cout, int cin, float *up, hipStream_t st) {
