@@ -8,7 +8,7 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "side", "libmonopor
 from monoport_amd import ops
 dev = torch.device("cuda", 0)
 with torch.no_grad():
-    for b, cin, cout, hw in ((1, 256, 128, 32), (1, 256, 128, 128), (20, 256, 128, 128), (20, 128, 128, 128)):
+    for b, cin, cout, hw in ((20, 256, 128, 128), (20, 128, 128, 128)):
         x = torch.randn((b, cin, hw, hw), device=dev)
         w = torch.randn((cout, cin, 3, 3), device=dev) * 0.05
         packed = ops.PackedConv3x3(w)
