@@ -90,6 +90,35 @@ __device__ __forceinline__ void seg_main(f32x16 (&acc)[MR][NR], f32x4 (&ring)[PF
   }
 }
 
+// seg_main for ONE row block x ONE column block (layer 3 of the wave-specialised table kernel: 32 rows per consumer
+// wave) with the k-steps alternating between TWO accumulators: a wave whose MFMAs chain through a single accumulator
+// runs at 2/3 of the matrix rate when another wave shares its SIMD (profiles/r03y_mfma_peak_probe.txt); two
+// independent chains restore it.  The caller adds the two accumulators at the end (addition order is free).
+template <int PF, int ROWB>
+__device__ __forceinline__ void seg_main_split(f32x16 &acc_e, f32x16 &acc_o, f32x4 (&ring)[PF + 1][1], const WStream &ws,
+                                               int a, int n_groups, const unsigned char *b, int swz) {
+  constexpr int RS = PF + 1;
+  f32x4 bcur = *reinterpret_cast<const f32x4 *>(b + (swz << 4));
+#pragma unroll 1
+  for (int g0 = 0; g0 < n_groups; g0 += RS) {
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+      const int g = g0 + r;
+      const int gp = min(g + PF, n_groups - 1);
+      ring[(r + PF) % RS][0] = wload128(ws, a + gp * 64);
+      const int boff = ((2 * min(g + 1, n_groups - 1)) ^ swz) << 4;
+      const f32x4 bnxt = *reinterpret_cast<const f32x4 *>(b + boff);
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x4 af = ring[r % RS][0];
+      acc_e = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bcur[0], acc_e, 0, 0, 0);
+      acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bcur[1], acc_o, 0, 0, 0);
+      acc_e = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bcur[2], acc_e, 0, 0, 0);
+      acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bcur[3], acc_o, 0, 0, 0);
+      bcur = bnxt;
+    }
+  }
+}
+
 // The z column: one k-step whose B operand is z_feat in lanes 0-31 and 0 in lanes 32-63.
 template <int MR, int NR>
 __device__ __forceinline__ void gemm_z(f32x16 (&acc)[MR][NR], const float (&az)[MR],

@@ -323,9 +323,9 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
         }
       }
       // ---------------- U0-U1: layer 3, rows [32 wv, +32), K = 256 hidden in 2 pairs ----------------
-      f32x16 acc3[1][1];
+      f32x16 acc3[1][1], acc3o;  // layer 3 on two accumulator chains (even / odd k-steps), added before piece 6
 #pragma unroll
-      for (int t = 0; t < 16; ++t) acc3[0][0][t] = 0.0f;
+      for (int t = 0; t < 16; ++t) acc3[0][0][t] = acc3o[t] = 0.0f;
       {
         f32x4 ring3[4][1];
         seg_prefetch<1, 3>(ring3, ws, a3, 0, 16);
@@ -335,9 +335,11 @@ __global__ __launch_bounds__(kWsThreads, 4) void pifu_query_tabws_kernel(MlpPack
 #pragma unroll
             for (int m = 0; m < 2; ++m) store_k(1, acc2[m][0], 2 * (wv - 2) + m);
           }
-          seg_main<1, 1, 3, kTabHbRow>(acc3, ring3, ws, a3 + pr * 16 * 64, 0, 16, xrow + (pr ? 1 : 2) * kWsXBytes, swz);
+          seg_main_split<3, kTabHbRow>(acc3[0][0], acc3o, ring3, ws, a3 + pr * 16 * 64, 16, xrow + (pr ? 1 : 2) * kWsXBytes, swz);
           if (pr == 0) seg_prefetch<1, 3>(ring3, ws, a3 + 16 * 64, 0, 16);
           if (pr == 1) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc3[0][0][t] += acc3o[t];
             add_piece(acc3, mlp.az[3] + wv * 64, 3);  // piece 6: written to PB in U0
             lrelu(acc3[0][0]);
             // layer 4 on the VALU: this wave's 32 hidden rows; the producers finish the sum
