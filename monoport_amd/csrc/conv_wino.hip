@@ -52,11 +52,6 @@ constexpr int kWnV = 2 * kWnRawBytes;
 constexpr int kWnXchBytes = 8 * 2 * 2 * 4 * 64 * 16;  // output-transform exchange: [wave][r][m][q][lane] f32x4 (128 KB)
 constexpr int kWnStat = kWnXchBytes;             // wino_epilogue's statistics scratch (8 KB)
 constexpr int kWnLds = kWnStat + 8192;
-#ifndef WN_ABL
-#define WN_ABL 0
-#endif
-// WN_ABL (side builds of tools/wino_ablate.py, wrong results): 1 no input transform, 2 no staging stores, 4 no chunk
-// barrier, 8 no B reads in the K loop, 16 no epilogue (statistics / stores), 32 no output transform exchange
 constexpr int kWnAhead = 3;                    // A fragments are requested this many steps (of 16 MRB MFMAs) ahead
 static_assert(kWnV + 2 * kWnVBytes <= kWnXchBytes, "the exchange region covers the K loop's buffers");
 static_assert(kWnLds <= 160 * 1024, "LDS");
@@ -270,9 +265,6 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
   float stg[kWnPasses][2];
   int ch_staged = 0;
   auto stage_load = [&](int chunk) {
-#ifdef WN_NO_STAGE
-    if (chunk >= 3) return;
-#endif
     const int ch = min(chunk, n_chunks - 1) * 16 + 2 * wv;
 #pragma unroll
     for (int it = 0; it < kWnPasses; ++it) {
@@ -352,9 +344,6 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
   // HBM round trip; at three steps (6 k cycles of the SIMD's MFMA work) those have landed
   f32x4 ring[4][MRB][2];
   auto a_load = [&](int slot, int step) {
-#ifdef WN_NO_A  // timing experiment (wrong results): the weight stream is requested once
-    if (step >= kWnAhead) return;
-#endif
 #pragma unroll
     for (int m = 0; m < MRB; ++m)
 #pragma unroll
@@ -362,13 +351,6 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
   };
   const int n_steps = 4 * n_chunks;
 
-#ifdef WN_STAMP
-  long long stamp[6];
-  stamp[0] = __builtin_readcyclecounter();
-#define WN_MARK(i) stamp[i] = __builtin_readcyclecounter()
-#else
-#define WN_MARK(i)
-#endif
   // ---- prologue ----
   stage_load(0);
   GnAffine affine;
@@ -387,7 +369,6 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
   stage_load(2);
   __syncthreads();
 
-  WN_MARK(1);
 #pragma unroll 1
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     const unsigned char *vb = smem + kWnV + (chunk & 1) * kWnVBytes + boff;
@@ -401,16 +382,16 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int step = 4 * chunk + i;
-      if (i < 3 && !((WN_ABL & 8) && chunk > 0)) {
+      if (i < 3) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
           b[(i + 1) & 1][g] = *reinterpret_cast<const f32x4 *>(vb + (i + 1) * 4 * 32 * kWnRow + g * 32);
       }
       // the two waves of a SIMD (rbh = 0 / 1) transform the next chunk at opposite ends of the iteration: one of them
       // is always in its MFMAs
-      if (!(WN_ABL & 1) && i == 0 && more1 && rbh == 0) transform((chunk + 1) & 1);
+      if (i == 0 && more1 && rbh == 0) transform((chunk + 1) & 1);
       a_load((i + kWnAhead) & 3, min(step + kWnAhead, n_steps - 1));
-      if (!(WN_ABL & 2) && i == 1) stage_store(chunk & 1);
+      if (i == 1) stage_store(chunk & 1);
       if (i == 1) stage_load(chunk + 3);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -420,12 +401,11 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
 #pragma unroll
           for (int m = 0; m < MRB; ++m)
             acc[i][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[i][m][g][ii], b[i & 1][g][ii], acc[i][m], 0, 0, 0);
-      if (!(WN_ABL & 1) && i == 3 && more1 && rbh == 1) transform((chunk + 1) & 1);
+      if (i == 3 && more1 && rbh == 1) transform((chunk + 1) & 1);
     }
-    if (!(WN_ABL & 4)) __syncthreads();
+    __syncthreads();
   }
 
-  WN_MARK(2);
   // ---- output transform, rows: S[r] = (A^T M)[r] over i:  r = 0: M0 + M1 + M2;  r = 1: M1 - M2 - M3 ----
   f32x4 *xch = reinterpret_cast<f32x4 *>(smem);
 #pragma unroll
@@ -460,17 +440,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void conv3x3_wino_kernel(ConvArgs p)
       pr[4 * q + e].y = (s[1][e] - s[2][e]) - s[3][e];
     }
   }
-  WN_MARK(3);
-  if (!(WN_ABL & 16) || p.n_img < 0) tail.finish(pr, smem + kWnStat);
-  else if (pr[0].x == 123.456f) p.y[0] = pr[5].y;
-#ifdef WN_STAMP
-  __builtin_amdgcn_s_waitcnt(0);
-  WN_MARK(4);
-  if (tid == 0 && p.y) {  // cycles of (prologue, K loop, output transform, epilogue) of this workgroup, over its first outputs
-    float *dst = p.y + ((long long)img * p.cout + NCH * blockIdx.y) * hw + (long long)y0 * p.w + x0;
-    for (int k = 0; k < 4; ++k) dst[k] = (float)(stamp[k + 1] - stamp[k]);
-  }
-#endif
+  tail.finish(pr, smem + kWnStat);
 }
 
 
@@ -533,9 +503,6 @@ __global__ __launch_bounds__(kWnThreads, 4) void conv3x3_wino64_kernel(ConvArgs 
   float stg[kWnPasses];
   int ch_staged = 0;
   auto stage_load = [&](int chunk) {
-#ifdef WN_NO_STAGE
-    if (chunk >= 3) return;
-#endif
     const int ch = min(chunk, n_chunks - 1) * 8 + wv;
 #pragma unroll
     for (int it = 0; it < kWnPasses; ++it)
@@ -599,9 +566,6 @@ __global__ __launch_bounds__(kWnThreads, 4) void conv3x3_wino64_kernel(ConvArgs 
     for (int t = 0; t < 16; ++t) acc[i][t] = 0.0f;
   f32x4 ring[4];  // the chunk's four fragments; pair (0, 1) of the next chunk is requested while pair (2, 3) runs
   auto a_load = [&](int i, int c) {
-#ifdef WN_NO_A
-    if (c >= 1) return;
-#endif
     const int cc = min(c, n_chunks - 1);
     ring[i] = wload128(ws, a_base + ((cc >> 1) * 8 + i * 2 + (cc & 1)) * 64);
   };
