@@ -56,7 +56,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from monoport_amd import ops, parallel, synthetic as syn  # noqa: E402
+from monoport_amd import _lib, ops, parallel, synthetic as syn  # noqa: E402
 from monoport_amd.pipeline import MAX_RECON_BATCH, FramePipeline  # noqa: E402
 from monoport_amd.recon import pifu_calib  # noqa: E402
 
@@ -472,11 +472,21 @@ def breakdown_leg(job, pipe, batch, resolutions):
         # with the state of torch's caching allocator this late in the process: 1.77 or 1.87 ms on the same code)
         enc_graph_ms = timed(slot.graph.replay, 10) / batch if slot.graph is not None else None
         enc1_ms = timed(lambda: slot.net.image_filter(slot.image[:1], last_only=True), 10)
+        # the same passes with every 3x3 convolution on the direct implicit-GEMM kernels (mp_conv3x3_tune(0x400): the
+        # launcher ignores the Winograd-domain weights) -- what csrc/conv_wino.hip buys, measured in this process
+        lib = _lib.load()
+        lib.mp_conv3x3_tune(0x400)
+        try:
+            enc_direct_ms = timed(lambda: slot.net.image_filter(slot.image, last_only=True), 10) / batch
+            enc1_direct_ms = timed(lambda: slot.net.image_filter(slot.image[:1], last_only=True), 10)
+        finally:
+            lib.mp_conv3x3_tune(0)
         rec_ms = timed(recon_only, 10)
         rec_batched_ms = timed(recon_batched, 5) / min(batch, MAX_RECON_BATCH)
     return {
         "encoder_ms_per_frame": enc_ms, "encoder_ms_batch1": enc1_ms,
         "encoder_ms_per_frame_as_run": enc_graph_ms,
+        "encoder_ms_per_frame_direct_conv3x3": enc_direct_ms, "encoder_ms_batch1_direct_conv3x3": enc1_direct_ms,
         "recon_vertices_render_ms": rec_ms,
         "recon_vertices_render_ms_per_frame_batched": rec_batched_ms,
         "recon_per_s_encoder_excluded": 1e3 / rec_batched_ms,

@@ -160,3 +160,28 @@ def test_winograd_is_chosen_only_where_it_is_built_and_large_enough():
     ctx = ops.get_encoder_context(torch.device(DEV))
     rc = lib.mp_conv3x3_ex(ctx.handle, ctypes.byref(a), None)
     assert rc != 0 and b"packed_wino" in lib.mp_last_error(ctx.handle)
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_whole_encoders_winograd_vs_direct_kernels(batch):
+    """netG.filter (HGFilter, 4 stacks: backbones/HGFilters.py:167-204) with its 3x3 convolutions on the Winograd kernels
+    against the same pass on the direct kernels (mp_conv3x3_tune(0x400)): every stack's feature map within 2e-5 -- a
+    fifth of the 1e-4 bar the encoders are held to against the reference (tests/test_encoder_dataflow_gpu.py).  At
+    batch 1 only the 128^2 launches are large enough for the Winograd kernels; at batch 4 the 64^2 ones as well."""
+    import bench
+    from monoport_amd import _lib, synthetic as syn
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    netG = bench.build_netg(dev)[0]
+    img = torch.stack([torch.from_numpy(syn.synthetic_image(40 + i)) for i in range(batch)]).to(dev)
+    with torch.no_grad():
+        wino = [f[0].clone() for f in netG.image_filter(img)]
+        lib.mp_conv3x3_tune(DIRECT)
+        try:
+            direct = [f[0].clone() for f in netG.image_filter(img)]
+        finally:
+            lib.mp_conv3x3_tune(0)
+    assert len(wino) == len(direct) == 4
+    errs = [(a - b).abs().max().item() for a, b in zip(wino, direct)]
+    print("netG.filter batch %d, Winograd vs direct 3x3 kernels per stack: %s" % (batch, ["%.2e" % e for e in errs]))
+    assert 0 < max(errs) <= 2e-5
