@@ -10,24 +10,27 @@
 // fewer MFMAs -- between an input transform (adds only) and an output transform (adds only).  The transformed weights
 // U = G g G^T are computed once, in double, by conv3x3_wino_pack_kernel.  Everything around the GEMMs is what
 // conv3x3.hip does: GroupNorm + ReLU applied while the input is staged (zero padding of the NORMALISED tensor, or the
-// reflection padding of the ResNet encoder), the
-// epilogue of conv3x3.hip (raw output, pyramid-block tail, the next GroupNorms' statistics by integer atomics).
+// reflection padding of the ResNet encoder), and conv3x3.hip's epilogue (raw output, pyramid-block tail, the next
+// GroupNorms' statistics by integer atomics).
 //
-// Decomposition (one workgroup = 8 waves = 512 threads, one per CU):
+// Two kernels.  conv3x3_wino_kernel<2> (below: one workgroup = 8 waves = 512 threads, one per CU) and, further down,
+// conv3x3_wino64_kernel (64 output channels, 8-channel chunks, two workgroups per CU); the launcher picks by size.
+// Decomposition of the first:
 //   * workgroup = 8 x 4 Winograd tiles (16 x 8 output pixels, 18 x 10 input patch) x 128 output channels;
 //   * K loop over 16-channel chunks of the input, one barrier per chunk, three stages in flight:
 //       chunk k + 2/3: global -> registers (lane = patch pixel, wave = 2 channel planes), GroupNorm + ReLU,
 //                      -> raw[2] in LDS, pixel-major (80-byte rows: 64 used, the pad keeps 128-bit accesses off each
 //                      other's banks);
 //       chunk k + 1:   input transform raw -> V[2][i][j][tile][16 ch]: thread = (tile, 4 channels, column j),
-//                      8 ds_read_b128 + 16 packed adds + 4 ds_write_b128;
+//                      8 ds_read_b128 + 14 packed multiply-adds / adds + 4 ds_write_b128;
 //       chunk k:       wave (j, half) multiplies frequencies (0..3, j) for its two 32-channel row blocks: A = U
 //                      fragments streamed from L2 in fragment order, B = V rows from LDS, 64 MFMAs per chunk;
 //   * output transform: rows in registers (A^T M), columns through LDS (. A); wave (j, half) then owns output row
 //     r = j & 1 of every tile for row block j >> 1 of its half and runs conv3x3.hip's epilogue on it.
 // Executed FLOPs: 2 * 16 * Cin * Cout per 2 x 2 output pixels = 4 / 9 of the direct form.  Rounding: the products are
 // exact-f32 MFMA FMA chains as before; the transforms add 2-3 roundings per side (F(2x2, 3x3) has the mildest
-// constants of the family: 0, +-1, +-1/2) -- measured against the fp64 convolution in tests/test_conv_gpu.py.
+// constants of the family: 0, +-1, +-1/2) -- measured against the fp64 convolution in tests/test_conv_wino_gpu.py
+// (closer to it than the direct kernel: 256 instead of 2304 additions per output).
 #include "mp_internal.h"
 #include "query_common.h"
 #include "gn_tail.h"
@@ -50,7 +53,7 @@ constexpr int kWnVBytes = 16 * 32 * kWnRow;      // one V buffer: [i][j][tile][1
 constexpr int kWnRaw = 0;
 constexpr int kWnV = 2 * kWnRawBytes;
 constexpr int kWnXchBytes = 8 * 2 * 2 * 4 * 64 * 16;  // output-transform exchange: [wave][r][m][q][lane] f32x4 (128 KB)
-constexpr int kWnStat = kWnXchBytes;             // wino_epilogue's statistics scratch (8 KB)
+constexpr int kWnStat = kWnXchBytes;             // WinoTail's statistics scratch (8 KB)
 constexpr int kWnLds = kWnStat + 8192;
 constexpr int kWnAhead = 3;                    // A fragments are requested this many steps (of 16 MRB MFMAs) ahead
 static_assert(kWnV + 2 * kWnVBytes <= kWnXchBytes, "the exchange region covers the K loop's buffers");
