@@ -115,21 +115,9 @@ def test_winograd_weights_are_g_g_gt_rounded_once():
     packed = ops.PackedConv3x3(wt)
     torch.cuda.synchronize()
     up = packed.wino.cpu().numpy()
-    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
-    U = np.einsum("ia,ocab,jb->ijoc", G, wt.cpu().numpy().astype(np.float64), G).astype(np.float32)  # [i][j][co][ci]
-    n_chunks = cin // 16
-    t = np.arange(up.size)
-    ii, lane = t & 3, (t >> 2) & 63
-    q = t >> 8
-    gg = q & 1
-    q >>= 1
-    i = q & 3
-    q >>= 2
-    chunk = q % n_chunks
-    q //= n_chunks
-    j, rb = q & 3, q >> 2
-    co = 32 * rb + (lane & 31)
-    ci = 16 * chunk + 8 * gg + 4 * (lane >> 5) + ii
+    from oracle import winograd  # the algebra in float64 (checked against the direct convolution in tests/test_winograd_cpu.py)
+    U = winograd.transformed_weights(wt.cpu().numpy()).astype(np.float32)  # [i][j][co][ci], rounded once
+    i, j, co, ci = winograd.fragment_index(cout, cin)
     assert np.array_equal(up, U[i, j, co, ci])
 
 
